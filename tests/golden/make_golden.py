@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Regenerates the fixture files in tests/golden/ from the reference checkout.
+
+Run in the authoring container only (needs /root/reference); the outputs are
+committed so that nothing at test/bench time reads /root/reference.
+
+  phix174.seq  <- data/phix174.gb   (BASELINE config 1 input; 5,386 bp, lower case)
+  puc19.seq    <- data/puc19.gbk    (seqhash_test.go:68-91 rotation fixture)
+
+Extraction follows io/genbank/genbank.go:125,627-633: every line between
+ORIGIN and // with all non-letters removed, case preserved.
+"""
+import os
+import re
+import sys
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def genbank_sequence(path: str) -> str:
+    seq, on = [], False
+    with open(path) as f:
+        for line in f:
+            if line.startswith("ORIGIN"):
+                on = True
+                continue
+            if on:
+                if line.startswith("//"):
+                    break
+                seq.append(re.sub(r"[^a-zA-Z]+", "", line))
+    return "".join(seq)
+
+
+def main() -> int:
+    for src, dst in (("data/phix174.gb", "phix174.seq"), ("data/puc19.gbk", "puc19.seq")):
+        s = genbank_sequence(os.path.join(REF, src))
+        with open(os.path.join(HERE, dst), "w") as f:
+            f.write(s + "\n")
+        print(dst, len(s))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

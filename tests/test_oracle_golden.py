@@ -1,0 +1,348 @@
+"""Pins the CPU oracle (oracle/) against every expectation the reference's own
+tests hold for the hot path.  CPU only.
+
+Each test names the reference test (file:line, relative to /root/reference)
+whose assertion it restates.  If these fail, no GPU parity claim means
+anything.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _read(name):
+    with open(os.path.join(GOLD, name)) as f:
+        return f.read().strip()
+
+
+# ---------------------------------------------------------------- murmur3 --
+def test_murmur3_canonical_vectors():
+    # The reference pins raw hashes only indirectly (mash_test.go:9-62), so the
+    # hash itself is pinned on the canonical MurmurHash3_x86_32 seed-0 vectors.
+    vec = {
+        b"": 0x00000000,
+        b"hello": 0x248BFA47,
+        b"hello, world": 0x149BBB7F,
+        b"19 Jan 2038 at 3:14:07 AM": 0xE31E8A70,
+        b"The quick brown fox jumps over the lazy dog.": 0xD5C48BFC,
+    }
+    for k, v in vec.items():
+        assert orc.murmur3_32(k) == v, k
+    # seeded vectors from the MurmurHash3 SMHasher verification set
+    assert orc.murmur3_32(b"", 1) == 0x514E28B7
+    assert orc.murmur3_32(b"", 0xFFFFFFFF) == 0x81F16F39
+    assert orc.murmur3_32(b"\x21\x43\x65\x87", 0x5082EDEE) == 0x2362F9DE
+    assert orc.murmur3_32(b"\x21\x43\x65", 0) == 0x7E4A8634
+    assert orc.murmur3_32(b"\x21\x43", 0) == 0xA0F7B07A
+    assert orc.murmur3_32(b"\x21", 0) == 0x72661CF4
+
+
+# ------------------------------------------------------------------- mash --
+SEQ1 = "ATGCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA"
+SEQ2 = "ATCGATCGATCGATCGATCGATCGATCGATCGATCGAATGCGATCGATCGATCGATCGATCG"
+
+
+def test_mash_TestMash():
+    """search/mash/mash_test.go:9-62"""
+    f1 = orc.Mash(17, 10)
+    f1.Sketch(SEQ1)
+    f2 = orc.Mash(17, 9)
+    f2.Sketch(SEQ1)
+    assert f1.Distance(f2) == 0  # :17-19
+    assert f2.Distance(f1) == 0  # :21-24
+    # pins duplicate-hash retention: sketch is 10x the same hash
+    assert list(f1.Sketches) == [0x096698DE] * 10
+
+    spoof = orc.Mash(17, 10)
+    spoof.Sketches[0] = 0
+    assert f1.Distance(spoof) == 1  # :26-32
+    spoof = orc.Mash(17, 9)
+    assert f1.Distance(spoof) == 1  # :34-39
+
+    f1 = orc.Mash(17, 10)
+    f1.Sketch(SEQ1)
+    f2 = orc.Mash(17, 5)
+    f2.Sketch(SEQ2)
+    d = f1.Distance(f2)
+    assert 0.19 < d < 0.21  # :47-50
+    assert d == 0.19999999999999996  # the value the error message names
+    assert list(f2.Sketches) == [0x08F7DC27] + [0x096698DE] * 4
+
+    f1 = orc.Mash(17, 10)
+    f1.Sketch(SEQ2)
+    f2 = orc.Mash(17, 5)
+    f2.Sketch(SEQ1)
+    assert f1.Distance(f2) == 0  # :52-61
+
+
+def test_mash_example():
+    """search/mash/example_test.go:9-22 prints 0"""
+    f1 = orc.Mash(17, 10)
+    f1.Sketch(SEQ1)
+    f2 = orc.Mash(17, 9)
+    f2.Sketch(SEQ1)
+    assert f1.Distance(f2) == 0
+
+
+def test_mash_phix174_config1():
+    """BASELINE config 1: mash.Sketch(data/phix174.gb, k=21, s=1000).
+
+    Provisional goldens of SURVEY 8c (computed at survey time by an independent
+    Python restatement); faithful (sort-on-accept) and insertion variants agree."""
+    seq = _read("phix174.seq")
+    assert len(seq) == 5386 and seq[:21] == "gagttttatcgcttccatgac"
+    assert orc.murmur3_32(seq[:21]) == 0x1595F355
+    for faithful in (False, True):
+        m = orc.Mash(21, 1000)
+        m.Sketch(seq, faithful=faithful)
+        sk = m.Sketches
+        assert [int(x) for x in sk[:5]] == [0x00006D6A, 0x0001273B, 0x002782B6, 0x002DCDAE, 0x004493CF]
+        assert int(sk[499]) == 0x170B41DF and int(sk[998]) == 0x2F29F5F7 and int(sk[999]) == 0x2F30D748
+        assert len(set(sk.tolist())) == 1000
+        assert int(sk.astype(np.uint64).sum() & 0xFFFFFFFF) == 0x2DCF8AAA
+        assert int(np.bitwise_xor.reduce(sk)) == 0x17EAB090
+        assert hashlib.sha256(sk.astype("<u4").tobytes()).hexdigest() == \
+            "943c9bb7559e8cb151b9382dbdab7ff8d1b642f64ad1ec7b9b03d709f8ad898a"
+
+
+def test_mash_sketch_quirks():
+    """mash.go:68-104 behaviours a textbook MinHash would get wrong."""
+    seq = orc.synth_dna(7, 400).tobytes()
+    k = 21
+    hashes = [orc.murmur3_32(seq[i:i + k]) for i in range(len(seq) - k + 1)]
+    # (1) last k-mer skipped: n-k windows (mash.go:73)
+    m = orc.Mash(k, 50)
+    m.Sketch(seq)
+    assert list(m.Sketches) == sorted(hashes[:-1])[:50]
+    # (2) fewer windows than s: positional, unsorted, tail untouched
+    m = orc.Mash(k, 1000)
+    m.Sketches[:] = 0xABCD
+    m.Sketch(seq)
+    nwin = len(seq) - k
+    assert list(m.Sketches[:nwin]) == hashes[:nwin]
+    assert all(int(x) == 0xABCD for x in m.Sketches[nwin:])
+    # (3) exactly s windows: sorted
+    m = orc.Mash(k, nwin)
+    m.Sketch(seq)
+    assert list(m.Sketches) == sorted(hashes[:nwin])
+    # (4) s-1 windows: positional (sort only happens at kmerStart == s-1)
+    m = orc.Mash(k, nwin + 1)
+    m.Sketch(seq)
+    assert list(m.Sketches[:nwin]) == hashes[:nwin] and int(m.Sketches[nwin]) == 0
+    # (5) shorter than k: no-op
+    m = orc.Mash(k, 5)
+    m.Sketch(seq[:k])
+    assert not m.Sketches.any()
+    m.Sketch(seq[:3])
+    assert not m.Sketches.any()
+    # (6) s == 0 panics as soon as there is a window; s == 1 when a smaller hash arrives
+    with pytest.raises(orc.GoPanic):
+        orc.Mash(k, 0).Sketch(seq)
+    with pytest.raises(orc.GoPanic):
+        orc.Mash(k, 1).Sketch(seq)
+
+
+# ------------------------------------------------------------------ align --
+def _mat3():
+    sc = [[0, 0, 0, 0, 0], [0, 3, -3, -3, -3], [0, -3, 3, -3, -3], [0, -3, -3, 3, -3], [0, -3, -3, -3, 3]]
+    return orc.SubstitutionMatrix("-ACGT", "-ACGT", sc)
+
+
+def test_align_TestSmithWaterman():
+    """search/align/align_test.go:139-292"""
+    m = _mat3()
+    assert orc.smith_waterman("TGTTACGG", "GGTTGACTA", m, -2)[:3] == (13, "GTT-AC", "GTTGAC")  # :158-175
+    assert orc.smith_waterman("ACACACTA", "AGCACACA", m, -2)[:3] == (17, "A-CACACTA", "AGCACAC-A")  # :177-194
+    assert orc.smith_waterman("", "GAT", m, -2)[:3] == (0, "", "")  # :199-215
+    assert orc.smith_waterman("", "", m, -2)[:3] == (0, "", "")  # :217-234
+    assert orc.smith_waterman("G", "A", m, -2)[:3] == (0, "", "")  # :236-253
+    assert orc.smith_waterman("G", "G", m, -2)[:3] == (3, "G", "G")  # :255-272
+    assert orc.smith_waterman("G", "GATTACA", m, -2)[:3] == (3, "G", "G")  # :274-291
+
+
+def test_align_examples():
+    """search/align/example_test.go:49-111"""
+    pm1 = (2 * np.eye(5, dtype=int) - 1).tolist()
+    m = orc.SubstitutionMatrix("ACGTU", "ACGTU", pm1)
+    assert orc.smith_waterman("GATTACA", "GCATGCU", m, -1)[:3] == (2, "AT", "AT")  # :82
+    assert orc.needleman_wunsch("GATTACA", "GCATGCU", m, -1) == (0, "G-ATTACA", "GCA-TGCU")  # :46
+    # NUC_4 indexed by a mis-ordered alphabet {A,C,G,T,-}: 'A' hits the all-zero row
+    m = orc.SubstitutionMatrix("ACGT-", "ACGT-", orc.NUC_4_SCORES)
+    assert orc.smith_waterman("GATTACA", "GCATGCT", m, -1)[:3] == (15, "GATTAC", "GCATGC")  # :110
+
+
+def test_align_TestNeedlemanWunsch():
+    """search/align/align_test.go:11-137 (all eight score assertions)"""
+    m = orc.SubstitutionMatrix("ACGTU", "ACGTU", (2 * np.eye(5, dtype=int) - 1).tolist())
+    assert orc.needleman_wunsch("GATTACA", "GCATGCU", m, -1) == (0, "G-ATTACA", "GCA-TGCU")
+    assert orc.needleman_wunsch("GATTACA", "GATTACA", m, -1) == (7, "GATTACA", "GATTACA")
+    assert orc.needleman_wunsch("GATTACA", "GAT", m, -1)[0] == -1
+    # traceback stops when either index hits 0 (align.go:141): leading residues dropped
+    assert orc.needleman_wunsch("", "GAT", m, -1) == (-3, "", "")
+    assert orc.needleman_wunsch("", "", m, -1) == (0, "", "")
+    assert orc.needleman_wunsch("G", "A", m, -1)[0] == -1
+    assert orc.needleman_wunsch("G", "G", m, -1) == (1, "G", "G")
+    assert orc.needleman_wunsch("G", "GATTACA", m, -1)[0] == -5
+
+
+def test_align_error_order():
+    """align.go:189-191 + matrix.go:29-36: first failing cell in row-major order,
+    first-alphabet error before second; no lookups when either string is empty."""
+    m = _mat3()
+    with pytest.raises(orc.AlphabetError, match="Symbol X not"):
+        orc.smith_waterman("XG", "GY", m, -2)  # a[0] invalid: reported before b
+    with pytest.raises(orc.AlphabetError, match="Symbol Y not"):
+        orc.smith_waterman("GX", "GY", m, -2)  # a[0] ok -> first invalid b[j]
+    with pytest.raises(orc.AlphabetError, match="Symbol X not"):
+        orc.smith_waterman("GX", "GA", m, -2)
+    assert orc.smith_waterman("", "!!", m, -2)[:3] == (0, "", "")
+    assert orc.smith_waterman("!!", "", m, -2)[:3] == (0, "", "")
+
+
+def test_matrix_score():
+    """search/align/matrix/matrix_test.go:11-49"""
+    m = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    assert m.Score("A", "A") == 5 and m.Score("A", "C") == -4 and m.Score("T", "G") == -4
+    assert m.Score("-", "A") == 0
+    with pytest.raises(orc.AlphabetError):
+        m.Score("X", "A")
+    d = orc.DEFAULT_MATRIX
+    assert d.Score("A", "A") == 1 and d.Score("A", "Z") == -1
+    lut, va, vb = m.flatten()
+    assert lut[ord("A"), ord("A")] == 5 and lut[ord("G"), ord("T")] == -4
+    assert va[ord("A")] and not va[ord("N")] and not va[0xC3]
+
+
+# ---------------------------------------------------------------- primers --
+def test_primers_goldens():
+    """primers/primers_test.go:13-84 and the full-precision values of SURVEY 8c"""
+    assert orc.marmur_doty("ACGTCCGGACTT") == 31.0  # :24
+    tm, dh, ds = orc.santalucia("ACGATGGCAGTAGCATGC", 0.1e-6, 350e-3, 0.0)
+    assert abs(62.7 - tm) / 62.7 < 0.02  # :47
+    assert abs(tm - 62.31695672635385) < 1e-9 and abs(dh - -144.0) < 1e-9
+    assert abs(ds - -394.46768721086363) < 1e-9
+    assert orc.reverse_complement("ACGTAGATCTACGT") == b"ACGTAGATCTACGT"  # :55-58
+    tm, dh, ds = orc.santalucia("ACGTAGATCTACGT", 0.1e-6, 350e-3, 0.0)
+    assert abs(47.428514 - tm) / 47.428514 < 0.02  # :62-63
+    assert abs(tm - 47.42851359405711) < 1e-9
+    assert abs(dh - -106.00000000000001) < 1e-9 and abs(ds - -298.6223490436017) < 1e-9
+    tm = orc.melting_temp("GTAAAACGACGGCCAGT")
+    assert abs(52.8 - tm) / 52.8 < 0.02  # :81
+    assert abs(tm - 52.63382276100299) < 1e-9
+    # lower case is folded (primers.go:71)
+    assert orc.melting_temp("gtaaaacgacggccagt") == tm
+
+
+def test_primers_go_log_matches_libm():
+    import math
+    rng = np.random.default_rng(1)
+    for x in [50e-3, 350e-3, 500e-9 / 4, 0.1e-6 / 4, 0.1e-6, 1.0, 2.0, 0.5] + rng.uniform(1e-9, 10, 200).tolist():
+        g, l = orc.go_log(x), math.log(x)
+        assert g == l or abs(g - l) <= abs(math.ulp(l)), x
+
+
+GENE = ("aataattacaccgagataacacatcatggataaaccgatactcaaagattctatgaagctatttgaggcacttggtacgatcaagtcgcgctcaatgtttggtggc"
+        "ttcggacttttcgctgatgaaacgatgtttgcactggttgtgaatgatcaacttcacatacgagcagaccagcaaacttcatctaacttcgagaagcaagggcta"
+        "aaaccgtacgtttataaaaagcgtggttttccagtcgttactaagtactacgcgatttccgacgacttgtgggaatccagtgaacgcttgatagaagtagcgaag"
+        "aagtcgttagaacaagccaatttggaaaaaaagcaacaggcaagtagtaagcccgacaggttgaaagacctgcctaacttacgactagcgactgaacgaatgctt"
+        "aagaaagctggtataaaatcagttgaacaacttgaagagaaaggtgcattgaatgcttacaaagcgatacgtgactctcactccgcaaaagtaagtattgagcta"
+        "ctctgggctttagaaggagcgataaacggcacgcactggagcgtcgttcctcaatctcgcagagaagagctggaaaatgcgctttcttaa")
+
+
+def _design_primers(seq: str, target: float):
+    """primers/pcr/pcr.go:44-53 grow-until-Tm loop, on top of the oracle's MeltingTemp"""
+    seq = seq.upper()
+    fwd = seq[:15]
+    add = 0
+    while orc.melting_temp(fwd) < target:
+        fwd = seq[: 15 + add]
+        add += 1
+    rev = orc.reverse_complement(seq[len(seq) - 15:]).decode()
+    add = 0
+    while orc.melting_temp(rev) < target:
+        rev = orc.reverse_complement(seq[len(seq) - (15 + add):]).decode()
+        add += 1
+    return fwd, rev
+
+
+def test_primers_pcr_threshold():
+    """primers/pcr/example_test.go:54 -- pins the length at which Tm crosses 55.0"""
+    assert _design_primers(GENE, 55.0) == ("AATAATTACACCGAGATAACACATCATGG", "TTAAGAAAGCGCATTTTCCAGC")
+
+
+# -------------------------------------------------------------- transform --
+def test_transform_reverse_complement():
+    """transform/transform_test.go:10-80, examples_test.go:9-30"""
+    assert orc.reverse_complement("GATTACA") == b"TGTAATC"
+    assert orc.reverse_complement("gattaca") == b"tgtaatc"
+    assert orc.reverse_complement("ACGTN") == b"NACGT"
+    assert orc.reverse_complement("AU-") == b"\x00\x00T"  # unmapped bytes -> 0x00 (transform.go:78-109)
+
+
+# ---------------------------------------------------------------- seqhash --
+def test_seqhash_TestHash():
+    """seqhash/seqhash_test.go:12-66, example_test.go:11-31"""
+    with pytest.raises(orc.SeqhashError, match="Only sequenceTypes"):
+        orc.seqhash("ATGGGCTAA", "TNA", True, True)
+    with pytest.raises(orc.SeqhashError, match="Got letter: X"):
+        orc.seqhash("XTGGCCTAA", "DNA", True, True)
+    with pytest.raises(orc.SeqhashError, match="Got letter: J"):
+        orc.seqhash("MGCJ*", "PROTEIN", False, False)
+    with pytest.raises(orc.SeqhashError, match="double stranded"):
+        orc.seqhash("MGCS*", "PROTEIN", False, True)
+    want = {
+        ("TTAGCCCAT", "DNA", True, True): "v1_DCD_a376845b679740014f3eb501429b45e592ecc32a6ba8ba922cbe99217f6e9287",
+        ("TTAGCCCAT", "DNA", True, False): "v1_DCS_ef79b6e62394e22a176942dfc6a5e62eeef7b5281ffcb2686ecde208ec836ba4",
+        ("TTAGCCCAT", "DNA", False, True): "v1_DLD_c2c9fc44df72035082a152e94b04492182331bc3be2f62729d203e072211bdbf",
+        ("TTAGCCCAT", "DNA", False, False): "v1_DLS_063ea37d1154351639f9a48546bdae62fd8a3c18f3d3d3061060c9a55352d967",
+        ("TTAGCCCAT", "RNA", False, False): "v1_RLS_063ea37d1154351639f9a48546bdae62fd8a3c18f3d3d3061060c9a55352d967",
+        ("MGC*", "PROTEIN", False, False): "v1_PLS_922ec11f5227ce77a42f07f565a7a1a479772b5cf3f1f6e93afc5ecbc0fd5955",
+        ("ATGC", "DNA", False, True): "v1_DLD_f4028f93e08c5c23cbb8daa189b0a9802b378f1a1c919dcbcf1608a615f46350",
+    }
+    for args, h in want.items():
+        assert orc.seqhash(*args) == h, args
+
+
+def test_blake3_empty_and_tree_consistency():
+    # published BLAKE3 digest of the empty input
+    assert orc.blake3_256(b"").hex() == "af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+    # multi-chunk inputs: no external vector offline; check determinism + avalanche only
+    a = bytes(i % 251 for i in range(5000))
+    b = bytearray(a)
+    b[4999] ^= 1
+    assert orc.blake3_256(a) == orc.blake3_256(a)
+    assert orc.blake3_256(a) != orc.blake3_256(bytes(b))
+
+
+def test_seqhash_rotation():
+    """seqhash/seqhash_test.go:68-91 (every rotation of pUC19), example_test.go:33-40"""
+    assert orc.rotate_sequence("TTAGCCCAT") == b"AGCCCATTT"
+    puc = _read("puc19.seq")
+    assert len(puc) == 2686
+    want = orc.rotate_sequence(puc)
+    assert orc.booth_least_rotation(puc) == 2356
+    assert want[:30] == b"aaaaaaaccaccgctaccagcggtggtttg"
+    for r in range(0, len(puc), 1):
+        assert orc.rotate_sequence(puc[r:] + puc[:r]) == want
+    # Booth == naive minimum over random strings, incl. periodic ones
+    rng = np.random.default_rng(3)
+    for _ in range(300):
+        n = int(rng.integers(1, 40))
+        s = bytes(rng.choice(list(b"ACGT"[: int(rng.integers(1, 5))]), n).tolist())
+        assert orc.rotate_sequence(s) == min(s[i:] + s[:i] for i in range(n))
+
+
+# --------------------------------------------------------------- synthetic --
+def test_synth_dna_is_position_addressable():
+    a = orc.synth_dna(0xC2, 10_000)
+    assert set(a.tobytes()) <= set(b"ACGT")
+    # same stream, shorter: prefix property the GPU generator relies on
+    assert (orc.synth_dna(0xC2, 1000) == a[:1000]).all()
+    counts = np.bincount(a, minlength=256)[[65, 67, 71, 84]]
+    assert counts.min() > 2300
