@@ -1,0 +1,99 @@
+/*
+ * polyhip.h -- C ABI of libpolyhip.so: the MI355X (gfx950) implementation of
+ * bebop/poly's search hot path.
+ *
+ * The reference (pure Go, no FFI of its own) exposes this path as the
+ * exported API of four packages; a drop-in keeps those Go signatures and
+ * binds the entry points below through cgo (stubs: INTEGRATION.md, go/).
+ * Each entry point names the reference function it replaces; citations are
+ * relative to the reference checkout.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.
+ *  - Every function returns POLYHIP_OK (0) or a negative polyhip_status; the
+ *    message of the last failure on the calling thread is
+ *    polyhip_last_error().
+ *  - Two flavours per operation:
+ *      NAME      host pointers (what cgo hands over).  Synchronous: stages
+ *                through device memory on the current device and returns
+ *                when the outputs are written.
+ *      NAME_dev  device pointers + a hipStream_t (passed as void*; NULL = the
+ *                null stream).  Asynchronous: enqueues on the stream and
+ *                returns; inputs/outputs stay resident in HBM.
+ *  - Batches are packed: one contiguous byte buffer + (n+1) uint64 offsets,
+ *    sequence i = bytes [offsets[i], offsets[i+1]).  The library never keeps
+ *    a caller pointer after returning (cgo pointer rule).
+ *  - Thread safe: no unsynchronised globals; the current HIP device of the
+ *    calling thread is used (polyhip_set_device is a thin hipSetDevice).
+ *  - There is NO CPU fallback: without a usable HIP device every compute
+ *    entry point fails with POLYHIP_ERR_HIP.
+ *  - Sequence bytes must be ASCII (< 0x80) wherever the reference would
+ *    case-fold or map them through string(byte) (Go treats bytes >= 0x80 as
+ *    UTF-8 there); such input is rejected with POLYHIP_ERR_INVALID rather
+ *    than silently diverging.
+ */
+#ifndef POLYHIP_H
+#define POLYHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POLYHIP_ABI_VERSION 1
+
+typedef enum {
+    POLYHIP_OK = 0,
+    POLYHIP_ERR_INVALID = -1,     /* bad argument (null pointer, unsorted offsets, ...) */
+    POLYHIP_ERR_HIP = -2,         /* HIP runtime / device failure (message has the hipError) */
+    POLYHIP_ERR_UNSUPPORTED = -3, /* outside the implemented range (documented per call) */
+    POLYHIP_ERR_PANIC = -4,       /* the reference would panic on these arguments */
+    POLYHIP_ERR_SYMBOL = -5       /* align: "Symbol X not in alphabet" (see polyhip_sw_*) */
+} polyhip_status;
+
+typedef void *polyhip_stream_t; /* hipStream_t */
+
+/* ---- runtime --------------------------------------------------------- */
+int polyhip_abi_version(void);
+const char *polyhip_last_error(void); /* thread-local, never NULL */
+int polyhip_device_count(void);       /* >= 0, or a negative status */
+int polyhip_set_device(int device);
+/* name of the current device's gcnArch (e.g. "gfx950:sramecc+:xnack-") */
+int polyhip_device_arch(char *buf, size_t buflen);
+
+/* ---- synthetic inputs (bench/test plumbing) ------------- */
+/* d_out[i] = "ACGT"[(x >> 2*(i&31)) & 3], x = splitmix64 output number
+ * (first + i)/32 + 1 of the stream seeded with `seed`; `first` must be a
+ * multiple of 32 (lets ranks generate disjoint slices of one stream). */
+int polyhip_synth_dna_dev(uint64_t seed, uint64_t first, uint8_t *d_out,
+                          uint64_t n, polyhip_stream_t stream);
+
+/* ---- K1: search/mash (*Mash).Sketch  (search/mash/mash.go:68-104) ------ */
+/*
+ * For every sequence i: hash each of the (len_i - k) windows (the reference
+ * skips the last k-mer, mash.go:73) with MurmurHash3_x86_32 seed 0
+ * (murmur3.Sum32, mash.go:76) over the raw bytes, and leave in
+ * out[i*s .. i*s+s) exactly what Sketch leaves in Mash.Sketches:
+ *   len_i - k >= s : the s smallest hashes, ascending, duplicates kept;
+ *   0 < len_i - k < s : out[i*s + j] = hash of window j for j < len_i - k,
+ *                       remaining entries NOT written (caller's prior state
+ *                       survives, as in the reference);
+ *   len_i - k <= 0 : nothing written.
+ * So `out` is in/out: pass the current Sketches (zeros after mash.New).
+ * Range: 0 <= k <= 4096; 2 <= s <= 8192.  s < 2 -> POLYHIP_ERR_PANIC
+ * (mash.go:96,98 index Sketches[-1]).
+ */
+int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets,
+                              uint64_t n, uint32_t k, uint32_t s,
+                              uint32_t *out);
+int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs,
+                                  const uint64_t *d_offsets, uint64_t n,
+                                  uint32_t k, uint32_t s, uint32_t *d_out,
+                                  polyhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POLYHIP_H */

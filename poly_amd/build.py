@@ -1,0 +1,72 @@
+"""Builds poly_amd/libpolyhip.so (hand-written HIP for gfx950) in-tree.
+
+    python -m poly_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Objects are cached next to the sources
+(csrc/*.o) and rebuilt when a source or header is newer.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libpolyhip.so")
+ARCH = "gfx950"
+
+CXXFLAGS = [
+    f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC",
+    # Tm parity with Go/amd64, which never fuses multiply-add
+    "-ffp-contract=off",
+    "-Wall", "-Wno-unused-function",
+    "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+    hipcc = _hipcc()
+    jobs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([hipcc] + CXXFLAGS + ["-c", s, "-o", o])
+    if jobs:
+        with cf.ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            for cmd, res in zip(jobs, ex.map(lambda c: subprocess.run(c, capture_output=True, text=True), jobs)):
+                if verbose or res.returncode:
+                    sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+                if res.returncode:
+                    raise RuntimeError(f"hipcc failed on {cmd[-3]}")
+    objs = [s[:-4] + ".o" for s in srcs]
+    if force or jobs or _newer(LIB, objs):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode:
+            sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+            raise RuntimeError("link of libpolyhip.so failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,51 @@
+// common.h -- shared host-side plumbing for libpolyhip.so (error reporting,
+// HIP call checking, scoped device buffers for the host-pointer entry points).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "polyhip.h"
+
+namespace polyhip {
+
+// thread-local message behind polyhip_last_error()
+int set_error(int status, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+void clear_error();
+
+#define PH_HIP(expr)                                                                  \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess)                                                         \
+            return ::polyhip::set_error(POLYHIP_ERR_HIP, "%s: %s (%s:%d)", #expr,     \
+                                        hipGetErrorString(_e), __FILE__, __LINE__);   \
+    } while (0)
+
+#define PH_REQUIRE(cond, ...)                                                         \
+    do {                                                                              \
+        if (!(cond))                                                                  \
+            return ::polyhip::set_error(POLYHIP_ERR_INVALID, __VA_ARGS__);            \
+    } while (0)
+
+// Device allocation that frees itself (host-pointer entry points only; the
+// _dev entry points never allocate).
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+inline hipStream_t as_stream(polyhip_stream_t s) { return static_cast<hipStream_t>(s); }
+
+} // namespace polyhip

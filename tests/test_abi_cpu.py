@@ -1,0 +1,60 @@
+"""CPU-only checks of the drop-in boundary: libpolyhip.so builds for gfx950,
+loads without a GPU, exports every symbol include/polyhip.h declares, and
+refuses to compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "polyhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(polyhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    from poly_amd import build, _lib
+    path = build.build_lib()
+    assert os.path.exists(path)
+    L = C.CDLL(path)
+    names = _declared()
+    assert len(names) >= 8
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in polyhip.h but not exported"
+    # and the Python binding table covers the header exactly
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib().polyhip_abi_version() == 1
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under poly_amd/ may load or link it."""
+    pkg = os.path.join(ROOT, "poly_amd")
+    banned = re.compile(r"import\s+oracle|from\s+oracle|libpolyoracle|poly_oracle")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not banned.search(txt), f"{os.path.join(dirpath, f)} references the oracle"
+
+
+def test_argument_errors_without_gpu():
+    from poly_amd import _lib, mash
+    with pytest.raises(_lib.GoPanic):  # s < 2: the reference indexes Sketches[-1]
+        mash.sketch_batch_packed(np.frombuffer(b"ACGT" * 10, np.uint8), np.array([0, 40], np.uint64), 3, 1)
+    with pytest.raises(_lib.PolyhipError):
+        mash.sketch_batch_packed(np.frombuffer(b"ACGT" * 10, np.uint8), np.array([0, 40], np.uint64), 3, 100000)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from poly_amd import _lib, mash
+    with pytest.raises(_lib.PolyhipError) as ei:
+        mash.New(21, 10).Sketch("ACGT" * 20)
+    assert ei.value.status == _lib.ERR_HIP
