@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the poly search hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Metric (BASELINE.json): k-mers hashed / s through mash.Sketch on
+configs[1] -- 1,000,000 synthetic 10 kb reads, k=21, s=1000, per GPU.
+A "step" is one pass of K1 (polyhip_mash_sketch_batch_dev) over the whole
+read set, inputs already resident in HBM.  For N > 1 the driver launches one
+rank per GPU (torch.distributed.run); every rank sketches its own 1M reads
+(disjoint slice of one splitmix64 stream, no data-path collective) -> weak
+scaling; the timed region is bracketed by barrier + synchronize and the MAX
+over ranks is used.
+
+Also reported in the same JSON line:
+  roofline      HBM roofline of the K1 kernel: algorithmic bytes per launch
+                (n_reads * (read_len + 4*s)) / mean launch time
+                measured with HIP events on the launch stream; peak 8 TB/s.
+  cpu_baseline  the CPU oracle's faithful restatement of mash.go:68-104
+                (sort-on-accept) timed on this box, 1 thread, bounded sample.
+  extra         secondary rates (SW cell updates/s, Tm windows/s, distance
+                pairs/s) when those kernels are built.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+READ_LEN = 10_000
+KMER = 21
+SKETCH = 1000
+SEED = 0xC2
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config: 1,000,000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=400, help="reads in the CPU-baseline sample")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
+    return ap.parse_args()
+
+
+def cpu_baseline(n_reads: int):
+    """Oracle (port of mash.go:68-104, sort on every accepted hash) on host core(s)."""
+    import numpy as np
+    import oracle as orc
+    buf = orc.synth_dna(SEED, n_reads * READ_LEN)
+    offs = np.arange(0, (n_reads + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
+    t = time.perf_counter()
+    orc.mash_sketch_batch(buf, offs, KMER, SKETCH, faithful=True)
+    dt = time.perf_counter() - t
+    t2 = time.perf_counter()
+    orc.mash_sketch_batch(buf, offs, KMER, SKETCH, faithful=False)
+    dt2 = time.perf_counter() - t2
+    kmers = n_reads * (READ_LEN - KMER)
+    return {
+        "value": kmers / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+        "sample": f"first {n_reads} reads of the same stream ({kmers} k-mers, {dt:.1f} s), "
+                  "oracle/poly_oracle.c orc_mash_sketch faithful=1 (full sort on accept, as mash.go:99)",
+        "insertion_variant_value": kmers / dt2,
+    }
+
+
+def main() -> int:
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from poly_amd import mash
+
+    n = args.reads
+    seqs = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(SEED, seqs, first=rank * n * READ_LEN)  # rank's slice of one stream
+    offs = torch.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
+    out = torch.zeros((n, SKETCH), dtype=torch.int32, device=dev)
+
+    def step():
+        mash.sketch_batch_dev(seqs, offs, KMER, SKETCH, out)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()  # same stream as the launch (torch's current stream)
+        step()
+        e1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)
+
+    kmers_per_step = n * (READ_LEN - KMER)
+    value = world * kmers_per_step * args.steps / elapsed
+    alg_bytes = n * (READ_LEN + 4 * SKETCH)  # per launch: reads in, sketches out
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    # parity spot check inside the bench: first reads vs the oracle (rank 0 only)
+    parity = None
+    if rank == 0:
+        import numpy as np
+        import oracle as orc
+        m = 8
+        host = orc.synth_dna(SEED, m * READ_LEN)
+        want = orc.mash_sketch_batch(host, np.arange(0, (m + 1) * READ_LEN, READ_LEN, dtype=np.uint64), KMER, SKETCH)
+        got = out[:m].cpu().numpy().view(np.uint32)
+        parity = bool((got == want).all())
+
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "k1_traffic.json")
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get("hbm_bytes_per_launch_1M_reads")
+            if traffic is not None and n != 1_000_000:
+                traffic = traffic * n / 1_000_000
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "mash.Sketch k-mers hashed/s", "value": value, "unit": "k-mers/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"mash.Sketch over {n} synthetic {READ_LEN} B reads per GPU, k={KMER} s={SKETCH} "
+                               f"(BASELINE configs[1]), splitmix64 seed 0x{SEED:X}",
+                   "reads_per_gpu": n, "read_len": READ_LEN, "k": KMER, "s": SKETCH,
+                   "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "polyhip::k1::sketch_kernel<21>", "kernel_ms": kern_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes},
+        "parity_spot_check": parity,
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_extra:
+            try:
+                from poly_amd import bench_extra
+                line["extra"] = bench_extra.run(dev)
+            except ImportError:
+                pass
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_reads)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
