@@ -93,6 +93,65 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs,
                                   uint32_t k, uint32_t s, uint32_t *d_out,
                                   polyhip_stream_t stream);
 
+/* ---- K3: search/align SmithWaterman  (search/align/align.go:171-232) ---- */
+/*
+ * align.Scoring{SubstitutionMatrix, GapPenalty} (align.go:73-95) flattened
+ * through the matrix's public Score() (its score table is unexported,
+ * matrix.go:13-17):  lut[a*256 + b] = Score(string(byte a), string(byte b)),
+ * validA[a] != 0 iff byte a is a symbol of FirstAlphabet, validB likewise
+ * for SecondAlphabet (bytes >= 0x80 are never valid: string(byte) is a
+ * two-byte UTF-8 string).  All three tables are HOST pointers (parameters,
+ * not data) and are copied.  The handle owns small device tables on the HIP
+ * device that is current at creation and must be used on that device.
+ * Range: |gap| and |scores| such that  max|score| * (lenA + lenB) < 2^31.
+ */
+typedef struct polyhip_scoring polyhip_scoring;
+int polyhip_scoring_create(const int32_t *lut256x256, const uint8_t *validA256,
+                           const uint8_t *validB256, int64_t gap,
+                           polyhip_scoring **out);
+int polyhip_scoring_destroy(polyhip_scoring *sc);
+
+/*
+ * Score pass of SmithWaterman for a batch of pairs (A_p, B_p):
+ *   H[i][j] = max(0, H[i-1][j-1] + S(a_i, b_j), H[i-1][j] + gap, H[i][j-1] + gap)
+ * (align.go:192-195) with the reference's argmax: first maximum in row-major
+ * order, i over A outer, j over B inner (strict '>' at align.go:197).
+ * Outputs per pair p:
+ *   score[p]        maxScore
+ *   endA[p],endB[p] (maxScoreRow, maxScoreCol), 1-based; 0,0 when score == 0
+ *   err[p]          0, or (which << 8) | symbol for the reference's
+ *                   "Symbol X not in alphabet" error (align.go:189-191):
+ *                   which = 1 (A / FirstAlphabet) or 2 (B / SecondAlphabet),
+ *                   symbol = the byte the reference would name -- a[0] if
+ *                   invalid, else the first invalid b[j], else the first
+ *                   invalid a[i]; never set when either string is empty.
+ *                   score/endA/endB are 0 for such pairs.
+ * A is a packed batch (d_A, d_offA).  B is either ONE shared sequence
+ * (d_offB == NULL, d_B[0..lenB)) or a packed batch (d_offB != NULL, lenB =
+ * the maximum B length).  max_lenA >= every A length (the Go wrapper knows it
+ * from packing; a longer A sets err[p] = 0xFFFFFFFF).
+ * d_work: polyhip_sw_workspace_bytes(...) bytes of device scratch.
+ */
+size_t polyhip_sw_workspace_bytes(const polyhip_scoring *sc, uint64_t npairs,
+                                  uint32_t max_lenA, uint64_t lenB,
+                                  int shared_B);
+int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A,
+                         const uint64_t *d_offA, uint64_t npairs,
+                         uint32_t max_lenA, const uint8_t *d_B,
+                         const uint64_t *d_offB, uint64_t lenB,
+                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB,
+                         uint32_t *d_err, void *d_work, size_t work_bytes,
+                         polyhip_stream_t stream);
+/* Host-pointer flavour (cgo): same outputs in host memory. offB == NULL ->
+ * shared B of length lenB. */
+int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A,
+                     const uint64_t *offA, uint64_t npairs, const uint8_t *B,
+                     const uint64_t *offB, uint64_t lenB, int64_t *score,
+                     uint32_t *endA, uint32_t *endB, uint32_t *err);
+/* which kernel family the last polyhip_sw_batch*_dev call on this thread
+ * used: 1 = register-tiled shared-B kernel, 2 = generic kernel (tests). */
+int polyhip_sw_last_path(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,129 @@
+"""search/align of bebop/poly on MI355X.
+
+Mirrors search/align/align.go: ``Scoring`` (:73-76), ``NewScoring`` (:79-87),
+``Scoring.Score`` (:89-95), ``SmithWaterman`` (:171-232), plus the batch entry
+points a GPU needs.  The DP runs in HIP (polyhip_sw_*); the substitution
+matrix and alphabets stay host objects and are flattened through their public
+``Score()`` exactly as the Go wrapper must (the score table is unexported).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, alphabet, matrix
+from .mash import _pack
+
+
+class Scoring:
+    """align.go:73-76"""
+
+    def __init__(self, substitution_matrix: matrix.SubstitutionMatrix, gap_penalty: int):
+        self.SubstitutionMatrix = substitution_matrix
+        self.GapPenalty = int(gap_penalty)
+        self._handle = None
+
+    def Score(self, a: int, b: int) -> int:
+        """align.go:89-95: string(byte) keys, so a byte >= 0x80 is a 2-byte string"""
+        return self.SubstitutionMatrix.Score(_go_string(a), _go_string(b))
+
+    # -- flatten + device handle -------------------------------------------
+    def flatten(self):
+        lut = np.zeros((256, 256), dtype=np.int32)
+        va = np.zeros(256, dtype=np.uint8)
+        vb = np.zeros(256, dtype=np.uint8)
+        m = self.SubstitutionMatrix
+        for a in range(128):
+            try:
+                m.FirstAlphabet.Encode(chr(a))
+                va[a] = 1
+            except alphabet.Error:
+                pass
+            try:
+                m.SecondAlphabet.Encode(chr(a))
+                vb[a] = 1
+            except alphabet.Error:
+                pass
+        for a in np.nonzero(va)[0]:
+            for b in np.nonzero(vb)[0]:
+                lut[a, b] = m.Score(chr(a), chr(b))
+        return lut, va, vb
+
+    def handle(self):
+        if self._handle is None:
+            lut, va, vb = self.flatten()
+            h = C.c_void_p()
+            _lib.check(_lib.lib().polyhip_scoring_create(lut.ctypes.data, va.ctypes.data, vb.ctypes.data,
+                                                         self.GapPenalty, C.byref(h)))
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        if getattr(self, "_handle", None) is not None:
+            try:
+                _lib.lib().polyhip_scoring_destroy(self._handle)
+            except Exception:
+                pass
+
+
+def _go_string(b: int) -> str:
+    return chr(b)  # Go string(byte b) == the rune U+00bb; for b < 0x80 a 1-byte string
+
+
+def NewScoring(substitution_matrix, gap_penalty: int) -> Scoring:
+    """align.go:79-87 (nil matrix -> matrix.Default; never errors)"""
+    if substitution_matrix is None:
+        substitution_matrix = matrix.Default
+    return Scoring(substitution_matrix, gap_penalty)
+
+
+def _raise_symbol(err: int):
+    raise alphabet.Error(f"Symbol {chr(err & 0xFF)} not in alphabet")
+
+
+def sw_batch_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.ndarray,
+                    offB: np.ndarray | None = None):
+    """Host-pointer entry point: (score int64[n], endA uint32[n], endB uint32[n], err uint32[n]).
+    ``offB is None`` -> one shared B for every pair."""
+    n = len(offA) - 1
+    A = np.ascontiguousarray(A, dtype=np.uint8)
+    B = np.ascontiguousarray(B, dtype=np.uint8)
+    offA = np.ascontiguousarray(offA, dtype=np.uint64)
+    score = np.zeros(n, dtype=np.int64)
+    endA = np.zeros(n, dtype=np.uint32)
+    endB = np.zeros(n, dtype=np.uint32)
+    err = np.zeros(n, dtype=np.uint32)
+    if offB is not None:
+        offB = np.ascontiguousarray(offB, dtype=np.uint64)
+    _lib.check(_lib.lib().polyhip_sw_batch(
+        scoring.handle(), A.ctypes.data, offA.ctypes.data, n, B.ctypes.data,
+        offB.ctypes.data if offB is not None else None, len(B) if offB is None else 0,
+        score.ctypes.data, endA.ctypes.data, endB.ctypes.data, err.ctypes.data))
+    return score, endA, endB, err
+
+
+def SmithWatermanScoreBatch(reads, ref, scoring: Scoring):
+    """Additive batch API: every read against one shared reference."""
+    A, offA = _pack(reads)
+    B, _ = _pack([ref])
+    return sw_batch_packed(scoring, A, offA, B, None)
+
+
+def sw_workspace_bytes(scoring: Scoring, npairs: int, max_lenA: int, lenB: int, shared: bool = True) -> int:
+    return int(_lib.lib().polyhip_sw_workspace_bytes(scoring.handle(), npairs, max_lenA, lenB, int(shared)))
+
+
+def sw_batch_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, lenB: int,
+                 score_t, endA_t, endB_t, err_t, work_t, stream=None) -> None:
+    """Device-resident entry point on torch CUDA tensors."""
+    n = offA_t.numel() - 1
+    _lib.check(_lib.lib().polyhip_sw_batch_dev(
+        scoring.handle(), A_t.data_ptr(), offA_t.data_ptr(), n, max_lenA, B_t.data_ptr(),
+        offB_t.data_ptr() if offB_t is not None else None, lenB,
+        score_t.data_ptr(), endA_t.data_ptr(), endB_t.data_ptr(), err_t.data_ptr(),
+        work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
+def last_path() -> int:
+    return int(_lib.lib().polyhip_sw_last_path())

@@ -1,0 +1,610 @@
+// sw_batch.hip -- K3: batched Smith-Waterman score pass for gfx950.
+//
+// Replaces the fill loop + argmax of align.SmithWaterman
+// (search/align/align.go:171-203) for a batch of pairs:
+//   H[i][j] = max(0, H[i-1][j-1] + S(a_i,b_j), H[i-1][j] + gap, H[i][j-1] + gap)
+// linear gap, arbitrary (possibly asymmetric) substitution matrix, argmax =
+// first maximum in row-major order (i over A outer, j over B inner).
+//
+// Two kernel families:
+//
+//  sw_shared_kernel<RA, CP>  -- the hot one (BASELINE config 4: 1M x 150 bp
+//    reads against ONE shared 5 kb reference).  Inter-sequence parallel: one
+//    pair per lane, all 64 lanes of a wave walk the SAME column b_j.  The whole
+//    H column of the pair (RA rows, int32) lives in VGPRs; the reference is
+//    turned once into a byte "profile" prof[j][code] = S(sym(code), b_j)
+//    (profile_kernel) that is streamed through LDS in chunks of <= 1024
+//    columns, so a cell costs one ds_read_i8 + ~6 VALU ops and no global
+//    traffic at all.  The row-major-first argmax is folded into one integer max
+//    per cell on the key (h << 18 | (255-i) << 10 | (1023-jrel)); chunks are
+//    visited in increasing j, so folding chunk winners with a strict compare
+//    on (h, 255-i) keeps the reference's tie-break.
+//    Conditions: shared B, lenA <= 256, scores in int8, gap <= -1,
+//    maxS * min(lenA, lenB) < 2^14.
+//
+//  sw_generic_kernel -- everything else (per-pair B, long A, odd scoring):
+//    one pair per lane, the reference's own loop nest with the previous row in
+//    a lane-interleaved global scratch.  Correct for any input; not tuned.
+//
+// HBM traffic of the hot kernel is the reads (150 B/pair) + 24 B/pair of
+// output: it is VALU bound by construction, the roofline that matters is the
+// integer-ALU one.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+struct polyhip_scoring {
+    int64_t gap;
+    int32_t lut[65536];
+    uint8_t validA[256], validB[256];
+    int ncodes;          // valid A symbols
+    uint8_t codeA[256];  // byte -> code, 0xFF = not in FirstAlphabet
+    int cp;              // profile bytes per column (>= ncodes + 1, multiple of 4)
+    int32_t smin, smax;  // over valid (a, b) pairs
+    int32_t absmax;      // max(|smin|, |smax|, |gap|)
+    bool int8_ok;
+    int device;
+    // device tables
+    int8_t *d_lutc;      // [ncodes][256] int8 (only if int8_ok)
+    uint8_t *d_codeA;    // [256]
+    int32_t *d_lut;      // [256][256]
+    uint8_t *d_validA, *d_validB;
+};
+
+namespace polyhip {
+namespace k3 {
+
+constexpr int THREADS = 256;
+constexpr int U = 4;          // columns per unrolled block
+constexpr int JC_MAX = 1024;  // columns per LDS chunk (10 key bits)
+constexpr int SCORE_LIMIT = 1 << 14;
+
+static thread_local int g_last_path = 0;
+
+// prof[j][c] = S(symA[c], b_j) as int8; pad columns / pad code = -128.
+// Also finds the first byte of B that is not in SecondAlphabet.
+__global__ __launch_bounds__(256) void profile_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t lenB_pad,
+                                                     const int8_t *__restrict__ lutc, int ncodes, int cp,
+                                                     const uint8_t *__restrict__ validB, int8_t *__restrict__ prof,
+                                                     uint32_t *__restrict__ binfo)
+{
+    // layout: prof[((j / 4) * cp + code) * 4 + (j % 4)] -- one dword holds the
+    // scores of one code against 4 consecutive columns
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lenB_pad)
+        return;
+    int8_t *col = prof + (size_t)(j >> 2) * cp * 4 + (j & 3);
+    if (j < lenB) {
+        const uint8_t b = B[j];
+        for (int c = 0; c < ncodes; ++c)
+            col[c * 4] = lutc[c * 256 + b];
+        for (int c = ncodes; c < cp; ++c)
+            col[c * 4] = -128;
+        if (!validB[b])
+            atomicMin(&binfo[0], j);
+    } else {
+        for (int c = 0; c < cp; ++c)
+            col[c * 4] = -128;
+    }
+}
+
+// address of row r's profile dword = block base + (code * 4), the code byte picked by SDWA
+#define PH_SW_ADDR(dst, pk, SEL)                                                                           \
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                 : "=v"(dst)                                                                               \
+                 : "v"(blk), "v"(pk))
+#define PH_SW_ISSUE(pk, w0, w1, w2, w3)                                 \
+    do {                                                                \
+        uint32_t a0_, a1_, a2_, a3_;                                    \
+        PH_SW_ADDR(a0_, pk, "BYTE_0");                                  \
+        PH_SW_ADDR(a1_, pk, "BYTE_1");                                  \
+        PH_SW_ADDR(a2_, pk, "BYTE_2");                                  \
+        PH_SW_ADDR(a3_, pk, "BYTE_3");                                  \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_));       \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_));       \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_));       \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_));       \
+    } while (0)
+// one row of the 4-column block (i is a compile-time constant after unrolling)
+#define PH_SW_ROW(I, W)                                                              \
+    do {                                                                             \
+        const int i_ = (I);                                                          \
+        const uint32_t w_ = (W);                                                     \
+        const int s0 = (int)(int8_t)(w_);                                            \
+        const int s1 = (int)(int8_t)(w_ >> 8);                                       \
+        const int s2 = (int)(int8_t)(w_ >> 16);                                      \
+        const int s3 = (int)w_ >> 24;                                                \
+        const int left = H[i_]; /* H[i][jb-1] */                                     \
+        const int h0 = max(max(pdiag + s0, max(pr0, left) + gap), 0);                \
+        const int h1 = max(max(pr0 + s1, max(pr1, h0) + gap), 0);                    \
+        const int h2 = max(max(pr1 + s2, max(pr2, h1) + gap), 0);                    \
+        const int h3 = max(max(pr2 + s3, max(pr3, h2) + gap), 0);                    \
+        pdiag = left;                                                                \
+        pr0 = h0;                                                                    \
+        pr1 = h1;                                                                    \
+        pr2 = h2;                                                                    \
+        pr3 = h3;                                                                    \
+        H[i_] = h3;                                                                  \
+        const uint32_t ci = (uint32_t)((255 - i_) << 10);                            \
+        const uint32_t k0 = ((uint32_t)h0 << 18) | (ci | sj0);                       \
+        const uint32_t k1 = ((uint32_t)h1 << 18) | (ci | (sj0 - 1u));                \
+        const uint32_t k2 = ((uint32_t)h2 << 18) | (ci | (sj0 - 2u));                \
+        const uint32_t k3 = ((uint32_t)h3 << 18) | (ci | (sj0 - 3u));                \
+        best = max(max(best, k0), k1);                                               \
+        best = max(max(best, k2), k3);                                               \
+    } while (0)
+
+template <int RA, int CP>
+__global__ __launch_bounds__(THREADS) void sw_shared_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    uint32_t lenB, uint32_t lenB_pad, const int8_t *__restrict__ prof, uint32_t jc_max,
+    const uint8_t *__restrict__ codeA, const uint32_t *__restrict__ binfo, int ncodes, int gap,
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+{
+    static_assert(RA % 4 == 0 && RA <= 256, "RA");
+    extern __shared__ __attribute__((aligned(16))) int8_t lds[];
+    int8_t *P = lds;
+    uint8_t *codeL = reinterpret_cast<uint8_t *>(lds + (size_t)jc_max * CP);
+
+    const int tid = threadIdx.x;
+    const uint64_t pair = (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < npairs;
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    // ---- my read -> packed codes (4 per VGPR); rows >= lenA use the pad code
+    const uint32_t PAD = (uint32_t)ncodes;
+    uint64_t o0 = 0;
+    uint32_t lenA = 0;
+    if (active) {
+        o0 = offA[pair];
+        const uint64_t l = offA[pair + 1] - o0;
+        lenA = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+    }
+    const bool too_long = lenA > RA;
+    if (too_long)
+        lenA = 0;
+    uint32_t apk[RA / 4];
+    int firstbad = -1;
+    uint32_t badsym = 0, a0sym = 0;
+    {
+        const uint8_t *ap = A + o0;
+#pragma unroll
+        for (int w = 0; w < RA / 4; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = 4 * w + b;
+                uint32_t code = PAD;
+                if ((uint32_t)i < lenA) {
+                    const uint32_t sym = ap[i];
+                    if (i == 0)
+                        a0sym = sym;
+                    code = codeL[sym];
+                    if (code == 0xFF) {
+                        if (firstbad < 0) {
+                            firstbad = i;
+                            badsym = sym;
+                        }
+                        code = PAD;
+                    }
+                }
+                pk |= (code * 4u) << (8 * b); // byte offset of the code's dword inside a profile block
+            }
+            apk[w] = pk;
+        }
+    }
+
+    int H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+    uint32_t gbest = 0, gbestj = 0; // gbest = h << 8 | (255 - i)
+
+    for (uint32_t c0 = 0; c0 < lenB_pad; c0 += jc_max) {
+        const uint32_t jc = min(jc_max, lenB_pad - c0);
+        __syncthreads(); // previous chunk fully consumed
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(prof + (size_t)c0 * CP);
+            uint4 *dst = reinterpret_cast<uint4 *>(P);
+            const uint32_t nvec = jc * CP / 16;
+            for (uint32_t v = tid; v < nvec; v += THREADS)
+                dst[v] = src[v];
+        }
+        __syncthreads();
+
+        uint32_t best = 0;
+        const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P)); // LDS byte address of P
+        for (uint32_t jb = 0; jb < jc; jb += U) {
+            // One block of U = 4 columns, swept row by row: the 4 cells of a row
+            // chain through `left`, the previous row's 4 values stay in pr[].
+            // The profile dwords are fetched by hand-placed ds_read_b32 one
+            // 4-row group ahead (hipcc sinks a plain load next to its use and
+            // exposes the LDS latency); addresses come from one SDWA byte-add
+            // per row on the packed code registers.
+            const uint32_t blk = lds_base + (jb >> 2) * (CP * 4);
+            const uint32_t sj0 = 1023u - jb; // key column part of column jb (low two bits are 3)
+            int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0; // H[i-1][jb..jb+3]; row 0 of H is 0
+            int pdiag = 0;                          // H[i-1][jb-1]
+            uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+            PH_SW_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+#pragma unroll
+            for (int g = 0; g < RA / 4; ++g) {
+                if (g + 1 < RA / 4) {
+                    PH_SW_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+                }
+                PH_SW_ROW(4 * g + 0, wa0);
+                PH_SW_ROW(4 * g + 1, wa1);
+                PH_SW_ROW(4 * g + 2, wa2);
+                PH_SW_ROW(4 * g + 3, wa3);
+                wa0 = wb0;
+                wa1 = wb1;
+                wa2 = wb2;
+                wa3 = wb3;
+            }
+        }
+        const uint32_t si = best >> 10;
+        if (si > gbest) { // strict: an earlier chunk (smaller j) wins ties on (h, i)
+            gbest = si;
+            gbestj = c0 + (1023u - (best & 1023u));
+        }
+    }
+
+    if (!active)
+        return;
+    uint32_t e = 0;
+    if (too_long) {
+        e = 0xFFFFFFFFu;
+    } else if (lenA > 0 && lenB > 0) {
+        // align.go:189-191 + matrix.go:29-36: row-major first failing cell
+        const uint32_t bbad = binfo[0];
+        if (firstbad == 0)
+            e = (1u << 8) | a0sym;
+        else if (bbad != 0xFFFFFFFFu)
+            e = (2u << 8) | B[bbad];
+        else if (firstbad > 0)
+            e = (1u << 8) | badsym;
+    }
+    const uint32_t sc = gbest >> 8;
+    const bool hit = e == 0 && sc > 0;
+    score[pair] = hit ? (int64_t)sc : 0;
+    endA[pair] = hit ? (255u - (gbest & 255u)) + 1u : 0u;
+    endB[pair] = hit ? gbestj + 1u : 0u;
+    err[pair] = e;
+}
+
+// The reference's loop nest, one pair per lane; previous row in global scratch
+// laid out [j][pair] so a wave's accesses coalesce.
+__global__ __launch_bounds__(256) void sw_generic_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    const uint64_t *__restrict__ offB, uint64_t lenB_shared, const int32_t *__restrict__ lut,
+    const uint8_t *__restrict__ validA, const uint8_t *__restrict__ validB, int gap, int32_t *__restrict__ work,
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+{
+    const uint64_t pair = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= npairs)
+        return;
+    const uint8_t *a = A + offA[pair];
+    const uint64_t m = offA[pair + 1] - offA[pair];
+    const uint8_t *b = offB ? B + offB[pair] : B;
+    const uint64_t n = offB ? offB[pair + 1] - offB[pair] : lenB_shared;
+    uint32_t e = 0;
+    if (m > 0 && n > 0) {
+        if (!validA[a[0]]) {
+            e = (1u << 8) | a[0];
+        } else {
+            for (uint64_t j = 0; j < n && !e; ++j)
+                if (!validB[b[j]])
+                    e = (2u << 8) | b[j];
+            for (uint64_t i = 1; i < m && !e; ++i)
+                if (!validA[a[i]])
+                    e = (1u << 8) | a[i];
+        }
+    }
+    int32_t best = 0;
+    uint64_t bi = 0, bj = 0;
+    if (!e && m > 0 && n > 0) {
+        int32_t *Hrow = work + pair;
+        const uint64_t stride = npairs;
+        for (uint64_t j = 0; j <= n; ++j)
+            Hrow[j * stride] = 0;
+        for (uint64_t i = 1; i <= m; ++i) {
+            const int32_t *lrow = lut + (uint32_t)a[i - 1] * 256;
+            int32_t diag = 0, left = 0;
+            for (uint64_t j = 1; j <= n; ++j) {
+                const int32_t up = Hrow[j * stride];
+                const int32_t s = lrow[b[j - 1]];
+                int32_t h = max(diag + s, max(up + gap, left + gap));
+                h = max(h, 0);
+                Hrow[j * stride] = h;
+                diag = up;
+                left = h;
+                if (h > best) {
+                    best = h;
+                    bi = i;
+                    bj = j;
+                }
+            }
+        }
+    }
+    score[pair] = best;
+    endA[pair] = (uint32_t)bi;
+    endB[pair] = (uint32_t)bj;
+    err[pair] = e;
+}
+
+struct Plan {
+    int path;      // 1 fast, 2 generic
+    int ra, cp;    // fast: template parameters
+    uint32_t lenB_pad, jc_max;
+    size_t work_bytes, smem_bytes;
+};
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, bool shared)
+{
+    Plan p{};
+    const uint64_t minlen = std::min<uint64_t>(max_lenA, lenB);
+    const bool fast = shared && sc->int8_ok && sc->gap <= -1 && max_lenA <= 256 && lenB < (1ull << 31) &&
+                      sc->cp <= 32 && (uint64_t)std::max(sc->smax, 0) * minlen < (uint64_t)SCORE_LIMIT;
+    if (fast) {
+        p.path = 1;
+        p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
+        p.cp = sc->cp <= 8 ? 8 : 32;
+        p.lenB_pad = (uint32_t)align_up(lenB, U);
+        p.jc_max = JC_MAX;
+        if (p.jc_max > p.lenB_pad)
+            p.jc_max = std::max<uint32_t>(p.lenB_pad, U);
+        p.smem_bytes = (size_t)p.jc_max * p.cp + 256;
+        p.work_bytes = 256 + align_up((size_t)p.lenB_pad * p.cp, 256);
+    } else {
+        p.path = 2;
+        p.work_bytes = align_up((size_t)npairs * (lenB + 1) * sizeof(int32_t), 256);
+    }
+    return p;
+}
+
+template <int RA, int CP>
+static int launch_fast(const polyhip_scoring *sc, const Plan &p, const uint8_t *d_A, const uint64_t *d_offA,
+                       uint64_t npairs, const uint8_t *d_B, uint32_t lenB, int8_t *prof, uint32_t *binfo,
+                       int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
+{
+    auto kern = sw_shared_kernel<RA, CP>;
+    if (p.smem_bytes > 48 * 1024)
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.smem_bytes));
+    const uint64_t blocks = (npairs + THREADS - 1) / THREADS;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.smem_bytes, st, d_A, d_offA, npairs, d_B, lenB,
+                       p.lenB_pad, prof, p.jc_max, sc->d_codeA, binfo, sc->ncodes, (int)sc->gap, d_score, d_endA,
+                       d_endB, d_err);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+} // namespace k3
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+int polyhip_scoring_create(const int32_t *lut, const uint8_t *validA, const uint8_t *validB, int64_t gap,
+                           polyhip_scoring **out)
+{
+    PH_REQUIRE(lut && validA && validB && out, "polyhip_scoring_create: null pointer");
+    polyhip_scoring *sc = new polyhip_scoring();
+    sc->gap = gap;
+    memcpy(sc->lut, lut, sizeof sc->lut);
+    for (int i = 0; i < 256; ++i) {
+        sc->validA[i] = validA[i] && i < 0x80;
+        sc->validB[i] = validB[i] && i < 0x80;
+    }
+    sc->ncodes = 0;
+    memset(sc->codeA, 0xFF, 256);
+    uint8_t symA[128];
+    for (int a = 0; a < 128; ++a)
+        if (sc->validA[a]) {
+            symA[sc->ncodes] = (uint8_t)a;
+            sc->codeA[a] = (uint8_t)sc->ncodes++;
+        }
+    sc->cp = (sc->ncodes + 1 + 3) & ~3;
+    sc->smin = 0;
+    sc->smax = 0;
+    bool any = false;
+    for (int a = 0; a < 128; ++a)
+        for (int b = 0; b < 128; ++b)
+            if (sc->validA[a] && sc->validB[b]) {
+                const int32_t v = lut[a * 256 + b];
+                sc->smin = any ? std::min(sc->smin, v) : v;
+                sc->smax = any ? std::max(sc->smax, v) : v;
+                any = true;
+            }
+    const int64_t ag = gap < 0 ? -gap : gap;
+    const int64_t am = std::max<int64_t>(std::max<int64_t>(std::llabs((long long)sc->smin), std::llabs((long long)sc->smax)), ag);
+    if (am > (1 << 24)) {
+        delete sc;
+        return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_scoring_create: |score| or |gap| %lld exceeds 2^24",
+                         (long long)am);
+    }
+    sc->absmax = (int32_t)am;
+    sc->int8_ok = sc->smin >= -127 && sc->smax <= 127; // -128 is the pad marker
+    sc->d_lutc = nullptr;
+    sc->d_codeA = nullptr;
+    sc->d_lut = nullptr;
+    sc->d_validA = sc->d_validB = nullptr;
+
+    auto fail = [&](hipError_t e, const char *what) {
+        polyhip_scoring_destroy(sc);
+        return set_error(POLYHIP_ERR_HIP, "polyhip_scoring_create: %s: %s", what, hipGetErrorString(e));
+    };
+    hipError_t e;
+    if ((e = hipGetDevice(&sc->device)) != hipSuccess)
+        return fail(e, "hipGetDevice");
+    if ((e = hipMalloc(&sc->d_lut, sizeof sc->lut)) != hipSuccess)
+        return fail(e, "hipMalloc");
+    if ((e = hipMalloc(&sc->d_codeA, 256)) != hipSuccess)
+        return fail(e, "hipMalloc");
+    if ((e = hipMalloc(&sc->d_validA, 256)) != hipSuccess)
+        return fail(e, "hipMalloc");
+    if ((e = hipMalloc(&sc->d_validB, 256)) != hipSuccess)
+        return fail(e, "hipMalloc");
+    if ((e = hipMemcpy(sc->d_lut, sc->lut, sizeof sc->lut, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(sc->d_codeA, sc->codeA, 256, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(sc->d_validA, sc->validA, 256, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(sc->d_validB, sc->validB, 256, hipMemcpyHostToDevice)) != hipSuccess)
+        return fail(e, "hipMemcpy");
+    if (sc->int8_ok && sc->ncodes > 0) {
+        std::vector<int8_t> lutc((size_t)sc->ncodes * 256);
+        for (int c = 0; c < sc->ncodes; ++c)
+            for (int b = 0; b < 256; ++b)
+                lutc[(size_t)c * 256 + b] = sc->validB[b] ? (int8_t)lut[symA[c] * 256 + b] : (int8_t)0;
+        if ((e = hipMalloc(&sc->d_lutc, lutc.size())) != hipSuccess)
+            return fail(e, "hipMalloc");
+        if ((e = hipMemcpy(sc->d_lutc, lutc.data(), lutc.size(), hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(e, "hipMemcpy");
+    }
+    *out = sc;
+    return POLYHIP_OK;
+}
+
+int polyhip_scoring_destroy(polyhip_scoring *sc)
+{
+    if (!sc)
+        return POLYHIP_OK;
+    (void)hipFree(sc->d_lutc);
+    (void)hipFree(sc->d_codeA);
+    (void)hipFree(sc->d_lut);
+    (void)hipFree(sc->d_validA);
+    (void)hipFree(sc->d_validB);
+    delete sc;
+    return POLYHIP_OK;
+}
+
+size_t polyhip_sw_workspace_bytes(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB,
+                                  int shared_B)
+{
+    if (!sc)
+        return 0;
+    return k3::plan(sc, npairs, max_lenA, lenB, shared_B != 0).work_bytes;
+}
+
+int polyhip_sw_last_path(void) { return k3::g_last_path; }
+
+int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                         uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, void *d_work,
+                         size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(sc, "polyhip_sw_batch: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_offA && d_score && d_endA && d_endB && d_err, "polyhip_sw_batch: null pointer");
+    PH_REQUIRE(npairs < (1ull << 31) * 256, "polyhip_sw_batch: too many pairs");
+    if ((int64_t)sc->absmax * (int64_t)((uint64_t)max_lenA + lenB) >= (1ll << 31))
+        return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_sw_batch: scores could overflow int32 (|s|max %d, lengths %u+%llu)",
+                         sc->absmax, max_lenA, (unsigned long long)lenB);
+    const bool shared = d_offB == nullptr;
+    const k3::Plan p = k3::plan(sc, npairs, max_lenA, lenB, shared);
+    PH_REQUIRE(d_work && work_bytes >= p.work_bytes, "polyhip_sw_batch: workspace too small (%zu < %zu)", work_bytes,
+               p.work_bytes);
+    hipStream_t st = as_stream(stream);
+    k3::g_last_path = p.path;
+    if (p.path == 1) {
+        uint32_t *binfo = static_cast<uint32_t *>(d_work);
+        int8_t *prof = static_cast<int8_t *>(d_work) + 256;
+        PH_HIP(hipMemsetAsync(binfo, 0xFF, 256, st));
+        if (p.lenB_pad > 0) {
+            hipLaunchKernelGGL(k3::profile_kernel, dim3((p.lenB_pad + 255) / 256), dim3(256), 0, st, d_B,
+                               (uint32_t)lenB, p.lenB_pad, sc->d_lutc, sc->ncodes, p.cp, sc->d_validB, prof, binfo);
+            PH_HIP(hipGetLastError());
+        }
+#define PH_SW_CASE(RA_, CP_)                                                                                       \
+    if (p.ra == RA_ && p.cp == CP_)                                                                                \
+        return k3::launch_fast<RA_, CP_>(sc, p, d_A, d_offA, npairs, d_B, (uint32_t)lenB, prof, binfo, d_score,     \
+                                         d_endA, d_endB, d_err, st);
+#ifndef PH_SW_FAST_LIST
+#define PH_SW_FAST_LIST(X) X(64, 8) X(152, 8) X(256, 8) X(64, 32) X(152, 32) X(256, 32)
+#endif
+        PH_SW_FAST_LIST(PH_SW_CASE)
+#undef PH_SW_CASE
+        return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_sw_batch: no kernel for RA=%d CP=%d", p.ra, p.cp);
+    }
+    const uint64_t blocks = (npairs + 255) / 256;
+    hipLaunchKernelGGL(k3::sw_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_A, d_offA, npairs, d_B, d_offB,
+                       lenB, sc->d_lut, sc->d_validA, sc->d_validB, (int)sc->gap, static_cast<int32_t *>(d_work),
+                       d_score, d_endA, d_endB, d_err);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                     const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                     uint32_t *endB, uint32_t *err)
+{
+    PH_REQUIRE(sc, "polyhip_sw_batch: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(offA && score && endA && endB && err, "polyhip_sw_batch: null pointer");
+    uint64_t maxA = 0, maxB = offB ? 0 : lenB;
+    for (uint64_t i = 0; i < npairs; ++i) {
+        PH_REQUIRE(offA[i] <= offA[i + 1], "polyhip_sw_batch: offA not ascending at %llu", (unsigned long long)i);
+        maxA = std::max(maxA, offA[i + 1] - offA[i]);
+        if (offB) {
+            PH_REQUIRE(offB[i] <= offB[i + 1], "polyhip_sw_batch: offB not ascending at %llu", (unsigned long long)i);
+            maxB = std::max(maxB, offB[i + 1] - offB[i]);
+        }
+    }
+    PH_REQUIRE(maxA < 0xFFFFFFFFull, "polyhip_sw_batch: A longer than 2^32");
+    const uint64_t a0 = offA[0], abytes = offA[npairs] - a0;
+    const uint64_t b0 = offB ? offB[0] : 0, bbytes = offB ? offB[npairs] - b0 : lenB;
+    PH_REQUIRE((A || abytes == 0) && (B || bbytes == 0), "polyhip_sw_batch: null sequence buffer");
+    DevBuf dA, doA, dB, doB, dscore, dea, deb, derr, dwork;
+    PH_HIP(dA.alloc(abytes + 16));
+    PH_HIP(doA.alloc((npairs + 1) * 8));
+    PH_HIP(dB.alloc(bbytes + 16));
+    PH_HIP(dscore.alloc(npairs * 8));
+    PH_HIP(dea.alloc(npairs * 4));
+    PH_HIP(deb.alloc(npairs * 4));
+    PH_HIP(derr.alloc(npairs * 4));
+    std::vector<uint64_t> tmp(npairs + 1);
+    for (uint64_t i = 0; i <= npairs; ++i)
+        tmp[i] = offA[i] - a0;
+    PH_HIP(hipMemcpy(doA.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+    if (abytes)
+        PH_HIP(hipMemcpy(dA.p, A + a0, abytes, hipMemcpyHostToDevice));
+    if (bbytes)
+        PH_HIP(hipMemcpy(dB.p, B + b0, bbytes, hipMemcpyHostToDevice));
+    if (offB) {
+        PH_HIP(doB.alloc((npairs + 1) * 8));
+        for (uint64_t i = 0; i <= npairs; ++i)
+            tmp[i] = offB[i] - b0;
+        PH_HIP(hipMemcpy(doB.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+    }
+    const size_t wb = polyhip_sw_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB, offB == nullptr);
+    PH_HIP(dwork.alloc(wb));
+    int rc = polyhip_sw_batch_dev(sc, dA.as<uint8_t>(), doA.as<uint64_t>(), npairs, (uint32_t)maxA, dB.as<uint8_t>(),
+                                  offB ? doB.as<uint64_t>() : nullptr, maxB, dscore.as<int64_t>(), dea.as<uint32_t>(),
+                                  deb.as<uint32_t>(), derr.as<uint32_t>(), dwork.p, wb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(endA, dea.p, npairs * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,236 @@
+"""K3 parity: poly_amd.align (HIP, through the C ABI) vs the CPU oracle.
+Score, argmax position and the alphabet-error symbol must be identical.
+
+Mirrors search/align/align_test.go:139-292 and example_test.go:49-111 where the
+reference has a test, then widens to batches on both kernel families."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def al():
+    from poly_amd import align, alphabet, matrix
+    return align, alphabet, matrix
+
+
+def _scoring(al, symbols, scores, gap):
+    align, alphabet, matrix = al
+    a = alphabet.NewAlphabet(list(symbols))
+    return align.NewScoring(matrix.NewSubstitutionMatrix(a, a, scores), gap)
+
+
+def _pack(seqs):
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return np.frombuffer(b"".join(seqs), np.uint8).copy(), offs
+
+
+def _oracle_batch(reads, refs, omat, gap):
+    out = []
+    for a, b in zip(reads, refs):
+        try:
+            sc, _, _, ea, eb = orc.smith_waterman(a, b, omat, gap)
+            out.append((sc, ea, eb, 0))
+        except orc.AlphabetError as e:
+            sym = str(e).split(" ")[1]
+            which = 1 if (len(a) and (not _in(omat.first, a[0:1]) or (all(_in(omat.second, bytes([c])) for c in b)))) else 2
+            out.append((0, 0, 0, (which << 8) | ord(sym)))
+    return out
+
+
+def _in(alpha, ch):
+    return len(ch) == 1 and ch[0] < 0x80 and chr(ch[0]) in alpha
+
+
+def _check(al, scoring, omat, gap, reads, ref=None, refs=None, expect_path=None):
+    align = al[0]
+    A, offA = _pack(reads)
+    if refs is None:
+        B, _ = _pack([ref])
+        got = align.sw_batch_packed(scoring, A, offA, B, None)
+        want = _oracle_batch(reads, [ref] * len(reads), omat, gap)
+    else:
+        B, offB = _pack(refs)
+        got = align.sw_batch_packed(scoring, A, offA, B, offB)
+        want = _oracle_batch(reads, refs, omat, gap)
+    if expect_path is not None:
+        assert align.last_path() == expect_path
+    for p, w in enumerate(want):
+        g = (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p]))
+        assert g == w, f"pair {p}: got {g} want {w} (lenA {len(reads[p])})"
+
+
+def _mutate(rng, seq: bytes, sub=0.05, indel=0.01) -> bytes:
+    out = bytearray()
+    for c in seq:
+        r = rng.random()
+        if r < indel / 2:
+            continue
+        if r < indel:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        out.append(int(rng.choice(list(b"ACGT"))) if rng.random() < sub else c)
+    return bytes(out)
+
+
+MAT3 = [[0, 0, 0, 0, 0], [0, 3, -3, -3, -3], [0, -3, 3, -3, -3], [0, -3, -3, 3, -3], [0, -3, -3, -3, 3]]
+
+
+def test_TestSmithWaterman_scores(al):
+    """search/align/align_test.go:139-292 (scores + the argmax the traceback starts from)"""
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", MAT3)
+    cases = [(b"TGTTACGG", b"GGTTGACTA", 13), (b"ACACACTA", b"AGCACACA", 17), (b"", b"GAT", 0), (b"", b"", 0),
+             (b"G", b"A", 0), (b"G", b"G", 3), (b"G", b"GATTACA", 3)]
+    for a, b, want in cases:
+        got = al[0].sw_batch_packed(sc, *_pack([a]), _pack([b])[0], None)
+        assert int(got[0][0]) == want, (a, b)
+        _check(al, sc, om, -2, [a], ref=b)
+        _check(al, sc, om, -2, [a], refs=[b])  # generic kernel, same answer
+
+
+def test_examples(al):
+    """search/align/example_test.go:49-111"""
+    pm1 = (2 * np.eye(5, dtype=int) - 1).tolist()
+    sc = _scoring(al, "ACGTU", pm1, -1)
+    got = al[0].sw_batch_packed(sc, *_pack([b"GATTACA"]), _pack([b"GCATGCU"])[0], None)
+    assert int(got[0][0]) == 2
+    # NUC_4 indexed by a mis-ordered alphabet {A,C,G,T,-}: 'A' hits the all-zero row
+    sc = _scoring(al, "ACGT-", al[2].NUC_4, -1)
+    got = al[0].sw_batch_packed(sc, *_pack([b"GATTACA"]), _pack([b"GCATGCT"])[0], None)
+    assert int(got[0][0]) == 15
+    _check(al, sc, orc.SubstitutionMatrix("ACGT-", "ACGT-", orc.NUC_4_SCORES), -1, [b"GATTACA"], ref=b"GCATGCT")
+
+
+def test_config4_shape_fast_kernel(al):
+    """BASELINE config 4 shape: 150 bp reads (5 % subs, 1 % indels) vs one 5 kb reference, NUC_4, gap -2"""
+    rng = np.random.default_rng(0xC4)
+    ref = orc.synth_dna(0xC4, 5000).tobytes()
+    reads = []
+    for _ in range(300):
+        p = int(rng.integers(0, 5000 - 150))
+        reads.append(_mutate(rng, ref[p:p + 150])[:152])
+    reads += [orc.synth_dna(99, 150).tobytes(), b"", b"A", ref[:152], ref[-150:]]
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    _check(al, sc, om, -2, reads, ref=ref, expect_path=1)
+
+
+@pytest.mark.parametrize("maxlen,reflen", [(64, 300), (152, 1024), (152, 1027), (256, 2100), (40, 3), (152, 4), (10, 1)])
+def test_ragged_fast_kernel(al, maxlen, reflen):
+    rng = np.random.default_rng(maxlen * 7 + reflen)
+    ref = orc.synth_dna(1234 + reflen, reflen).tobytes()
+    reads = [orc.synth_dna(int(rng.integers(1, 1 << 30)), int(rng.integers(0, maxlen + 1))).tobytes() for _ in range(300)]
+    reads[0] = orc.synth_dna(5, maxlen).tobytes()
+    # plant near-copies so that long, high-scoring alignments and ties exist
+    for i in range(1, 60):
+        L = int(rng.integers(1, min(maxlen, reflen) + 1))
+        p = int(rng.integers(0, reflen - L + 1))
+        reads[i] = _mutate(rng, ref[p:p + L], 0.03, 0.02)[:maxlen]
+    pm = [[0, 0, 0, 0, 0], [0, 2, -1, -1, -1], [0, -1, 2, -1, -1], [0, -1, -1, 2, -1], [0, -1, -1, -1, 2]]
+    sc = _scoring(al, "-ACGT", pm, -1)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", pm)
+    _check(al, sc, om, -1, reads, ref=ref, expect_path=1)
+
+
+def test_tie_breaking_repeats(al):
+    """many co-optimal cells: the first maximum in row-major order must win (align.go:197)"""
+    ref = (b"ACGT" * 300)[:1100]
+    reads = [b"ACGT" * k for k in range(1, 30)] + [b"CGTA" * 5, b"TTTT", b"GTAC" * 30, b"A"]
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", MAT3)
+    _check(al, sc, om, -2, reads, ref=ref, expect_path=1)
+    _check(al, sc, om, -2, reads, refs=[ref] * len(reads), expect_path=2)
+
+
+def test_default_matrix_protein_like(al):
+    """matrix.Default (26 letters, +1/-1), gap -1 -> CP=32 instantiation"""
+    rng = np.random.default_rng(26)
+    letters = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", np.uint8)
+    ref = rng.choice(letters, 900).tobytes()
+    reads = [rng.choice(letters, int(rng.integers(0, 150))).tobytes() for _ in range(200)]
+    for i in range(40):
+        p = int(rng.integers(0, 800))
+        reads[i] = ref[p:p + int(rng.integers(5, 100))]
+    sc = al[0].NewScoring(None, -1)
+    _check(al, sc, orc.DEFAULT_MATRIX, -1, reads, ref=ref, expect_path=1)
+
+
+def test_generic_kernel_long_and_per_pair(al):
+    rng = np.random.default_rng(77)
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", MAT3)
+    ref = orc.synth_dna(31, 700).tobytes()
+    # A longer than the register tile -> generic
+    reads = [orc.synth_dna(100 + i, int(rng.integers(257, 500))).tobytes() for i in range(20)]
+    reads[0] = _mutate(rng, ref[100:450])
+    _check(al, sc, om, -2, reads, ref=ref, expect_path=2)
+    # per-pair B of ragged lengths
+    refs = [orc.synth_dna(500 + i, int(rng.integers(0, 300))).tobytes() for i in range(64)]
+    reads = [orc.synth_dna(900 + i, int(rng.integers(0, 200))).tobytes() for i in range(64)]
+    _check(al, sc, om, -2, reads, refs=refs, expect_path=2)
+    # odd scoring: positive gap, large scores, asymmetric matrix
+    asym = [[0, 0, 0, 0, 0], [0, 300, -7, 2, -1], [0, -100, 250, 0, 3], [0, 5, -3, 400, -9], [0, 1, 2, -300, 200]]
+    sc2 = _scoring(al, "-ACGT", asym, 1)
+    om2 = orc.SubstitutionMatrix("-ACGT", "-ACGT", asym)
+    _check(al, sc2, om2, 1, reads[:16], ref=ref[:120], expect_path=2)
+
+
+def test_asymmetric_two_alphabets_fast(al):
+    align, alphabet, matrix = al
+    rows, cols = "ACGT", "ACGTN"
+    scores = [[4, -2, -1, -3, 0], [-2, 5, -3, -1, 0], [-1, -4, 6, -2, 0], [-3, -1, -2, 3, 0]]
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(alphabet.NewAlphabet(list(rows)), alphabet.NewAlphabet(list(cols)), scores), -3)
+    om = orc.SubstitutionMatrix(rows, cols, scores)
+    rng = np.random.default_rng(3)
+    ref = bytes(rng.choice(list(b"ACGTN"), 500).tolist())
+    reads = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(0, 64))).tolist()) for _ in range(100)]
+    _check(al, sc, om, -3, reads, ref=ref, expect_path=1)
+
+
+def test_error_symbol_order(al):
+    """align.go:189-191 + matrix.go:29-36"""
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", MAT3)
+    reads = [b"XG", b"GX", b"GGGGXGY", b"", b"ACGT", b"NACGT", b"ACGTacgt"]
+    for ref in (b"GY", b"GA", b"", b"ZZZ", b"ACGTNNACGT"):
+        _check(al, sc, om, -2, reads, ref=ref, expect_path=1)
+        _check(al, sc, om, -2, reads, refs=[ref] * len(reads), expect_path=2)
+    # bytes >= 0x80 are never in a one-byte-symbol alphabet (string(byte) is 2 bytes of UTF-8)
+    got = al[0].sw_batch_packed(sc, *_pack([b"AC\xc3G"]), _pack([b"ACG"])[0], None)
+    assert int(got[3][0]) == (1 << 8) | 0xC3 and int(got[0][0]) == 0
+
+
+def test_device_resident_config4_sample(al):
+    """device-resident entry point + size-independent property at full read size:
+    an exact substring of the reference scores 5*len and ends where it was cut"""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    ref = orc.synth_dna(0xC4, 5000)
+    n, L = 4096, 150
+    rng = np.random.default_rng(1)
+    starts = rng.integers(0, 5000 - L, n)
+    reads = np.stack([ref[s:s + L] for s in starts])
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    A = torch.from_numpy(reads.reshape(-1).copy()).to(dev)
+    offA = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    B = torch.from_numpy(ref.copy()).to(dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea = torch.zeros(n, dtype=torch.int32, device=dev)
+    eb = torch.zeros(n, dtype=torch.int32, device=dev)
+    er = torch.zeros(n, dtype=torch.int32, device=dev)
+    work = torch.empty(align.sw_workspace_bytes(sc, n, L, 5000), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, A, offA, L, B, None, 5000, score, ea, eb, er, work)
+    torch.cuda.synchronize()
+    assert align.last_path() == 1
+    assert (score.cpu().numpy() == 5 * L).all()
+    assert (ea.cpu().numpy() == L).all()
+    assert (er.cpu().numpy() == 0).all()
+    # first row-major maximum: the earliest occurrence of the read in the reference
+    refb = ref.tobytes()
+    first = np.array([refb.find(reads[i].tobytes()) + L for i in range(n)])
+    assert (eb.cpu().numpy() == first).all()
