@@ -152,6 +152,54 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A,
  * used: 1 = register-tiled shared-B kernel, 2 = generic kernel (tests). */
 int polyhip_sw_last_path(void);
 
+/* ---- K4: primers SantaLucia / MarmurDoty / MeltingTemp  (primers/primers.go:70-128) */
+/*
+ * SCAN: SantaLucia(seq[i : i+L], primer_conc, salt_conc, mg_conc)
+ * (primers.go:70-105) for every start i in [start0, start0 + nstarts) and every
+ * length L in [Lmin, Lmax] of ONE sequence of `len` bytes (the caller of
+ * primers/pcr's grow-until-Tm loops, pcr.go:47-53, reads its answers from this
+ * table).  Output planes, one per length:
+ *     d_tm[(L - Lmin) * ld + (i - start0)]   (likewise d_dH, d_dS),  ld >= nstarts
+ * A window that runs past the end of the sequence (i + L > len) gets quiet
+ * NaNs.  start0/nstarts let each rank of a multi-GPU job scan its own slice of
+ * the starts while reading its (Lmax - 1)-byte halo from the same buffer.
+ * Results are bit-identical to the Go code: same fp64 operation order, no FMA
+ * contraction, Go's math.Log algorithm for the two logarithms.
+ * Lmin == 0 -> POLYHIP_ERR_PANIC (SantaLucia("") panics, primers.go:89).
+ * Range: Lmax <= 1024.  MeltingTemp (primers.go:121-128) is this call with
+ * (500e-9, 50e-3, 0).
+ */
+int polyhip_santalucia_scan_dev(const uint8_t *d_seq, uint64_t len,
+                                uint64_t start0, uint64_t nstarts,
+                                uint32_t Lmin, uint32_t Lmax,
+                                double primer_conc, double salt_conc,
+                                double mg_conc, double *d_tm, double *d_dH,
+                                double *d_dS, uint64_t ld,
+                                polyhip_stream_t stream);
+/* host flavour: all starts 0 .. len - Lmin, ld = len - Lmin + 1; outputs hold
+ * (Lmax - Lmin + 1) * ld doubles each.  Non-ASCII bytes -> POLYHIP_ERR_INVALID. */
+int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin,
+                            uint32_t Lmax, double primer_conc,
+                            double salt_conc, double mg_conc, double *tm,
+                            double *dH, double *dS);
+/* BATCH: one SantaLucia call per packed sequence.  An empty sequence is
+ * POLYHIP_ERR_PANIC in the host flavour (quiet NaN outputs in the _dev one). */
+int polyhip_santalucia_batch_dev(const uint8_t *d_seqs,
+                                 const uint64_t *d_offsets, uint64_t n,
+                                 double primer_conc, double salt_conc,
+                                 double mg_conc, double *d_tm, double *d_dH,
+                                 double *d_dS, polyhip_stream_t stream);
+int polyhip_santalucia_batch(const uint8_t *seqs, const uint64_t *offsets,
+                             uint64_t n, double primer_conc, double salt_conc,
+                             double mg_conc, double *tm, double *dH,
+                             double *dS);
+/* MarmurDoty (primers.go:108-118) per packed sequence. */
+int polyhip_marmurdoty_batch_dev(const uint8_t *d_seqs,
+                                 const uint64_t *d_offsets, uint64_t n,
+                                 double *d_tm, polyhip_stream_t stream);
+int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets,
+                             uint64_t n, double *tm);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,516 @@
+// primers.hip -- K4: SantaLucia nearest-neighbour Tm (scan + batch) and
+// Marmur-Doty Tm for gfx950.
+//
+// Replaces primers.SantaLucia (primers/primers.go:70-105), MarmurDoty
+// (:108-118) and MeltingTemp (:121-128) for
+//   * a SCAN: every window of every length Lmin..Lmax at every start of one
+//     long sequence (BASELINE config 5: all 18..30-mers of a 5 Mb genome), and
+//   * a packed BATCH of independent primers.
+//
+// Bit-level parity with the Go code is kept, not just the 1e-6 C tolerance:
+//   - fp64 throughout, compiled with -ffp-contract=off (Go/amd64 never fuses);
+//   - every addition happens in the reference's order: init (+0.2, -5.7),
+//     symmetry (-1.4), terminal A/T (+2.2, +6.9), salt term, then the
+//     nearest-neighbour terms left to right.  The windows that share a start
+//     share their nearest-neighbour TERMS but not their partial sums (the
+//     start values differ per length), so the scan keeps one running (dH, dS)
+//     pair per length in registers and feeds all of them from ONE table
+//     lookup per dinucleotide: 29 LDS lookups + 598 fp64 adds per start for
+//     18..30 instead of 299 lookups;
+//   - the two logarithms are evaluated once per call on the host with the
+//     algorithm Go's math.Log uses (FreeBSD e_log.c), so no device libm
+//     rounding enters.
+//
+// The scan is HBM-WRITE bound: 24 B of (Tm, dH, dS) per window against
+// ~0.08 B of genome read.  One thread per start, outputs in
+// per-length planes so that a wave's 64 lanes store 512 contiguous bytes.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace polyhip {
+namespace k4 {
+
+constexpr int THREADS = 256;
+constexpr int NL_MAX = 16;    // lengths per launch (longer ranges are split by the host loop)
+constexpr int LMAX_MAX = 1024; // longest window the scan stages
+
+// ---- Go's math.Log (src/math/log.go = FreeBSD e_log.c) -----------------------
+// log(x) = k*ln2 + log(1+f), 1+f in [sqrt2/2, sqrt2), log(1+f) = f - f^2/2 + s*(f^2/2 + R(s^2)).
+static double go_log(double x)
+{
+    if (std::isnan(x) || (std::isinf(x) && x > 0))
+        return x;
+    if (x < 0)
+        return std::nan("");
+    if (x == 0)
+        return -INFINITY;
+    int e = 0;
+    double m = std::frexp(x, &e); // [0.5, 1)
+    if (m < 0.70710678118654752440) {
+        m *= 2;
+        --e;
+    }
+    const double f = m - 1;
+    const double k = (double)e;
+    const double s = f / (2 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double odd = z * (6.666666666666735130e-01 +
+                            w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double even = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double R = odd + even;
+    const double hfsq = 0.5 * f * f;
+    return k * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + R) + k * 1.90821492927058770002e-10)) - f);
+}
+
+// per-call constants (kernel argument, lands in SGPRs / the scalar cache)
+struct Consts {
+    double rlog_sym;   // 1.9872 * ln(conc / 1)   self-complementary        primers.go:85,103
+    double rlog_non;   // 1.9872 * ln(conc / 4)                              primers.go:87,103
+    double ln_salt;    // ln(Na + 140 * Mg)                                  primers.go:94-95
+    double salt[NL_MAX]; // (0.368 * float64(L-1)) * ln_salt for L = Lmin + l (scan only)
+};
+
+static Consts make_consts(double conc, double na, double mg, uint32_t Lmin, uint32_t nl)
+{
+    Consts c;
+    const double gas = 1.9872;
+    c.rlog_sym = gas * go_log(conc / 1.0);
+    c.rlog_non = gas * go_log(conc / 4.0);
+    const double saltEffect = na + (mg * 140);
+    c.ln_salt = go_log(saltEffect);
+    for (uint32_t l = 0; l < NL_MAX; ++l)
+        c.salt[l] = l < nl ? (0.368 * (double)((int64_t)(Lmin + l) - 1)) * c.ln_salt : 0.0;
+    return c;
+}
+
+// nearest-neighbour table indexed by code(x)*5 + code(y), codes A C G T other = 0..4
+// (primers.go:42-59; a key that is not in the map reads {0, 0}, primers.go:98)
+__constant__ double2 c_nn[25] = {
+    /*AA*/ {-7.6, -21.3}, /*AC*/ {-8.4, -22.4}, /*AG*/ {-7.8, -21.0}, /*AT*/ {-7.2, -20.4}, {0.0, 0.0},
+    /*CA*/ {-8.5, -22.7}, /*CC*/ {-8.0, -19.9}, /*CG*/ {-10.6, -27.2}, /*CT*/ {-7.8, -21.0}, {0.0, 0.0},
+    /*GA*/ {-8.2, -22.2}, /*GC*/ {-9.8, -24.4}, /*GG*/ {-8.0, -19.9}, /*GT*/ {-8.4, -22.4}, {0.0, 0.0},
+    /*TA*/ {-7.2, -21.3}, /*TC*/ {-8.2, -22.2}, /*TG*/ {-8.5, -22.7}, /*TT*/ {-7.6, -21.3}, {0.0, 0.0},
+    {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+
+__device__ __forceinline__ uint32_t ascii_upper(uint32_t b) { return (b - 'a' < 26u) ? b - 32u : b; }
+
+__device__ __forceinline__ uint32_t nt_code(uint32_t up)
+{
+    return up == 'A' ? 0u : up == 'C' ? 1u : up == 'G' ? 2u : up == 'T' ? 3u : 4u;
+}
+
+// transform.complementTable restricted to upper case (the input has been
+// upper-cased, primers.go:71): IUPAC pairs, everything else -> 0x00
+__device__ __forceinline__ uint32_t complement_upper(uint32_t up)
+{
+    switch (up) {
+    case 'A': return 'T';
+    case 'T': return 'A';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'B': return 'V';
+    case 'V': return 'B';
+    case 'D': return 'H';
+    case 'H': return 'D';
+    case 'K': return 'M';
+    case 'M': return 'K';
+    case 'R': return 'Y';
+    case 'Y': return 'R';
+    case 'N': return 'N';
+    case 'S': return 'S';
+    case 'W': return 'W';
+    default: return 0;
+    }
+}
+
+__device__ __forceinline__ double melting(double dH, double dS, double rlog)
+{
+    return dH * 1000 / (dS + rlog) - 273.15; // primers.go:103
+}
+
+// ---- scan ---------------------------------------------------------------------
+// LMIN_CT > 0: lengths LMIN_CT..LMAX_CT known at compile time (everything unrolls,
+// no predicated adds); LMIN_CT == 0: runtime Lmin, nl <= NL_MAX lengths.
+template <int LMIN_CT, int LMAX_CT>
+__global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict__ seq, uint64_t len, uint64_t start0,
+                                                      uint64_t nstarts, uint32_t Lmin_rt, uint32_t nl_rt, Consts cst,
+                                                      double *__restrict__ tm, double *__restrict__ dHo,
+                                                      double *__restrict__ dSo, uint64_t ld)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t Lmin = LMIN_CT > 0 ? (uint32_t)LMIN_CT : Lmin_rt;
+    const uint32_t nl = LMIN_CT > 0 ? (uint32_t)(LMAX_CT - LMIN_CT + 1) : nl_rt;
+    const uint32_t Lmax = Lmin + nl - 1;
+    const uint32_t span = THREADS + Lmax - 1;       // bytes this block looks at
+    const uint32_t span_pad = (span + 15u) & ~15u;
+    double2 *nn = reinterpret_cast<double2 *>(lds);  // 25 entries (400 B, padded to 512)
+    uint8_t *up = lds + 512;                         // upper-cased bytes
+    uint8_t *cp = up + span_pad;                     // complement of the upper-cased byte
+    uint8_t *cd = cp + span_pad;                     // nearest-neighbour code 0..4
+
+    const int tid = threadIdx.x;
+    const uint64_t b0 = start0 + (uint64_t)blockIdx.x * THREADS;
+    if (tid < 25)
+        nn[tid] = c_nn[tid];
+    for (uint32_t t = tid; t < span; t += THREADS) {
+        const uint64_t g = b0 + t;
+        const uint32_t u = g < len ? ascii_upper(seq[g]) : 0xFFu;
+        up[t] = (uint8_t)u;
+        cp[t] = (uint8_t)complement_upper(u);
+        cd[t] = (uint8_t)nt_code(u);
+    }
+    __syncthreads();
+
+    const uint64_t g = b0 + tid; // my start
+    if (g >= start0 + nstarts)
+        return;
+    const uint64_t col = g - start0;
+
+    double aH[NL_MAX], aS[NL_MAX];
+    bool sym[NL_MAX];
+#pragma unroll
+    for (int l = 0; l < NL_MAX; ++l) {
+        if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
+            break;
+        const uint32_t L = Lmin + l;
+        // seq == ReverseComplement(seq), primers.go:81
+        bool pal = true;
+        for (uint32_t t = 0; t < L && pal; ++t)
+            pal = up[tid + t] == cp[tid + L - 1 - t];
+        sym[l] = pal;
+        double h = 0.0, s = 0.0;
+        h += 0.2; // primers.go:78-79
+        s += -5.7;
+        if (pal) { // :82-83
+            h += 0.0;
+            s += -1.4;
+        }
+        const uint32_t last = cd[tid + L - 1];
+        if (last == 0u || last == 3u) { // :89-92, 3' end is A or T
+            h += 2.2;
+            s += 6.9;
+        }
+        s += cst.salt[l]; // :95
+        aH[l] = h;
+        aS[l] = s;
+    }
+
+    // nearest-neighbour terms, left to right (:97-101): one lookup per
+    // dinucleotide, added to every length that still contains it
+    if (LMIN_CT > 0) {
+        uint32_t c0 = cd[tid];
+#pragma unroll
+        for (int j = 0; j + 1 < LMAX_CT; ++j) {
+            const uint32_t c1 = cd[tid + j + 1];
+            const double2 t = nn[c0 * 5u + c1];
+            c0 = c1;
+#pragma unroll
+            for (int l = 0; l < LMAX_CT - LMIN_CT + 1; ++l)
+                if (j + 1 < LMIN_CT + l) {
+                    aH[l] += t.x;
+                    aS[l] += t.y;
+                }
+        }
+    } else {
+        uint32_t c0 = cd[tid];
+        for (uint32_t j = 0; j + 1 < Lmax; ++j) {
+            const uint32_t c1 = cd[tid + j + 1];
+            const double2 t = nn[c0 * 5u + c1];
+            c0 = c1;
+#pragma unroll
+            for (int l = 0; l < NL_MAX; ++l) {
+                // x + 0.0 == x for every value an accumulator can hold (never -0.0)
+                const bool in = (uint32_t)l < nl && j + 1 < Lmin + (uint32_t)l;
+                aH[l] += in ? t.x : 0.0;
+                aS[l] += in ? t.y : 0.0;
+            }
+        }
+    }
+
+#pragma unroll
+    for (int l = 0; l < NL_MAX; ++l) {
+        if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
+            break;
+        if ((uint32_t)l < nl) {
+            const uint32_t L = Lmin + l;
+            const uint64_t o = (uint64_t)l * ld + col;
+            if (g + L <= len) {
+                tm[o] = melting(aH[l], aS[l], sym[l] ? cst.rlog_sym : cst.rlog_non);
+                dHo[o] = aH[l];
+                dSo[o] = aS[l];
+            } else { // window runs off the end of the sequence
+                const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+                tm[o] = qnan;
+                dHo[o] = qnan;
+                dSo[o] = qnan;
+            }
+        }
+    }
+}
+
+// ---- batch: one primer per lane, the reference's loop ---------------------------
+__global__ __launch_bounds__(THREADS) void batch_kernel(const uint8_t *__restrict__ seqs,
+                                                       const uint64_t *__restrict__ offs, uint64_t n, Consts cst,
+                                                       double *__restrict__ tm, double *__restrict__ dHo,
+                                                       double *__restrict__ dSo)
+{
+    __shared__ double2 nn[25];
+    if (threadIdx.x < 25)
+        nn[threadIdx.x] = c_nn[threadIdx.x];
+    __syncthreads();
+    const uint64_t p = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint8_t *s = seqs + offs[p];
+    const uint64_t L = offs[p + 1] - offs[p];
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    if (L == 0) { // the reference indexes sequence[-1] and panics (primers.go:89)
+        tm[p] = qnan;
+        dHo[p] = qnan;
+        dSo[p] = qnan;
+        return;
+    }
+    bool pal = true;
+    for (uint64_t t = 0; t < L && pal; ++t)
+        pal = ascii_upper(s[t]) == complement_upper(ascii_upper(s[L - 1 - t]));
+    double h = 0.0, e = 0.0;
+    h += 0.2;
+    e += -5.7;
+    if (pal) {
+        h += 0.0;
+        e += -1.4;
+    }
+    const uint32_t last = ascii_upper(s[L - 1]);
+    if (last == 'A' || last == 'T') {
+        h += 2.2;
+        e += 6.9;
+    }
+    e += (0.368 * (double)((int64_t)L - 1)) * cst.ln_salt;
+    uint32_t c0 = nt_code(ascii_upper(s[0]));
+    for (uint64_t i = 0; i + 1 < L; ++i) {
+        const uint32_t c1 = nt_code(ascii_upper(s[i + 1]));
+        const double2 t = nn[c0 * 5u + c1];
+        c0 = c1;
+        h += t.x;
+        e += t.y;
+    }
+    tm[p] = melting(h, e, pal ? cst.rlog_sym : cst.rlog_non);
+    dHo[p] = h;
+    dSo[p] = e;
+}
+
+// MarmurDoty, primers.go:108-118: 2(A+T) + 4(C+G) - 7 on the upper-cased sequence
+__global__ __launch_bounds__(THREADS) void marmur_doty_kernel(const uint8_t *__restrict__ seqs,
+                                                             const uint64_t *__restrict__ offs, uint64_t n,
+                                                             double *__restrict__ tm)
+{
+    const uint64_t p = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= n)
+        return;
+    const uint8_t *s = seqs + offs[p];
+    const uint64_t L = offs[p + 1] - offs[p];
+    uint64_t at = 0, cg = 0;
+    for (uint64_t i = 0; i < L; ++i) {
+        const uint32_t c = nt_code(ascii_upper(s[i]));
+        at += (c == 0u) | (c == 3u);
+        cg += (c == 1u) | (c == 2u);
+    }
+    // aCount..gCount are exact small integers in float64, so is the result
+    tm[p] = 2 * (double)at + 4 * (double)cg - 7.0;
+}
+
+static size_t scan_smem(uint32_t Lmax)
+{
+    const uint32_t span_pad = (THREADS + Lmax - 1 + 15u) & ~15u;
+    return 512 + 3 * (size_t)span_pad;
+}
+
+} // namespace k4
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+int polyhip_santalucia_scan_dev(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64_t nstarts, uint32_t Lmin,
+                                uint32_t Lmax, double primer_conc, double salt_conc, double mg_conc, double *d_tm,
+                                double *d_dH, double *d_dS, uint64_t ld, polyhip_stream_t stream)
+{
+    if (Lmin == 0)
+        return set_error(POLYHIP_ERR_PANIC, "primers.SantaLucia(\"\") indexes sequence[-1] (primers.go:89): the reference panics");
+    PH_REQUIRE(Lmin <= Lmax, "polyhip_santalucia_scan: Lmin %u > Lmax %u", Lmin, Lmax);
+    PH_REQUIRE(Lmax <= (uint32_t)k4::LMAX_MAX, "polyhip_santalucia_scan: Lmax %u > %d is not implemented", Lmax,
+               k4::LMAX_MAX);
+    if (nstarts == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_seq && d_tm && d_dH && d_dS, "polyhip_santalucia_scan: null pointer");
+    PH_REQUIRE(ld >= nstarts, "polyhip_santalucia_scan: plane stride %llu < nstarts %llu", (unsigned long long)ld,
+               (unsigned long long)nstarts);
+    PH_REQUIRE(start0 <= len && nstarts <= len - start0 + 0, "polyhip_santalucia_scan: starts [%llu, +%llu) outside the sequence",
+               (unsigned long long)start0, (unsigned long long)nstarts);
+    hipStream_t st = as_stream(stream);
+    const uint64_t blocks = (nstarts + k4::THREADS - 1) / k4::THREADS;
+    PH_REQUIRE(blocks < (1ull << 31), "polyhip_santalucia_scan: too many starts for one call");
+    for (uint32_t L0 = Lmin; L0 <= Lmax; L0 += k4::NL_MAX) {
+        const uint32_t nl = Lmax - L0 + 1 < (uint32_t)k4::NL_MAX ? Lmax - L0 + 1 : (uint32_t)k4::NL_MAX;
+        const k4::Consts c = k4::make_consts(primer_conc, salt_conc, mg_conc, L0, nl);
+        const uint64_t plane0 = (uint64_t)(L0 - Lmin) * ld;
+        const size_t smem = k4::scan_smem(L0 + nl - 1);
+        if (L0 == 18 && nl == 13) {
+            hipLaunchKernelGGL((k4::scan_kernel<18, 30>), dim3((unsigned)blocks), dim3(k4::THREADS), smem, st, d_seq,
+                               len, start0, nstarts, L0, nl, c, d_tm + plane0, d_dH + plane0, d_dS + plane0, ld);
+        } else {
+            hipLaunchKernelGGL((k4::scan_kernel<0, 0>), dim3((unsigned)blocks), dim3(k4::THREADS), smem, st, d_seq,
+                               len, start0, nstarts, L0, nl, c, d_tm + plane0, d_dH + plane0, d_dS + plane0, ld);
+        }
+        PH_HIP(hipGetLastError());
+    }
+    return POLYHIP_OK;
+}
+
+static int validate_ascii(const uint8_t *p, uint64_t n, const char *who)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        if (p[i] >= 0x80)
+            return set_error(POLYHIP_ERR_INVALID, "%s: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
+                             who, p[i], (unsigned long long)i);
+    return POLYHIP_OK;
+}
+
+int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uint32_t Lmax, double primer_conc,
+                            double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+{
+    if (Lmin == 0)
+        return polyhip_santalucia_scan_dev(nullptr, 0, 0, 0, 0, Lmax, primer_conc, salt_conc, mg_conc, nullptr, nullptr,
+                                           nullptr, 0, nullptr);
+    PH_REQUIRE(Lmin <= Lmax, "polyhip_santalucia_scan: Lmin %u > Lmax %u", Lmin, Lmax);
+    if (len < Lmin)
+        return POLYHIP_OK; // no window fits
+    PH_REQUIRE(seq && tm && dH && dS, "polyhip_santalucia_scan: null pointer");
+    int rc = validate_ascii(seq, len, "polyhip_santalucia_scan");
+    if (rc != POLYHIP_OK)
+        return rc;
+    const uint64_t nstarts = len - Lmin + 1;
+    const uint64_t nout = nstarts * (uint64_t)(Lmax - Lmin + 1);
+    DevBuf dseq, dtm, ddh, dds;
+    PH_HIP(dseq.alloc(len));
+    PH_HIP(dtm.alloc(nout * 8));
+    PH_HIP(ddh.alloc(nout * 8));
+    PH_HIP(dds.alloc(nout * 8));
+    PH_HIP(hipMemcpy(dseq.p, seq, len, hipMemcpyHostToDevice));
+    rc = polyhip_santalucia_scan_dev(dseq.as<uint8_t>(), len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
+                                     dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nstarts, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(tm, dtm.p, nout * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(dH, ddh.p, nout * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(dS, dds.p, nout * 8, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+int polyhip_santalucia_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, double primer_conc,
+                                 double salt_conc, double mg_conc, double *d_tm, double *d_dH, double *d_dS,
+                                 polyhip_stream_t stream)
+{
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_seqs && d_offsets && d_tm && d_dH && d_dS, "polyhip_santalucia_batch: null pointer");
+    const uint64_t blocks = (n + k4::THREADS - 1) / k4::THREADS;
+    PH_REQUIRE(blocks < (1ull << 31), "polyhip_santalucia_batch: too many sequences for one call");
+    const k4::Consts c = k4::make_consts(primer_conc, salt_conc, mg_conc, 1, 0);
+    hipLaunchKernelGGL(k4::batch_kernel, dim3((unsigned)blocks), dim3(k4::THREADS), 0, as_stream(stream), d_seqs,
+                       d_offsets, n, c, d_tm, d_dH, d_dS);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+// shared staging for the two packed-batch host entry points
+static int stage_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, const char *who, bool empty_panics,
+                       DevBuf &dseq, DevBuf &doff)
+{
+    PH_REQUIRE(seqs && offsets, "%s: null pointer", who);
+    for (uint64_t i = 0; i < n; ++i) {
+        PH_REQUIRE(offsets[i] <= offsets[i + 1], "%s: offsets not ascending at %llu", who, (unsigned long long)i);
+        if (empty_panics && offsets[i] == offsets[i + 1])
+            return set_error(POLYHIP_ERR_PANIC, "%s: sequence %llu is empty; primers.SantaLucia(\"\") panics (primers.go:89)",
+                             who, (unsigned long long)i);
+    }
+    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
+    int rc = validate_ascii(seqs + b0, nbytes, who);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(dseq.alloc(nbytes));
+    PH_HIP(doff.alloc((n + 1) * 8));
+    std::vector<uint64_t> tmp(n + 1);
+    for (uint64_t i = 0; i <= n; ++i)
+        tmp[i] = offsets[i] - b0;
+    PH_HIP(hipMemcpy(doff.p, tmp.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    if (nbytes)
+        PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
+    return POLYHIP_OK;
+}
+
+int polyhip_santalucia_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double primer_conc,
+                             double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+{
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(tm && dH && dS, "polyhip_santalucia_batch: null pointer");
+    DevBuf dseq, doff, dtm, ddh, dds;
+    int rc = stage_batch(seqs, offsets, n, "polyhip_santalucia_batch", true, dseq, doff);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(dtm.alloc(n * 8));
+    PH_HIP(ddh.alloc(n * 8));
+    PH_HIP(dds.alloc(n * 8));
+    rc = polyhip_santalucia_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, primer_conc, salt_conc, mg_conc,
+                                      dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(tm, dtm.p, n * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(dH, ddh.p, n * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(dS, dds.p, n * 8, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+int polyhip_marmurdoty_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, double *d_tm,
+                                 polyhip_stream_t stream)
+{
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_seqs && d_offsets && d_tm, "polyhip_marmurdoty_batch: null pointer");
+    const uint64_t blocks = (n + k4::THREADS - 1) / k4::THREADS;
+    PH_REQUIRE(blocks < (1ull << 31), "polyhip_marmurdoty_batch: too many sequences for one call");
+    hipLaunchKernelGGL(k4::marmur_doty_kernel, dim3((unsigned)blocks), dim3(k4::THREADS), 0, as_stream(stream), d_seqs,
+                       d_offsets, n, d_tm);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double *tm)
+{
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(tm, "polyhip_marmurdoty_batch: null pointer");
+    DevBuf dseq, doff, dtm;
+    int rc = stage_batch(seqs, offsets, n, "polyhip_marmurdoty_batch", false, dseq, doff);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(dtm.alloc(n * 8));
+    rc = polyhip_marmurdoty_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, dtm.as<double>(), nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(tm, dtm.p, n * 8, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

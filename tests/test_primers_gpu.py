@@ -1,0 +1,129 @@
+"""K4 parity: poly_amd.primers (HIP, through the C ABI) vs the CPU oracle.
+Bit-exact (the kernels keep the reference's fp64 operation order); the
+north-star tolerance is 1e-6 C, asserted as well.
+
+Mirrors primers/primers_test.go:13-84 where the reference has a test."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL_C = 1e-6  # BASELINE.json north_star: Tm within 1e-6 C
+
+
+@pytest.fixture(scope="module")
+def pr():
+    from poly_amd import primers
+    return primers
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+def test_reference_goldens(pr):
+    # primers_test.go:41-50
+    tm, dH, dS = pr.SantaLucia("ACGATGGCAGTAGCATGC", 0.1e-6, 350e-3, 0)
+    assert abs(tm - 62.7) / 62.7 < 0.02
+    assert (tm, dH, dS) == orc.santalucia(b"ACGATGGCAGTAGCATGC", 0.1e-6, 350e-3, 0)
+    assert tm == 62.31695672635385  # SURVEY 8c full-precision value
+    # primers_test.go:52-66 (self-complementary)
+    tm, dH, dS = pr.SantaLucia("ACGTAGATCTACGT", 0.1e-6, 350e-3, 0)
+    assert abs(tm - 47.428514) / 47.428514 < 0.02
+    assert tm == 47.42851359405711
+    # primers_test.go:68-84
+    tm = pr.MeltingTemp("GTAAAACGACGGCCAGT")
+    assert abs(tm - 52.8) / 52.8 < 0.02
+    assert tm == orc.melting_temp(b"GTAAAACGACGGCCAGT") == 52.63382276100299
+    # primers_test.go:13-27
+    assert pr.MarmurDoty("ACGTCCGGACTT") == 31.0
+
+
+def test_batch_matches_oracle_bit_exact(pr):
+    rng = np.random.default_rng(7)
+    seqs = []
+    for i in range(600):
+        L = int(rng.integers(1, 220))
+        alphabet = b"ACGT" if i % 3 else b"ACGTacgtNnRYUu-*"
+        seqs.append(bytes(rng.choice(list(alphabet), L).astype(np.uint8)))
+    seqs += [b"A", b"T", b"AT", b"TA", b"GC", b"ACGT", b"acgt", b"NNNN", b"SWSW", b"\x00\x00", b"GAATTC", b"gaattc",
+             b"ACGTUACGT", b"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA"]
+    for conc, na, mg in [(500e-9, 50e-3, 0.0), (0.1e-6, 350e-3, 0.0), (250e-9, 50e-3, 1.5e-3)]:
+        tm, dH, dS = pr.SantaLuciaBatch(seqs, conc, na, mg)
+        for i, s in enumerate(seqs):
+            w = orc.santalucia(s, conc, na, mg)
+            assert abs(tm[i] - w[0]) <= TOL_C or (math.isnan(w[0]) and math.isnan(tm[i])) or w[0] == tm[i], (s, tm[i], w)
+            assert (_bits(tm[i]), _bits(dH[i]), _bits(dS[i])) == (_bits(w[0]), _bits(w[1]), _bits(w[2])), (s, conc)
+    md = pr.marmurdoty_batch_packed(*__import__("poly_amd.mash", fromlist=["_pack"])._pack(seqs))
+    for i, s in enumerate(seqs):
+        assert md[i] == orc.marmur_doty(s)
+
+
+def _scan_oracle(g, Lmin, Lmax, conc, na, mg):
+    ns = len(g) - Lmin + 1
+    out = np.full((3, Lmax - Lmin + 1, ns), np.nan)
+    for L in range(Lmin, Lmax + 1):
+        for i in range(0, len(g) - L + 1):
+            out[:, L - Lmin, i] = orc.santalucia(g[i:i + L], conc, na, mg)
+    return out
+
+
+@pytest.mark.parametrize("Lmin,Lmax", [(18, 30), (17, 30), (1, 5), (20, 20), (10, 45)])
+def test_scan_matches_oracle_bit_exact(pr, Lmin, Lmax):
+    g = bytes(orc.synth_dna(0xC5, 700))
+    # splice in a palindrome, lower case and non-ACGT bytes
+    g = g[:100] + b"GAATTCGAATTCGAATTCGAATTC" + g[124:300] + b"acgtnnacgt" + g[310:500] + b"NNSWNNSWNN" + g[510:]
+    conc, na, mg = 500e-9, 50e-3, 0.0
+    tm, dH, dS = pr.SantaLuciaScan(g, Lmin, Lmax, conc, na, mg)
+    want = _scan_oracle(g, Lmin, Lmax, conc, na, mg)
+    assert tm.shape == want[0].shape
+    for got, w, name in ((tm, want[0], "tm"), (dH, want[1], "dH"), (dS, want[2], "dS")):
+        nan_ok = np.isnan(got) == np.isnan(w)
+        assert nan_ok.all(), name
+        m = ~np.isnan(w)
+        assert (np.abs(got[m] - w[m]) <= TOL_C).all(), name
+        assert (_bits(got[m]) == _bits(w[m])).all(), name
+
+
+def test_scan_slices_agree_with_whole(pr):
+    """start0/nstarts slicing (the multi-GPU partition) gives the same planes."""
+    import torch
+    from poly_amd import mash
+    dev = torch.device("cuda:0")
+    n, Lmin, Lmax = 20_000, 18, 30
+    g = torch.empty(n, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC5, g)
+    ns = n - Lmin + 1
+    nl = Lmax - Lmin + 1
+    whole = [torch.zeros(nl * ns, dtype=torch.float64, device=dev) for _ in range(3)]
+    pr.santalucia_scan_dev(g, n, 0, ns, Lmin, Lmax, 500e-9, 50e-3, 0.0, *whole, ns)
+    parts = [torch.zeros(nl * ns, dtype=torch.float64, device=dev) for _ in range(3)]
+    cuts = [0, 4999, 10_000, 15_001, ns]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        sl = [torch.zeros(nl * (b - a), dtype=torch.float64, device=dev) for _ in range(3)]
+        pr.santalucia_scan_dev(g, n, a, b - a, Lmin, Lmax, 500e-9, 50e-3, 0.0, *sl, b - a)
+        for P, S in zip(parts, sl):
+            P.view(nl, ns)[:, a:b] = S.view(nl, b - a)
+    torch.cuda.synchronize()
+    for W, P in zip(whole, parts):
+        assert torch.equal(W.view(torch.int64), P.view(torch.int64))
+    # last starts run off the end -> NaN
+    tmw = whole[0].view(nl, ns).cpu().numpy()
+    assert np.isnan(tmw[nl - 1, ns - 1]) and not np.isnan(tmw[0, ns - 1])
+    # spot-check against the oracle
+    host = g.cpu().numpy().tobytes()
+    for i in (0, 1234, 19_970):
+        for L in (18, 25, 30):
+            assert tmw[L - Lmin, i] == orc.santalucia(host[i:i + L], 500e-9, 50e-3, 0.0)[0]
+
+
+def test_errors(pr):
+    from poly_amd import _lib
+    with pytest.raises(_lib.GoPanic):
+        pr.SantaLucia("", 500e-9, 50e-3, 0)  # primers.go:89 indexes sequence[-1]
+    with pytest.raises(_lib.PolyhipError):
+        pr.SantaLucia(b"AC\xc3\xa9GT", 500e-9, 50e-3, 0)
+    assert pr.MarmurDoty("") == -7.0
