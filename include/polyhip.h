@@ -93,6 +93,53 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs,
                                   uint32_t k, uint32_t s, uint32_t *d_out,
                                   polyhip_stream_t stream);
 
+/* ---- K2: search/mash (*Mash).Similarity / Distance  (search/mash/mash.go:107-140) */
+/*
+ * For two sets of sketches X (nx x sx, the receivers) and Y (ny x sy):
+ *     d_counts[i * ld + j] = sameHashes of X_i.Similarity(Y_j)   (mash.go:108-132)
+ * i.e. the reference's result before the division, INCLUDING its behaviour on
+ * sketches that are not ascending (a sequence with fewer than SketchSize
+ * windows leaves a positional, zero/stale-padded sketch, mash.go:81-84): those
+ * pairs run the reference's own range early-out + merge loop.  All-vs-all on
+ * one GPU: X == Y.  Sharded over ranks: Y = the all-gathered sketches, X = this
+ * rank's row block of Y, d_counts = its row block of the matrix.
+ * Similarity = counts / min(sx, sy); Distance = 1 - that (next call).
+ * SketchSize 0 -> POLYHIP_ERR_PANIC (mash.go:117 indexes Sketches[-1]).
+ * Range: sx, sy <= 65535; nx, ny < 2^31; ny*sy < 2^32 per call.
+ * d_work: polyhip_mash_shared_counts_workspace_bytes(...) bytes of scratch.
+ */
+size_t polyhip_mash_shared_counts_workspace_bytes(uint64_t nx, uint32_t sx,
+                                                  uint64_t ny, uint32_t sy);
+int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx,
+                                   uint32_t sx, const uint32_t *d_Y,
+                                   uint64_t ny, uint32_t sy,
+                                   uint16_t *d_counts, uint64_t ld,
+                                   void *d_work, size_t work_bytes,
+                                   polyhip_stream_t stream);
+/* What the last polyhip_mash_shared_counts_dev call on this workspace did
+ * (synchronous read-back; tests and profiling): mode 0 = hash join, 1 = the
+ * reference's merge for every pair; the number of non-ascending sketches on
+ * each side; the rows the join handed to the merge (more related sketches
+ * than its LDS table holds); the index's self-join size sum_b |Y_b|^2.
+ * Any pointer may be NULL. */
+int polyhip_mash_shared_counts_mode_dev(const void *d_work, uint32_t *mode,
+                                        uint32_t *n_irregular_x,
+                                        uint32_t *n_irregular_y,
+                                        uint32_t *n_overflow_rows,
+                                        uint64_t *join_estimate);
+/* d_dist[i * ld_dist + j] = 1 - float64(counts[i][j]) / float64(min(sx, sy))
+ * (mash.go:134,139; so 8 shared of 10 gives 0.19999999999999996). */
+int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts,
+                                          uint64_t nx, uint64_t ny,
+                                          uint64_t ld_counts, uint32_t sx,
+                                          uint32_t sy, double *d_dist,
+                                          uint64_t ld_dist,
+                                          polyhip_stream_t stream);
+/* host flavour: counts (nx*ny u16) and/or dist (nx*ny f64) may be NULL. */
+int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx,
+                                 const uint32_t *Y, uint64_t ny, uint32_t sy,
+                                 uint16_t *counts, double *dist);
+
 /* ---- K3: search/align SmithWaterman  (search/align/align.go:171-232) ---- */
 /*
  * align.Scoring{SubstitutionMatrix, GapPenalty} (align.go:73-95) flattened
@@ -199,6 +246,25 @@ int polyhip_marmurdoty_batch_dev(const uint8_t *d_seqs,
                                  double *d_tm, polyhip_stream_t stream);
 int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets,
                              uint64_t n, double *tm);
+
+/* ---- K5: seqhash RotateSequence  (seqhash/seqhash.go:78-138) ------------------ */
+/*
+ * For every packed sequence: d_rot_index[i] = boothLeastRotation(seq_i)
+ * (seqhash.go:78-124: the smallest index of the lexicographically least
+ * rotation, byte order, no case folding), and -- if d_rotated != NULL, same
+ * packed layout as the input -- RotateSequence(seq_i) = (seq_i + seq_i)[r : r+n]
+ * (seqhash.go:127-138).  Empty and one-byte sequences give index 0.
+ * max_len >= every sequence length (sizes the LDS staging).
+ */
+int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs,
+                                     const uint64_t *d_offsets, uint64_t n,
+                                     uint64_t max_len, uint64_t *d_rot_index,
+                                     uint8_t *d_rotated,
+                                     polyhip_stream_t stream);
+/* host flavour; rotated may be NULL, else it is indexed by the same offsets. */
+int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets,
+                                 uint64_t n, uint64_t *rot_index,
+                                 uint8_t *rotated);
 
 #ifdef __cplusplus
 }

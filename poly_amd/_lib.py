@@ -36,6 +36,11 @@ SIGNATURES = {
     "polyhip_synth_dna_dev": (C.c_int, [_u64, _u64, _vp, _u64, _vp]),
     "polyhip_mash_sketch_batch": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp]),
     "polyhip_mash_sketch_batch_dev": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp, _vp]),
+    "polyhip_mash_shared_counts_workspace_bytes": (C.c_size_t, [_u64, _u32, _u64, _u32]),
+    "polyhip_mash_shared_counts_dev": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
+    "polyhip_mash_shared_counts_mode_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "polyhip_mash_distance_from_counts_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _vp, _u64, _vp]),
+    "polyhip_mash_distance_matrix": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _vp]),
     "polyhip_scoring_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.POINTER(C.c_void_p)]),
     "polyhip_scoring_destroy": (C.c_int, [_vp]),
     "polyhip_sw_workspace_bytes": (C.c_size_t, [_vp, _u64, _u32, _u64, C.c_int]),
@@ -50,6 +55,8 @@ SIGNATURES = {
     "polyhip_santalucia_batch": (C.c_int, [_vp, _vp, _u64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "polyhip_marmurdoty_batch_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
     "polyhip_marmurdoty_batch": (C.c_int, [_vp, _vp, _u64, _vp]),
+    "polyhip_least_rotation_batch_dev": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
+    "polyhip_least_rotation_batch": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
 }
 
 

@@ -1,0 +1,298 @@
+// least_rotation.hip -- K5: batched seqhash.RotateSequence for gfx950.
+//
+// Replaces boothLeastRotation + RotateSequence (seqhash/seqhash.go:78-138) for a
+// packed batch of circular sequences: for each one, the index of its
+// lexicographically (byte order) least rotation -- the SMALLEST such index, which
+// is what Booth's algorithm returns on s+s (checked against the oracle on
+// periodic strings) -- and, optionally, the rotated sequence itself.
+//
+// Booth's algorithm is a serial scan with a 2n-entry failure table.  On a GPU
+// the same answer comes from candidate elimination, one workgroup per sequence
+// with the sequence staged in LDS:
+//   1. every position's first 4 bytes as one big-endian word; block-wide min;
+//      the candidates are the positions that attain it (for DNA: ~n/256 of them)
+//   2. rounds of 4 more bytes: min of the next word over the surviving
+//      candidates, keep those that attain it -- until one is left, or the
+//      compared depth reaches n (the survivors are then equal rotations and the
+//      smallest index wins)
+//   3. low-complexity / periodic input that does not thin out (more candidates
+//      than the LDS list holds, or too many rounds) is finished by wave 0 with
+//      the exact two-pointer minimal-rotation algorithm, its match-extension
+//      loop vectorised 64 bytes per step with a ballot.
+// Sequences too long for LDS run the same code reading global memory.
+//
+// Byte compare / integer work, no MFMA.  Algorithmic HBM bytes per sequence:
+// n (read) [+ n if the rotated sequence is written] + 8.
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "common.h"
+
+namespace polyhip {
+namespace k5 {
+
+constexpr int THREADS = 256;
+constexpr uint32_t LIST_CAP = 4096;      // candidates kept in LDS
+constexpr uint32_t MAX_ROUNDS = 64;      // 4 bytes per round before the serial fallback
+constexpr uint32_t LDS_SEQ_MAX = 120 * 1024;
+
+__device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    __syncthreads(); // red[] free again
+    if ((threadIdx.x & 63) == 0)
+        red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return min(min(red[0], red[1]), min(red[2], red[3]));
+}
+
+// big-endian word of the 4 bytes at cyclic position p (p < n); the staged copy
+// carries s[0..3] again behind s[n-1] so no wrap is needed inside the word
+template <class Ptr> __device__ __forceinline__ uint32_t word_at(Ptr s, uint64_t p)
+{
+    return ((uint32_t)s[p] << 24) | ((uint32_t)s[p + 1] << 16) | ((uint32_t)s[p + 2] << 8) | (uint32_t)s[p + 3];
+}
+
+// exact minimal rotation (smallest index) by the two-pointer algorithm, run by
+// ONE wave; cyc(p) reads the byte at cyclic position p < 2n
+template <class Ptr> __device__ uint64_t two_pointer_wave(Ptr s, uint64_t n)
+{
+    const int lane = threadIdx.x & 63;
+    uint64_t i = 0, j = 1, k = 0;
+    while (i < n && j < n && k < n) {
+        const uint64_t t = k + lane;
+        const bool valid = t < n;
+        uint64_t pi = i + t, pj = j + t;
+        pi -= pi >= n ? n : 0;
+        pj -= pj >= n ? n : 0;
+        const uint32_t a = valid ? s[pi] : 0u, b = valid ? s[pj] : 0u;
+        const uint64_t ne = __ballot(valid && a != b);
+        if (ne == 0) {
+            k += 64;
+            continue;
+        }
+        const int f = __builtin_ctzll(ne);
+        k += f;
+        const uint32_t af = (uint32_t)__builtin_amdgcn_readlane((int)a, f);
+        const uint32_t bf = (uint32_t)__builtin_amdgcn_readlane((int)b, f);
+        if (af > bf)
+            i += k + 1;
+        else
+            j += k + 1;
+        if (i == j)
+            ++j;
+        k = 0;
+    }
+    return i < j ? i : j;
+}
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *__restrict__ seqs,
+                                                                const uint64_t *__restrict__ offs, uint64_t nseq,
+                                                                uint64_t lds_seq_bytes, uint64_t *__restrict__ rot,
+                                                                uint8_t *__restrict__ rotated)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint32_t listA[LIST_CAP], listB[LIST_CAP];
+    __shared__ uint32_t red[4];
+    __shared__ uint32_t cnt;
+    __shared__ uint64_t answer;
+    const int tid = threadIdx.x;
+
+    for (uint64_t q = blockIdx.x; q < nseq; q += gridDim.x) {
+        const uint64_t o0 = offs[q];
+        const uint64_t n = offs[q + 1] - o0;
+        const uint8_t *g = seqs + o0;
+        if (n <= 1) {
+            if (tid == 0)
+                rot[q] = 0;
+            if (rotated && n == 1 && tid == 0)
+                rotated[o0] = g[0];
+            continue;
+        }
+        if (IN_LDS && n + 4 > lds_seq_bytes)
+            continue; // the global-memory launch handles this one
+        if (!IN_LDS && n + 4 <= lds_seq_bytes)
+            continue;
+
+        // ---- stage the sequence (+ 4 wrapped bytes so a word never wraps)
+        __syncthreads();
+        if (IN_LDS) {
+            for (uint64_t t = tid; t < n + 4; t += THREADS)
+                lds[t] = g[t < n ? t : (t - n) % n];
+        }
+        if (tid == 0) {
+            cnt = 0;
+            answer = ~0ull;
+        }
+        __syncthreads();
+
+        auto byte_at = [&](uint64_t p) -> uint32_t { // cyclic position p < 2n
+            return IN_LDS ? lds[p] : g[p >= n ? p - n : p];
+        };
+        auto word = [&](uint64_t p) -> uint32_t { // big-endian 4 bytes at cyclic position p < 2n
+            p -= p >= n ? n : 0;
+            if (IN_LDS)
+                return word_at(lds, p);
+            return ((uint32_t)g[p] << 24) | ((uint32_t)g[(p + 1) % n] << 16) | ((uint32_t)g[(p + 2) % n] << 8) |
+                   (uint32_t)g[(p + 3) % n];
+        };
+
+        // ---- 1. least first word
+        uint32_t m = 0xFFFFFFFFu;
+        for (uint64_t p = tid; p < n; p += THREADS)
+            m = min(m, word(p));
+        m = block_min(m, red);
+        bool serial = false;
+        for (uint64_t p0 = 0; p0 < n; p0 += THREADS) {
+            const uint64_t p = p0 + tid;
+            const bool is = p < n && word(p) == m;
+            if (is) {
+                const uint32_t slot = atomicAdd(&cnt, 1u);
+                if (slot < LIST_CAP)
+                    listA[slot] = (uint32_t)p;
+            }
+        }
+        __syncthreads();
+        uint32_t c = cnt;
+        if (c > LIST_CAP || n > 0xFFFFFFFFull)
+            serial = true;
+
+        // ---- 2. rounds of 4 more bytes
+        uint32_t *cur = listA, *nxt = listB;
+        uint64_t depth = 4;
+        uint32_t rounds = 0;
+        while (!serial && c > 1 && depth < n) {
+            if (++rounds > MAX_ROUNDS) {
+                serial = true;
+                break;
+            }
+            uint32_t mm = 0xFFFFFFFFu;
+            for (uint32_t e = tid; e < c; e += THREADS)
+                mm = min(mm, word((uint64_t)cur[e] + depth));
+            mm = block_min(mm, red);
+            if (tid == 0)
+                cnt = 0;
+            __syncthreads();
+            for (uint32_t e = tid; e < c; e += THREADS) {
+                const uint32_t p = cur[e];
+                if (word((uint64_t)p + depth) == mm)
+                    nxt[atomicAdd(&cnt, 1u)] = p;
+            }
+            __syncthreads();
+            c = cnt;
+            uint32_t *t = cur;
+            cur = nxt;
+            nxt = t;
+            depth += 4;
+        }
+
+        // ---- 3. answer
+        if (serial) {
+            if (tid < 64) {
+                uint64_t r;
+                if (IN_LDS)
+                    r = two_pointer_wave(lds, n);
+                else
+                    r = two_pointer_wave(g, n);
+                if (tid == 0)
+                    answer = r;
+            }
+        } else {
+            // survivors are equal rotations (or a single one): the smallest index wins
+            uint32_t best = 0xFFFFFFFFu;
+            for (uint32_t e = tid; e < c; e += THREADS)
+                best = min(best, cur[e]);
+            best = block_min(best, red);
+            if (tid == 0)
+                answer = best;
+        }
+        __syncthreads();
+        const uint64_t r = answer;
+        if (tid == 0)
+            rot[q] = r;
+        if (rotated) { // RotateSequence: (s + s)[r : r + n], seqhash.go:131-137
+            for (uint64_t t = tid; t < n; t += THREADS) {
+                uint64_t p = t + r;
+                p -= p >= n ? n : 0;
+                rotated[o0 + t] = (uint8_t)byte_at(p);
+            }
+        }
+    }
+}
+
+} // namespace k5
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
+                                     uint64_t *d_rot_index, uint8_t *d_rotated, polyhip_stream_t stream)
+{
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_seqs && d_offsets && d_rot_index, "polyhip_least_rotation_batch: null pointer");
+    hipStream_t st = as_stream(stream);
+    // LDS holds sequences up to LDS_SEQ_MAX; size the allocation to the batch's longest
+    uint64_t lds_seq = max_len + 4;
+    if (lds_seq > k5::LDS_SEQ_MAX)
+        lds_seq = k5::LDS_SEQ_MAX;
+    lds_seq = (lds_seq + 15) & ~15ull;
+    const unsigned blocks = (unsigned)(n < 256ull * 32ull ? n : 256ull * 32ull);
+    auto kl = k5::least_rotation_kernel<true>;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds_seq));
+    hipLaunchKernelGGL(kl, dim3(blocks), dim3(k5::THREADS), lds_seq, st, d_seqs, d_offsets, n, lds_seq, d_rot_index,
+                       d_rotated);
+    PH_HIP(hipGetLastError());
+    if (max_len + 4 > lds_seq) {
+        hipLaunchKernelGGL((k5::least_rotation_kernel<false>), dim3(blocks), dim3(k5::THREADS), 0, st, d_seqs, d_offsets,
+                           n, lds_seq, d_rot_index, d_rotated);
+        PH_HIP(hipGetLastError());
+    }
+    return POLYHIP_OK;
+}
+
+int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint64_t *rot_index,
+                                 uint8_t *rotated)
+{
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(seqs && offsets && rot_index, "polyhip_least_rotation_batch: null pointer");
+    uint64_t max_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        PH_REQUIRE(offsets[i] <= offsets[i + 1], "polyhip_least_rotation_batch: offsets not ascending at %llu",
+                   (unsigned long long)i);
+        if (offsets[i + 1] - offsets[i] > max_len)
+            max_len = offsets[i + 1] - offsets[i];
+    }
+    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
+    DevBuf dseq, doff, drot, dout;
+    PH_HIP(dseq.alloc(nbytes));
+    PH_HIP(doff.alloc((n + 1) * 8));
+    PH_HIP(drot.alloc(n * 8));
+    std::vector<uint64_t> tmp(n + 1);
+    for (uint64_t i = 0; i <= n; ++i)
+        tmp[i] = offsets[i] - b0;
+    PH_HIP(hipMemcpy(doff.p, tmp.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    if (nbytes)
+        PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
+    if (rotated)
+        PH_HIP(dout.alloc(nbytes));
+    int rc = polyhip_least_rotation_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, max_len, drot.as<uint64_t>(),
+                                              rotated ? dout.as<uint8_t>() : nullptr, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(rot_index, drot.p, n * 8, hipMemcpyDeviceToHost));
+    if (rotated && nbytes)
+        PH_HIP(hipMemcpy(rotated + b0, dout.p, nbytes, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,664 @@
+// mash_distance.hip -- K2: all-pairs (*Mash).Similarity / Distance for gfx950.
+//
+// Replaces the merge loop of search/mash/mash.go:107-135 (and Distance,
+// :138-140) for every pair (X_i, Y_j) of two sets of sketches:
+//     counts[i][j] = sameHashes of X_i.Similarity(Y_j)          (u16)
+//     dist[i][j]   = 1 - float64(counts[i][j]) / float64(min(sx, sy))
+// (all-vs-all: Y = every gathered sketch, X = this rank's row block of Y.)
+//
+// The reference merges two sorted lists, <= sx+sy serial steps per pair; doing
+// that for 1e10 pairs is 2e13 dependent steps.  Sketches are sorted, so the
+// same number falls out of a JOIN ON THE HASH VALUE instead:
+//     sameHashes(X_i, Y_j) = sum over values v of min(mult_Xi(v), mult_Yj(v))
+// which is a sparse product (sketch x value incidence) * (value x sketch), and
+// the work becomes proportional to the number of shared hashes, not to the
+// number of pairs:
+//
+//   check    every sketch: ascending?  (a sketch of a sequence with fewer than
+//            s windows is positional/unsorted, mash.go:81-84)  -> per-sketch
+//            "irregular" flag; max Y value -> bucket shift
+//   index    the Y side becomes an inverted index: items (value, sketch id,
+//            occurrence number among equal values of that sketch) partitioned
+//            into NBK buckets by value >> shift (histogram, scan, scatter)
+//   rowjoin  one workgroup per X row (Gustavson with an LDS hash accumulator):
+//            for every distinct value v of the row (multiplicity a) read v's
+//            bucket -- one coalesced load -- and for every item (v, j, occ) with
+//            occ < a bump the row's LDS hash table at key j (LDS atomics, no
+//            global atomics); then flush the table's entries to counts[i][*].
+//            "occ < a" makes a value that is a times in X_i and b times in Y_j
+//            count min(a, b) times: what the reference's two-pointer merge counts.
+//   generic  the reference's own loop, one pair per lane, for every pair that
+//            involves an irregular sketch (the range early-out of mash.go:117
+//            and the merge both read unsorted data there), for rows whose table
+//            overflows (thousands of related sketches), and for ALL pairs when
+//            the index says the input is dense (huge buckets: many near-identical
+//            sketches), where merging is cheaper than joining.
+//
+// No MFMA (integer compares).  HBM-bound part: the counts/distance matrix
+// itself (2 or 8 B per pair) -- see DESIGN.md, K2.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace polyhip {
+namespace k2 {
+
+constexpr int THREADS = 256;
+constexpr uint32_t MAX_OCC = 255; // occurrence number packed above the sketch id
+constexpr uint32_t ID_BITS = 24;
+constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
+constexpr uint32_t SCAN_CHUNK = 2048; // histogram entries per scan block
+constexpr uint32_t TAB = 2048;        // LDS hash accumulator slots per row
+constexpr uint32_t TAB_LIMIT = 1536;  // distinct columns a row may hit before it goes to the merge
+constexpr uint32_t S_MAX = 8192;      // X SketchSize rowjoin stages in LDS
+constexpr int JOIN_U = 4;             // buckets a wave keeps in flight
+
+enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_pad, H_EST_LO, H_EST_HI, H_WORDS = 16 };
+enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
+
+struct Layout {
+    uint32_t nbk, nscan;
+    size_t off_flagsX, off_flagsY, off_irrX, off_regX, off_irrY, off_ovfX;
+    size_t off_start, off_cur, off_bsum, off_items;
+    size_t total;
+};
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
+{
+    Layout L;
+    (void)sx;
+    // ~32 Y items per bucket; a bucket is a value range of one width (a power of two)
+    const uint64_t itemsY = ny * (uint64_t)sy;
+    uint32_t nbk = SCAN_CHUNK;
+    while (nbk < (1u << 23) && (uint64_t)nbk * 32 < itemsY)
+        nbk <<= 1;
+    L.nbk = nbk;
+    L.nscan = nbk / SCAN_CHUNK;
+    size_t o = al(H_WORDS * 4);
+    L.off_flagsX = o; o += al(nx);
+    L.off_flagsY = o; o += al(ny);
+    L.off_irrX = o; o += al(nx * 4);
+    L.off_regX = o; o += al(nx * 4);
+    L.off_ovfX = o; o += al(nx * 4);
+    L.off_irrY = o; o += al(ny * 4);
+    L.off_start = o; o += al(((size_t)nbk + 1) * 4);
+    L.off_cur = o; o += al((size_t)nbk * 4);
+    L.off_bsum = o; o += al((size_t)L.nscan * 4);
+    L.off_items = o; o += al(ny * (size_t)sy * 8);
+    L.total = o;
+    return L;
+}
+
+// ---- check: ascending? occurrence number representable? max value.  One block per sketch.
+__global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restrict__ sk, uint32_t s,
+                                                       uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
+                                                       int force_irregular, int track_max)
+{
+    const uint64_t q = blockIdx.x;
+    const uint32_t *p = sk + q * s;
+    uint32_t v = 0;
+    bool bad = force_irregular != 0;
+    for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
+        const uint32_t x = p[e];
+        v = max(v, x);
+        if (e + 1 < s && x > p[e + 1])
+            bad = true;
+        if (e >= MAX_OCC + 1 && p[e - (MAX_OCC + 1)] == x) // > 256 equal values in one sketch
+            bad = true;
+    }
+    if (bad)
+        flags[q] = 1;
+    if (track_max) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+        // nearly every wave sees a maximum that is already recorded: read before the atomic
+        if ((threadIdx.x & 63) == 0 &&
+            v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&hdr[H_MAXVAL], v);
+    }
+}
+
+// ---- lists of irregular / regular sketches, bucket shift ---------------------------
+__global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restrict__ flagsX, uint64_t nx,
+                                                       const uint8_t *__restrict__ flagsY, uint64_t ny,
+                                                       uint32_t *__restrict__ irrX, uint32_t *__restrict__ regX,
+                                                       uint32_t *__restrict__ irrY, uint32_t *__restrict__ hdr,
+                                                       uint32_t nbk_log2)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (t < nx) {
+        if (flagsX[t])
+            irrX[atomicAdd(&hdr[H_NIRRX], 1u)] = (uint32_t)t;
+        else
+            regX[atomicAdd(&hdr[H_NREGX], 1u)] = (uint32_t)t;
+    }
+    if (t < ny && flagsY[t])
+        irrY[atomicAdd(&hdr[H_NIRRY], 1u)] = (uint32_t)t;
+    if (t == 0) {
+        const uint32_t mv = hdr[H_MAXVAL];
+        const uint32_t bits = 32u - (uint32_t)__builtin_clz(mv | 1u);
+        hdr[H_SHIFT] = bits > nbk_log2 ? bits - nbk_log2 : 0u;
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void hist_kernel(const uint32_t *__restrict__ sk, uint32_t s,
+                                                      const uint8_t *__restrict__ flags,
+                                                      const uint32_t *__restrict__ hdr, uint32_t *__restrict__ start)
+{
+    const uint64_t q = blockIdx.x;
+    if (flags[q])
+        return;
+    const uint32_t shift = hdr[H_SHIFT];
+    const uint32_t *p = sk + q * s;
+    for (uint32_t e = threadIdx.x; e < s; e += THREADS)
+        atomicAdd(&start[p[e] >> shift], 1u);
+}
+
+// ---- exclusive scan of the histogram in three launches ------------------------------
+// a: per-chunk sums (+ the self-join size sum_b cnt_b^2 that picks sparse vs generic)
+__global__ __launch_bounds__(THREADS) void scan_sums_kernel(const uint32_t *__restrict__ start,
+                                                           uint32_t *__restrict__ bsum, uint32_t *__restrict__ hdr)
+{
+    __shared__ uint32_t ws[4];
+    __shared__ unsigned long long wq[4];
+    const uint32_t base = blockIdx.x * SCAN_CHUNK;
+    uint32_t sum = 0;
+    unsigned long long sq = 0;
+#pragma unroll
+    for (int i = 0; i < (int)(SCAN_CHUNK / THREADS); ++i) {
+        const uint32_t c = start[base + i * THREADS + threadIdx.x];
+        sum += c;
+        sq += (unsigned long long)c * c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += (uint32_t)__shfl_xor((int)sum, d, 64);
+        sq += __shfl_xor(sq, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        ws[threadIdx.x >> 6] = sum;
+        wq[threadIdx.x >> 6] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+        const unsigned long long t = wq[0] + wq[1] + wq[2] + wq[3];
+        if (t)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), t);
+    }
+}
+
+// b: one block scans the chunk sums (nscan <= 4096) and takes the sparse/generic decision
+__global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t *__restrict__ bsum, uint32_t nscan,
+                                                       uint32_t *__restrict__ start, uint32_t nbk,
+                                                       uint32_t *__restrict__ hdr, double est_scale,
+                                                       double generic_cost)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < nscan; base += 1024) {
+        const uint32_t i = base + tid;
+        const uint32_t v = i < nscan ? bsum[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w)
+            pre += wsum[w];
+        if (i < nscan)
+            bsum[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        start[nbk] = carry;
+        const unsigned long long self = *reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]);
+        if ((double)self * est_scale > generic_cost)
+            hdr[H_MODE] = MODE_GENERIC;
+    }
+}
+
+// c: scan inside each chunk, add the chunk's offset; cursor = copy
+__global__ __launch_bounds__(THREADS) void scan_chunks_kernel(uint32_t *__restrict__ start,
+                                                             uint32_t *__restrict__ cur,
+                                                             const uint32_t *__restrict__ bsum)
+{
+    __shared__ uint32_t ws[4];
+    constexpr int PER = SCAN_CHUNK / THREADS;
+    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * PER;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        v[i] = start[base + i];
+        sum += v[i];
+    }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if ((threadIdx.x & 63) >= (unsigned)d)
+            incl += t;
+    }
+    if ((threadIdx.x & 63) == 63)
+        ws[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t run = bsum[blockIdx.x] + incl - sum;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w)
+        run += ws[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        start[base + i] = run;
+        cur[base + i] = run;
+        run += v[i];
+    }
+}
+
+__global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t *__restrict__ sk, uint32_t s,
+                                                         const uint8_t *__restrict__ flags,
+                                                         const uint32_t *__restrict__ hdr, uint32_t *__restrict__ cur,
+                                                         uint2 *__restrict__ items)
+{
+    if (hdr[H_MODE] != MODE_SPARSE)
+        return;
+    const uint64_t q = blockIdx.x;
+    if (flags[q])
+        return;
+    const uint32_t shift = hdr[H_SHIFT];
+    const uint32_t *p = sk + q * s;
+    for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
+        const uint32_t v = p[e];
+        uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
+        while (occ < e && p[e - occ - 1] == v)
+            ++occ;
+        items[atomicAdd(&cur[v >> shift], 1u)] = make_uint2(v, (uint32_t)q | (occ << ID_BITS));
+    }
+}
+
+// ---- rowjoin: one workgroup per X row -------------------------------------------------
+// counts one shared hash for column j in the row's LDS table; false = table full
+__device__ __forceinline__ bool table_add(uint32_t *__restrict__ keys, uint32_t *__restrict__ cnts,
+                                          uint32_t *__restrict__ nkeys, uint32_t j)
+{
+    static_assert(TAB == 2048, "hash shift below assumes 2^11 slots");
+    uint32_t h = (j * 2654435761u) >> (32 - 11);
+    const uint32_t key = j + 1u; // 0 = empty slot
+    for (uint32_t probe = 0; probe < TAB; ++probe) {
+        uint32_t k = keys[h];
+        if (k == 0u) {
+            k = atomicCAS(&keys[h], 0u, key);
+            if (k == 0u) {
+                atomicAdd(nkeys, 1u);
+                k = key;
+            }
+        }
+        if (k == key) {
+            atomicAdd(&cnts[h], 1u);
+            return true;
+        }
+        h = (h + 1u) & (TAB - 1u);
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(THREADS) void rowjoin_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
+                                                         const uint8_t *__restrict__ flagsX,
+                                                         const uint32_t *__restrict__ start,
+                                                         const uint2 *__restrict__ items, uint32_t nbk,
+                                                         uint32_t *__restrict__ hdr, uint32_t *__restrict__ ovfX,
+                                                         uint16_t *__restrict__ counts, uint64_t ld)
+{
+    if (hdr[H_MODE] != MODE_SPARSE)
+        return;
+    // per distinct value d of the row: dval, dmul (multiplicity), dbeg/dend (its bucket in `items`)
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    uint32_t *xv = dyn, *dval = dyn + sx, *dmul = dyn + 2 * (size_t)sx, *dbeg = dyn + 3 * (size_t)sx,
+             *dend = dyn + 4 * (size_t)sx;
+    __shared__ uint32_t keys[TAB], cnts[TAB];
+    __shared__ uint32_t nkeys, ndist;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t shift = hdr[H_SHIFT];
+
+    for (uint64_t i = blockIdx.x; i < nx; i += gridDim.x) {
+        if (flagsX[i])
+            continue;
+        __syncthreads(); // previous row flushed
+        for (uint32_t h = tid; h < TAB; h += THREADS) {
+            keys[h] = 0;
+            cnts[h] = 0;
+        }
+        if (tid == 0) {
+            nkeys = 0;
+            ndist = 0;
+        }
+        const uint32_t *xp = X + i * sx;
+        for (uint32_t p = tid; p < sx; p += THREADS)
+            xv[p] = xp[p];
+        __syncthreads();
+        // distinct values of the row and their buckets (all the `start` loads in flight at once)
+        for (uint32_t p = tid; p < sx; p += THREADS) {
+            const uint32_t v = xv[p];
+            if (p != 0 && xv[p - 1] == v)
+                continue; // not the first copy
+            const uint32_t b = v >> shift;
+            if (b >= nbk)
+                continue; // beyond every Y value: shares nothing
+            const uint32_t bs = start[b], be = start[b + 1];
+            if (be == bs)
+                continue;
+            uint32_t a = 1;
+            while (p + a < sx && xv[p + a] == v)
+                ++a;
+            const uint32_t slot = atomicAdd(&ndist, 1u);
+            dval[slot] = v;
+            dmul[slot] = a;
+            dbeg[slot] = bs;
+            dend[slot] = be;
+        }
+        __syncthreads();
+        const uint32_t nd = ndist;
+        bool ok = true;
+        // waves take JOIN_U distinct values at a time: their buckets' first 64 items are
+        // loaded back to back, then consumed
+        for (uint32_t d0 = wave * JOIN_U; d0 < nd && ok; d0 += (THREADS / 64) * JOIN_U) {
+            uint2 it[JOIN_U];
+#pragma unroll
+            for (int u = 0; u < JOIN_U; ++u) {
+                const uint32_t d = d0 + u;
+                it[u] = make_uint2(0u, 0xFFFFFFFFu);
+                if (d < nd && dbeg[d] + lane < dend[d])
+                    it[u] = items[dbeg[d] + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < JOIN_U; ++u) {
+                const uint32_t d = d0 + u;
+                if (d >= nd)
+                    break;
+                const uint32_t v = dval[d], a = dmul[d];
+                if (it[u].y != 0xFFFFFFFFu && it[u].x == v && (it[u].y >> ID_BITS) < a)
+                    ok &= table_add(keys, cnts, &nkeys, it[u].y & ID_MASK);
+                for (uint32_t t = dbeg[d] + 64 + lane; t < dend[d]; t += 64) { // rest of a long bucket
+                    const uint2 r = items[t];
+                    if (r.x == v && (r.y >> ID_BITS) < a)
+                        ok &= table_add(keys, cnts, &nkeys, r.y & ID_MASK);
+                }
+            }
+            if (nkeys > TAB_LIMIT)
+                ok = false;
+        }
+        // a full table / too many distinct columns sends the whole row to the merge
+        const int bad = __syncthreads_or((!ok || nkeys > TAB_LIMIT) ? 1 : 0);
+        if (bad) {
+            if (tid == 0)
+                ovfX[atomicAdd(&hdr[H_NOVF], 1u)] = (uint32_t)i;
+            continue;
+        }
+        for (uint32_t h = tid; h < TAB; h += THREADS)
+            if (keys[h])
+                counts[i * ld + (keys[h] - 1u)] = (uint16_t)cnts[h];
+    }
+}
+
+// mash.go:107-135 for one pair, receiver = X_i
+__device__ uint32_t similarity_count(const uint32_t *__restrict__ x, uint32_t sx, const uint32_t *__restrict__ y,
+                                     uint32_t sy)
+{
+    const uint32_t *lg = x, *sm = y;
+    uint32_t sl = sx, ss = sy;
+    if (sx < sy) { // :112-115
+        lg = y;
+        sm = x;
+        sl = sy;
+        ss = sx;
+    }
+    if (lg[sl - 1] < sm[0] || sm[ss - 1] < lg[0]) // :117
+        return 0;
+    uint32_t same = 0, a = 0, b = 0;
+    uint32_t va = sm[0], vb = lg[0];
+    while (true) { // :121-132
+        if (va == vb) {
+            ++same;
+            ++a;
+            ++b;
+            if (a >= ss || b >= sl)
+                break;
+            va = sm[a];
+            vb = lg[b];
+        } else if (va < vb) {
+            if (++a >= ss)
+                break;
+            va = sm[a];
+        } else {
+            if (++b >= sl)
+                break;
+            vb = lg[b];
+        }
+    }
+    return same;
+}
+
+__global__ __launch_bounds__(THREADS) void generic_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
+                                                         const uint32_t *__restrict__ Y, uint64_t ny, uint32_t sy,
+                                                         const uint32_t *__restrict__ hdr,
+                                                         const uint32_t *__restrict__ irrX,
+                                                         const uint32_t *__restrict__ regX,
+                                                         const uint32_t *__restrict__ irrY,
+                                                         const uint32_t *__restrict__ ovfX,
+                                                         uint16_t *__restrict__ counts, uint64_t ld)
+{
+    const bool all = hdr[H_MODE] == MODE_GENERIC;
+    const uint64_t nIrrX = hdr[H_NIRRX], nIrrY = hdr[H_NIRRY], nRegX = hdr[H_NREGX], nOvf = hdr[H_NOVF];
+    const uint64_t partA = all ? nx * ny : nIrrX * ny; // (irregular row) x (every column)
+    const uint64_t partB = all ? 0 : nRegX * nIrrY;    // (regular row) x (irregular column)
+    const uint64_t partC = all ? 0 : nOvf * ny;        // (overflowed row) x (every column)
+    const uint64_t total = partA + partB + partC;
+    for (uint64_t p = (uint64_t)blockIdx.x * THREADS + threadIdx.x; p < total; p += (uint64_t)gridDim.x * THREADS) {
+        uint64_t i, j;
+        if (p < partA) {
+            const uint64_t r = p / ny;
+            j = p - r * ny;
+            i = all ? r : irrX[r];
+        } else if (p < partA + partB) {
+            const uint64_t q = p - partA;
+            const uint64_t r = q / nIrrY;
+            i = regX[r];
+            j = irrY[q - r * nIrrY];
+        } else {
+            const uint64_t q = p - partA - partB;
+            const uint64_t r = q / ny;
+            i = ovfX[r];
+            j = q - r * ny;
+        }
+        counts[i * ld + j] = (uint16_t)similarity_count(X + i * sx, sx, Y + j * sy, sy);
+    }
+}
+
+// mash.go:134,139: 1 - float64(same)/float64(smaller.SketchSize)
+__global__ __launch_bounds__(THREADS) void distance_kernel(const uint16_t *__restrict__ counts, uint64_t nx,
+                                                          uint64_t ny, uint64_t ldc, double smaller,
+                                                          double *__restrict__ dist, uint64_t ldd)
+{
+    const uint64_t total = nx * ny;
+    for (uint64_t p = (uint64_t)blockIdx.x * THREADS + threadIdx.x; p < total; p += (uint64_t)gridDim.x * THREADS) {
+        const uint64_t i = p / ny, j = p - i * ny;
+        dist[i * ldd + j] = 1 - (double)counts[i * ldc + j] / smaller;
+    }
+}
+
+} // namespace k2
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+size_t polyhip_mash_shared_counts_workspace_bytes(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
+{
+    return k2::layout(nx, sx, ny, sy).total;
+}
+
+int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
+                                   uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
+                                   polyhip_stream_t stream)
+{
+    if (sx == 0 || sy == 0)
+        return set_error(POLYHIP_ERR_PANIC,
+                         "mash.Similarity with SketchSize 0 indexes Sketches[-1] (mash.go:117): the reference panics");
+    PH_REQUIRE(sx <= 65535 && sy <= 65535, "polyhip_mash_shared_counts: SketchSize > 65535 does not fit the u16 counts");
+    if (nx == 0 || ny == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_X && d_Y && d_counts && d_work, "polyhip_mash_shared_counts: null pointer");
+    PH_REQUIRE(ld >= ny, "polyhip_mash_shared_counts: row stride %llu < ny %llu", (unsigned long long)ld,
+               (unsigned long long)ny);
+    PH_REQUIRE(nx < (1ull << 31) && ny < (1ull << 31) && ny * (uint64_t)sy < (1ull << 32),
+               "polyhip_mash_shared_counts: more than 2^31 sketches or 2^32 Y hashes in one call (split it)");
+    const k2::Layout L = k2::layout(nx, sx, ny, sy);
+    PH_REQUIRE(work_bytes >= L.total, "polyhip_mash_shared_counts: workspace too small (%zu < %zu)", work_bytes, L.total);
+    hipStream_t st = as_stream(stream);
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(w);
+    uint8_t *flagsX = w + L.off_flagsX, *flagsY = w + L.off_flagsY;
+    uint32_t *irrX = reinterpret_cast<uint32_t *>(w + L.off_irrX), *regX = reinterpret_cast<uint32_t *>(w + L.off_regX),
+             *ovfX = reinterpret_cast<uint32_t *>(w + L.off_ovfX), *irrY = reinterpret_cast<uint32_t *>(w + L.off_irrY);
+    uint32_t *start = reinterpret_cast<uint32_t *>(w + L.off_start), *cur = reinterpret_cast<uint32_t *>(w + L.off_cur),
+             *bsum = reinterpret_cast<uint32_t *>(w + L.off_bsum);
+    uint2 *items = reinterpret_cast<uint2 *>(w + L.off_items);
+
+    // header, flags and the histogram start at zero; so do the counts (rowjoin stores only non-zero cells)
+    PH_HIP(hipMemsetAsync(w, 0, L.off_irrX, st));
+    PH_HIP(hipMemsetAsync(start, 0, ((size_t)L.nbk + 1) * 4, st));
+    if (ld == ny) {
+        PH_HIP(hipMemsetAsync(d_counts, 0, nx * ny * 2, st));
+    } else {
+        PH_HIP(hipMemset2DAsync(d_counts, ld * 2, 0, ny * 2, nx, st));
+    }
+
+    // the join packs the Y sketch id into 24 bits and stages an X row in LDS
+    const int force = (ny > k2::ID_MASK + 1ull || sx > k2::S_MAX) ? 1 : 0;
+    const unsigned gx = (unsigned)nx, gy = (unsigned)ny; // one block per sketch
+    hipLaunchKernelGGL(k2::check_kernel, dim3(gx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0);
+    hipLaunchKernelGGL(k2::check_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1);
+    uint32_t nbk_log2 = 0;
+    while ((1u << nbk_log2) < L.nbk)
+        ++nbk_log2;
+    const uint64_t nmax = std::max(nx, ny);
+    hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nmax + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
+                       flagsX, nx, flagsY, ny, irrX, regX, irrY, hdr, nbk_log2);
+    hipLaunchKernelGGL(k2::hist_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, start);
+    // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
+    // value with its whole bucket: about (nx*sx/(ny*sy)) * sum_b cntY_b^2 compares when X is
+    // distributed like Y (exact for the all-vs-all).  The join only loses on huge buckets.
+    const double est_scale = ((double)nx * sx) / ((double)ny * sy);
+    const double generic_cost = (double)nx * (double)ny * (double)(sx + sy) * 4.0;
+    hipLaunchKernelGGL(k2::scan_sums_kernel, dim3(L.nscan), dim3(k2::THREADS), 0, st, start, bsum, hdr);
+    hipLaunchKernelGGL(k2::scan_top_kernel, dim3(1), dim3(1024), 0, st, bsum, L.nscan, start, L.nbk, hdr, est_scale,
+                       generic_cost);
+    hipLaunchKernelGGL(k2::scan_chunks_kernel, dim3(L.nscan), dim3(k2::THREADS), 0, st, start, cur, bsum);
+    hipLaunchKernelGGL(k2::scatter_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, cur, items);
+    if (!force) {
+        const size_t smem = (size_t)sx * 20;
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull * 16ull);
+        hipLaunchKernelGGL(k2::rowjoin_kernel, dim3(blocks), dim3(k2::THREADS), smem, st, d_X, nx, sx, flagsX, start, items,
+                           L.nbk, hdr, ovfX, d_counts, ld);
+    }
+    {
+        const uint64_t pairs = nx * ny;
+        const unsigned blocks = (unsigned)std::min<uint64_t>((pairs + k2::THREADS - 1) / k2::THREADS, 256ull * 16ull);
+        hipLaunchKernelGGL(k2::generic_kernel, dim3(blocks), dim3(k2::THREADS), 0, st, d_X, nx, sx, d_Y, ny, sy, hdr, irrX,
+                           regX, irrY, ovfX, d_counts, ld);
+    }
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_shared_counts_mode_dev(const void *d_work, uint32_t *mode, uint32_t *n_irregular_x,
+                                        uint32_t *n_irregular_y, uint32_t *n_overflow_rows, uint64_t *join_estimate)
+{
+    PH_REQUIRE(d_work, "polyhip_mash_shared_counts_mode: null workspace");
+    uint32_t h[k2::H_WORDS];
+    PH_HIP(hipMemcpy(h, d_work, sizeof h, hipMemcpyDeviceToHost));
+    if (mode)
+        *mode = h[k2::H_MODE];
+    if (n_irregular_x)
+        *n_irregular_x = h[k2::H_NIRRX];
+    if (n_irregular_y)
+        *n_irregular_y = h[k2::H_NIRRY];
+    if (n_overflow_rows)
+        *n_overflow_rows = h[k2::H_NOVF];
+    if (join_estimate)
+        *join_estimate = (uint64_t)h[k2::H_EST_LO] | ((uint64_t)h[k2::H_EST_HI] << 32);
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts, uint64_t nx, uint64_t ny, uint64_t ld_counts,
+                                          uint32_t sx, uint32_t sy, double *d_dist, uint64_t ld_dist,
+                                          polyhip_stream_t stream)
+{
+    if (sx == 0 || sy == 0)
+        return set_error(POLYHIP_ERR_PANIC, "mash.Distance with SketchSize 0: the reference panics (mash.go:117)");
+    if (nx == 0 || ny == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_counts && d_dist, "polyhip_mash_distance_from_counts: null pointer");
+    PH_REQUIRE(ld_counts >= ny && ld_dist >= ny, "polyhip_mash_distance_from_counts: row stride < ny");
+    const uint64_t pairs = nx * ny;
+    const unsigned blocks = (unsigned)std::min<uint64_t>((pairs + k2::THREADS - 1) / k2::THREADS, 256ull * 32ull);
+    hipLaunchKernelGGL(k2::distance_kernel, dim3(blocks), dim3(k2::THREADS), 0, as_stream(stream), d_counts, nx, ny,
+                       ld_counts, (double)std::min(sx, sy), d_dist, ld_dist);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,
+                                 uint16_t *counts, double *dist)
+{
+    if (sx == 0 || sy == 0)
+        return polyhip_mash_shared_counts_dev(nullptr, nx, sx, nullptr, ny, sy, nullptr, 0, nullptr, 0, nullptr);
+    if (nx == 0 || ny == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(X && Y && (counts || dist), "polyhip_mash_distance_matrix: null pointer");
+    DevBuf dX, dY, dC, dD, dW;
+    PH_HIP(dX.alloc(nx * (size_t)sx * 4));
+    PH_HIP(dY.alloc(ny * (size_t)sy * 4));
+    PH_HIP(dC.alloc(nx * ny * 2 + 16));
+    const size_t wb = polyhip_mash_shared_counts_workspace_bytes(nx, sx, ny, sy);
+    PH_HIP(dW.alloc(wb));
+    PH_HIP(hipMemcpy(dX.p, X, nx * (size_t)sx * 4, hipMemcpyHostToDevice));
+    PH_HIP(hipMemcpy(dY.p, Y, ny * (size_t)sy * 4, hipMemcpyHostToDevice));
+    int rc = polyhip_mash_shared_counts_dev(dX.as<uint32_t>(), nx, sx, dY.as<uint32_t>(), ny, sy, dC.as<uint16_t>(), ny, dW.p,
+                                            wb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    if (dist) {
+        PH_HIP(dD.alloc(nx * ny * 8));
+        rc = polyhip_mash_distance_from_counts_dev(dC.as<uint16_t>(), nx, ny, ny, sx, sy, dD.as<double>(), ny, nullptr);
+        if (rc != POLYHIP_OK)
+            return rc;
+    }
+    PH_HIP(hipStreamSynchronize(nullptr));
+    if (counts)
+        PH_HIP(hipMemcpy(counts, dC.p, nx * ny * 2, hipMemcpyDeviceToHost));
+    if (dist)
+        PH_HIP(hipMemcpy(dist, dD.p, nx * ny * 8, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

@@ -89,3 +89,80 @@ def synth_dna_dev(seed: int, out_t, first: int = 0, stream=None) -> None:
     assert out_t.is_cuda and out_t.is_contiguous() and out_t.element_size() == 1
     _lib.check(_lib.lib().polyhip_synth_dna_dev(seed & 0xFFFFFFFFFFFFFFFF, first, out_t.data_ptr(),
                                                 out_t.numel(), _lib.stream_ptr(stream)))
+
+
+# ---- K2: Similarity / Distance (mash.go:107-140) ------------------------------------
+
+def distance_matrix_packed(X: np.ndarray, Y: np.ndarray, want_counts: bool = True, want_dist: bool = True):
+    """Host-pointer entry point: X (nx, sx) and Y (ny, sy) uint32 sketches ->
+    (counts uint16 (nx, ny) | None, dist float64 (nx, ny) | None); receiver = X row."""
+    X = np.ascontiguousarray(X, dtype=np.uint32)
+    Y = np.ascontiguousarray(Y, dtype=np.uint32)
+    nx, sx = X.shape
+    ny, sy = Y.shape
+    counts = np.zeros((nx, ny), dtype=np.uint16) if want_counts else None
+    dist = np.zeros((nx, ny), dtype=np.float64) if want_dist else None
+    _lib.check(_lib.lib().polyhip_mash_distance_matrix(
+        X.ctypes.data, nx, sx, Y.ctypes.data, ny, sy,
+        counts.ctypes.data if counts is not None else None, dist.ctypes.data if dist is not None else None))
+    return counts, dist
+
+
+def _similarity(self: "Mash", other: "Mash") -> float:
+    """mash.go:107-135"""
+    if self.SketchSize == 0 or other.SketchSize == 0:
+        raise _lib.GoPanic(_lib.ERR_PANIC, "index out of range [-1] (mash.go:117)")
+    counts, _ = distance_matrix_packed(self.Sketches.reshape(1, -1), other.Sketches.reshape(1, -1), True, False)
+    return float(counts[0, 0]) / float(min(self.SketchSize, other.SketchSize))
+
+
+def _distance(self: "Mash", other: "Mash") -> float:
+    """mash.go:138-140"""
+    _, dist = distance_matrix_packed(self.Sketches.reshape(1, -1), other.Sketches.reshape(1, -1), False, True)
+    return float(dist[0, 0])
+
+
+Mash.Similarity = _similarity
+Mash.Distance = _distance
+
+
+def DistanceMatrix(sketches: list[Mash]) -> np.ndarray:
+    """Additive batch API: dist[i][j] = sketches[i].Distance(sketches[j]); one SketchSize."""
+    S = np.stack([m.Sketches for m in sketches]).astype(np.uint32)
+    return distance_matrix_packed(S, S, False, True)[1]
+
+
+def shared_counts_workspace_bytes(nx: int, sx: int, ny: int, sy: int) -> int:
+    return int(_lib.lib().polyhip_mash_shared_counts_workspace_bytes(nx, sx, ny, sy))
+
+
+def shared_counts_dev(X_t, Y_t, counts_t, work_t, stream=None) -> None:
+    """Device-resident K2 on torch CUDA tensors: X (nx, sx) / Y (ny, sy) int32|uint32,
+    counts (nx, ld >= ny) int16|uint16, work uint8[shared_counts_workspace_bytes]."""
+    nx, sx = X_t.shape
+    ny, sy = Y_t.shape
+    assert X_t.is_cuda and Y_t.is_cuda and counts_t.is_cuda and work_t.is_cuda
+    assert X_t.is_contiguous() and Y_t.is_contiguous() and X_t.element_size() == 4 and Y_t.element_size() == 4
+    assert counts_t.element_size() == 2 and counts_t.shape[0] == nx and counts_t.stride(1) == 1
+    ld = counts_t.stride(0)
+    _lib.check(_lib.lib().polyhip_mash_shared_counts_dev(
+        X_t.data_ptr(), nx, sx, Y_t.data_ptr(), ny, sy, counts_t.data_ptr(), ld,
+        work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
+def shared_counts_mode(work_t):
+    """(mode, irregular X, irregular Y, overflow rows, index self-join size) of the last
+    shared_counts_dev on this workspace."""
+    import ctypes as C
+    m, ix, iy, ov, est = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    _lib.check(_lib.lib().polyhip_mash_shared_counts_mode_dev(work_t.data_ptr(), C.addressof(m), C.addressof(ix),
+                                                             C.addressof(iy), C.addressof(ov), C.addressof(est)))
+    return m.value, ix.value, iy.value, ov.value, est.value
+
+
+def distance_from_counts_dev(counts_t, sx: int, sy: int, dist_t, stream=None) -> None:
+    nx, ny = counts_t.shape
+    assert counts_t.is_cuda and dist_t.is_cuda and dist_t.element_size() == 8 and dist_t.shape == counts_t.shape
+    _lib.check(_lib.lib().polyhip_mash_distance_from_counts_dev(
+        counts_t.data_ptr(), nx, ny, counts_t.stride(0), sx, sy, dist_t.data_ptr(), dist_t.stride(0),
+        _lib.stream_ptr(stream)))

@@ -1,0 +1,190 @@
+"""K2 parity: poly_amd.mash Similarity / Distance / distance matrix (HIP, through
+the C ABI) vs the CPU oracle's restatement of mash.go:107-140.  Counts are
+integers and must be identical; distances are one fp64 divide + subtract and must
+be bit-identical.
+
+Mirrors search/mash/mash_test.go:9-62 and example_test.go where the reference has a test."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+S62 = "ATGCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA"
+S62B = "ATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGAT"[:62]
+
+
+@pytest.fixture(scope="module")
+def mash():
+    from poly_amd import mash
+    return mash
+
+
+def _oracle_counts(X, Y):
+    out = np.zeros((len(X), len(Y)), np.uint16)
+    for i, x in enumerate(X):
+        for j, y in enumerate(Y):
+            out[i, j] = orc.mash_shared(x, y)
+    return out
+
+
+def _oracle_dist(X, Y):
+    out = np.zeros((len(X), len(Y)), np.float64)
+    for i, x in enumerate(X):
+        for j, y in enumerate(Y):
+            out[i, j] = orc.lib().orc_mash_distance(x.ctypes.data, len(x), y.ctypes.data, len(y))
+    return out
+
+
+def test_TestMash(mash):
+    """search/mash/mash_test.go:9-62"""
+    f1 = mash.New(17, 10)
+    f1.Sketch(S62)
+    f2 = mash.New(17, 9)
+    f2.Sketch(S62)
+    assert f1.Distance(f2) == 0
+    assert f2.Distance(f1) == 0
+    spoofed = mash.New(17, 10)
+    spoofed.Sketches[0] = 0  # already zero-filled: mash_test.go:26-39
+    assert spoofed.Distance(f1) == 1
+    assert f1.Distance(spoofed) == 1
+    f3 = mash.New(17, 10)
+    f3.Sketch("ATGCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA")
+    f4 = mash.New(17, 5)
+    f4.Sketch("ATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGAT")
+    # against the oracle on the same sketches (the reference accepts (0.19, 0.21))
+    for a, b in ((f3, f4), (f4, f3), (f1, f4), (f4, f2)):
+        want = orc.lib().orc_mash_distance(a.Sketches.ctypes.data, a.SketchSize, b.Sketches.ctypes.data, b.SketchSize)
+        assert a.Distance(b) == want
+        assert a.Similarity(b) == 1 - want or abs(a.Similarity(b) - (1 - want)) < 1e-15
+
+
+def test_example(mash):
+    """search/mash/example_test.go:9-22 prints 0"""
+    a = mash.New(17, 10)
+    a.Sketch("ATGCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA")
+    b = mash.New(17, 9)
+    b.Sketch("ATGCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGA")
+    assert a.Distance(b) == 0
+
+
+def _families(rng, nfam, copies, L, sub, k, s):
+    """SURVEY 8d C3 generator in miniature: families of mutated copies, sketched by the oracle."""
+    seqs = []
+    for _ in range(nfam):
+        g = rng.choice(list(b"ACGT"), L).astype(np.uint8)
+        for _ in range(copies):
+            m = g.copy()
+            hit = rng.random(L) < sub
+            m[hit] = rng.choice(list(b"ACGT"), int(hit.sum())).astype(np.uint8)
+            seqs.append(m.tobytes())
+    buf = np.frombuffer(b"".join(seqs), np.uint8)
+    offs = np.arange(0, (len(seqs) + 1) * L, L, dtype=np.uint64)
+    return orc.mash_sketch_batch(buf, offs, k, s)
+
+
+def test_allvsall_families_join_path(mash):
+    rng = np.random.default_rng(3)
+    S = _families(rng, 6, 8, 1500, 0.01, 21, 200)
+    counts, dist = mash.distance_matrix_packed(S, S)
+    want = _oracle_counts(S, S)
+    assert (counts == want).all()
+    assert (counts.diagonal() == 200).all() and counts.max() == 200 and (counts == 0).any()
+    assert (dist.view(np.uint64) == _oracle_dist(S, S).view(np.uint64)).all()
+
+
+def test_duplicates_and_different_sizes(mash):
+    """multiset semantics of the merge: a value a times in X and b times in Y counts min(a,b)"""
+    rng = np.random.default_rng(5)
+    X = np.sort(rng.integers(0, 40, (30, 64), dtype=np.uint32), axis=1)   # heavy duplication
+    Y = np.sort(rng.integers(0, 40, (25, 48), dtype=np.uint32), axis=1)
+    counts, dist = mash.distance_matrix_packed(X, Y)
+    assert (counts == _oracle_counts(X, Y)).all()
+    assert (dist.view(np.uint64) == _oracle_dist(X, Y).view(np.uint64)).all()
+    # hundreds of equal values in one sketch
+    X2 = np.sort(rng.integers(0, 3, (4, 900), dtype=np.uint32), axis=1)
+    counts2, _ = mash.distance_matrix_packed(X2, X2, True, False)
+    assert (counts2 == _oracle_counts(X2, X2)).all()
+
+
+def test_irregular_sketches_use_reference_loop(mash):
+    """positional / unsorted / zero-padded sketches (mash.go:81-84) mixed with regular ones"""
+    import torch
+    rng = np.random.default_rng(9)
+    S = np.sort(rng.integers(0, 1 << 30, (40, 100), dtype=np.uint32), axis=1)
+    S[5, :50] = S[6, :50]                                        # two related sketches
+    S[5].sort(); S[6].sort()
+    S[3] = rng.integers(0, 1 << 30, 100, dtype=np.uint32)       # unsorted
+    S[17, 60:] = 0                                               # short sequence: zero tail
+    S[29] = 0                                                    # mash.New, never sketched
+    want = _oracle_counts(S, S)
+    counts, _ = mash.distance_matrix_packed(S, S, True, False)
+    assert (counts == want).all()
+    dev = torch.device("cuda:0")
+    St = torch.from_numpy(S.view(np.int32)).to(dev)
+    ct = torch.full((40, 48), -1, dtype=torch.int16, device=dev)[:, :40]  # ld 48 > ny
+    work = torch.empty(mash.shared_counts_workspace_bytes(40, 100, 40, 100), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(St, St, ct, work)
+    torch.cuda.synchronize()
+    assert (ct.cpu().numpy().view(np.uint16) == want).all()
+    mode, ix, iy, ovf, est = mash.shared_counts_mode(work)
+    assert (mode, ix, iy, ovf) == (0, 2, 2, 0) and est > 0  # row 29 (all zero) is ascending
+
+
+def test_dense_input_falls_back_to_merge(mash):
+    """many identical sketches: the join estimate exceeds the merge cost -> generic mode, same answer"""
+    import torch
+    S = np.full((600, 64), 0x096698DE, dtype=np.uint32)  # like the TestMash sketches: one repeated hash
+    S[::7, 60:] = 0x0A000000
+    S[::5, 0] = 5
+    dev = torch.device("cuda:0")
+    St = torch.from_numpy(S.view(np.int32)).to(dev)
+    ct = torch.zeros((600, 600), dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(600, 64, 600, 64), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(St, St, ct, work)
+    torch.cuda.synchronize()
+    assert mash.shared_counts_mode(work)[0] == 1
+    assert (ct.cpu().numpy().view(np.uint16) == _oracle_counts(S, S)).all()
+
+
+def test_row_block_equals_whole(mash):
+    """the multi-GPU partition: row blocks against all columns stack to the full matrix"""
+    rng = np.random.default_rng(11)
+    S = _families(rng, 5, 6, 1200, 0.02, 21, 150)
+    whole, _ = mash.distance_matrix_packed(S, S, True, False)
+    from poly_amd.sharding import shard_range
+    for world in (2, 3):
+        rows = []
+        for r in range(world):
+            lo, hi = shard_range(len(S), r, world)
+            rows.append(mash.distance_matrix_packed(S[lo:hi], S, True, False)[0])
+        assert (np.vstack(rows) == whole).all()
+
+
+def test_errors(mash):
+    from poly_amd import _lib
+    with pytest.raises(_lib.GoPanic):
+        mash.New(17, 0).Distance(mash.New(17, 5))
+
+
+def test_rows_with_many_relatives_overflow_to_merge(mash):
+    """a row related to more sketches than the join's LDS table holds is merged instead"""
+    import torch
+    rng = np.random.default_rng(13)
+    base = np.sort(rng.choice(1 << 31, 64, replace=False).astype(np.uint32))
+    S = np.sort(rng.integers(0, 1 << 31, (2400, 64), dtype=np.uint32), axis=1)
+    S[:2000, :8] = base[:8]          # 2000 sketches share 8 hashes
+    S = np.sort(S, axis=1)
+    dev = torch.device("cuda:0")
+    St = torch.from_numpy(S.view(np.int32)).to(dev)
+    ct = torch.zeros((2400, 2400), dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(2400, 64, 2400, 64), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(St, St, ct, work)
+    torch.cuda.synchronize()
+    mode, ix, iy, ovf, est = mash.shared_counts_mode(work)
+    assert mode == 0 and ovf >= 2000
+    got = ct.cpu().numpy().view(np.uint16)
+    rows = list(range(0, 2400, 97)) + [1999, 2000, 2399]
+    for i in rows:
+        assert (got[i] == _oracle_counts(S[i:i + 1], S)[0]).all()
