@@ -195,6 +195,41 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A,
                      const uint64_t *offA, uint64_t npairs, const uint8_t *B,
                      const uint64_t *offB, uint64_t lenB, int64_t *score,
                      uint32_t *endA, uint32_t *endB, uint32_t *err);
+/*
+ * Traceback of SmithWaterman (align.go:205-229) for the same batch, from the
+ * score pass's outputs: walk back from (endA, endB) while H > 0 preferring
+ * diagonal, then up (alignB gets '-'), then left (alignA gets '-').
+ * Pair p's strings are the LAST d_alnLen[p] bytes of its aln_stride-byte slots:
+ *     alignA_p = d_alnA[p*aln_stride + aln_stride - len .. p*aln_stride + aln_stride)
+ * (the reference builds them by prepending).  Pairs with err != 0 or score 0
+ * get length 0, as the reference returns "".
+ * aln_stride >= polyhip_sw_traceback_stride(sc, max_lenA, lenB).
+ * d_work: any size >= 256 pairs' worth; polyhip_sw_traceback_workspace_bytes
+ * returns enough for all pairs at once (capped at 8 GiB); smaller workspaces
+ * make the call loop over chunks of pairs.
+ */
+uint32_t polyhip_sw_traceback_stride(const polyhip_scoring *sc,
+                                     uint32_t max_lenA, uint64_t lenB);
+size_t polyhip_sw_traceback_workspace_bytes(const polyhip_scoring *sc,
+                                            uint64_t npairs, uint32_t max_lenA,
+                                            uint64_t lenB);
+int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A,
+                             const uint64_t *d_offA, uint64_t npairs,
+                             uint32_t max_lenA, const uint8_t *d_B,
+                             const uint64_t *d_offB, uint64_t lenB,
+                             const uint32_t *d_endA, const uint32_t *d_endB,
+                             const uint32_t *d_err, uint8_t *d_alnA,
+                             uint8_t *d_alnB, uint32_t *d_alnLen,
+                             uint32_t aln_stride, void *d_work,
+                             size_t work_bytes, polyhip_stream_t stream);
+/* Host-pointer flavour of the whole SmithWaterman: score pass + traceback. */
+int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
+                           const uint64_t *offA, uint64_t npairs,
+                           const uint8_t *B, const uint64_t *offB,
+                           uint64_t lenB, int64_t *score, uint32_t *endA,
+                           uint32_t *endB, uint32_t *err, uint8_t *alnA,
+                           uint8_t *alnB, uint32_t *alnLen,
+                           uint32_t aln_stride);
 /* which kernel family the last polyhip_sw_batch*_dev call on this thread
  * used: 1 = register-tiled shared-B kernel, 2 = generic kernel (tests). */
 int polyhip_sw_last_path(void);

@@ -48,6 +48,11 @@ SIGNATURES = {
                                        C.c_size_t, _vp]),
     "polyhip_sw_batch": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "polyhip_sw_last_path": (C.c_int, []),
+    "polyhip_sw_traceback_stride": (C.c_uint32, [_vp, _u32, _u64]),
+    "polyhip_sw_traceback_workspace_bytes": (C.c_size_t, [_vp, _u64, _u32, _u64]),
+    "polyhip_sw_traceback_dev": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
+                                           _vp, C.c_size_t, _vp]),
+    "polyhip_sw_align_batch": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32]),
     "polyhip_santalucia_scan_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp,
                                               _u64, _vp]),
     "polyhip_santalucia_scan": (C.c_int, [_vp, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp]),

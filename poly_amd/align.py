@@ -127,3 +127,79 @@ def sw_batch_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, lenB
 
 def last_path() -> int:
     return int(_lib.lib().polyhip_sw_last_path())
+
+
+# ---- full SmithWaterman: score pass + traceback (align.go:171-232) -------------------
+
+def sw_align_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.ndarray,
+                    offB: np.ndarray | None = None):
+    """Host-pointer entry point: (score, endA, endB, err, alignA list[bytes], alignB list[bytes])."""
+    n = len(offA) - 1
+    A = np.ascontiguousarray(A, dtype=np.uint8)
+    B = np.ascontiguousarray(B, dtype=np.uint8)
+    offA = np.ascontiguousarray(offA, dtype=np.uint64)
+    if offB is not None:
+        offB = np.ascontiguousarray(offB, dtype=np.uint64)
+    lensA = np.diff(offA.astype(np.int64))
+    max_lenA = int(lensA.max()) if n else 0
+    lenB = len(B) if offB is None else (int(np.diff(offB.astype(np.int64)).max()) if n else 0)
+    stride = int(_lib.lib().polyhip_sw_traceback_stride(scoring.handle(), max_lenA, lenB))
+    score = np.zeros(n, dtype=np.int64)
+    endA = np.zeros(n, dtype=np.uint32)
+    endB = np.zeros(n, dtype=np.uint32)
+    err = np.zeros(n, dtype=np.uint32)
+    alnA = np.zeros((n, stride), dtype=np.uint8)
+    alnB = np.zeros((n, stride), dtype=np.uint8)
+    alen = np.zeros(n, dtype=np.uint32)
+    _lib.check(_lib.lib().polyhip_sw_align_batch(
+        scoring.handle(), A.ctypes.data, offA.ctypes.data, n, B.ctypes.data,
+        offB.ctypes.data if offB is not None else None, len(B) if offB is None else 0,
+        score.ctypes.data, endA.ctypes.data, endB.ctypes.data, err.ctypes.data,
+        alnA.ctypes.data, alnB.ctypes.data, alen.ctypes.data, stride))
+    sa = [alnA[p, stride - int(alen[p]):].tobytes() for p in range(n)]
+    sb = [alnB[p, stride - int(alen[p]):].tobytes() for p in range(n)]
+    return score, endA, endB, err, sa, sb
+
+
+def SmithWaterman(stringA, stringB, scoring: Scoring):
+    """align.go:171-232 -> (score, alignA, alignB); raises alphabet.Error like the reference's err."""
+    A, offA = _pack([stringA])
+    B, _ = _pack([stringB])
+    score, _, _, err, sa, sb = sw_align_packed(scoring, A, offA, B, None)
+    if err[0]:
+        _raise_symbol(int(err[0]))
+    return int(score[0]), sa[0].decode("latin-1"), sb[0].decode("latin-1")
+
+
+def SmithWatermanBatch(reads, ref, scoring: Scoring):
+    """Additive batch API: every read against one shared reference ->
+    list of (score, alignA, alignB) or alphabet.Error instances."""
+    A, offA = _pack(reads)
+    B, _ = _pack([ref])
+    score, _, _, err, sa, sb = sw_align_packed(scoring, A, offA, B, None)
+    out = []
+    for p in range(len(reads)):
+        if err[p]:
+            out.append(alphabet.Error(f"Symbol {chr(int(err[p]) & 0xFF)} not in alphabet"))
+        else:
+            out.append((int(score[p]), sa[p].decode("latin-1"), sb[p].decode("latin-1")))
+    return out
+
+
+def sw_traceback_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, lenB: int, endA_t, endB_t, err_t,
+                     alnA_t, alnB_t, alnLen_t, work_t, stream=None) -> None:
+    """Device-resident traceback on torch CUDA tensors (alnA/alnB: (n, stride) uint8)."""
+    n = offA_t.numel() - 1
+    _lib.check(_lib.lib().polyhip_sw_traceback_dev(
+        scoring.handle(), A_t.data_ptr(), offA_t.data_ptr(), n, max_lenA, B_t.data_ptr(),
+        offB_t.data_ptr() if offB_t is not None else None, lenB, endA_t.data_ptr(), endB_t.data_ptr(),
+        err_t.data_ptr(), alnA_t.data_ptr(), alnB_t.data_ptr(), alnLen_t.data_ptr(), alnA_t.shape[1],
+        work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
+def sw_traceback_stride(scoring: Scoring, max_lenA: int, lenB: int) -> int:
+    return int(_lib.lib().polyhip_sw_traceback_stride(scoring.handle(), max_lenA, lenB))
+
+
+def sw_traceback_workspace_bytes(scoring: Scoring, npairs: int, max_lenA: int, lenB: int) -> int:
+    return int(_lib.lib().polyhip_sw_traceback_workspace_bytes(scoring.handle(), npairs, max_lenA, lenB))

@@ -38,23 +38,7 @@
 
 #include "common.h"
 
-struct polyhip_scoring {
-    int64_t gap;
-    int32_t lut[65536];
-    uint8_t validA[256], validB[256];
-    int ncodes;          // valid A symbols
-    uint8_t codeA[256];  // byte -> code, 0xFF = not in FirstAlphabet
-    int cp;              // profile bytes per column (>= ncodes + 1, multiple of 4)
-    int32_t smin, smax;  // over valid (a, b) pairs
-    int32_t absmax;      // max(|smin|, |smax|, |gap|)
-    bool int8_ok;
-    int device;
-    // device tables
-    int8_t *d_lutc;      // [ncodes][256] int8 (only if int8_ok)
-    uint8_t *d_codeA;    // [256]
-    int32_t *d_lut;      // [256][256]
-    uint8_t *d_validA, *d_validB;
-};
+#include "sw_scoring.h"
 
 namespace polyhip {
 namespace k3 {
@@ -416,6 +400,14 @@ int polyhip_scoring_create(const int32_t *lut, const uint8_t *validA, const uint
             symA[sc->ncodes] = (uint8_t)a;
             sc->codeA[a] = (uint8_t)sc->ncodes++;
         }
+    sc->ncodesB = 0;
+    memset(sc->codeB, 0xFF, 256);
+    uint8_t symB[128];
+    for (int b = 0; b < 128; ++b)
+        if (sc->validB[b]) {
+            symB[sc->ncodesB] = (uint8_t)b;
+            sc->codeB[b] = (uint8_t)sc->ncodesB++;
+        }
     sc->cp = (sc->ncodes + 1 + 3) & ~3;
     sc->smin = 0;
     sc->smax = 0;
@@ -438,6 +430,8 @@ int polyhip_scoring_create(const int32_t *lut, const uint8_t *validA, const uint
     sc->absmax = (int32_t)am;
     sc->int8_ok = sc->smin >= -127 && sc->smax <= 127; // -128 is the pad marker
     sc->d_lutc = nullptr;
+    sc->d_codeB = nullptr;
+    sc->d_lutcc = nullptr;
     sc->d_codeA = nullptr;
     sc->d_lut = nullptr;
     sc->d_validA = sc->d_validB = nullptr;
@@ -465,6 +459,21 @@ int polyhip_scoring_create(const int32_t *lut, const uint8_t *validA, const uint
         return fail(e, "hipMemcpy");
     if ((e = hipMemcpy(sc->d_validB, sc->validB, 256, hipMemcpyHostToDevice)) != hipSuccess)
         return fail(e, "hipMemcpy");
+    {
+        const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+        std::vector<int32_t> cc((size_t)na * nb, 0);
+        for (int a = 0; a < sc->ncodes; ++a)
+            for (int b = 0; b < sc->ncodesB; ++b)
+                cc[(size_t)a * nb + b] = lut[symA[a] * 256 + symB[b]];
+        if ((e = hipMalloc(&sc->d_codeB, 256)) != hipSuccess)
+            return fail(e, "hipMalloc");
+        if ((e = hipMemcpy(sc->d_codeB, sc->codeB, 256, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(e, "hipMemcpy");
+        if ((e = hipMalloc(&sc->d_lutcc, cc.size() * 4)) != hipSuccess)
+            return fail(e, "hipMalloc");
+        if ((e = hipMemcpy(sc->d_lutcc, cc.data(), cc.size() * 4, hipMemcpyHostToDevice)) != hipSuccess)
+            return fail(e, "hipMemcpy");
+    }
     if (sc->int8_ok && sc->ncodes > 0) {
         std::vector<int8_t> lutc((size_t)sc->ncodes * 256);
         for (int c = 0; c < sc->ncodes; ++c)
@@ -484,6 +493,8 @@ int polyhip_scoring_destroy(polyhip_scoring *sc)
     if (!sc)
         return POLYHIP_OK;
     (void)hipFree(sc->d_lutc);
+    (void)hipFree(sc->d_codeB);
+    (void)hipFree(sc->d_lutcc);
     (void)hipFree(sc->d_codeA);
     (void)hipFree(sc->d_lut);
     (void)hipFree(sc->d_validA);

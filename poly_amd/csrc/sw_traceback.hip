@@ -1,0 +1,453 @@
+// sw_traceback.hip -- K3b: the traceback half of align.SmithWaterman for gfx950.
+//
+// Replaces search/align/align.go:205-229: starting from the score pass's argmax
+// (endA, endB) walk back while H > 0, preferring the diagonal, then "up" (gap in
+// B, alignB gets '-'), then "left" (gap in A), and return the two aligned strings.
+//
+// The reference keeps the whole (m+1) x (n+1) int matrix (6 MB for 150 x 5000).
+// Here the score pass (sw_batch.hip) keeps nothing; the traceback re-runs the
+// recurrence on a WINDOW of columns that ends at endB and stores 2 bits per
+// cell (0 = H is 0, 1 = diag, 2 = up, 3 = left -- the first equality the
+// reference's if-chain would hit), then walks the bits.
+//
+// Why a window is exact (gap < 0): a cell with H > 0 is the end of a path whose
+// score is positive; it has at most lenA diagonal/up moves and, because every
+// left move costs |gap| out of at most smax per diagonal move, fewer than
+// smax * lenA / |gap| left moves.  So no positive path spans more than
+//     W = lenA + floor(smax * lenA / |gap|)
+// columns: H[.][j] computed from a zero boundary at column j - W - 1 equals the
+// true H[.][j].  The walk itself is such a path (<= W columns back from endB) and
+// reads neighbours one column further, so a DP that starts at endB - 2W - 1 has
+// exact values everywhere the walk looks.  With gap >= 0 (or no positive score)
+// the window is the whole of B.  BASELINE config 4: W = 150 + 5*150/2 = 525, the
+// window is 1052 of the 5000 columns.
+//
+// One pair per lane, H column in registers (RA rows) like the score pass; the
+// direction words are written lane-interleaved (a wave stores 256 contiguous
+// bytes per word) into the caller's workspace, which bounds how many pairs one
+// launch covers (~42 KB per pair at config 4; the entry point loops over chunks).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+#include "sw_scoring.h"
+
+namespace polyhip {
+namespace k3t {
+
+constexpr int THREADS = 256;
+
+struct Window {
+    uint32_t wcols;   // columns of the re-run DP (<= lenB)
+    uint32_t stride;  // bytes per aligned string slot
+};
+
+static Window window(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
+{
+    Window w;
+    const uint64_t full = lenB;
+    uint64_t W = (uint64_t)max_lenA + lenB; // unbounded
+    if (sc->gap < 0 && sc->smax > 0)
+        W = (uint64_t)max_lenA + ((uint64_t)sc->smax * max_lenA) / (uint64_t)(-sc->gap);
+    if (sc->smax <= 0)
+        W = 0; // every H is 0: nothing to trace
+    w.wcols = (uint32_t)std::min<uint64_t>(full, 2 * W + 2);
+    const uint64_t len = std::min<uint64_t>((uint64_t)max_lenA + lenB, W);
+    w.stride = (uint32_t)std::max<uint64_t>(len, 1);
+    return w;
+}
+
+// shared by both kernels: walk the direction bits of one pair (one lane)
+__device__ __forceinline__ uint32_t walk(const uint32_t *__restrict__ dirw, uint32_t nw, uint32_t lane_stride,
+                                         const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint32_t eA,
+                                         uint32_t eB, uint32_t c_s, uint8_t *__restrict__ outA,
+                                         uint8_t *__restrict__ outB, uint32_t stride)
+{
+    uint32_t i = eA, j = eB, len = 0;
+    while (i > 0 && j >= c_s && j > 0) {
+        const uint32_t jr = j - c_s;
+        // L2-served load: the words were stored by this same lane a moment ago
+        const uint32_t word = __hip_atomic_load(&dirw[((size_t)jr * nw + ((i - 1) >> 4)) * lane_stride], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t code = (word >> (2 * ((i - 1) & 15))) & 3u;
+        if (code == 0u || len >= stride)
+            break;
+        uint8_t ca, cb;
+        if (code == 1u) { // align.go:215-219
+            ca = a[i - 1];
+            cb = b[j - 1];
+            --i;
+            --j;
+        } else if (code == 2u) { // :220-223
+            ca = a[i - 1];
+            cb = '-';
+            --i;
+        } else { // :224-227
+            ca = '-';
+            cb = b[j - 1];
+            --j;
+        }
+        outA[stride - 1 - len] = ca; // strings are built by prepending: fill from the back
+        outB[stride - 1 - len] = cb;
+        ++len;
+    }
+    return len;
+}
+
+template <int RA>
+__global__ __launch_bounds__(THREADS) void tb_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                    uint64_t pair0, uint64_t pair1, const uint8_t *__restrict__ B,
+                                                    const uint64_t *__restrict__ offB, uint64_t lenB_shared,
+                                                    const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
+                                                    const int32_t *__restrict__ lutcc, int na, int nb, int gap,
+                                                    const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
+                                                    const uint32_t *__restrict__ err, uint32_t wcols,
+                                                    uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
+                                                    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen,
+                                                    uint32_t stride)
+{
+    static_assert(RA % 16 == 0 || RA == 152, "RA");
+    constexpr int NW = (RA + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb] then codeA[256], codeB[256]
+    uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < na * nb; t += THREADS)
+        T[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+
+    const uint64_t pair = pair0 + (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < pair1;
+    uint32_t lenA = 0, eA = 0, eB = 0;
+    const uint8_t *ap = A, *bp = B;
+    if (active) {
+        const uint64_t o0 = offA[pair];
+        lenA = (uint32_t)(offA[pair + 1] - o0);
+        ap = A + o0;
+        if (offB)
+            bp = B + offB[pair];
+        if (err[pair] == 0u) {
+            eA = endA[pair];
+            eB = endB[pair];
+        }
+    }
+    const bool work = active && eA > 0 && eB > 0 && lenA <= RA;
+    const uint32_t c_s = (work && eB > wcols) ? eB - wcols + 1u : 1u; // first column (1-based) of my window
+    const uint32_t ncol = work ? eB - c_s + 1u : 0u;
+
+    // row offsets into T (code * nb), two per register; rows >= lenA use the pad row (all zero)
+    uint32_t aoff[RA / 2];
+#pragma unroll
+    for (int r = 0; r < RA / 2; ++r) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * r + h;
+            uint32_t code = (uint32_t)(na - 1);
+            if (work && (uint32_t)i < lenA) {
+                const uint32_t c = cA[ap[i]];
+                code = c == 0xFFu ? (uint32_t)(na - 1) : c;
+            }
+            pk |= (code * (uint32_t)nb) << (16 * h);
+        }
+        aoff[r] = pk;
+    }
+
+    int H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+
+    // my direction words: word (jr, w) at dirbuf[((wave slab) + jr * NW + w) * 64 + lane]
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)wcols * NW * 64) + lane;
+
+    for (uint32_t jr = 0; jr < wcols; ++jr) {
+        if (!__any(jr < ncol))
+            break;
+        if (jr < ncol) {
+            const uint32_t j = c_s + jr; // 1-based column
+            uint32_t cb = cB[bp[j - 1]];
+            cb = cb == 0xFFu ? (uint32_t)(nb - 1) : cb;
+            int diag = 0, up = 0;
+            uint32_t word = 0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const uint32_t ro = (aoff[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const int s = T[ro + cb];
+                const int left = H[i];
+                const int d = diag + s, u = up + gap, l = left + gap;
+                const int h = max(0, max(d, max(u, l)));
+                // the reference's if-chain (align.go:215-228): diag, then up, then left
+                const uint32_t code = h == 0 ? 0u : (h == d ? 1u : (h == u ? 2u : 3u));
+                word |= code << (2 * (i & 15));
+                diag = left;
+                up = h;
+                H[i] = h;
+                if ((i & 15) == 15 || i == RA - 1) {
+                    dirw[((size_t)jr * NW + (i >> 4)) * 64] = word;
+                    word = 0;
+                }
+            }
+        }
+    }
+
+    if (!active)
+        return;
+    uint32_t len = 0;
+    if (work) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
+        len = walk(dirw, NW, 64, ap, bp, eA, eB, c_s, alnA + pair * stride, alnB + pair * stride, stride);
+    }
+    alnLen[pair] = (active && eA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
+}
+
+// any lenA: H column and direction words in global scratch, lane-interleaved
+__global__ __launch_bounds__(THREADS) void tb_generic_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ B, const uint64_t *__restrict__ offB, uint64_t lenB_shared,
+    const int32_t *__restrict__ lut, int gap, const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
+    const uint32_t *__restrict__ err, uint32_t wcols, uint32_t max_lenA, int32_t *__restrict__ hbuf,
+    uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB,
+    uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    const uint64_t local = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    const uint64_t pair = pair0 + local;
+    if (pair >= pair1)
+        return;
+    const uint64_t nl = (uint64_t)gridDim.x * THREADS; // lanes in this launch
+    const uint32_t nw = (max_lenA + 15) / 16;
+    const uint64_t o0 = offA[pair];
+    const uint32_t lenA = (uint32_t)(offA[pair + 1] - o0);
+    const uint8_t *ap = A + o0;
+    const uint8_t *bp = offB ? B + offB[pair] : B;
+    uint32_t eA = 0, eB = 0;
+    if (err[pair] == 0u) {
+        eA = endA[pair];
+        eB = endB[pair];
+    }
+    uint32_t len = 0;
+    if (eA > 0 && eB > 0) {
+        const uint32_t c_s = eB > wcols ? eB - wcols + 1u : 1u;
+        const uint32_t ncol = eB - c_s + 1u;
+        int32_t *Hc = hbuf + local;
+        uint32_t *dirw = dirbuf + local;
+        for (uint32_t i = 0; i < eA; ++i)
+            Hc[(size_t)i * nl] = 0;
+        for (uint32_t jr = 0; jr < ncol; ++jr) {
+            const uint32_t bsym = bp[c_s + jr - 1];
+            int diag = 0, up = 0;
+            uint32_t word = 0;
+            for (uint32_t i = 0; i < eA; ++i) { // rows below endA never matter
+                const int s = lut[(uint32_t)ap[i] * 256u + bsym];
+                const int left = Hc[(size_t)i * nl];
+                const int d = diag + s, u = up + gap, l = left + gap;
+                const int h = max(0, max(d, max(u, l)));
+                const uint32_t code = h == 0 ? 0u : (h == d ? 1u : (h == u ? 2u : 3u));
+                word |= code << (2 * (i & 15));
+                diag = left;
+                up = h;
+                Hc[(size_t)i * nl] = h;
+                if ((i & 15) == 15 || i == eA - 1) {
+                    dirw[((size_t)jr * nw + (i >> 4)) * nl] = word;
+                    word = 0;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        len = walk(dirw, nw, (uint32_t)nl, ap, bp, eA, eB, c_s, alnA + pair * stride, alnB + pair * stride, stride);
+    }
+    (void)lenB_shared;
+    (void)lenA;
+    alnLen[pair] = len;
+}
+
+struct Plan {
+    int ra;            // 0 = generic
+    Window win;
+    size_t per_pair;   // workspace bytes per pair
+    size_t smem;
+};
+
+static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
+{
+    Plan p;
+    p.win = window(sc, max_lenA, lenB);
+    const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+    p.smem = (size_t)na * nb * 4 + 512;
+    const bool reg = max_lenA <= 256 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536;
+    if (reg) {
+        p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
+        p.per_pair = (size_t)p.win.wcols * ((p.ra + 15) / 16) * 4;
+    } else {
+        p.ra = 0;
+        p.per_pair = (size_t)p.win.wcols * ((max_lenA + 15) / 16) * 4 + (size_t)max_lenA * 4;
+    }
+    if (p.per_pair == 0)
+        p.per_pair = 4;
+    return p;
+}
+
+} // namespace k3t
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+uint32_t polyhip_sw_traceback_stride(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
+{
+    if (!sc)
+        return 0;
+    return k3t::window(sc, max_lenA, lenB).stride;
+}
+
+size_t polyhip_sw_traceback_workspace_bytes(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB)
+{
+    if (!sc)
+        return 0;
+    const k3t::Plan p = k3t::plan(sc, max_lenA, lenB);
+    // enough for every pair in one launch, capped at 8 GiB (the entry point loops over chunks);
+    // never less than one workgroup's worth
+    const uint64_t padded = (npairs + k3t::THREADS - 1) / k3t::THREADS * k3t::THREADS;
+    uint64_t want = padded * p.per_pair;
+    const uint64_t cap = 8ull << 30, floor_ = (uint64_t)k3t::THREADS * p.per_pair;
+    if (want > cap)
+        want = cap / floor_ * floor_;
+    if (want < floor_)
+        want = floor_;
+    return (size_t)want + 256;
+}
+
+int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                             uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                             const uint32_t *d_endA, const uint32_t *d_endB, const uint32_t *d_err, uint8_t *d_alnA,
+                             uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
+                             polyhip_stream_t stream)
+{
+    PH_REQUIRE(sc, "polyhip_sw_traceback: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_offA && d_endA && d_endB && d_err && d_alnA && d_alnB && d_alnLen && d_work,
+               "polyhip_sw_traceback: null pointer");
+    const k3t::Plan p = k3t::plan(sc, max_lenA, lenB);
+    PH_REQUIRE(aln_stride >= p.win.stride, "polyhip_sw_traceback: aln_stride %u < %u (polyhip_sw_traceback_stride)",
+               aln_stride, p.win.stride);
+    const size_t usable = work_bytes & ~(size_t)255;
+    const uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
+    PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_sw_traceback: workspace too small (%zu B; %zu B per pair, >= %d pairs)",
+               work_bytes, p.per_pair, k3t::THREADS);
+    hipStream_t st = as_stream(stream);
+    const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+    for (uint64_t p0 = 0; p0 < npairs; p0 += chunk) {
+        const uint64_t p1 = std::min(npairs, p0 + chunk);
+        const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
+        uint32_t *dirbuf = static_cast<uint32_t *>(d_work);
+#define PH_TB_LAUNCH(RA_)                                                                                              \
+    do {                                                                                                               \
+        auto kern = k3t::tb_kernel<RA_>;                                                                               \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                   (int)p.smem));                                                                      \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.smem, st, d_A, d_offA, p0, p1, d_B, d_offB, lenB,  \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err,         \
+                           p.win.wcols, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);                                 \
+    } while (0)
+        if (p.ra == 64)
+            PH_TB_LAUNCH(64);
+        else if (p.ra == 152)
+            PH_TB_LAUNCH(152);
+        else if (p.ra == 256)
+            PH_TB_LAUNCH(256);
+        else {
+            const size_t nl = (size_t)blocks * k3t::THREADS;
+            int32_t *hbuf = static_cast<int32_t *>(d_work);
+            uint32_t *dirg = reinterpret_cast<uint32_t *>(hbuf + nl * max_lenA);
+            hipLaunchKernelGGL(k3t::tb_generic_kernel, dim3(blocks), dim3(k3t::THREADS), 0, st, d_A, d_offA, p0, p1, d_B,
+                               d_offB, lenB, sc->d_lut, (int)sc->gap, d_endA, d_endB, d_err, p.win.wcols, max_lenA, hbuf,
+                               dirg, d_alnA, d_alnB, d_alnLen, aln_stride);
+        }
+#undef PH_TB_LAUNCH
+        PH_HIP(hipGetLastError());
+    }
+    return POLYHIP_OK;
+}
+
+int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                           const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                           uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen,
+                           uint32_t aln_stride)
+{
+    PH_REQUIRE(sc, "polyhip_sw_align_batch: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(offA && score && endA && endB && err && alnA && alnB && alnLen, "polyhip_sw_align_batch: null pointer");
+    uint64_t maxA = 0, maxB = offB ? 0 : lenB;
+    for (uint64_t i = 0; i < npairs; ++i) {
+        PH_REQUIRE(offA[i] <= offA[i + 1], "polyhip_sw_align_batch: offA not ascending at %llu", (unsigned long long)i);
+        maxA = std::max(maxA, offA[i + 1] - offA[i]);
+        if (offB) {
+            PH_REQUIRE(offB[i] <= offB[i + 1], "polyhip_sw_align_batch: offB not ascending at %llu", (unsigned long long)i);
+            maxB = std::max(maxB, offB[i + 1] - offB[i]);
+        }
+    }
+    PH_REQUIRE(maxA < 0xFFFFFFFFull, "polyhip_sw_align_batch: A longer than 2^32");
+    const uint64_t a0 = offA[0], abytes = offA[npairs] - a0;
+    const uint64_t b0 = offB ? offB[0] : 0, bbytes = offB ? offB[npairs] - b0 : lenB;
+    PH_REQUIRE((A || abytes == 0) && (B || bbytes == 0), "polyhip_sw_align_batch: null sequence buffer");
+    DevBuf dA, doA, dB, doB, dscore, dea, deb, derr, dwork, dalA, dalB, dlen, dtb;
+    PH_HIP(dA.alloc(abytes + 16));
+    PH_HIP(doA.alloc((npairs + 1) * 8));
+    PH_HIP(dB.alloc(bbytes + 16));
+    PH_HIP(dscore.alloc(npairs * 8));
+    PH_HIP(dea.alloc(npairs * 4));
+    PH_HIP(deb.alloc(npairs * 4));
+    PH_HIP(derr.alloc(npairs * 4));
+    PH_HIP(dalA.alloc(npairs * (size_t)aln_stride));
+    PH_HIP(dalB.alloc(npairs * (size_t)aln_stride));
+    PH_HIP(dlen.alloc(npairs * 4));
+    std::vector<uint64_t> tmp(npairs + 1);
+    for (uint64_t i = 0; i <= npairs; ++i)
+        tmp[i] = offA[i] - a0;
+    PH_HIP(hipMemcpy(doA.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+    if (abytes)
+        PH_HIP(hipMemcpy(dA.p, A + a0, abytes, hipMemcpyHostToDevice));
+    if (bbytes)
+        PH_HIP(hipMemcpy(dB.p, B + b0, bbytes, hipMemcpyHostToDevice));
+    if (offB) {
+        PH_HIP(doB.alloc((npairs + 1) * 8));
+        for (uint64_t i = 0; i <= npairs; ++i)
+            tmp[i] = offB[i] - b0;
+        PH_HIP(hipMemcpy(doB.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+    }
+    const size_t wb = polyhip_sw_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB, offB == nullptr);
+    PH_HIP(dwork.alloc(wb));
+    int rc = polyhip_sw_batch_dev(sc, dA.as<uint8_t>(), doA.as<uint64_t>(), npairs, (uint32_t)maxA, dB.as<uint8_t>(),
+                                  offB ? doB.as<uint64_t>() : nullptr, maxB, dscore.as<int64_t>(), dea.as<uint32_t>(),
+                                  deb.as<uint32_t>(), derr.as<uint32_t>(), dwork.p, wb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    const size_t tb = polyhip_sw_traceback_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB);
+    PH_HIP(dtb.alloc(tb));
+    rc = polyhip_sw_traceback_dev(sc, dA.as<uint8_t>(), doA.as<uint64_t>(), npairs, (uint32_t)maxA, dB.as<uint8_t>(),
+                                  offB ? doB.as<uint64_t>() : nullptr, maxB, dea.as<uint32_t>(), deb.as<uint32_t>(),
+                                  derr.as<uint32_t>(), dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(),
+                                  aln_stride, dtb.p, tb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(endA, dea.p, npairs * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

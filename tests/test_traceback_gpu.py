@@ -1,0 +1,191 @@
+"""K3b parity: the full align.SmithWaterman (score + aligned strings) in HIP vs the
+CPU oracle's restatement of align.go:171-232.  Strings must be identical, including the
+reference's tie-breaking (first row-major maximum; diagonal, then up, then left).
+
+Mirrors search/align/align_test.go:139-292 and example_test.go:49-111."""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+MAT3 = [[0, 0, 0, 0, 0], [0, 3, -3, -3, -3], [0, -3, 3, -3, -3], [0, -3, -3, 3, -3], [0, -3, -3, -3, 3]]
+
+
+@pytest.fixture(scope="module")
+def al():
+    from poly_amd import align, alphabet, matrix
+    return align, alphabet, matrix
+
+
+def _scoring(al, symbols, scores, gap):
+    align, alphabet, matrix = al
+    a = alphabet.NewAlphabet(list(symbols))
+    return align.NewScoring(matrix.NewSubstitutionMatrix(a, a, scores), gap)
+
+
+def _pack(seqs):
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return np.frombuffer(b"".join(seqs), np.uint8).copy(), offs
+
+
+def _mutate(rng, seq: bytes, sub=0.05, indel=0.01) -> bytes:
+    out = bytearray()
+    for c in seq:
+        r = rng.random()
+        if r < indel / 2:
+            continue
+        if r < indel:
+            out.append(int(rng.choice(list(b"ACGT"))))
+        out.append(int(rng.choice(list(b"ACGT"))) if rng.random() < sub else c)
+    return bytes(out)
+
+
+def _check(al, scoring, omat, gap, reads, ref=None, refs=None):
+    align = al[0]
+    A, offA = _pack(reads)
+    if refs is None:
+        B, _ = _pack([ref])
+        got = align.sw_align_packed(scoring, A, offA, B, None)
+        refs = [ref] * len(reads)
+    else:
+        B, offB = _pack(refs)
+        got = align.sw_align_packed(scoring, A, offA, B, offB)
+    for p, (a, b) in enumerate(zip(reads, refs)):
+        try:
+            sc, sa, sb, ea, eb = orc.smith_waterman(a, b, omat, gap)
+        except orc.AlphabetError:
+            assert int(got[3][p]) != 0 and got[4][p] == b"" and got[5][p] == b""
+            continue
+        sa = sa if isinstance(sa, bytes) else sa.encode("latin-1")
+        sb = sb if isinstance(sb, bytes) else sb.encode("latin-1")
+        g = (int(got[0][p]), got[4][p], got[5][p])
+        assert g == (sc, sa, sb), f"pair {p}: got {g} want {(sc, sa, sb)}"
+
+
+def test_TestSmithWaterman(al):
+    """search/align/align_test.go:139-292"""
+    align = al[0]
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    assert align.SmithWaterman("TGTTACGG", "GGTTGACTA", sc) == (13, "GTT-AC", "GTTGAC")      # :158-175
+    assert align.SmithWaterman("ACACACTA", "AGCACACA", sc) == (17, "A-CACACTA", "AGCACAC-A")  # :177-194
+    for a, b in (("", "GAT"), ("GAT", ""), ("", ""), ("G", "A")):                                # :199-291
+        assert align.SmithWaterman(a, b, sc) == (0, "", "")
+    assert align.SmithWaterman("G", "G", sc) == (3, "G", "G")
+
+
+def test_examples(al):
+    """search/align/example_test.go:49-111"""
+    align = al[0]
+    pm1 = (2 * np.eye(5, dtype=int) - 1).tolist()
+    assert align.SmithWaterman("GATTACA", "GCATGCU", _scoring(al, "ACGTU", pm1, -1)) == (2, "AT", "AT")
+    assert align.SmithWaterman("GATTACA", "GCATGCT", _scoring(al, "ACGT-", al[2].NUC_4, -1)) == (15, "GATTAC", "GCATGC")
+    with pytest.raises(al[1].Error, match="Symbol X not in alphabet"):
+        align.SmithWaterman("GAXTACA", "GCATGCT", _scoring(al, "ACGT-", al[2].NUC_4, -1))
+
+
+def test_config4_shape(al):
+    """BASELINE config 4 shape: 150 bp reads (5 % subs, 1 % indels) vs one 5 kb reference, NUC_4, gap -2:
+    the windowed re-DP (1052 of 5000 columns) must reproduce the full-matrix traceback"""
+    rng = np.random.default_rng(0xC4)
+    ref = orc.synth_dna(0xC4, 5000).tobytes()
+    reads = []
+    for _ in range(400):
+        p = int(rng.integers(0, 5000 - 150))
+        reads.append(_mutate(rng, ref[p:p + 150])[:152])
+    reads += [orc.synth_dna(99, 150).tobytes(), b"", b"A", ref[:152], ref[-150:], ref[2000:2150]]
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    _check(al, sc, om, -2, reads, ref=ref)
+
+
+@pytest.mark.parametrize("maxlen,reflen", [(64, 300), (152, 1500), (256, 2100), (40, 3), (10, 1)])
+def test_ragged(al, maxlen, reflen):
+    rng = np.random.default_rng(maxlen * 7 + reflen)
+    ref = orc.synth_dna(1234 + reflen, reflen).tobytes()
+    reads = [orc.synth_dna(int(rng.integers(1, 1 << 30)), int(rng.integers(0, maxlen + 1))).tobytes() for _ in range(200)]
+    reads[0] = orc.synth_dna(5, maxlen).tobytes()
+    for i in range(1, 80):
+        L = int(rng.integers(1, min(maxlen, reflen) + 1))
+        p = int(rng.integers(0, reflen - L + 1))
+        reads[i] = _mutate(rng, ref[p:p + L], 0.03, 0.03)[:maxlen]
+    pm = [[0, 0, 0, 0, 0], [0, 2, -1, -1, -1], [0, -1, 2, -1, -1], [0, -1, -1, 2, -1], [0, -1, -1, -1, 2]]
+    _check(al, _scoring(al, "-ACGT", pm, -1), orc.SubstitutionMatrix("-ACGT", "-ACGT", pm), -1, reads, ref=ref)
+
+
+def test_ties_and_repeats(al):
+    ref = (b"ACGT" * 300)[:1100]
+    reads = [b"ACGT" * k for k in range(1, 30)] + [b"CGTA" * 5, b"TTTT", b"GTAC" * 30, b"A", b"ACGTTGCA" * 8]
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", MAT3)
+    _check(al, sc, om, -2, reads, ref=ref)
+    _check(al, sc, om, -2, reads, refs=[ref] * len(reads))
+
+
+def test_generic_paths(al):
+    """A longer than the register tile, per-pair B, and scoring without a window bound (gap >= 0)"""
+    rng = np.random.default_rng(77)
+    sc = _scoring(al, "-ACGT", MAT3, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", MAT3)
+    ref = orc.synth_dna(31, 700).tobytes()
+    reads = [orc.synth_dna(100 + i, int(rng.integers(257, 400))).tobytes() for i in range(12)]
+    reads[0] = _mutate(rng, ref[100:450])
+    _check(al, sc, om, -2, reads, ref=ref)
+    refs = [orc.synth_dna(500 + i, int(rng.integers(0, 300))).tobytes() for i in range(64)]
+    reads = [orc.synth_dna(900 + i, int(rng.integers(0, 200))).tobytes() for i in range(64)]
+    for i in range(0, 64, 3):
+        reads[i] = _mutate(rng, refs[i][:150], 0.05, 0.03)
+    _check(al, sc, om, -2, reads, refs=refs)
+    asym = [[0, 0, 0, 0, 0], [0, 30, -7, 2, -1], [0, -10, 25, 0, 3], [0, 5, -3, 40, -9], [0, 1, 2, -30, 20]]
+    for gap in (1, 0):
+        _check(al, _scoring(al, "-ACGT", asym, gap), orc.SubstitutionMatrix("-ACGT", "-ACGT", asym), gap, reads[:16],
+               ref=ref[:120])
+
+
+def test_default_matrix(al):
+    rng = np.random.default_rng(26)
+    letters = np.frombuffer(b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", np.uint8)
+    ref = rng.choice(letters, 900).tobytes()
+    reads = [rng.choice(letters, int(rng.integers(0, 150))).tobytes() for _ in range(100)]
+    for i in range(40):
+        p = int(rng.integers(0, 800))
+        reads[i] = ref[p:p + int(rng.integers(5, 100))]
+    _check(al, al[0].NewScoring(None, -1), orc.DEFAULT_MATRIX, -1, reads, ref=ref)
+
+
+def test_device_resident_chunked_workspace(al):
+    """a workspace smaller than the batch needs makes the call loop over chunks: same strings"""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2)
+    ref = orc.synth_dna(0xC4, 5000)
+    refb = ref.tobytes()
+    n, L = 1500, 150
+    reads = [(_mutate(rng, refb[s:s + L]) + b"A" * L)[:L] for s in rng.integers(0, 5000 - L, n)]
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    A = torch.from_numpy(np.frombuffer(b"".join(reads), np.uint8).copy()).to(dev)
+    offA = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    B = torch.from_numpy(ref.copy()).to(dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er, ln = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, L, 5000), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, A, offA, L, B, None, 5000, score, ea, eb, er, work)
+    stride = align.sw_traceback_stride(sc, L, 5000)
+    assert stride == 150 + 5 * 150 // 2
+    full = align.sw_traceback_workspace_bytes(sc, n, L, 5000)
+    small = torch.empty(full // 5, dtype=torch.uint8, device=dev)  # forces >= 5 chunks
+    alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    align.sw_traceback_dev(sc, A, offA, L, B, None, 5000, ea, eb, er, alnA, alnB, ln, small)
+    torch.cuda.synchronize()
+    a_h, b_h, l_h = alnA.cpu().numpy(), alnB.cpu().numpy(), ln.cpu().numpy()
+    for p in range(0, n, 11):
+        s, sa, sb, _, _ = orc.smith_waterman(reads[p], refb, om, -2)
+        sa = sa if isinstance(sa, bytes) else sa.encode()
+        sb = sb if isinstance(sb, bytes) else sb.encode()
+        assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb
+        assert int(score[p]) == s
