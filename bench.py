@@ -72,6 +72,48 @@ def cpu_baseline(n_reads: int):
     }
 
 
+def allgather_distance(dev, rank: int, world: int):
+    """N = 100k sketches over `world` ranks: each rank sketches its own families, all ranks all-gather
+    (one ncclAllGather over xGMI), each computes its row block of the shared-count matrix."""
+    import torch
+    import torch.distributed as dist
+    from poly_amd import bench_extra, mash, sharding
+
+    s, total = SKETCH, 100_000
+    lo, hi = sharding.shard_range(total // 100, rank, world)  # families of 100 copies, sharded by family
+    local = bench_extra.family_sketches(dev, hi - lo, 100, READ_LEN, KMER, s, 0xC3 + 1000 * rank)
+    state = {}
+
+    def step():
+        def compute(X, Y):
+            if "counts" not in state:
+                state["counts"] = torch.empty((X.shape[0], Y.shape[0]), dtype=torch.int16, device=dev)
+                state["work"] = torch.empty(mash.shared_counts_workspace_bytes(X.shape[0], s, Y.shape[0], s),
+                                            dtype=torch.uint8, device=dev)
+            mash.shared_counts_dev(X, Y, state["counts"], state["work"])
+            return state["counts"]
+        return sharding.allvsall_row_block(local, compute)
+
+    step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        counts, row0, gathered = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    N = gathered.shape[0]
+    ok = bool((counts[:, row0:row0 + counts.shape[0]].diagonal() == s).all())
+    return {"workload": f"all-vs-all shared counts over {N} sketches (s={s}) sharded by rows over {world} GPUs, "
+                        "sketches all-gathered with one RCCL all-gather per step",
+            "pairs_per_s": N * N / float(dt.item()), "ms_per_step": float(dt.item()) * 1e3,
+            "allgather_bytes_per_rank": local.numel() * 4, "self_pairs_share_all_hashes": ok}
+
+
 def main() -> int:
     args = parse()
     import torch
@@ -166,6 +208,18 @@ def main() -> int:
         "parity_spot_check": parity,
     }
 
+    # free the headline's buffers before the secondary kernels allocate theirs
+    del seqs, out, offs
+    torch.cuda.empty_cache()
+    if world > 1 and not args.no_extra:
+        # BASELINE configs[2]: per-rank sketches -> RCCL all-gather -> this rank's row block of the
+        # all-vs-all shared-count matrix (the one collective on the path)
+        try:
+            line_extra = allgather_distance(dev, rank, world)
+        except Exception as e:
+            line_extra = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            line["extra"] = {"mash_distance_allgather": line_extra}
     if rank == 0 and world == 1:
         if not args.no_extra:
             try:

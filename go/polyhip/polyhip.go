@@ -1,0 +1,206 @@
+// Package polyhip is the cgo binding of libpolyhip.so (include/polyhip.h), the MI355X
+// implementation of poly's search hot path.  UNCOMPILED in the authoring image (no Go toolchain).
+//
+// Conventions: every function packs Go strings into one contiguous byte buffer + offsets (the
+// library never keeps a Go pointer after returning, so the cgo pointer rules hold), calls the
+// host-pointer flavour of the entry point, and converts a negative status into an error whose
+// text is polyhip_last_error().  POLYHIP_ERR_PANIC is turned into a Go panic with the same
+// message the reference would panic with.
+package polyhip
+
+/*
+#cgo LDFLAGS: -lpolyhip
+#include <stdlib.h>
+#include "polyhip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"runtime"
+	"unsafe"
+)
+
+// Pack concatenates sequences and returns the byte buffer and the n+1 offsets.
+func Pack(seqs []string) ([]byte, []uint64) {
+	offs := make([]uint64, len(seqs)+1)
+	total := 0
+	for i, s := range seqs {
+		total += len(s)
+		offs[i+1] = uint64(total)
+	}
+	buf := make([]byte, 0, total+1)
+	for _, s := range seqs {
+		buf = append(buf, s...)
+	}
+	if len(buf) == 0 {
+		buf = append(buf, 0) // a valid pointer for cgo even when every sequence is empty
+	}
+	return buf, offs
+}
+
+func check(rc C.int) error {
+	if rc == C.POLYHIP_OK {
+		return nil
+	}
+	msg := C.GoString(C.polyhip_last_error())
+	if rc == C.POLYHIP_ERR_PANIC {
+		panic(msg)
+	}
+	return errors.New(msg)
+}
+
+// call pins the calling goroutine to its OS thread for the duration: the current HIP device and
+// polyhip_last_error() are per-thread state.
+func call(f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	return check(f())
+}
+
+// MashSketchBatch: out is n*s uint32, in/out (prior Sketches), see polyhip_mash_sketch_batch.
+func MashSketchBatch(seqs []byte, offs []uint64, k, s int, out []uint32) error {
+	return call(func() C.int {
+		return C.polyhip_mash_sketch_batch((*C.uint8_t)(unsafe.Pointer(&seqs[0])), (*C.uint64_t)(unsafe.Pointer(&offs[0])),
+			C.uint64_t(len(offs)-1), C.uint32_t(k), C.uint32_t(s), (*C.uint32_t)(unsafe.Pointer(&out[0])))
+	})
+}
+
+// MashDistanceMatrix: X is nx*sx, Y is ny*sy; counts (nx*ny) and dist (nx*ny) may be nil.
+func MashDistanceMatrix(X []uint32, nx, sx int, Y []uint32, ny, sy int, counts []uint16, dist []float64) error {
+	var pc *C.uint16_t
+	var pd *C.double
+	if counts != nil {
+		pc = (*C.uint16_t)(unsafe.Pointer(&counts[0]))
+	}
+	if dist != nil {
+		pd = (*C.double)(unsafe.Pointer(&dist[0]))
+	}
+	return call(func() C.int {
+		return C.polyhip_mash_distance_matrix((*C.uint32_t)(unsafe.Pointer(&X[0])), C.uint64_t(nx), C.uint32_t(sx),
+			(*C.uint32_t)(unsafe.Pointer(&Y[0])), C.uint64_t(ny), C.uint32_t(sy), pc, pd)
+	})
+}
+
+// Scoring wraps polyhip_scoring; Close releases the device tables.
+type Scoring struct{ h *C.polyhip_scoring }
+
+func NewScoring(lut *[65536]int32, validA, validB *[256]uint8, gap int) (*Scoring, error) {
+	s := &Scoring{}
+	err := call(func() C.int {
+		return C.polyhip_scoring_create((*C.int32_t)(unsafe.Pointer(&lut[0])), (*C.uint8_t)(unsafe.Pointer(&validA[0])),
+			(*C.uint8_t)(unsafe.Pointer(&validB[0])), C.int64_t(gap), &s.h)
+	})
+	if err != nil {
+		return nil, err
+	}
+	runtime.SetFinalizer(s, func(s *Scoring) { s.Close() })
+	return s, nil
+}
+
+func (s *Scoring) Close() {
+	if s.h != nil {
+		C.polyhip_scoring_destroy(s.h)
+		s.h = nil
+	}
+}
+
+// AlignResult is one pair's SmithWaterman outcome; Err != 0 encodes "Symbol X not in alphabet".
+type AlignResult struct {
+	Score        int64
+	AlignA       string
+	AlignB       string
+	Err          uint32
+	EndA, EndB   uint32
+}
+
+// SWAlignBatch: every A against one shared B (offB == nil) or pairwise.
+func (s *Scoring) SWAlignBatch(A []byte, offA []uint64, B []byte, offB []uint64, maxLenA int) ([]AlignResult, error) {
+	n := len(offA) - 1
+	lenB := uint64(len(B))
+	var pOffB *C.uint64_t
+	if offB != nil {
+		pOffB = (*C.uint64_t)(unsafe.Pointer(&offB[0]))
+		lenB = 0
+		for i := 0; i < n; i++ {
+			if d := offB[i+1] - offB[i]; d > lenB {
+				lenB = d
+			}
+		}
+	}
+	stride := int(C.polyhip_sw_traceback_stride(s.h, C.uint32_t(maxLenA), C.uint64_t(lenB)))
+	score := make([]int64, n)
+	endA, endB, errs, alen := make([]uint32, n), make([]uint32, n), make([]uint32, n), make([]uint32, n)
+	alnA, alnB := make([]byte, n*stride+1), make([]byte, n*stride+1)
+	err := call(func() C.int {
+		shared := C.uint64_t(0)
+		if offB == nil {
+			shared = C.uint64_t(len(B))
+		}
+		return C.polyhip_sw_align_batch(s.h, (*C.uint8_t)(unsafe.Pointer(&A[0])), (*C.uint64_t)(unsafe.Pointer(&offA[0])),
+			C.uint64_t(n), (*C.uint8_t)(unsafe.Pointer(&B[0])), pOffB, shared, (*C.int64_t)(unsafe.Pointer(&score[0])),
+			(*C.uint32_t)(unsafe.Pointer(&endA[0])), (*C.uint32_t)(unsafe.Pointer(&endB[0])),
+			(*C.uint32_t)(unsafe.Pointer(&errs[0])), (*C.uint8_t)(unsafe.Pointer(&alnA[0])),
+			(*C.uint8_t)(unsafe.Pointer(&alnB[0])), (*C.uint32_t)(unsafe.Pointer(&alen[0])), C.uint32_t(stride))
+	})
+	if err != nil {
+		return nil, err
+	}
+	res := make([]AlignResult, n)
+	for p := 0; p < n; p++ {
+		hi := (p + 1) * stride
+		lo := hi - int(alen[p])
+		res[p] = AlignResult{Score: score[p], AlignA: string(alnA[lo:hi]), AlignB: string(alnB[lo:hi]), Err: errs[p],
+			EndA: endA[p], EndB: endB[p]}
+	}
+	return res, nil
+}
+
+// SantaLuciaBatch / SantaLuciaScan / MarmurDotyBatch / LeastRotationBatch follow the same pattern:
+
+func SantaLuciaBatch(seqs []byte, offs []uint64, conc, na, mg float64) (tm, dH, dS []float64, err error) {
+	n := len(offs) - 1
+	tm, dH, dS = make([]float64, n), make([]float64, n), make([]float64, n)
+	err = call(func() C.int {
+		return C.polyhip_santalucia_batch((*C.uint8_t)(unsafe.Pointer(&seqs[0])), (*C.uint64_t)(unsafe.Pointer(&offs[0])),
+			C.uint64_t(n), C.double(conc), C.double(na), C.double(mg), (*C.double)(unsafe.Pointer(&tm[0])),
+			(*C.double)(unsafe.Pointer(&dH[0])), (*C.double)(unsafe.Pointer(&dS[0])))
+	})
+	return
+}
+
+func SantaLuciaScan(genome []byte, minLen, maxLen int, conc, na, mg float64) (tm, dH, dS []float64, ld int, err error) {
+	ld = len(genome) - minLen + 1
+	if ld < 0 {
+		ld = 0
+	}
+	m := (maxLen-minLen+1)*ld + 1
+	tm, dH, dS = make([]float64, m), make([]float64, m), make([]float64, m)
+	err = call(func() C.int {
+		return C.polyhip_santalucia_scan((*C.uint8_t)(unsafe.Pointer(&genome[0])), C.uint64_t(len(genome)), C.uint32_t(minLen),
+			C.uint32_t(maxLen), C.double(conc), C.double(na), C.double(mg), (*C.double)(unsafe.Pointer(&tm[0])),
+			(*C.double)(unsafe.Pointer(&dH[0])), (*C.double)(unsafe.Pointer(&dS[0])))
+	})
+	return
+}
+
+func MarmurDotyBatch(seqs []byte, offs []uint64) ([]float64, error) {
+	n := len(offs) - 1
+	tm := make([]float64, n)
+	err := call(func() C.int {
+		return C.polyhip_marmurdoty_batch((*C.uint8_t)(unsafe.Pointer(&seqs[0])), (*C.uint64_t)(unsafe.Pointer(&offs[0])),
+			C.uint64_t(n), (*C.double)(unsafe.Pointer(&tm[0])))
+	})
+	return tm, err
+}
+
+func LeastRotationBatch(seqs []byte, offs []uint64) (rot []uint64, rotated []byte, err error) {
+	n := len(offs) - 1
+	rot = make([]uint64, n)
+	rotated = make([]byte, len(seqs))
+	err = call(func() C.int {
+		return C.polyhip_least_rotation_batch((*C.uint8_t)(unsafe.Pointer(&seqs[0])), (*C.uint64_t)(unsafe.Pointer(&offs[0])),
+			C.uint64_t(n), (*C.uint64_t)(unsafe.Pointer(&rot[0])), (*C.uint8_t)(unsafe.Pointer(&rotated[0])))
+	})
+	return
+}

@@ -1,0 +1,48 @@
+// Package primers: drop-in for the Tm scorers of github.com/bebop/poly/primers (primers.go:70-128) over
+// libpolyhip; the barcode generator (primers.go:226-319) is not on the path and keeps the reference's code.
+// UNCOMPILED here.
+package primers
+
+import "github.com/bebop/poly/internal/polyhip"
+
+// SantaLucia is primers.go:70-105.  Bit-identical results (same fp64 operation order, Go's math.Log algorithm).
+func SantaLucia(sequence string, primerConcentration, saltConcentration, magnesiumConcentration float64) (meltingTemp, dH, dS float64) {
+	buf, offs := polyhip.Pack([]string{sequence})
+	tm, h, s, err := polyhip.SantaLuciaBatch(buf, offs, primerConcentration, saltConcentration, magnesiumConcentration)
+	if err != nil {
+		panic(err)
+	}
+	return tm[0], h[0], s[0]
+}
+
+// MarmurDoty is primers.go:108-118.
+func MarmurDoty(sequence string) float64 {
+	buf, offs := polyhip.Pack([]string{sequence})
+	tm, err := polyhip.MarmurDotyBatch(buf, offs)
+	if err != nil {
+		panic(err)
+	}
+	return tm[0]
+}
+
+// MeltingTemp is primers.go:121-128.
+func MeltingTemp(sequence string) float64 {
+	tm, _, _ := SantaLucia(sequence, 500e-9, 50e-3, 0.0)
+	return tm
+}
+
+// TmTable is the result of SantaLuciaScan: Tm/DH/DS[(L-MinLen)*Stride + start]; NaN where the window runs off the end.
+type TmTable struct {
+	MinLen, MaxLen, Stride int
+	Tm, DH, DS             []float64
+}
+
+// SantaLuciaScan evaluates every window of every length minLen..maxLen of genome in one device call; the
+// grow-until-Tm loops of primers/pcr (pcr.go:47-53, 94-101) become lookups into this table.
+func SantaLuciaScan(genome string, minLen, maxLen int, primerConcentration, saltConcentration, magnesiumConcentration float64) TmTable {
+	tm, h, s, ld, err := polyhip.SantaLuciaScan([]byte(genome), minLen, maxLen, primerConcentration, saltConcentration, magnesiumConcentration)
+	if err != nil {
+		panic(err)
+	}
+	return TmTable{MinLen: minLen, MaxLen: maxLen, Stride: ld, Tm: tm, DH: h, DS: s}
+}

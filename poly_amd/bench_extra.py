@@ -1,0 +1,137 @@
+"""Secondary rates reported next to bench.py's headline k-mers/s (BASELINE configs 3-5
+and seqhash): SW cell updates/s, Tm windows/s, distance pairs/s, least-rotation bases/s.
+Device-resident timing with events on the launch stream; synthetic inputs per SURVEY 8d."""
+from __future__ import annotations
+
+import torch
+
+from . import align, alphabet, mash, matrix, primers, seqhash
+
+HBM_PEAK_GBS = 8000.0
+
+
+def _time(fn, reps: int, warm: int = 1) -> float:
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def family_sketches(dev, nfam: int, copies: int, L: int, k: int, s: int, seed: int, sub: float = 0.01):
+    """`nfam` random genomes x `copies` copies at `sub` substitution rate, sketched by K1."""
+    N = nfam * copies
+    g = torch.empty(nfam * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(seed, g)
+    seqs = g.view(nfam, 1, L).expand(nfam, copies, L).contiguous().view(N, L)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    step = max(1, min(N, (256 << 20) // L))
+    for c0 in range(0, N, step):
+        blk = seqs[c0:c0 + step]
+        hit = torch.rand(blk.shape, device=dev, generator=gen) < sub
+        rnd = torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)
+        blk[hit] = lut[rnd]
+    offs = torch.arange(0, (N + 1) * L, L, dtype=torch.int64, device=dev)
+    sk = torch.zeros((N, s), dtype=torch.int32, device=dev)
+    mash.sketch_batch_dev(seqs.view(-1), offs, k, s, sk)
+    torch.cuda.synchronize()
+    return sk
+
+
+def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000):
+    """config 4: n reads of LA bp (substrings of the reference, 5 % substitutions) vs one LB reference, NUC_4, gap -2"""
+    a = alphabet.NewAlphabet(list("-ACGT"))
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
+    B = torch.empty(LB, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC4, B)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xC4 + 1)
+    starts = torch.randint(0, LB - LA, (n,), device=dev, generator=gen)
+    A = B[starts[:, None] + torch.arange(LA, device=dev)[None, :]]
+    hit = torch.rand(A.shape, device=dev, generator=gen) < 0.05
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    A[hit] = lut[torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)]
+    A = A.reshape(-1).contiguous()
+    offA = torch.arange(0, (n + 1) * LA, LA, dtype=torch.int64, device=dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er, ln = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, LA, LB, True), dtype=torch.uint8, device=dev)
+    ms_score = _time(lambda: align.sw_batch_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, work), 3)
+    stride = align.sw_traceback_stride(sc, LA, LB)
+    tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, LA, LB), dtype=torch.uint8, device=dev)
+    alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    ms_tb = _time(lambda: align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw), 2)
+    cells = n * LA * LB
+    alg = n * (LA + 8 + 8)  # read + score + end position per pair
+    return {
+        "workload": f"{n} x {LA} bp reads vs one {LB} bp reference, NUC_4, gap -2 (BASELINE configs[3])",
+        "cell_updates_per_s": cells / ms_score * 1e3, "score_pass_ms": ms_score,
+        "cell_updates_per_s_with_traceback": cells / (ms_score + ms_tb) * 1e3, "traceback_ms": ms_tb,
+        "algorithmic_GBs_score_pass": alg / ms_score * 1e3 / 1e9,
+        "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
+    }
+
+
+def tm_scan(dev, n: int = 5_000_000, Lmin: int = 18, Lmax: int = 30):
+    """config 5 (one GPU's view: the whole genome): SantaLucia of every Lmin..Lmax-mer"""
+    g = torch.empty(n, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC5, g)
+    ns, nl = n - Lmin + 1, Lmax - Lmin + 1
+    out = [torch.zeros(nl * ns, dtype=torch.float64, device=dev) for _ in range(3)]
+    ms = _time(lambda: primers.santalucia_scan_dev(g, n, 0, ns, Lmin, Lmax, 500e-9, 50e-3, 0.0, *out, ns), 10)
+    win = sum(n - L + 1 for L in range(Lmin, Lmax + 1))
+    gbs = (win * 24 + n) / ms * 1e3 / 1e9
+    return {"workload": f"SantaLucia Tm/dH/dS of all {Lmin}..{Lmax}-mers of a {n} B genome (BASELINE configs[4])",
+            "windows_per_s": win / ms * 1e3, "ms": ms, "algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+
+
+def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
+    """config 3, one rank's share: N sketches, this rank's N/rows_div rows against all N columns"""
+    s = 1000
+    sk = family_sketches(dev, nfam, copies, 10_000, 21, s, 0xC3)
+    N = sk.shape[0]
+    nrows = N // rows_div
+    counts = torch.empty((nrows, N), dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(nrows, s, N, s), dtype=torch.uint8, device=dev)
+    ms = _time(lambda: mash.shared_counts_dev(sk[:nrows], sk, counts, work), 3)
+    dist = torch.empty((nrows, N), dtype=torch.float64, device=dev)
+    ms_d = _time(lambda: mash.distance_from_counts_dev(counts, s, s, dist), 3)
+    mode = mash.shared_counts_mode(work)
+    pairs = nrows * N
+    return {"workload": f"{nrows} x {N} sketch pairs (row block 1/{rows_div} of the all-vs-all over {N} sketches of s={s}; "
+                        f"{nfam} families x {copies} copies at 1 % substitution) (BASELINE configs[2], one rank)",
+            "pairs_per_s_counts": pairs / ms * 1e3, "counts_ms": ms,
+            "pairs_per_s_counts_plus_fp64_distance": pairs / (ms + ms_d) * 1e3, "distance_ms": ms_d,
+            "algorithmic_GBs_fp64_out": pairs * 8 / (ms + ms_d) * 1e3 / 1e9,
+            "join_mode": mode[0], "nonzero_pairs": int((counts != 0).sum())}
+
+
+def rotation(dev, n: int = 100_000, L: int = 5000):
+    seqs = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0x5EED, seqs)
+    offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    rot = torch.zeros(n, dtype=torch.int64, device=dev)
+    out = torch.zeros_like(seqs)
+    ms = _time(lambda: seqhash.least_rotation_batch_dev(seqs, offs, L, rot, out), 5)
+    return {"workload": f"RotateSequence of {n} circular sequences of {L} bp", "bases_per_s": n * L / ms * 1e3, "ms": ms,
+            "algorithmic_GBs": (2 * n * L + 8 * n) / ms * 1e3 / 1e9}
+
+
+def run(dev) -> dict:
+    out = {}
+    for name, fn in (("smith_waterman", sw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
+                     ("least_rotation", rotation)):
+        try:
+            out[name] = fn(dev)
+        except Exception as e:  # a secondary number must never take the headline down
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    return out
