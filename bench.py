@@ -203,7 +203,7 @@ def main() -> int:
                    "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "polyhip::k1::sketch_kernel<21>", "kernel_ms": kern_ms,
+                     "kernel": "polyhip::k1::sketch_fast_kernel<21>", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "parity_spot_check": parity,
     }

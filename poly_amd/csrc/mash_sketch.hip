@@ -11,29 +11,47 @@
 //           position and shared by the k/4 windows that use it
 //           (2 multiplies per window instead of 2*(k/4))
 //   hash    each lane owns 4 consecutive windows: k/4 ds_read_b128 of P, the
-//           h = rotl(h ^ P, 13) * 5 + c chain, tail bytes, fmix32
-//   select  hashes <= tau are appended (wave ballot + one LDS atomic per
-//           wave) to a candidate buffer; tau starts from the count a uniform
-//           hash would need (s + 6 sqrt(s) + 16 expected survivors) and the
-//           result is VERIFIED: fewer than s survivors -> the sequence is
-//           redone accepting everything, so the output is exact for any input.
-//   shrink  when the buffer fills, and at the end: exact bottom-s of the
-//           buffer by LDS counting sort on the top bits (2048 bins) + in-bin
-//           ranking; duplicates keep distinct ranks, as the reference keeps
-//           duplicate hashes.
+//           h = rotl(h ^ P, 13) * 5 + c chain, the tail byte(s) -- for
+//           k % 4 == 1 a 256-entry LDS table of premix(byte) ^ k, the 4 windows'
+//           tail bytes being one aligned dword -- and fmix32
+//   select  FAST kernel: hashes <= tau are appended to a small shared LDS buffer (hipcc
+//           aggregates the append per wave: one LDS atomic + lane ranks); tau is the value
+//           a uniform hash would need for s + 6 sqrt(s) + 16 survivors, and the pass is
+//           VERIFIED: fewer than s survivors, or more than the buffer holds, and the
+//           sequence goes on a redo list for the GENERAL kernel (tau = 2^32-1, buffer of
+//           s + one round of tiles, shrunk whenever it could overflow), so the output is
+//           exact for any input.  Keeping the fast kernel's LDS at ~24 KB (6 workgroups per
+//           CU) matters more than its instruction count: the kernel is latency bound
+//           (halving the occupancy costs 1.6x, profiles/r01_k1_ablation.md).
+//   shrink  exact bottom-s of the survivors by LDS counting sort on the top
+//           bits (2048 bins) + in-bin ranking; duplicates keep distinct ranks,
+//           as the reference keeps duplicate hashes.
 //
-// Integer ALU/LDS bound (no MFMA: this is hashing, not a contraction).
+// Integer VALU / LDS-latency bound (no MFMA: this is hashing, not a contraction).
 // Algorithmic HBM bytes per sequence: len + 4*s (read once, sketch written once).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
+
+// PH_ABL != 0 only in scripts/ubench/k1_ablate.hip: knocks out one phase to measure its cost
+// (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage
+#ifndef PH_ABL
+#define PH_ABL 0
+#endif
 
 namespace polyhip {
 namespace k1 {
 
 constexpr int THREADS = 256;
-constexpr int TW = 2048;  // windows per tile (8 per lane = 2 groups of 4)
-constexpr int GROUPS = TW / (4 * THREADS);
+constexpr int WAVES = THREADS / 64;
+#ifndef PH_WTW
+#define PH_WTW 512
+#endif
+constexpr int WTW = PH_WTW;        // windows per WAVE tile (4 * GROUPS per lane)
+constexpr int TW = WTW * WAVES;    // windows the workgroup covers per round
+constexpr int GROUPS = WTW / (4 * 64);
 constexpr int NB = 2048;  // counting-sort bins
 constexpr uint32_t C1 = 0xcc9e2d51u, C2 = 0x1b873593u;
 
@@ -47,11 +65,8 @@ __device__ __forceinline__ uint32_t premix(uint32_t k)
     return k;
 }
 
-__device__ __forceinline__ uint32_t chain(uint32_t h)
-{
-    h = rotl32(h, 13);
-    return h * 5u + 0xe6546b64u;
-}
+// one instruction (v_mad_u64_u32) for "* 5 + c" beats shift-add + add: issue slots, not ALU width, bound this kernel
+__device__ __forceinline__ uint32_t chain(uint32_t h) { return rotl32(h, 13) * 5u + 0xe6546b64u; }
 
 __device__ __forceinline__ uint32_t fmix32(uint32_t h)
 {
@@ -69,37 +84,38 @@ __device__ __forceinline__ uint32_t funnel_bytes(uint32_t hi, uint32_t lo, uint3
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
-__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
 struct Smem {
     uint32_t *seqb;   // tile bytes, window 0 at byte 0
     uint32_t *P;      // premixed blocks per byte position; aliased by `bins`
     uint32_t *cand;   // candidate hashes (<= tau)
     uint32_t *binned; // counting-sort scratch
-    uint32_t *misc;   // [0] count  [1] tau  [2] restart flag  [4..8) wave totals
+    uint32_t *misc;   // [0] count  [1] tau  [3] survivors  [4..8) wave totals
+    uint32_t *lut;    // [256] premix(byte) ^ k for a single tail byte (k % 4 == 1)
 };
 
-// Exact bottom-s of cand[0..C): leaves cand[0..s) ascending, count = s,
-// tau = cand[s-1].  Requires C >= s.  All threads of the block call it.
-__device__ void shrink(const Smem &sm, uint32_t s)
+// ---- exact bottom-s ------------------------------------------------------------------
+// The survivors are given by `for_each(f)`: every thread calls f(h) for its share.
+// Returns (block-uniform) the number T of values <= tau.  If T >= s and T <= binned_cap:
+// cand[0..s) = the s smallest ascending, misc[0] = s, misc[1] = cand[s-1].
+// If T < s (and keep_partial): cand[0..T) = those values (any order), misc[0] = T.
+template <class ForEach>
+__device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t binned_cap, bool keep_partial,
+                             ForEach for_each)
 {
     const int tid = threadIdx.x;
     uint32_t *bins = sm.P;
-    const uint32_t C = sm.misc[0];
-    const uint32_t tau = sm.misc[1];
-    // every candidate is <= tau: pick the shift that spreads [0, tau] over <= NB bins
-    const int sig = 32 - __builtin_clz(tau | 1u); // significant bits of tau
+    // every survivor is <= tau: pick the shift that spreads [0, tau] over <= NB bins
+    const int sig = 32 - __builtin_clz(tau | 1u);
     const int shift = sig > 11 ? sig - 11 : 0;
-    __syncthreads(); // everyone has read misc / finished with P before it becomes bins
+    __syncthreads(); // everyone is done with P before it becomes bins
 
     for (int b = tid; b < NB; b += THREADS)
         bins[b] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < C; i += THREADS)
-        atomicAdd(&bins[sm.cand[i] >> shift], 1u);
+    for_each([&](uint32_t h) {
+        if (h <= tau)
+            atomicAdd(&bins[h >> shift], 1u);
+    });
     __syncthreads();
 
     // exclusive scan of NB bins: 8 per thread, wave scan, cross-wave fix-up
@@ -128,29 +144,42 @@ __device__ void shrink(const Smem &sm, uint32_t s)
             bins[8 * tid + i] = run; // start of bin
             run += v[i];
         }
+        if (tid == THREADS - 1)
+            sm.misc[3] = run; // T
     }
     __syncthreads();
+    const uint32_t T = sm.misc[3];
+    if (T > binned_cap || (T < s && !keep_partial))
+        return T;
     // scatter: afterwards bins[b] = end of bin b, start of bin b = bins[b-1]
-    for (uint32_t i = tid; i < C; i += THREADS) {
-        uint32_t h = sm.cand[i];
-        uint32_t slot = atomicAdd(&bins[h >> shift], 1u);
-        sm.binned[slot] = h;
-    }
+    for_each([&](uint32_t h) {
+        if (h <= tau)
+            sm.binned[atomicAdd(&bins[h >> shift], 1u)] = h;
+    });
     __syncthreads();
+    if (T < s) {
+        for (uint32_t j = tid; j < T; j += THREADS)
+            sm.cand[j] = sm.binned[j];
+        __syncthreads();
+        if (tid == 0)
+            sm.misc[0] = T;
+        __syncthreads();
+        return T;
+    }
     // rank inside the bin; ties broken by slot so duplicates get distinct ranks
-    for (uint32_t j = tid; j < C; j += THREADS) {
-        uint32_t h = sm.binned[j];
-        uint32_t b = h >> shift;
-        uint32_t start = b ? bins[b - 1] : 0u;
+    for (uint32_t j = tid; j < T; j += THREADS) {
+        const uint32_t h = sm.binned[j];
+        const uint32_t b = h >> shift;
+        const uint32_t start = b ? bins[b - 1] : 0u;
         if (start >= s)
             continue;
-        uint32_t end = bins[b];
+        const uint32_t end = bins[b];
         uint32_t rank = 0;
         for (uint32_t x = start; x < end; ++x) {
-            uint32_t o = sm.binned[x];
+            const uint32_t o = sm.binned[x];
             rank += (o < h) || (o == h && x < j);
         }
-        uint32_t pos = start + rank;
+        const uint32_t pos = start + rank;
         if (pos < s)
             sm.cand[pos] = h;
     }
@@ -160,210 +189,484 @@ __device__ void shrink(const Smem &sm, uint32_t s)
         sm.misc[1] = sm.cand[s - 1];
     }
     __syncthreads();
+    return T;
 }
 
-// KS > 0: k known at compile time (full unroll of the block chain); KS == 0: runtime k.
-template <int KS>
-__global__ __launch_bounds__(THREADS) void sketch_kernel(const uint8_t *__restrict__ seqs,
-                                                        const uint64_t *__restrict__ offs, uint32_t k_rt,
-                                                        uint32_t s, uint32_t *__restrict__ out,
-                                                        uint32_t n_seq_dw, uint32_t n_P, uint32_t cap)
+// Tiles are WAVE-private: each wave stages, premixes and hashes its own WTW windows in its own
+// slice of LDS, so the tile loop has no workgroup barrier at all (LDS operations of one wave
+// execute in order; the fences below only stop the compiler from reordering them).
+__device__ __forceinline__ void wave_sync()
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
-    Smem sm;
-    sm.seqb = smem_raw;
-    sm.P = sm.seqb + n_seq_dw;
-    sm.cand = sm.P + n_P;
-    sm.binned = sm.cand + cap;
-    sm.misc = sm.binned + cap;
+    // A wavefront-scope fence would do, but hipcc lowers it to s_waitcnt vmcnt(0) lgkmcnt(0), which
+    // also waits for the NEXT tile's global loads that were just put in flight.  The DS queue of a
+    // wave is in order, so a compiler barrier is all that is needed.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
 
-    const uint32_t k = KS > 0 ? (uint32_t)KS : k_rt;
+// ---- staging: tile bytes [t0, t0 + WTW + k + 4) -> the wave's seqb, through registers so that
+// the NEXT tile's global loads are in flight while the current tile is premixed and hashed
+template <int KS> struct Stager {
+    // dwords per lane for a compile-time k; runtime k stages without the register hop
+    static constexpr int NI = KS > 0 ? ((WTW / 4 + KS / 4 + 2 + 3) + 63) / 64 : 1;
+    uint32_t lo[NI], hi[NI]; // raw aligned dwords; the byte funnel is applied when they are stored
+
+    __device__ __forceinline__ static void fetch(const uint32_t *__restrict__ gdw, uint32_t gsh, int64_t gbytes,
+                                                 int64_t gi, bool full, uint32_t &l, uint32_t &h)
+    {
+        if (PH_ABL == 6) {
+            l = (uint32_t)gi * 0x9E3779B9u;
+            h = l;
+            return;
+        }
+        h = 0u;
+        if (full) { // the whole staging range lies inside the sequence's aligned view
+            l = gdw[gi];
+            if (gsh)
+                h = gdw[gi + 1];
+        } else {
+            l = (gi * 4 < gbytes) ? gdw[gi] : 0u;
+            if (gsh)
+                h = ((gi + 1) * 4 < gbytes) ? gdw[gi + 1] : 0u;
+        }
+    }
+
+    __device__ __forceinline__ void load(const uint32_t *__restrict__ gdw, uint32_t gsh, int64_t gbytes, int64_t t0,
+                                         uint32_t n_seq_dw, bool full)
+    {
+        if (KS > 0) {
+            const int64_t dbase = t0 >> 2; // t0 is a multiple of WTW, so of 4
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t d = (threadIdx.x & 63) + i * 64;
+                if (d < n_seq_dw)
+                    fetch(gdw, gsh, gbytes, dbase + d, full, lo[i], hi[i]);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(uint32_t *__restrict__ seqb, const uint32_t *__restrict__ gdw, uint32_t gsh,
+                                          int64_t gbytes, int64_t t0, uint32_t n_seq_dw, bool full)
+    {
+        if (KS > 0) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const uint32_t d = (threadIdx.x & 63) + i * 64;
+                if (d < n_seq_dw)
+                    seqb[d] = gsh ? funnel_bytes(hi[i], lo[i], gsh) : lo[i];
+            }
+        } else { // runtime k: fetch + store in one go
+            const int64_t dbase = t0 >> 2;
+            for (uint32_t d = threadIdx.x & 63; d < n_seq_dw; d += 64) {
+                uint32_t l, h;
+                fetch(gdw, gsh, gbytes, dbase + d, full, l, h);
+                seqb[d] = gsh ? funnel_bytes(h, l, gsh) : l;
+            }
+        }
+    }
+};
+
+// ---- one staged wave tile: premix, then hash; `emit(window_in_tile, h)` consumes the hashes ----
+template <int KS, class Emit>
+__device__ __forceinline__ void tile_compute(const uint32_t *__restrict__ seqb, uint32_t *__restrict__ P,
+                                             const uint32_t *__restrict__ lut, uint32_t k, Emit emit)
+{
+    const int lane = threadIdx.x & 63;
     const int nblk = (int)(k >> 2);
     const int tail = (int)(k & 3);
     const uint32_t tailmask = tail == 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * tail));
 
+    // ---- premix: P[p..p+3] for p = 4*q
+    {
+        const int nq = (WTW >> 2) + nblk; // quads of byte positions needed
+        for (int q = lane; q < (PH_ABL == 1 ? 0 : nq); q += 64) {
+            const uint32_t d0 = seqb[q], d1 = seqb[q + 1];
+            uint4 p;
+            p.x = premix(d0);
+            p.y = premix(funnel_bytes(d1, d0, 1));
+            p.z = premix(funnel_bytes(d1, d0, 2));
+            p.w = premix(funnel_bytes(d1, d0, 3));
+            reinterpret_cast<uint4 *>(P)[q] = p;
+        }
+    }
+    wave_sync();
+
+    // ---- hash
+    const uint4 *P4 = reinterpret_cast<const uint4 *>(P);
+#pragma unroll
+    for (int g = 0; g < GROUPS; ++g) {
+        const int wq = lane + 64 * g; // quad of windows inside the tile
+        uint32_t h[4] = {0u, 0u, 0u, 0u};
+        if (KS > 0) {
+#pragma unroll
+            for (int j = 0; j < (PH_ABL == 2 ? 1 : (KS >> 2)); ++j) {
+                const uint4 p = P4[wq + j];
+                h[0] = chain(h[0] ^ p.x);
+                h[1] = chain(h[1] ^ p.y);
+                h[2] = chain(h[2] ^ p.z);
+                h[3] = chain(h[3] ^ p.w);
+            }
+        } else {
+            for (int j = 0; j < nblk; ++j) {
+                const uint4 p = P4[wq + j];
+                h[0] = chain(h[0] ^ p.x);
+                h[1] = chain(h[1] ^ p.y);
+                h[2] = chain(h[2] ^ p.z);
+                h[3] = chain(h[3] ^ p.w);
+            }
+        }
+        if (PH_ABL == 3) {
+        } else if (tail == 1) {
+            // the 4 windows' tail bytes are one aligned dword; lut[b] = premix(b) ^ k
+            const uint32_t tb = seqb[wq + nblk];
+            h[0] ^= lut[tb & 0xFFu];
+            h[1] ^= lut[(tb >> 8) & 0xFFu];
+            h[2] ^= lut[(tb >> 16) & 0xFFu];
+            h[3] ^= lut[tb >> 24];
+        } else if (tail) {
+            const uint32_t d0 = seqb[wq + nblk], d1 = seqb[wq + nblk + 1];
+            h[0] ^= premix(d0 & tailmask) ^ k;
+            h[1] ^= premix(funnel_bytes(d1, d0, 1) & tailmask) ^ k;
+            h[2] ^= premix(funnel_bytes(d1, d0, 2) & tailmask) ^ k;
+            h[3] ^= premix(funnel_bytes(d1, d0, 3) & tailmask) ^ k;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                h[c] ^= k;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            emit(4u * (uint32_t)wq + (uint32_t)c, PH_ABL == 3 ? h[c] : fmix32(h[c]));
+    }
+    wave_sync(); // seqb / P are rewritten by this wave's next tile
+}
+
+// All tiles of one sequence; wave w takes tiles w, w + WAVES, ...  LOCKSTEP: the workgroup
+// meets at `before(T0)` (block-uniform hook; the general pass shrinks there) before every round
+// of WAVES tiles; otherwise the waves run free.  emit_full(t0, w, h) for tiles whose WTW windows
+// all exist, emit_part(t0, w, h) (already bounds-checked) for the last one.
+template <int KS, bool LOCKSTEP, class Before, class EmitFull, class EmitPart>
+__device__ __forceinline__ void run_tiles(const Smem &sm, const uint32_t *__restrict__ gdw, uint32_t gsh,
+                                          int64_t gbytes, int64_t nwin, uint32_t k, uint32_t n_seq_dw, uint32_t n_P_w,
+                                          Before before, EmitFull emit_full, EmitPart emit_part)
+{
+    const int wave = threadIdx.x >> 6;
+    uint32_t *seqb = sm.seqb + wave * n_seq_dw;
+    uint32_t *P = sm.P + wave * n_P_w;
+    const int64_t stage_bytes = (int64_t)n_seq_dw * 4 + 4;
+    auto is_full = [&](int64_t t0) { return (nwin - t0) >= (int64_t)WTW && t0 + stage_bytes <= gbytes; };
+    Stager<KS> st;
+    const int64_t first = (int64_t)wave * WTW;
+    if (first < nwin)
+        st.load(gdw, gsh, gbytes, first, n_seq_dw, is_full(first));
+    for (int64_t T0 = 0; T0 < nwin; T0 += TW) {
+        if (LOCKSTEP)
+            before(T0);
+        const int64_t t0 = T0 + first;
+        if (t0 >= nwin)
+            continue;
+        const bool full = is_full(t0);
+        st.store(seqb, gdw, gsh, gbytes, t0, n_seq_dw, full);
+        wave_sync();
+        if (t0 + TW < nwin)
+            st.load(gdw, gsh, gbytes, t0 + TW, n_seq_dw, is_full(t0 + TW));
+        if (full) {
+            tile_compute<KS>(seqb, P, sm.lut, k, [&](uint32_t w, uint32_t h) { emit_full(t0, w, h); });
+        } else {
+            const uint32_t wl = (uint32_t)((nwin - t0) < (int64_t)WTW ? (nwin - t0) : (int64_t)WTW);
+            tile_compute<KS>(seqb, P, sm.lut, k, [&](uint32_t w, uint32_t h) {
+                if (w < wl)
+                    emit_part(t0, w, h);
+            });
+        }
+    }
+}
+
+// ---- fast pass's bottom-s: cand[0..C) all <= tau0, s <= C <= capf.  Counting sort on the top
+// bits + in-bin ranking, written straight to the output row.  All threads call it.
+__device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t C, uint32_t nbf_log2,
+                              uint32_t *__restrict__ outp)
+{
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const uint64_t r = blockIdx.x;
+    uint32_t *bins = sm.P;
+    const uint32_t nbf = 1u << nbf_log2;  // 1024 or 2048 bins, whatever fits in the P region
+    const int per = (int)(nbf / THREADS); // 4 or 8 bins per thread
+    const int sig = 32 - __builtin_clz(tau | 1u);
+    const int shift = sig > (int)nbf_log2 ? sig - (int)nbf_log2 : 0;
+    for (uint32_t b = tid; b < nbf; b += THREADS) // (the caller's barrier freed P)
+        bins[b] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < C; i += THREADS)
+        atomicAdd(&bins[sm.cand[i] >> shift], 1u);
+    __syncthreads();
+    {
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            v[i] = i < per ? bins[per * tid + i] : 0u;
+            sum += v[i];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            sm.misc[4 + (tid >> 6)] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (int w = 0; w < (tid >> 6); ++w)
+            run += sm.misc[4 + w];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < per)
+                bins[per * tid + i] = run; // start of bin
+            run += v[i];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < C; i += THREADS) { // afterwards bins[b] = end of bin b
+        const uint32_t h = sm.cand[i];
+        sm.binned[atomicAdd(&bins[h >> shift], 1u)] = h;
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < C; j += THREADS) {
+        const uint32_t h = sm.binned[j];
+        const uint32_t b = h >> shift;
+        const uint32_t start = b ? bins[b - 1] : 0u;
+        if (start >= s)
+            continue;
+        const uint32_t end = bins[b];
+        uint32_t rank = 0;
+        for (uint32_t x = start; x < end; ++x) {
+            const uint32_t o = sm.binned[x];
+            rank += (o < h) || (o == h && x < j); // duplicates keep distinct ranks
+        }
+        const uint32_t pos = start + rank;
+        if (pos < s)
+            outp[pos] = h;
+    }
+}
+
+struct ReadView {
+    const uint32_t *gdw; // dword-aligned view of the sequence
+    uint32_t gsh;        // byte offset of the sequence inside it
+    int64_t gbytes, nwin;
+};
+
+__device__ __forceinline__ ReadView view(const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offs,
+                                         uint64_t r, uint32_t k)
+{
+    ReadView v;
     const uint64_t o0 = offs[r], o1 = offs[r + 1];
     const int64_t n = (int64_t)(o1 - o0);
-    const int64_t nwin = n - (int64_t)k; // mash.go:73: len-k windows, last k-mer skipped
-    if (nwin <= 0)
-        return;
-    uint32_t *__restrict__ outp = out + r * (uint64_t)s;
-    const bool positional = nwin < (int64_t)s; // mash.go:81-84: sketch never fills, never sorted
+    v.nwin = n - (int64_t)k; // mash.go:73: len-k windows, last k-mer skipped
+    // derived from the kernel argument so the loads stay global_load
+    v.gsh = (uint32_t)((uintptr_t)(seqs + o0) & 3);
+    v.gdw = reinterpret_cast<const uint32_t *>(seqs + o0 - v.gsh);
+    v.gbytes = n + v.gsh;
+    return v;
+}
 
-    // global source, dword-aligned view
-    const uintptr_t g0 = (uintptr_t)(seqs + o0);
-    const uint32_t gsh = (uint32_t)(g0 & 3);
-    const uint32_t *__restrict__ gdw = (const uint32_t *)(g0 - gsh);
-    const int64_t gbytes = n + gsh; // bytes of the aligned view that may be touched
+// ---- FAST kernel: every sequence, under a verified threshold -------------------------------
+// KS > 0: k known at compile time (full unroll of the block chain); KS == 0: runtime k.
+// Persistent workgroups: each one walks the batch with stride gridDim.x.  Sequences the fast
+// pass cannot finish exactly are appended to `redo` for the general kernel.
+template <int KS>
+__global__ __launch_bounds__(THREADS) void sketch_fast_kernel(const uint8_t *__restrict__ seqs,
+                                                             const uint64_t *__restrict__ offs, uint64_t nseq,
+                                                             uint32_t k_rt, uint32_t s, uint32_t *__restrict__ out,
+                                                             uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P,
+                                                             uint32_t capf, uint32_t nbf_log2,
+                                                             uint32_t *__restrict__ redo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
+    Smem sm;
+    sm.seqb = smem_raw;                    // WAVES slices of n_seq_dw
+    sm.P = sm.seqb + WAVES * n_seq_dw;     // WAVES slices of n_P_w (whole region doubles as `bins`)
+    sm.cand = sm.P + n_P;
+    sm.binned = sm.cand + capf;
+    sm.misc = sm.binned + capf;
+    sm.lut = sm.misc + 16;
 
-    // initial threshold: uniform-hash estimate with a 6-sigma margin (verified below)
-    uint32_t tau0 = 0xFFFFFFFFu;
-    {
-        uint64_t target = (uint64_t)s + 6ull * (uint64_t)__builtin_sqrtf((float)s) + 16ull;
-        if ((int64_t)target < nwin)
-            tau0 = (uint32_t)((target << 32) / (uint64_t)nwin);
+    const uint32_t k = KS > 0 ? (uint32_t)KS : k_rt;
+    const int tid = threadIdx.x;
+    sm.lut[tid] = premix((uint32_t)tid) ^ k; // THREADS == 256; visible after the first barrier
+    auto nothing = [](int64_t) {};
+
+    for (uint64_t r = blockIdx.x; r < nseq; r += gridDim.x) {
+        const ReadView rv = view(seqs, offs, r, k);
+        if (rv.nwin <= 0)
+            continue;
+        uint32_t *__restrict__ outp = out + r * (uint64_t)s;
+
+        // ---- mash.go:81-84: fewer windows than SketchSize -> positional, unsorted, tail untouched
+        if (rv.nwin < (int64_t)s) {
+            __syncthreads();
+            auto put = [&](int64_t t0, uint32_t w, uint32_t h) { outp[t0 + w] = h; };
+            run_tiles<KS, false>(sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w, nothing, put, put);
+            continue;
+        }
+
+        // threshold a uniform hash would need for s + 6 sqrt(s) + 16 survivors
+        uint32_t tau0 = 0xFFFFFFFFu;
+        {
+            const uint64_t target = (uint64_t)s + 6ull * (uint64_t)__builtin_sqrtf((float)s) + 16ull;
+            if ((int64_t)target < rv.nwin)
+                tau0 = (uint32_t)((target << 32) / (uint64_t)rv.nwin);
+        }
+        bool ok = tau0 != 0xFFFFFFFFu || rv.nwin <= (int64_t)capf; // short sequence: keep every hash
+        __syncthreads(); // the previous sequence is done with LDS
+        if (tid == 0)
+            sm.misc[0] = 0;
+        __syncthreads();
+        uint32_t C = 0;
+        if (ok) {
+            auto keep = [&](int64_t, uint32_t, uint32_t h) {
+                if (PH_ABL == 4 ? h == 12345u : h <= tau0) {
+                    const uint32_t idx = atomicAdd(&sm.misc[0], 1u); // hipcc aggregates this per wave
+                    if (idx < capf)
+                        sm.cand[idx] = h;
+                }
+            };
+            run_tiles<KS, false>(sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w, nothing, keep, keep);
+            __syncthreads();
+            C = sm.misc[0];
+            ok = C >= s && C <= capf; // enough survivors, none lost
+        }
+        if (ok) {
+            if (PH_ABL == 5) {
+                for (uint32_t i = tid; i < s; i += THREADS)
+                    outp[i] = sm.cand[i];
+            } else {
+                bottom_s_fast(sm, s, tau0, C, nbf_log2, outp);
+            }
+        } else if (tid == 0) {
+            redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r;
+        }
     }
+}
 
-    for (int attempt = 0; attempt < 2; ++attempt) {
+// ---- GENERAL kernel: the sequences on the redo list, any input -------------------------------
+// Accepts every hash, shared candidate buffer of cap >= s + TW + 64, shrunk to the exact bottom-s
+// whenever a round of tiles might overflow it.
+template <int KS>
+__global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *__restrict__ seqs,
+                                                                const uint64_t *__restrict__ offs, uint32_t k_rt,
+                                                                uint32_t s, uint32_t *__restrict__ out,
+                                                                uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P,
+                                                                uint32_t cap, const uint32_t *__restrict__ redo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
+    Smem sm;
+    sm.seqb = smem_raw;
+    sm.P = sm.seqb + WAVES * n_seq_dw;
+    sm.cand = sm.P + n_P;
+    sm.binned = sm.cand + cap;
+    sm.misc = sm.binned + cap;
+    sm.lut = sm.misc + 16;
+
+    const uint32_t k = KS > 0 ? (uint32_t)KS : k_rt;
+    const int tid = threadIdx.x;
+    sm.lut[tid] = premix((uint32_t)tid) ^ k;
+    const uint32_t nredo = redo[0];
+
+    for (uint32_t q = blockIdx.x; q < nredo; q += gridDim.x) {
+        const uint64_t r = redo[1 + q];
+        const ReadView rv = view(seqs, offs, r, k);
+        uint32_t *__restrict__ outp = out + r * (uint64_t)s;
+        __syncthreads(); // the previous sequence is done with LDS
         if (tid == 0) {
             sm.misc[0] = 0;
-            sm.misc[1] = attempt == 0 ? tau0 : 0xFFFFFFFFu;
+            sm.misc[1] = 0xFFFFFFFFu;
         }
         __syncthreads();
-
-        for (int64_t t0 = 0; t0 < nwin; t0 += TW) {
-            const int64_t wleft = nwin - t0; // windows from t0 on
-            // ---- make room: the tile may append up to TW candidates
-            if (!positional) {
-                if (sm.misc[0] + (uint32_t)TW > cap)
-                    shrink(sm, s);
-            }
-            const uint32_t tau = sm.misc[1];
-
-            // ---- stage: tile bytes [t0, t0 + TW + k + 4) -> seqb
-            {
-                const int64_t dbase = t0 >> 2; // t0 is a multiple of TW, so of 4
-                for (uint32_t d = tid; d < n_seq_dw; d += THREADS) {
-                    const int64_t gi = dbase + d;
-                    uint32_t lo = (gi * 4 < gbytes) ? gdw[gi] : 0u;
-                    uint32_t v = lo;
-                    if (gsh) {
-                        uint32_t hi = ((gi + 1) * 4 < gbytes) ? gdw[gi + 1] : 0u;
-                        v = funnel_bytes(hi, lo, gsh);
-                    }
-                    sm.seqb[d] = v;
-                }
-            }
-            __syncthreads();
-
-            // ---- premix: P[p..p+3] for p = 4*q
-            {
-                const int nq = (TW >> 2) + nblk; // quads of byte positions needed
-                for (int q = tid; q < nq; q += THREADS) {
-                    const uint32_t d0 = sm.seqb[q], d1 = sm.seqb[q + 1];
-                    uint4 p;
-                    p.x = premix(d0);
-                    p.y = premix(funnel_bytes(d1, d0, 1));
-                    p.z = premix(funnel_bytes(d1, d0, 2));
-                    p.w = premix(funnel_bytes(d1, d0, 3));
-                    reinterpret_cast<uint4 *>(sm.P)[q] = p;
-                }
-            }
-            __syncthreads();
-
-            // ---- hash + select
-            const uint4 *P4 = reinterpret_cast<const uint4 *>(sm.P);
-#pragma unroll
-            for (int g = 0; g < GROUPS; ++g) {
-                const int wq = tid + THREADS * g; // quad of windows inside the tile
-                uint32_t h[4] = {0u, 0u, 0u, 0u};
-                if (KS > 0) {
-#pragma unroll
-                    for (int j = 0; j < (KS >> 2); ++j) {
-                        const uint4 p = P4[wq + j];
-                        h[0] = chain(h[0] ^ p.x);
-                        h[1] = chain(h[1] ^ p.y);
-                        h[2] = chain(h[2] ^ p.z);
-                        h[3] = chain(h[3] ^ p.w);
-                    }
-                } else {
-                    for (int j = 0; j < nblk; ++j) {
-                        const uint4 p = P4[wq + j];
-                        h[0] = chain(h[0] ^ p.x);
-                        h[1] = chain(h[1] ^ p.y);
-                        h[2] = chain(h[2] ^ p.z);
-                        h[3] = chain(h[3] ^ p.w);
-                    }
-                }
-                if (tail) {
-                    const uint32_t d0 = sm.seqb[wq + nblk], d1 = sm.seqb[wq + nblk + 1];
-                    h[0] ^= premix(d0 & tailmask);
-                    h[1] ^= premix(funnel_bytes(d1, d0, 1) & tailmask);
-                    h[2] ^= premix(funnel_bytes(d1, d0, 2) & tailmask);
-                    h[3] ^= premix(funnel_bytes(d1, d0, 3) & tailmask);
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    h[c] = fmix32(h[c] ^ k);
-
-                const int64_t w0 = (int64_t)4 * wq; // first window of the quad, tile-relative
-                if (positional) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (w0 + c < wleft)
-                            outp[t0 + w0 + c] = h[c];
-                } else {
-                    bool a[4];
-                    uint64_t m[4];
-                    uint32_t tot = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        a[c] = (w0 + c < wleft) && (h[c] <= tau);
-                        m[c] = __ballot(a[c]);
-                        tot += (uint32_t)__popcll(m[c]);
-                    }
-                    if (tot) { // wave-uniform
-                        uint32_t base = 0;
-                        if (lane == 0)
-                            base = atomicAdd(&sm.misc[0], tot);
-                        base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            if (a[c])
-                                sm.cand[base + lane_rank(m[c])] = h[c];
-                            base += (uint32_t)__popcll(m[c]);
-                        }
-                    }
-                }
-            }
-            __syncthreads(); // seqb / P are rewritten by the next tile
-        }
-
-        if (positional)
-            return;
-        if (sm.misc[0] >= s)
-            break;
-        // the threshold guess kept fewer than s hashes: redo, accepting everything
+        auto shrink_shared = [&]() {
+            const uint32_t C = sm.misc[0];
+            bottom_s(sm, s, sm.misc[1], cap, true, [&](auto f) {
+                for (uint32_t i = tid; i < C; i += THREADS)
+                    f(sm.cand[i]);
+            });
+        };
+        auto append = [&](int64_t, uint32_t, uint32_t h) {
+            if (h <= sm.misc[1])
+                sm.cand[atomicAdd(&sm.misc[0], 1u)] = h;
+        };
+        run_tiles<KS, true>(
+            sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w,
+            [&](int64_t) {
+                __syncthreads(); // every wave's appends of the previous round are counted
+                const bool room = sm.misc[0] + (uint32_t)TW <= cap; // this round may append up to TW
+                __syncthreads();
+                if (!room)
+                    shrink_shared();
+            },
+            append, append);
         __syncthreads();
+        shrink_shared();
+        for (uint32_t i = tid; i < s; i += THREADS)
+            outp[i] = sm.cand[i];
     }
-
-    shrink(sm, s);
-    for (uint32_t i = tid; i < s; i += THREADS)
-        outp[i] = sm.cand[i];
 }
 
 struct Launch {
-    uint32_t n_seq_dw, n_P, cap;
-    size_t smem_bytes;
+    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap;
+    size_t smem_fast, smem_general;
 };
 
 static Launch plan(uint32_t k, uint32_t s)
 {
     Launch L;
     const uint32_t nblk = k / 4;
-    L.n_seq_dw = ((TW / 4 + nblk + 2) + 3u) & ~3u;
-    L.n_P = TW + 4 * nblk;
+    L.n_seq_dw = ((WTW / 4 + nblk + 2) + 3u) & ~3u;   // per wave
+    L.n_P_w = WTW + 4 * nblk;                         // per wave
+    L.n_P = WAVES * L.n_P_w;
+    L.n_P_fast = L.n_P < 1024u ? 1024u : L.n_P; // the fast pass sorts with 1024 bins if that is all P offers
+    L.nbf_log2 = L.n_P_fast >= 2048u ? 11u : 10u;
+    if (L.n_P < (uint32_t)NB)
+        L.n_P = NB; // `bins` aliases P
     const uint32_t s4 = (s + 3u) & ~3u;
-    L.cap = s4 + ((s / 2 + 64u + 3u) & ~3u) + TW;
-    L.smem_bytes = (size_t)(L.n_seq_dw + L.n_P + 2 * L.cap + 16) * 4;
+    // fast pass: expected survivors s + 6 sqrt(s) + 16, standard deviation ~ sqrt(s): 12 sigma of room
+    uint32_t rt = 1;
+    while ((uint64_t)rt * rt < s)
+        ++rt;
+    L.capf = (s4 + 12u * rt + 64u + 63u) & ~63u;
+    L.cap = s4 + TW + 64u; // general pass: shrink to s, then one more round always fits
+    const size_t common = (size_t)WAVES * L.n_seq_dw + L.n_P + 16 + 256;
+    L.smem_fast = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + 2 * (size_t)L.capf) * 4;
+    if (PH_ABL == 7)
+        L.smem_fast = 70 * 1024; // occupancy probe
+    L.smem_general = (common + 2 * (size_t)L.cap) * 4;
     return L;
+}
+
+static unsigned persistent_grid(size_t smem, uint64_t n)
+{
+    // as many workgroups as fit the chip at once (LDS-limited, <= 8 per CU), a few rounds deep
+    const uint64_t per_cu = std::max<uint64_t>(1, std::min<uint64_t>(8, (160 * 1024) / std::max<size_t>(smem, 1)));
+    return (unsigned)std::min<uint64_t>(n, 256 * per_cu * 4);
 }
 
 template <int KS>
 static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uint32_t k, uint32_t s,
-                  uint32_t *d_out, const Launch &L, hipStream_t st)
+                  uint32_t *d_out, const Launch &L, uint32_t *d_redo, hipStream_t st)
 {
-    auto kern = sketch_kernel<KS>;
-    if (L.smem_bytes > 48 * 1024) {
-        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.smem_bytes));
-    }
-    // grid.x is limited to 2^31-1 blocks; batches beyond that are split by the caller loop below
-    hipLaunchKernelGGL(kern, dim3((unsigned)n), dim3(THREADS), L.smem_bytes, st, d_seqs, d_offs, k, s, d_out,
-                       L.n_seq_dw, L.n_P, L.cap);
+    auto fast = sketch_fast_kernel<KS>;
+    auto general = sketch_general_kernel<KS>;
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)L.smem_fast));
+    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(general), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)L.smem_general));
+    PH_HIP(hipMemsetAsync(d_redo, 0, 4, st));
+    hipLaunchKernelGGL(fast, dim3(persistent_grid(L.smem_fast, n)), dim3(THREADS), L.smem_fast, st, d_seqs, d_offs, n,
+                       k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capf, L.nbf_log2, d_redo);
+    PH_HIP(hipGetLastError());
+    // normally the list is empty and these workgroups exit at once
+    hipLaunchKernelGGL(general, dim3(persistent_grid(L.smem_general, n)), dim3(THREADS), L.smem_general, st, d_seqs,
+                       d_offs, k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P, L.cap, d_redo);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
@@ -388,25 +691,31 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
         return POLYHIP_OK;
     PH_REQUIRE(d_seqs && d_offsets && d_out, "polyhip_mash_sketch_batch: null pointer");
     const k1::Launch L = k1::plan(k, s);
-    if (L.smem_bytes > 160 * 1024)
+    if (L.smem_general > 160 * 1024)
         return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_mash_sketch_batch: k=%u s=%u needs %zu B of LDS", k, s,
-                         L.smem_bytes);
+                         L.smem_general);
     hipStream_t st = as_stream(stream);
     const uint64_t CHUNK = 1ull << 30;
+    // redo list of the fast kernel (count + sequence indices), stream-ordered scratch
+    uint32_t *d_redo = nullptr;
+    PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_redo), (std::min<uint64_t>(n, CHUNK) + 1) * 4, st));
     for (uint64_t i0 = 0; i0 < n; i0 += CHUNK) {
         const uint64_t m = n - i0 < CHUNK ? n - i0 : CHUNK;
         const uint64_t *offs = d_offsets + i0;
         uint32_t *outp = d_out + i0 * (uint64_t)s;
         int rc;
         switch (k) {
-        case 17: rc = k1::launch<17>(d_seqs, offs, m, k, s, outp, L, st); break;
-        case 21: rc = k1::launch<21>(d_seqs, offs, m, k, s, outp, L, st); break;
-        case 31: rc = k1::launch<31>(d_seqs, offs, m, k, s, outp, L, st); break;
-        default: rc = k1::launch<0>(d_seqs, offs, m, k, s, outp, L, st); break;
+        case 17: rc = k1::launch<17>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
+        case 21: rc = k1::launch<21>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
+        case 31: rc = k1::launch<31>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
+        default: rc = k1::launch<0>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
         }
-        if (rc != POLYHIP_OK)
+        if (rc != POLYHIP_OK) {
+            (void)hipFreeAsync(d_redo, st);
             return rc;
+        }
     }
+    PH_HIP(hipFreeAsync(d_redo, st));
     return POLYHIP_OK;
 }
 

@@ -20,5 +20,5 @@ run ${R}_bench_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${
 run ${R}_bench_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_bench_write -o x -- $BENCH
 run ${R}_calib_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_calib_fetch -o x -- scripts/ubench/hbm_calib
 run ${R}_calib_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_calib_write -o x -- scripts/ubench/hbm_calib
-for t in bench_stats bench_fetch bench_write calib_fetch calib_write; do echo "== $t"; grep -E "sketch_kernel|read4|read16|write4|write8|write16|failed" $ROOT/gpurun_out/${R}_$t.md | head -12; done
+for t in bench_stats bench_fetch bench_write calib_fetch calib_write; do echo "== $t"; grep -E "sketch_fast_kernel|sketch_general|read4|read16|write4|write8|write16|failed" $ROOT/gpurun_out/${R}_$t.md | head -12; done
 rm -rf $ROOT/gpurun_out/prof_${R}_*   # keep the summaries, drop the databases

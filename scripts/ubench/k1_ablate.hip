@@ -1,0 +1,28 @@
+// Phase ablation of K1 (mash_sketch.hip): build once per PH_ABL value, run on the GPU box.
+//   for a in 0 1 2 3 4 5 6; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPH_ABL=$a -I include -I poly_amd/csrc \
+//       scripts/ubench/k1_ablate.hip poly_amd/csrc/runtime.hip -o scripts/ubench/k1_ablate_$a; done
+#include "../../poly_amd/csrc/mash_sketch.hip"
+#include <cstdio>
+#include <vector>
+int main()
+{
+    const uint64_t n = 100000, L = 10000;
+    const uint32_t k = 21, s = 1000;
+    uint8_t *seqs; uint64_t *offs; uint32_t *out;
+    hipMalloc(&seqs, n * L + 64); hipMalloc(&offs, (n + 1) * 8); hipMalloc(&out, n * s * 4);
+    polyhip_synth_dna_dev(0xC2, 0, seqs, n * L, nullptr);
+    std::vector<uint64_t> h(n + 1);
+    for (uint64_t i = 0; i <= n; ++i) h[i] = i * L;
+    hipMemcpy(offs, h.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    hipMemset(out, 0, n * s * 4);
+    polyhip_mash_sketch_batch_dev(seqs, offs, n, k, s, out, nullptr);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int r = 0; r < 5; ++r) polyhip_mash_sketch_batch_dev(seqs, offs, n, k, s, out, nullptr);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    static const char *what[] = {"full kernel", "no premix", "1 chain block of 5", "no tail/fmix", "no select stores", "no bottom_s", "no global loads", "2 workgroups per CU"};
+    printf("PH_ABL=%d %-20s %.3f ms per 100k reads\n", PH_ABL, what[PH_ABL], ms);
+    return 0;
+}
