@@ -204,3 +204,28 @@ func LeastRotationBatch(seqs []byte, offs []uint64) (rot []uint64, rotated []byt
 	})
 	return
 }
+
+// SeqhashBatch: 71-character seqhashes ("" on error) and per-sequence error codes, see polyhip_seqhash_batch.
+func SeqhashBatch(seqs []byte, offs []uint64, seqType int, circular, doubleStranded bool) ([]string, []uint32, error) {
+	n := len(offs) - 1
+	out := make([]byte, n*72+1)
+	codes := make([]uint32, n+1)
+	b2i := func(b bool) C.int {
+		if b {
+			return 1
+		}
+		return 0
+	}
+	err := call(func() C.int {
+		return C.polyhip_seqhash_batch((*C.uint8_t)(unsafe.Pointer(&seqs[0])), (*C.uint64_t)(unsafe.Pointer(&offs[0])),
+			C.uint64_t(n), C.int(seqType), b2i(circular), b2i(doubleStranded), (*C.char)(unsafe.Pointer(&out[0])),
+			(*C.uint32_t)(unsafe.Pointer(&codes[0])))
+	})
+	res := make([]string, n)
+	for i := 0; i < n; i++ {
+		if codes[i] == 0 {
+			res[i] = string(out[i*72 : i*72+71])
+		}
+	}
+	return res, codes[:n], err
+}

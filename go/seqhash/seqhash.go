@@ -1,9 +1,60 @@
-// Package seqhash: RotateSequence of github.com/bebop/poly/seqhash (seqhash.go:78-138) over libpolyhip.
-// Hash (seqhash.go:141-224) keeps the reference's host code (upper-casing, validation, BLAKE3 via
-// lukechampine.com/blake3) and only its two RotateSequence calls (:182,:188) change callee.  UNCOMPILED here.
+// Package seqhash: RotateSequence (seqhash.go:78-138) and Hash (seqhash.go:141-224) of
+// github.com/bebop/poly/seqhash over libpolyhip.  UNCOMPILED here.
 package seqhash
 
-import "github.com/bebop/poly/internal/polyhip"
+import (
+	"errors"
+
+	"github.com/bebop/poly/internal/polyhip"
+)
+
+// SequenceType is seqhash.go:66-74.
+type SequenceType string
+
+const (
+	DNA     SequenceType = "DNA"
+	RNA     SequenceType = "RNA"
+	PROTEIN SequenceType = "PROTEIN"
+)
+
+// Hash is seqhash.go:141-224 (same seqhash strings, same error texts).
+func Hash(sequence string, sequenceType SequenceType, circular bool, doubleStranded bool) (string, error) {
+	res, errs := HashBatch([]string{sequence}, sequenceType, circular, doubleStranded)
+	return res[0], errs[0]
+}
+
+// HashBatch hashes many sequences under one (type, circular, doubleStranded) in one device call
+// (the shape of clone's dedup loop, clone.go:269-320).
+func HashBatch(sequences []string, sequenceType SequenceType, circular bool, doubleStranded bool) ([]string, []error) {
+	code := map[SequenceType]int{DNA: 0, RNA: 1, PROTEIN: 2}
+	out, errs := make([]string, len(sequences)), make([]error, len(sequences))
+	c, ok := code[sequenceType]
+	if !ok { // seqhash.go:152
+		for i := range errs {
+			errs[i] = errors.New("Only sequenceTypes of DNA, RNA, or PROTEIN allowed. Got sequenceType: " + string(sequenceType))
+		}
+		return out, errs
+	}
+	ds := doubleStranded && sequenceType != PROTEIN
+	buf, offs := polyhip.Pack(sequences)
+	hashes, codes, err := polyhip.SeqhashBatch(buf, offs, c, circular, ds)
+	if err != nil {
+		panic(err)
+	}
+	for i := range sequences {
+		switch {
+		case codes[i]>>8 == 2: // seqhash.go:157
+			errs[i] = errors.New("Only letters ATUGCYRSWKMBDHVNZ are allowed for DNA/RNA. Got letter: " + string(rune(codes[i]&0xFF)))
+		case codes[i]>>8 == 3: // seqhash.go:169
+			errs[i] = errors.New("Only letters ACDEFGHIKLMNPQRSTVWYUO*BXZ are allowed for Proteins. Got letter: " + string(rune(codes[i]&0xFF)))
+		case sequenceType == PROTEIN && doubleStranded: // seqhash.go:175
+			errs[i] = errors.New("Proteins cannot be double stranded")
+		default:
+			out[i] = hashes[i]
+		}
+	}
+	return out, errs
+}
 
 // RotateSequence is seqhash.go:127-138.
 func RotateSequence(sequence string) string {

@@ -301,6 +301,32 @@ int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets,
                                  uint64_t n, uint64_t *rot_index,
                                  uint8_t *rotated);
 
+/* ---- S2: seqhash.Hash  (seqhash/seqhash.go:141-224) --------------------------- */
+/*
+ * Hash(seq_i, sequenceType, circular, doubleStranded) for every packed sequence,
+ * one (type, circular, doubleStranded) triple per call: upper-case, RNA U->T,
+ * alphabet check, least rotation / reverse complement / bytewise-smaller choice,
+ * BLAKE3-256, "v1_" + {D,R,P}{C,L}{D,S} + "_" + 64 hex digits.
+ * seq_type: 0 DNA, 1 RNA, 2 PROTEIN; anything else -> POLYHIP_ERR_INVALID with the
+ * reference's message (seqhash.go:152); PROTEIN + double_stranded likewise (:175).
+ * d_out: n slots of 72 bytes (71 characters + NUL; empty string on error).
+ * d_err[i]: 0, or (2 << 8) | letter for seqhash.go:157 ("Only letters
+ * ATUGCYRSWKMBDHVNZ are allowed for DNA/RNA. Got letter: X"), (3 << 8) | letter
+ * for seqhash.go:169 (proteins) -- the first offending letter, as the reference.
+ * total_bytes = d_offsets[n] - d_offsets[0]; max_len >= every sequence length.
+ */
+size_t polyhip_seqhash_workspace_bytes(uint64_t n, uint64_t total_bytes,
+                                       int circular, int double_stranded);
+int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets,
+                              uint64_t n, uint64_t total_bytes,
+                              uint64_t max_len, int seq_type, int circular,
+                              int double_stranded, char *d_out,
+                              uint32_t *d_err, void *d_work, size_t work_bytes,
+                              polyhip_stream_t stream);
+int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets,
+                          uint64_t n, int seq_type, int circular,
+                          int double_stranded, char *out, uint32_t *err);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,6 +62,10 @@ SIGNATURES = {
     "polyhip_marmurdoty_batch": (C.c_int, [_vp, _vp, _u64, _vp]),
     "polyhip_least_rotation_batch_dev": (C.c_int, [_vp, _vp, _u64, _u64, _vp, _vp, _vp]),
     "polyhip_least_rotation_batch": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),
+    "polyhip_seqhash_workspace_bytes": (C.c_size_t, [_u64, _u64, C.c_int, C.c_int]),
+    "polyhip_seqhash_batch_dev": (C.c_int, [_vp, _vp, _u64, _u64, _u64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp,
+                                            C.c_size_t, _vp]),
+    "polyhip_seqhash_batch": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
 }
 
 

@@ -1,0 +1,471 @@
+// seqhash.hip -- S2: batched seqhash.Hash for gfx950.
+//
+// Replaces seqhash.Hash (seqhash/seqhash.go:141-224) for a packed batch that shares one
+// (sequenceType, circular, doubleStranded) triple -- the shape of clone's dedup loop
+// (clone/clone.go:269-320) and of bulk database hashing:
+//   normalise  strings.ToUpper (:143), RNA: U -> T (:146-148), alphabet check with the first
+//              offending letter (:156-176)                                   [prepare_kernel]
+//   strands    transform.ReverseComplement (transform.go:15-23,78-109) when doubleStranded
+//   rotate     RotateSequence (:127-138) of each strand when circular       [K5, least_rotation.hip]
+//   choose     sort.Strings(...)[0]: the bytewise smaller candidate (:180-193)
+//   hash       BLAKE3-256 (lukechampine.com/blake3 v1.1.5 Sum256, :221): 1 KiB chunks of 16
+//              64-byte blocks, chaining values merged pairwise level by level (with the odd one
+//              promoted this IS BLAKE3's left-full tree), ROOT flag on the last compression
+//   format     "v1_" + {D,R,P}{C,L}{D,S} + "_" + 64 hex digits (:196-222), 71 characters
+//
+// One workgroup per sequence for the byte passes, one 64-thread workgroup per sequence for
+// BLAKE3 (a lane per chunk, then a lane per parent).  Integer/byte work, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace polyhip {
+namespace s2 {
+
+constexpr int THREADS = 256;
+constexpr int BTHREADS = 64;
+constexpr uint32_t CHUNK = 1024;
+enum { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
+
+__constant__ uint32_t c_iv[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                 0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+
+#define PH_G(a, b, c, d, mx, my)   \
+    do {                           \
+        a = a + b + (mx);          \
+        d = rotr(d ^ a, 16);       \
+        c = c + d;                 \
+        b = rotr(b ^ c, 12);       \
+        a = a + b + (my);          \
+        d = rotr(d ^ a, 8);        \
+        c = c + d;                 \
+        b = rotr(b ^ c, 7);        \
+    } while (0)
+
+// BLAKE3 compression function; out[0..8) = the new chaining value (first 8 output words)
+__device__ void compress(const uint32_t cv[8], const uint32_t block[16], uint64_t counter, uint32_t block_len,
+                         uint32_t flags, uint32_t out[8])
+{
+    uint32_t m[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        m[i] = block[i];
+    uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6], s7 = cv[7];
+    uint32_t s8 = c_iv[0], s9 = c_iv[1], s10 = c_iv[2], s11 = c_iv[3];
+    uint32_t s12 = (uint32_t)counter, s13 = (uint32_t)(counter >> 32), s14 = block_len, s15 = flags;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        PH_G(s0, s4, s8, s12, m[0], m[1]);
+        PH_G(s1, s5, s9, s13, m[2], m[3]);
+        PH_G(s2, s6, s10, s14, m[4], m[5]);
+        PH_G(s3, s7, s11, s15, m[6], m[7]);
+        PH_G(s0, s5, s10, s15, m[8], m[9]);
+        PH_G(s1, s6, s11, s12, m[10], m[11]);
+        PH_G(s2, s7, s8, s13, m[12], m[13]);
+        PH_G(s3, s4, s9, s14, m[14], m[15]);
+        if (r < 6) { // message permutation 2 6 3 10 7 0 4 13 1 11 12 5 9 14 15 8
+            uint32_t t[16];
+            t[0] = m[2]; t[1] = m[6]; t[2] = m[3]; t[3] = m[10]; t[4] = m[7]; t[5] = m[0]; t[6] = m[4]; t[7] = m[13];
+            t[8] = m[1]; t[9] = m[11]; t[10] = m[12]; t[11] = m[5]; t[12] = m[9]; t[13] = m[14]; t[14] = m[15];
+            t[15] = m[8];
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                m[i] = t[i];
+        }
+    }
+    out[0] = s0 ^ s8;
+    out[1] = s1 ^ s9;
+    out[2] = s2 ^ s10;
+    out[3] = s3 ^ s11;
+    out[4] = s4 ^ s12;
+    out[5] = s5 ^ s13;
+    out[6] = s6 ^ s14;
+    out[7] = s7 ^ s15;
+}
+
+// chaining value of chunk `idx` of data[0..len); root = this chunk is the whole input
+__device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_t idx, bool root, uint32_t cv[8])
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        cv[i] = c_iv[i];
+    const uint64_t base = idx * CHUNK;
+    const uint64_t clen = len - base < CHUNK ? len - base : CHUNK; // 0 only for the empty input
+    const uint32_t nblocks = clen == 0 ? 1u : (uint32_t)((clen + 63) / 64);
+    for (uint32_t b = 0; b < nblocks; ++b) {
+        const uint64_t off = base + (uint64_t)b * 64;
+        const uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
+        uint32_t w[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            uint32_t x = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t p = 4 * i + j;
+                if (p < blen)
+                    x |= (uint32_t)data[off + p] << (8 * j);
+            }
+            w[i] = x;
+        }
+        uint32_t flags = 0;
+        if (b == 0)
+            flags |= CHUNK_START;
+        if (b == nblocks - 1) {
+            flags |= CHUNK_END;
+            if (root)
+                flags |= ROOT;
+        }
+        uint32_t o[8];
+        compress(cv, w, idx, blen, flags, o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            cv[i] = o[i];
+    }
+}
+
+__device__ __forceinline__ uint32_t ascii_upper(uint32_t b) { return (b - 'a' < 26u) ? b - 32u : b; }
+
+// transform.complementTable (transform.go:78-109), upper case rows; unmapped bytes -> 0x00
+__device__ __forceinline__ uint32_t complement_upper(uint32_t up)
+{
+    switch (up) {
+    case 'A': return 'T';
+    case 'T': return 'A';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'B': return 'V';
+    case 'V': return 'B';
+    case 'D': return 'H';
+    case 'H': return 'D';
+    case 'K': return 'M';
+    case 'M': return 'K';
+    case 'R': return 'Y';
+    case 'Y': return 'R';
+    case 'N': return 'N';
+    case 'S': return 'S';
+    case 'W': return 'W';
+    default: return 0;
+    }
+}
+
+__device__ __forceinline__ bool in_set(uint32_t c, const char *set)
+{
+    for (const char *p = set; *p; ++p)
+        if ((uint32_t)(uint8_t)*p == c)
+            return true;
+    return false;
+}
+
+// normalise + validate (+ reverse complement).  err[q] = 0 or (code << 8) | first offending letter
+__global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restrict__ seqs,
+                                                         const uint64_t *__restrict__ offs, uint64_t n, int seq_type,
+                                                         int want_rc, uint8_t *__restrict__ norm,
+                                                         uint8_t *__restrict__ rc, uint32_t *__restrict__ err)
+{
+    __shared__ unsigned long long first_bad; // (position << 8) | letter
+    for (uint64_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            first_bad = ~0ull;
+        __syncthreads();
+        for (uint64_t t = threadIdx.x; t < len; t += THREADS) {
+            uint32_t c = ascii_upper(seqs[o0 + t]);
+            if (seq_type == 1 && c == 'U') // seqhash.go:146-148
+                c = 'T';
+            const bool good = seq_type == 2 ? in_set(c, "ACDEFGHIKLMNPQRSTVWYUO*BXZ") : in_set(c, "ATUGCYRSWKMBDHVNZ");
+            if (!good)
+                atomicMin(&first_bad, ((unsigned long long)t << 8) | c);
+            norm[o0 + t] = (uint8_t)c;
+            if (want_rc)
+                rc[o0 + (len - 1 - t)] = (uint8_t)complement_upper(c); // transform.go:15-23
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            err[q] = first_bad == ~0ull ? 0u : (((seq_type == 2 ? 3u : 2u) << 8) | (uint32_t)(first_bad & 0xFF));
+    }
+}
+
+// choose the bytewise smaller candidate (sort.Strings), BLAKE3 it, format the seqhash
+__global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restrict__ cand0,
+                                                       const uint8_t *__restrict__ cand1,
+                                                       const uint64_t *__restrict__ offs, uint64_t n,
+                                                       const uint64_t *__restrict__ cvoff, uint32_t *__restrict__ cvbuf,
+                                                       const uint32_t *__restrict__ err, uint32_t prefix_letters,
+                                                       char *__restrict__ out)
+{
+    __shared__ unsigned long long first_diff;
+    const int tid = threadIdx.x;
+    for (uint64_t q = blockIdx.x; q < n; q += gridDim.x) {
+        char *o = out + q * 72;
+        if (err[q] != 0u) {
+            if (tid == 0)
+                o[0] = 0;
+            continue;
+        }
+        const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
+        const uint8_t *data = cand0 + o0;
+        if (cand1) { // first differing byte decides
+            __syncthreads();
+            if (tid == 0)
+                first_diff = ~0ull;
+            __syncthreads();
+            for (uint64_t t0 = 0; t0 < len; t0 += BTHREADS) {
+                const uint64_t t = t0 + tid;
+                if (t < len && cand0[o0 + t] != cand1[o0 + t])
+                    atomicMin(&first_diff, (unsigned long long)t);
+                __syncthreads();
+                if (first_diff != ~0ull)
+                    break;
+                __syncthreads();
+            }
+            __syncthreads();
+            const unsigned long long d = first_diff;
+            if (d != ~0ull && cand1[o0 + d] < cand0[o0 + d])
+                data = cand1 + o0;
+        }
+        const uint64_t nchunks = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
+        uint32_t *A = cvbuf + cvoff[q] * 16, *B = A + nchunks * 8; // two levels of chaining values
+        uint32_t root[8];
+        if (nchunks == 1) {
+            if (tid == 0)
+                chunk_cv(data, len, 0, true, root);
+        } else {
+            for (uint64_t c = tid; c < nchunks; c += BTHREADS) {
+                uint32_t cv[8];
+                chunk_cv(data, len, c, false, cv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    A[c * 8 + i] = cv[i];
+            }
+            uint64_t m = nchunks;
+            uint32_t *src = A, *dst = B;
+            while (m > 2) {
+                __threadfence_block();
+                __syncthreads();
+                const uint64_t pairs = m / 2;
+                for (uint64_t p = tid; p < pairs; p += BTHREADS) {
+                    uint32_t blk[16], cv[8], iv[8];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        blk[i] = src[p * 16 + i];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        iv[i] = c_iv[i];
+                    compress(iv, blk, 0, 64, PARENT, cv);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        dst[p * 8 + i] = cv[i];
+                }
+                if ((m & 1) && tid == 0) // the odd one is promoted unchanged
+                    for (int i = 0; i < 8; ++i)
+                        dst[pairs * 8 + i] = src[(m - 1) * 8 + i];
+                m = pairs + (m & 1);
+                uint32_t *t = src;
+                src = dst;
+                dst = t;
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t blk[16], iv[8];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    blk[i] = src[i];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    iv[i] = c_iv[i];
+                compress(iv, blk, 0, 64, PARENT | ROOT, root);
+            }
+        }
+        if (tid == 0) {
+            o[0] = 'v';
+            o[1] = '1';
+            o[2] = '_';
+            o[3] = (char)(prefix_letters & 0xFF);
+            o[4] = (char)((prefix_letters >> 8) & 0xFF);
+            o[5] = (char)((prefix_letters >> 16) & 0xFF);
+            o[6] = '_';
+            const char *hex = "0123456789abcdef";
+            for (int i = 0; i < 8; ++i)
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t byte = (root[i] >> (8 * j)) & 0xFF; // little-endian words
+                    o[7 + (4 * i + j) * 2] = hex[byte >> 4];
+                    o[7 + (4 * i + j) * 2 + 1] = hex[byte & 15];
+                }
+            o[71] = 0;
+        }
+    }
+}
+
+// cvoff[q] = number of chunks of the sequences before q (exclusive scan; single block is plenty here)
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__restrict__ offs, uint64_t n,
+                                                         uint64_t *__restrict__ cvoff)
+{
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + tid;
+        uint64_t v = 0;
+        if (i < n) {
+            const uint64_t len = offs[i + 1] - offs[i];
+            v = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
+        }
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w)
+            pre += wsum[w];
+        if (i < n)
+            cvoff[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry = pre + incl;
+        __syncthreads();
+    }
+}
+
+struct Layout {
+    size_t off_norm, off_rc, off_rot0, off_rot1, off_rotidx, off_cvoff, off_cv, total;
+};
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static Layout layout(uint64_t n, uint64_t total_bytes, int circular, int ds)
+{
+    Layout L;
+    size_t o = 0;
+    L.off_norm = o; o += al(total_bytes + 16);
+    L.off_rc = o; o += ds ? al(total_bytes + 16) : 0;
+    L.off_rot0 = o; o += circular ? al(total_bytes + 16) : 0;
+    L.off_rot1 = o; o += (circular && ds) ? al(total_bytes + 16) : 0;
+    L.off_rotidx = o; o += circular ? al(n * 8) : 0;
+    L.off_cvoff = o; o += al(n * 8);
+    // two levels of 8-word chaining values per chunk; chunks <= total_bytes / 1024 + n
+    L.off_cv = o; o += al((total_bytes / s2::CHUNK + n + 1) * 16 * 4);
+    L.total = o;
+    return L;
+}
+
+} // namespace s2
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
+                                     uint64_t *d_rot_index, uint8_t *d_rotated, polyhip_stream_t stream);
+
+size_t polyhip_seqhash_workspace_bytes(uint64_t n, uint64_t total_bytes, int circular, int double_stranded)
+{
+    return s2::layout(n, total_bytes, circular, double_stranded).total;
+}
+
+int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t total_bytes,
+                              uint64_t max_len, int seq_type, int circular, int double_stranded, char *d_out,
+                              uint32_t *d_err, void *d_work, size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(seq_type >= 0 && seq_type <= 2,
+               "Only sequenceTypes of DNA, RNA, or PROTEIN allowed. Got sequenceType code: %d", seq_type); // seqhash.go:152
+    PH_REQUIRE(!(seq_type == 2 && double_stranded), "Proteins cannot be double stranded");                 // seqhash.go:175
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_seqs && d_offsets && d_out && d_err && d_work, "polyhip_seqhash_batch: null pointer");
+    const s2::Layout L = s2::layout(n, total_bytes, circular, double_stranded);
+    PH_REQUIRE(work_bytes >= L.total, "polyhip_seqhash_batch: workspace too small (%zu < %zu)", work_bytes, L.total);
+    hipStream_t st = as_stream(stream);
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    uint8_t *norm = w + L.off_norm, *rc = double_stranded ? w + L.off_rc : nullptr;
+    uint8_t *rot0 = w + L.off_rot0, *rot1 = w + L.off_rot1;
+    uint64_t *rotidx = reinterpret_cast<uint64_t *>(w + L.off_rotidx);
+    uint64_t *cvoff = reinterpret_cast<uint64_t *>(w + L.off_cvoff);
+    uint32_t *cvbuf = reinterpret_cast<uint32_t *>(w + L.off_cv);
+
+    const unsigned blocks = (unsigned)std::min<uint64_t>(n, 256ull * 32ull);
+    hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type,
+                       double_stranded ? 1 : 0, norm, rc, d_err);
+    PH_HIP(hipGetLastError());
+    const uint8_t *c0 = norm, *c1 = rc;
+    if (circular) {
+        int r = polyhip_least_rotation_batch_dev(norm, d_offsets, n, max_len, rotidx, rot0, stream);
+        if (r != POLYHIP_OK)
+            return r;
+        c0 = rot0;
+        if (double_stranded) {
+            r = polyhip_least_rotation_batch_dev(rc, d_offsets, n, max_len, rotidx, rot1, stream);
+            if (r != POLYHIP_OK)
+                return r;
+            c1 = rot1;
+        }
+    }
+    hipLaunchKernelGGL(s2::chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d_offsets, n, cvoff);
+    const uint32_t letters = (uint32_t)(seq_type == 0 ? 'D' : seq_type == 1 ? 'R' : 'P') |
+                             ((uint32_t)(circular ? 'C' : 'L') << 8) | ((uint32_t)(double_stranded ? 'D' : 'S') << 16);
+    hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvoff, cvbuf, d_err,
+                       letters, d_out);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int seq_type, int circular,
+                          int double_stranded, char *out, uint32_t *err)
+{
+    PH_REQUIRE(seq_type >= 0 && seq_type <= 2,
+               "Only sequenceTypes of DNA, RNA, or PROTEIN allowed. Got sequenceType code: %d", seq_type);
+    PH_REQUIRE(!(seq_type == 2 && double_stranded), "Proteins cannot be double stranded");
+    if (n == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(seqs && offsets && out && err, "polyhip_seqhash_batch: null pointer");
+    uint64_t max_len = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        PH_REQUIRE(offsets[i] <= offsets[i + 1], "polyhip_seqhash_batch: offsets not ascending at %llu",
+                   (unsigned long long)i);
+        max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
+    }
+    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
+    for (uint64_t i = 0; i < nbytes; ++i)
+        PH_REQUIRE(seqs[b0 + i] < 0x80, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
+                   seqs[b0 + i], (unsigned long long)i);
+    DevBuf dseq, doff, dout, derr, dwork;
+    PH_HIP(dseq.alloc(nbytes));
+    PH_HIP(doff.alloc((n + 1) * 8));
+    PH_HIP(dout.alloc(n * 72));
+    PH_HIP(derr.alloc(n * 4));
+    std::vector<uint64_t> tmp(n + 1);
+    for (uint64_t i = 0; i <= n; ++i)
+        tmp[i] = offsets[i] - b0;
+    PH_HIP(hipMemcpy(doff.p, tmp.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    if (nbytes)
+        PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
+    const size_t wb = polyhip_seqhash_workspace_bytes(n, nbytes, circular, double_stranded);
+    PH_HIP(dwork.alloc(wb));
+    int rc = polyhip_seqhash_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, nbytes, max_len, seq_type, circular,
+                                       double_stranded, dout.as<char>(), derr.as<uint32_t>(), dwork.p, wb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(out, dout.p, n * 72, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(err, derr.p, n * 4, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

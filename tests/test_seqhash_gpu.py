@@ -88,3 +88,54 @@ def test_device_batch(sh):
         s = host[i * L:(i + 1) * L].tobytes()
         assert int(r[i]) == orc.booth_least_rotation(s)
         assert o[i * L:(i + 1) * L].tobytes() == orc.rotate_sequence(s)
+
+
+# ---- Hash (seqhash.go:141-224) ----------------------------------------------------------
+def test_TestHash(sh):
+    """seqhash/seqhash_test.go:12-66, example_test.go:11-31: error texts and the 7 exact seqhashes"""
+    with pytest.raises(ValueError, match="Only sequenceTypes of DNA, RNA, or PROTEIN allowed. Got sequenceType: TNA"):
+        sh.Hash("ATGGGCTAA", "TNA", True, True)
+    with pytest.raises(ValueError, match="Only letters ATUGCYRSWKMBDHVNZ are allowed for DNA/RNA. Got letter: X"):
+        sh.Hash("XTGGCCTAA", "DNA", True, True)
+    with pytest.raises(ValueError, match=r"Only letters ACDEFGHIKLMNPQRSTVWYUO\*BXZ are allowed for Proteins. Got letter: J"):
+        sh.Hash("MGCJ*", "PROTEIN", False, False)
+    with pytest.raises(ValueError, match="Proteins cannot be double stranded"):
+        sh.Hash("MGCS*", "PROTEIN", False, True)
+    want = {
+        ("TTAGCCCAT", "DNA", True, True): "v1_DCD_a376845b679740014f3eb501429b45e592ecc32a6ba8ba922cbe99217f6e9287",
+        ("TTAGCCCAT", "DNA", True, False): "v1_DCS_ef79b6e62394e22a176942dfc6a5e62eeef7b5281ffcb2686ecde208ec836ba4",
+        ("TTAGCCCAT", "DNA", False, True): "v1_DLD_c2c9fc44df72035082a152e94b04492182331bc3be2f62729d203e072211bdbf",
+        ("TTAGCCCAT", "DNA", False, False): "v1_DLS_063ea37d1154351639f9a48546bdae62fd8a3c18f3d3d3061060c9a55352d967",
+        ("TTAGCCCAT", "RNA", False, False): "v1_RLS_063ea37d1154351639f9a48546bdae62fd8a3c18f3d3d3061060c9a55352d967",
+        ("MGC*", "PROTEIN", False, False): "v1_PLS_922ec11f5227ce77a42f07f565a7a1a479772b5cf3f1f6e93afc5ecbc0fd5955",
+        ("ATGC", "DNA", False, True): "v1_DLD_f4028f93e08c5c23cbb8daa189b0a9802b378f1a1c919dcbcf1608a615f46350",
+    }
+    for args, h in want.items():
+        assert sh.Hash(*args) == h, args
+    # published BLAKE3 digest of the empty input
+    assert sh.Hash("", "DNA", False, False) == "v1_DLS_af1349b9f5f9a1a6a0404dea36dcc9499bcb25c9adc112b7cc9a93cae41f3262"
+
+
+@pytest.mark.parametrize("stype,circular,ds", [("DNA", c, d) for c in (False, True) for d in (False, True)] +
+                         [("RNA", True, True), ("RNA", False, False), ("PROTEIN", False, False), ("PROTEIN", True, False)])
+def test_hash_batch_matches_oracle(sh, stype, circular, ds):
+    rng = np.random.default_rng(hash((stype, circular, ds)) % (1 << 31))
+    if stype == "PROTEIN":
+        alpha = b"ACDEFGHIKLMNPQRSTVWYUO*BXZacdxz"
+    else:
+        alpha = b"ACGTacgtUuNRYSWKMBDHVZ"
+    seqs = [b"", b"A", b"AT", b"TA", b"GAATTC", b"ACGU", b"acgu", b"ZZZ", b"AAAA"]
+    # lengths around the 64-byte block and 1024-byte chunk edges, and multi-level trees
+    for L in (63, 64, 65, 127, 128, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 4097, 5000, 7 * 1024, 8 * 1024 + 1, 20_000):
+        seqs.append(bytes(rng.choice(list(alpha), L).astype(np.uint8)))
+    for _ in range(60):
+        seqs.append(bytes(rng.choice(list(alpha[:4] if stype != "PROTEIN" else alpha), int(rng.integers(1, 3000))).astype(np.uint8)))
+    seqs += [b"ACGTXACGT", b"ACG-T", b"JJJ", b"acgtj"]  # alphabet errors (first offending letter)
+    got = sh.HashBatch(seqs, stype, circular, ds)
+    for s, g in zip(seqs, got):
+        try:
+            want = orc.seqhash(s, stype, circular, ds)
+        except orc.SeqhashError as e:
+            assert isinstance(g, ValueError) and str(g) == str(e), (s[:20], g, e)
+            continue
+        assert g == want, (s[:30], len(s))
