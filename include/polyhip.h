@@ -230,6 +230,34 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
                            uint32_t *endB, uint32_t *err, uint8_t *alnA,
                            uint8_t *alnB, uint32_t *alnLen,
                            uint32_t aln_stride);
+/* ---- search/align NeedlemanWunsch  (search/align/align.go:100-166) -------------- */
+/*
+ * Global alignment of every pair (A_p, B_p) (B shared when d_offB == NULL): score
+ * = H[lenA][lenB] with the gap-penalty boundary (:112-120), aligned strings from the
+ * reference's traceback, which stops when EITHER index reaches 0 (:141) -- so
+ * ("", "GAT") gives score 3*gap and two empty strings.  err as polyhip_sw_batch.
+ * Strings: last d_alnLen[p] bytes of the aln_stride-byte slots, aln_stride >=
+ * max_lenA + lenB.  Workspace: polyhip_nw_workspace_bytes (whole direction matrix
+ * per pair; the call loops over chunks of pairs if given less, >= 256 pairs' worth).
+ */
+size_t polyhip_nw_workspace_bytes(uint64_t npairs, uint32_t max_lenA,
+                                  uint64_t max_lenB);
+int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A,
+                               const uint64_t *d_offA, uint64_t npairs,
+                               uint32_t max_lenA, const uint8_t *d_B,
+                               const uint64_t *d_offB, uint64_t lenB,
+                               int64_t *d_score, uint32_t *d_err,
+                               uint8_t *d_alnA, uint8_t *d_alnB,
+                               uint32_t *d_alnLen, uint32_t aln_stride,
+                               void *d_work, size_t work_bytes,
+                               polyhip_stream_t stream);
+int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
+                           const uint64_t *offA, uint64_t npairs,
+                           const uint8_t *B, const uint64_t *offB,
+                           uint64_t lenB, int64_t *score, uint32_t *err,
+                           uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen,
+                           uint32_t aln_stride);
+
 /* which kernel family the last polyhip_sw_batch*_dev call on this thread
  * used: 1 = register-tiled shared-B kernel, 2 = generic kernel (tests). */
 int polyhip_sw_last_path(void);

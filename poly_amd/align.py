@@ -203,3 +203,40 @@ def sw_traceback_stride(scoring: Scoring, max_lenA: int, lenB: int) -> int:
 
 def sw_traceback_workspace_bytes(scoring: Scoring, npairs: int, max_lenA: int, lenB: int) -> int:
     return int(_lib.lib().polyhip_sw_traceback_workspace_bytes(scoring.handle(), npairs, max_lenA, lenB))
+
+
+# ---- NeedlemanWunsch (align.go:100-166) -----------------------------------------------------
+
+def nw_align_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.ndarray, offB: np.ndarray | None = None):
+    """Host-pointer entry point: (score int64[n], err uint32[n], alignA list[bytes], alignB list[bytes])."""
+    n = len(offA) - 1
+    A = np.ascontiguousarray(A, dtype=np.uint8)
+    B = np.ascontiguousarray(B, dtype=np.uint8)
+    offA = np.ascontiguousarray(offA, dtype=np.uint64)
+    if offB is not None:
+        offB = np.ascontiguousarray(offB, dtype=np.uint64)
+    max_lenA = int(np.diff(offA.astype(np.int64)).max()) if n else 0
+    lenB = len(B) if offB is None else (int(np.diff(offB.astype(np.int64)).max()) if n else 0)
+    stride = max(1, max_lenA + lenB)
+    score = np.zeros(n, dtype=np.int64)
+    err = np.zeros(n, dtype=np.uint32)
+    alnA = np.zeros((n, stride), dtype=np.uint8)
+    alnB = np.zeros((n, stride), dtype=np.uint8)
+    alen = np.zeros(n, dtype=np.uint32)
+    _lib.check(_lib.lib().polyhip_nw_align_batch(
+        scoring.handle(), A.ctypes.data, offA.ctypes.data, n, B.ctypes.data,
+        offB.ctypes.data if offB is not None else None, len(B) if offB is None else 0,
+        score.ctypes.data, err.ctypes.data, alnA.ctypes.data, alnB.ctypes.data, alen.ctypes.data, stride))
+    sa = [alnA[p, stride - int(alen[p]):].tobytes() for p in range(n)]
+    sb = [alnB[p, stride - int(alen[p]):].tobytes() for p in range(n)]
+    return score, err, sa, sb
+
+
+def NeedlemanWunsch(stringA, stringB, scoring: Scoring):
+    """align.go:100-166 -> (score, alignA, alignB); raises alphabet.Error like the reference's err."""
+    A, offA = _pack([stringA])
+    B, _ = _pack([stringB])
+    score, err, sa, sb = nw_align_packed(scoring, A, offA, B, None)
+    if err[0]:
+        _raise_symbol(int(err[0]))
+    return int(score[0]), sa[0].decode("latin-1"), sb[0].decode("latin-1")

@@ -267,6 +267,112 @@ __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
     alnLen[pair] = len;
 }
 
+// ---- NeedlemanWunsch (align.go:100-166): global alignment, any lengths --------------------------
+// One pair per lane; the H column and the direction words of the WHOLE matrix live in global
+// scratch (lane-interleaved).  Boundary H[i][0] = i*gap, H[0][j] = j*gap (:112-120); the cell is
+// max(diag + s, up + gap, left + gap) (:131-134); the traceback stops as soon as EITHER index
+// reaches 0 (:141), so leading residues are dropped exactly like the reference drops them; its
+// last branch is an unconditional else (:154-158).
+__global__ __launch_bounds__(THREADS) void nw_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                    uint64_t pair0, uint64_t pair1, const uint8_t *__restrict__ B,
+                                                    const uint64_t *__restrict__ offB, uint64_t lenB_shared,
+                                                    const int32_t *__restrict__ lut,
+                                                    const uint8_t *__restrict__ validA,
+                                                    const uint8_t *__restrict__ validB, int gap, uint32_t max_lenA,
+                                                    int32_t *__restrict__ hbuf, uint32_t *__restrict__ dirbuf,
+                                                    int64_t *__restrict__ score, uint32_t *__restrict__ err,
+                                                    uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB,
+                                                    uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    const uint64_t local = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    const uint64_t pair = pair0 + local;
+    if (pair >= pair1)
+        return;
+    const uint64_t nl = (uint64_t)gridDim.x * THREADS;
+    const uint32_t nw = (max_lenA + 15) / 16;
+    const uint64_t o0 = offA[pair];
+    const uint32_t m = (uint32_t)(offA[pair + 1] - o0);
+    const uint8_t *a = A + o0;
+    const uint8_t *b = offB ? B + offB[pair] : B;
+    const uint32_t n = (uint32_t)(offB ? offB[pair + 1] - offB[pair] : lenB_shared);
+    // align.go:126-129 + matrix.go:29-36: the first failing Score() in row-major order
+    uint32_t e = 0;
+    if (m > 0 && n > 0) {
+        if (!validA[a[0]]) {
+            e = (1u << 8) | a[0];
+        } else {
+            for (uint32_t j = 0; j < n && !e; ++j)
+                if (!validB[b[j]])
+                    e = (2u << 8) | b[j];
+            for (uint32_t i = 1; i < m && !e; ++i)
+                if (!validA[a[i]])
+                    e = (1u << 8) | a[i];
+        }
+    }
+    err[pair] = e;
+    if (e) {
+        score[pair] = 0;
+        alnLen[pair] = 0;
+        return;
+    }
+    int32_t *Hc = hbuf + local;
+    uint32_t *dirw = dirbuf + local;
+    for (uint32_t i = 0; i < m; ++i)
+        Hc[(size_t)i * nl] = (int32_t)(i + 1) * gap; // H[i+1][0]
+    int top = 0;                                      // H[0][j-1]
+    for (uint32_t j = 1; j <= n; ++j) {
+        const uint32_t bsym = b[j - 1];
+        int diag = top;          // H[i-1][j-1], starting at H[0][j-1]
+        int up = top + gap;      // H[0][j]
+        top = up;
+        uint32_t word = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+            const int s = lut[(uint32_t)a[i] * 256u + bsym];
+            const int left = Hc[(size_t)i * nl]; // H[i+1][j-1]
+            const int d = diag + s, u = up + gap, l = left + gap;
+            const int h = max(d, max(u, l));
+            const uint32_t code = h == d ? 1u : (h == u ? 2u : 3u);
+            word |= code << (2 * (i & 15));
+            diag = left;
+            up = h;
+            Hc[(size_t)i * nl] = h;
+            if ((i & 15) == 15 || i == m - 1) {
+                dirw[((size_t)(j - 1) * nw + (i >> 4)) * nl] = word;
+                word = 0;
+            }
+        }
+    }
+    score[pair] = m == 0 ? (int64_t)n * gap : (n == 0 ? (int64_t)m * gap : (int64_t)Hc[(size_t)(m - 1) * nl]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // traceback (:141-160); strings are built by append + reverse = filled from the back here
+    uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+    uint32_t i = m, j = n, len = 0;
+    while (i > 0 && j > 0 && len < stride) {
+        const uint32_t word = __hip_atomic_load(&dirw[((size_t)(j - 1) * nw + ((i - 1) >> 4)) * nl], __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t code = (word >> (2 * ((i - 1) & 15))) & 3u;
+        uint8_t ca, cb;
+        if (code == 1u) {
+            ca = a[i - 1];
+            cb = b[j - 1];
+            --i;
+            --j;
+        } else if (code == 2u) {
+            ca = a[i - 1];
+            cb = '-';
+            --i;
+        } else {
+            ca = '-';
+            cb = b[j - 1];
+            --j;
+        }
+        outA[stride - 1 - len] = ca;
+        outB[stride - 1 - len] = cb;
+        ++len;
+    }
+    alnLen[pair] = len;
+}
+
 struct Plan {
     int ra;            // 0 = generic
     Window win;
@@ -446,6 +552,116 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
     PH_HIP(hipMemcpy(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
     PH_HIP(hipMemcpy(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"
+
+extern "C" {
+
+size_t polyhip_nw_workspace_bytes(uint64_t npairs, uint32_t max_lenA, uint64_t max_lenB)
+{
+    const uint64_t per_pair = (uint64_t)max_lenB * ((max_lenA + 15) / 16) * 4 + (uint64_t)max_lenA * 4 + 8;
+    const uint64_t padded = (npairs + k3t::THREADS - 1) / k3t::THREADS * k3t::THREADS;
+    uint64_t want = padded * per_pair;
+    const uint64_t cap = 8ull << 30, floor_ = (uint64_t)k3t::THREADS * per_pair;
+    if (want > cap)
+        want = std::max(cap / floor_, (uint64_t)1) * floor_;
+    return (size_t)want + 256;
+}
+
+int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                               uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                               int64_t *d_score, uint32_t *d_err, uint8_t *d_alnA, uint8_t *d_alnB, uint32_t *d_alnLen,
+                               uint32_t aln_stride, void *d_work, size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(sc, "polyhip_nw_align_batch: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(d_offA && d_score && d_err && d_alnA && d_alnB && d_alnLen && d_work, "polyhip_nw_align_batch: null pointer");
+    PH_REQUIRE((uint64_t)aln_stride >= (uint64_t)max_lenA + lenB || aln_stride == 0xFFFFFFFFu,
+               "polyhip_nw_align_batch: aln_stride %u < max_lenA + lenB", aln_stride);
+    if ((int64_t)sc->absmax * (int64_t)((uint64_t)max_lenA + lenB) >= (1ll << 31))
+        return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_nw_align_batch: scores could overflow int32");
+    const uint64_t per_pair = (uint64_t)lenB * ((max_lenA + 15) / 16) * 4 + (uint64_t)max_lenA * 4 + 8;
+    const uint64_t chunk = (work_bytes & ~(size_t)255) / per_pair / k3t::THREADS * k3t::THREADS;
+    PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_nw_align_batch: workspace too small (%zu B; %llu B per pair, >= %d pairs)",
+               work_bytes, (unsigned long long)per_pair, k3t::THREADS);
+    hipStream_t st = as_stream(stream);
+    for (uint64_t p0 = 0; p0 < npairs; p0 += chunk) {
+        const uint64_t p1 = std::min(npairs, p0 + chunk);
+        const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
+        const size_t nl = (size_t)blocks * k3t::THREADS;
+        int32_t *hbuf = static_cast<int32_t *>(d_work);
+        uint32_t *dirg = reinterpret_cast<uint32_t *>(hbuf + nl * (max_lenA ? max_lenA : 1));
+        hipLaunchKernelGGL(k3t::nw_kernel, dim3(blocks), dim3(k3t::THREADS), 0, st, d_A, d_offA, p0, p1, d_B, d_offB, lenB,
+                           sc->d_lut, sc->d_validA, sc->d_validB, (int)sc->gap, max_lenA, hbuf, dirg, d_score, d_err, d_alnA,
+                           d_alnB, d_alnLen, aln_stride);
+        PH_HIP(hipGetLastError());
+    }
+    return POLYHIP_OK;
+}
+
+int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                           const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *err,
+                           uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen, uint32_t aln_stride)
+{
+    PH_REQUIRE(sc, "polyhip_nw_align_batch: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(offA && score && err && alnA && alnB && alnLen, "polyhip_nw_align_batch: null pointer");
+    uint64_t maxA = 0, maxB = offB ? 0 : lenB;
+    for (uint64_t i = 0; i < npairs; ++i) {
+        PH_REQUIRE(offA[i] <= offA[i + 1], "polyhip_nw_align_batch: offA not ascending at %llu", (unsigned long long)i);
+        maxA = std::max(maxA, offA[i + 1] - offA[i]);
+        if (offB) {
+            PH_REQUIRE(offB[i] <= offB[i + 1], "polyhip_nw_align_batch: offB not ascending at %llu", (unsigned long long)i);
+            maxB = std::max(maxB, offB[i + 1] - offB[i]);
+        }
+    }
+    PH_REQUIRE(maxA < 0xFFFFFFFFull && maxB < 0xFFFFFFFFull, "polyhip_nw_align_batch: sequence longer than 2^32");
+    const uint64_t a0 = offA[0], abytes = offA[npairs] - a0;
+    const uint64_t b0 = offB ? offB[0] : 0, bbytes = offB ? offB[npairs] - b0 : lenB;
+    PH_REQUIRE((A || abytes == 0) && (B || bbytes == 0), "polyhip_nw_align_batch: null sequence buffer");
+    DevBuf dA, doA, dB, doB, dscore, derr, dalA, dalB, dlen, dwork;
+    PH_HIP(dA.alloc(abytes + 16));
+    PH_HIP(doA.alloc((npairs + 1) * 8));
+    PH_HIP(dB.alloc(bbytes + 16));
+    PH_HIP(dscore.alloc(npairs * 8));
+    PH_HIP(derr.alloc(npairs * 4));
+    PH_HIP(dalA.alloc(npairs * (size_t)aln_stride + 1));
+    PH_HIP(dalB.alloc(npairs * (size_t)aln_stride + 1));
+    PH_HIP(dlen.alloc(npairs * 4));
+    std::vector<uint64_t> tmp(npairs + 1);
+    for (uint64_t i = 0; i <= npairs; ++i)
+        tmp[i] = offA[i] - a0;
+    PH_HIP(hipMemcpy(doA.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+    if (abytes)
+        PH_HIP(hipMemcpy(dA.p, A + a0, abytes, hipMemcpyHostToDevice));
+    if (bbytes)
+        PH_HIP(hipMemcpy(dB.p, B + b0, bbytes, hipMemcpyHostToDevice));
+    if (offB) {
+        PH_HIP(doB.alloc((npairs + 1) * 8));
+        for (uint64_t i = 0; i <= npairs; ++i)
+            tmp[i] = offB[i] - b0;
+        PH_HIP(hipMemcpy(doB.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+    }
+    const size_t wb = polyhip_nw_workspace_bytes(npairs, (uint32_t)maxA, maxB);
+    PH_HIP(dwork.alloc(wb));
+    int rc = polyhip_nw_align_batch_dev(sc, dA.as<uint8_t>(), doA.as<uint64_t>(), npairs, (uint32_t)maxA, dB.as<uint8_t>(),
+                                        offB ? doB.as<uint64_t>() : nullptr, maxB, dscore.as<int64_t>(), derr.as<uint32_t>(),
+                                        dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(), aln_stride, dwork.p, wb,
+                                        nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
+    if (aln_stride) {
+        PH_HIP(hipMemcpy(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+        PH_HIP(hipMemcpy(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+    }
     PH_HIP(hipMemcpy(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost));
     return POLYHIP_OK;
 }
