@@ -49,7 +49,6 @@ constexpr int THREADS = 256;
 constexpr uint32_t MAX_OCC = 255; // occurrence number packed above the sketch id
 constexpr uint32_t ID_BITS = 24;
 constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
-constexpr uint32_t SCAN_CHUNK = 2048; // histogram entries per scan block
 constexpr uint32_t TAB = 2048;        // LDS hash accumulator slots per row
 constexpr uint32_t TAB_LIMIT = 1536;  // distinct columns a row may hit before it goes to the merge
 constexpr uint32_t S_MAX = 8192;      // X SketchSize rowjoin stages in LDS
@@ -59,9 +58,9 @@ enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_pad, 
 enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
 
 struct Layout {
-    uint32_t nbk, nscan;
+    uint32_t nbk, nbk_log2, nc, nc_log2, fpc_log2;
     size_t off_flagsX, off_flagsY, off_irrX, off_regX, off_irrY, off_ovfX;
-    size_t off_start, off_cur, off_bsum, off_items;
+    size_t off_start, off_gcount, off_cstart, off_gcur, off_citems, off_items;
     size_t total;
 };
 
@@ -73,11 +72,16 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     (void)sx;
     // ~32 Y items per bucket; a bucket is a value range of one width (a power of two)
     const uint64_t itemsY = ny * (uint64_t)sy;
-    uint32_t nbk = SCAN_CHUNK;
+    uint32_t nbk = 2048;
     while (nbk < (1u << 23) && (uint64_t)nbk * 32 < itemsY)
         nbk <<= 1;
     L.nbk = nbk;
-    L.nscan = nbk / SCAN_CHUNK;
+    L.nbk_log2 = 0;
+    while ((1u << L.nbk_log2) < nbk)
+        ++L.nbk_log2;
+    L.nc_log2 = L.nbk_log2 < 12u ? L.nbk_log2 : 12u; // NC_LOG2_MAX
+    L.nc = 1u << L.nc_log2;
+    L.fpc_log2 = L.nbk_log2 - L.nc_log2;
     size_t o = al(H_WORDS * 4);
     L.off_flagsX = o; o += al(nx);
     L.off_flagsY = o; o += al(ny);
@@ -86,8 +90,10 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     L.off_ovfX = o; o += al(nx * 4);
     L.off_irrY = o; o += al(ny * 4);
     L.off_start = o; o += al(((size_t)nbk + 1) * 4);
-    L.off_cur = o; o += al((size_t)nbk * 4);
-    L.off_bsum = o; o += al((size_t)L.nscan * 4);
+    L.off_gcount = o; o += al((size_t)L.nc * 4);
+    L.off_cstart = o; o += al(((size_t)L.nc + 1) * 4);
+    L.off_gcur = o; o += al((size_t)L.nc * 4);
+    L.off_citems = o; o += al(ny * (size_t)sy * 8);
     L.off_items = o; o += al(ny * (size_t)sy * 8);
     L.total = o;
     return L;
@@ -146,58 +152,46 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
     }
 }
 
-__global__ __launch_bounds__(THREADS) void hist_kernel(const uint32_t *__restrict__ sk, uint32_t s,
-                                                      const uint8_t *__restrict__ flags,
-                                                      const uint32_t *__restrict__ hdr, uint32_t *__restrict__ start)
-{
-    const uint64_t q = blockIdx.x;
-    if (flags[q])
-        return;
-    const uint32_t shift = hdr[H_SHIFT];
-    const uint32_t *p = sk + q * s;
-    for (uint32_t e = threadIdx.x; e < s; e += THREADS)
-        atomicAdd(&start[p[e] >> shift], 1u);
-}
+// ---- two-level partition of the Y items into value buckets ---------------------------------
+// 1e8 global atomics (one per item, twice) cost 10 ms; partitioning in two levels keeps the
+// per-item atomics in LDS.  Level 1: NC coarse buckets (the top bits of the fine bucket): every
+// workgroup histograms its batch of sketches in LDS and touches global memory once per (workgroup,
+// coarse bucket).  Level 2: one workgroup per coarse bucket splits it into its fine buckets with an
+// LDS histogram + scan, writes start[] and the final item order.
 
-// ---- exclusive scan of the histogram in three launches ------------------------------
-// a: per-chunk sums (+ the self-join size sum_b cnt_b^2 that picks sparse vs generic)
-__global__ __launch_bounds__(THREADS) void scan_sums_kernel(const uint32_t *__restrict__ start,
-                                                           uint32_t *__restrict__ bsum, uint32_t *__restrict__ hdr)
+constexpr uint32_t FPC_MAX = 2048;   // fine buckets per coarse bucket (nbk <= 2^23)
+constexpr uint32_t BATCH_ITEMS = 16384; // items a level-1 workgroup takes at a time
+
+// coarse histogram: gcount[c] += items of my batch in coarse bucket c
+__global__ __launch_bounds__(THREADS) void coarse_count_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
+                                                              const uint8_t *__restrict__ flags,
+                                                              const uint32_t *__restrict__ hdr, uint32_t cshift_extra,
+                                                              uint32_t nc, uint32_t per_batch,
+                                                              uint32_t *__restrict__ gcount)
 {
-    __shared__ uint32_t ws[4];
-    __shared__ unsigned long long wq[4];
-    const uint32_t base = blockIdx.x * SCAN_CHUNK;
-    uint32_t sum = 0;
-    unsigned long long sq = 0;
-#pragma unroll
-    for (int i = 0; i < (int)(SCAN_CHUNK / THREADS); ++i) {
-        const uint32_t c = start[base + i * THREADS + threadIdx.x];
-        sum += c;
-        sq += (unsigned long long)c * c;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        sum += (uint32_t)__shfl_xor((int)sum, d, 64);
-        sq += __shfl_xor(sq, d, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        ws[threadIdx.x >> 6] = sum;
-        wq[threadIdx.x >> 6] = sq;
+    extern __shared__ uint32_t lh[]; // nc
+    const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
+    for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+        lh[c] = 0;
+    __syncthreads();
+    const uint64_t q0 = (uint64_t)blockIdx.x * per_batch, q1 = min(n, q0 + per_batch);
+    for (uint64_t q = q0; q < q1; ++q) {
+        if (flags[q])
+            continue;
+        const uint32_t *p = sk + q * s;
+        for (uint32_t e = threadIdx.x; e < s; e += THREADS)
+            atomicAdd(&lh[p[e] >> cshift], 1u);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-        const unsigned long long t = wq[0] + wq[1] + wq[2] + wq[3];
-        if (t)
-            atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), t);
-    }
+    for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+        if (lh[c])
+            atomicAdd(&gcount[c], lh[c]);
 }
 
-// b: one block scans the chunk sums (nscan <= 4096) and takes the sparse/generic decision
-__global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t *__restrict__ bsum, uint32_t nscan,
-                                                       uint32_t *__restrict__ start, uint32_t nbk,
-                                                       uint32_t *__restrict__ hdr, double est_scale,
-                                                       double generic_cost)
+// exclusive scan of gcount[nc] (nc <= 4096) -> cstart[nc + 1], gcur = copy; one workgroup
+__global__ __launch_bounds__(1024) void coarse_scan_kernel(const uint32_t *__restrict__ gcount, uint32_t nc,
+                                                          uint32_t *__restrict__ cstart, uint32_t *__restrict__ gcur,
+                                                          uint32_t *__restrict__ start, uint32_t nbk)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
@@ -205,9 +199,9 @@ __global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t *__restrict__ b
     if (tid == 0)
         carry = 0;
     __syncthreads();
-    for (uint32_t base = 0; base < nscan; base += 1024) {
+    for (uint32_t base = 0; base < nc; base += 1024) {
         const uint32_t i = base + tid;
-        const uint32_t v = i < nscan ? bsum[i] : 0u;
+        const uint32_t v = i < nc ? gcount[i] : 0u;
         uint32_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -221,75 +215,136 @@ __global__ __launch_bounds__(1024) void scan_top_kernel(uint32_t *__restrict__ b
         uint32_t pre = carry;
         for (int w = 0; w < (tid >> 6); ++w)
             pre += wsum[w];
-        if (i < nscan)
-            bsum[i] = pre + incl - v;
+        if (i < nc) {
+            cstart[i] = pre + incl - v;
+            gcur[i] = pre + incl - v;
+        }
         __syncthreads();
         if (tid == 1023)
             carry = pre + incl;
         __syncthreads();
     }
     if (tid == 0) {
+        cstart[nc] = carry;
         start[nbk] = carry;
-        const unsigned long long self = *reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]);
-        if ((double)self * est_scale > generic_cost)
-            hdr[H_MODE] = MODE_GENERIC;
     }
 }
 
-// c: scan inside each chunk, add the chunk's offset; cursor = copy
-__global__ __launch_bounds__(THREADS) void scan_chunks_kernel(uint32_t *__restrict__ start,
-                                                             uint32_t *__restrict__ cur,
-                                                             const uint32_t *__restrict__ bsum)
+// level 1 scatter: items of my batch -> citems, grouped by coarse bucket
+__global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
+                                                                const uint8_t *__restrict__ flags,
+                                                                const uint32_t *__restrict__ hdr, uint32_t cshift_extra,
+                                                                uint32_t nc, uint32_t per_batch,
+                                                                uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
 {
-    __shared__ uint32_t ws[4];
-    constexpr int PER = SCAN_CHUNK / THREADS;
-    const uint32_t base = blockIdx.x * SCAN_CHUNK + threadIdx.x * PER;
-    uint32_t v[PER], sum = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        v[i] = start[base + i];
-        sum += v[i];
-    }
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 64);
-        if ((threadIdx.x & 63) >= (unsigned)d)
-            incl += t;
-    }
-    if ((threadIdx.x & 63) == 63)
-        ws[threadIdx.x >> 6] = incl;
+    extern __shared__ uint32_t lh[]; // count[nc] then base[nc]
+    uint32_t *lbase = lh + nc;
+    const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
+    for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+        lh[c] = 0;
     __syncthreads();
-    uint32_t run = bsum[blockIdx.x] + incl - sum;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w)
-        run += ws[w];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        start[base + i] = run;
-        cur[base + i] = run;
-        run += v[i];
+    const uint64_t q0 = (uint64_t)blockIdx.x * per_batch, q1 = min(n, q0 + per_batch);
+    for (uint64_t q = q0; q < q1; ++q) {
+        if (flags[q])
+            continue;
+        const uint32_t *p = sk + q * s;
+        for (uint32_t e = threadIdx.x; e < s; e += THREADS)
+            atomicAdd(&lh[p[e] >> cshift], 1u);
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < nc; c += THREADS) {
+        const uint32_t cnt = lh[c];
+        lbase[c] = cnt ? atomicAdd(&gcur[c], cnt) : 0u; // my slice of coarse bucket c
+        lh[c] = 0;                                     // becomes the cursor inside the slice
+    }
+    __syncthreads();
+    for (uint64_t q = q0; q < q1; ++q) {
+        if (flags[q])
+            continue;
+        const uint32_t *p = sk + q * s;
+        for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
+            const uint32_t v = p[e];
+            uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
+            while (occ < e && p[e - occ - 1] == v)
+                ++occ;
+            const uint32_t c = v >> cshift;
+            citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << ID_BITS));
+        }
     }
 }
 
-__global__ __launch_bounds__(THREADS) void scatter_kernel(const uint32_t *__restrict__ sk, uint32_t s,
-                                                         const uint8_t *__restrict__ flags,
-                                                         const uint32_t *__restrict__ hdr, uint32_t *__restrict__ cur,
-                                                         uint2 *__restrict__ items)
+// level 2: one workgroup per coarse bucket -> fine start[] + final item order (+ self-join size)
+__global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__ citems,
+                                                      const uint32_t *__restrict__ cstart, uint32_t nc,
+                                                      uint32_t fpc_log2, uint32_t *__restrict__ hdr,
+                                                      uint32_t *__restrict__ start, uint2 *__restrict__ items)
 {
-    if (hdr[H_MODE] != MODE_SPARSE)
-        return;
-    const uint64_t q = blockIdx.x;
-    if (flags[q])
-        return;
+    __shared__ uint32_t cnt[FPC_MAX];
+    __shared__ uint32_t ws[4];
+    const uint32_t fpc = 1u << fpc_log2;
     const uint32_t shift = hdr[H_SHIFT];
-    const uint32_t *p = sk + q * s;
-    for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
-        const uint32_t v = p[e];
-        uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
-        while (occ < e && p[e - occ - 1] == v)
-            ++occ;
-        items[atomicAdd(&cur[v >> shift], 1u)] = make_uint2(v, (uint32_t)q | (occ << ID_BITS));
+    const int tid = threadIdx.x;
+    unsigned long long sq = 0;
+    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const uint32_t lo = cstart[c], hi = cstart[c + 1];
+        __syncthreads();
+        for (uint32_t f = tid; f < fpc; f += THREADS)
+            cnt[f] = 0;
+        __syncthreads();
+        for (uint32_t t = lo + tid; t < hi; t += THREADS)
+            atomicAdd(&cnt[(citems[t].x >> shift) & (fpc - 1u)], 1u);
+        __syncthreads();
+        // exclusive scan of cnt[0..fpc): PER consecutive entries per thread
+        const uint32_t per = (fpc + THREADS - 1) / THREADS; // <= 8
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t f = tid * per + i;
+            v[i] = ((uint32_t)i < per && f < fpc) ? cnt[f] : 0u;
+            sum += v[i];
+            sq += (unsigned long long)v[i] * v[i];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            ws[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t run = lo + incl - sum;
+        for (int w = 0; w < (tid >> 6); ++w)
+            run += ws[w];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t f = tid * per + i;
+            if ((uint32_t)i < per && f < fpc) {
+                start[((size_t)c << fpc_log2) + f] = run;
+                cnt[f] = run; // becomes the write cursor of fine bucket f
+            }
+            run += v[i];
+        }
+        __syncthreads();
+        for (uint32_t t = lo + tid; t < hi; t += THREADS) {
+            const uint2 it = citems[t];
+            items[atomicAdd(&cnt[(it.x >> shift) & (fpc - 1u)], 1u)] = it;
+        }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        sq += __shfl_xor(sq, d, 64);
+    if ((tid & 63) == 0 && sq)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), sq);
+}
+
+// sparse / generic decision from the index's self-join size
+__global__ void decide_kernel(uint32_t *__restrict__ hdr, double est_scale, double generic_cost)
+{
+    const unsigned long long self = *reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]);
+    if ((double)self * est_scale > generic_cost)
+        hdr[H_MODE] = MODE_GENERIC;
 }
 
 // ---- rowjoin: one workgroup per X row -------------------------------------------------
@@ -537,13 +592,15 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
     uint8_t *flagsX = w + L.off_flagsX, *flagsY = w + L.off_flagsY;
     uint32_t *irrX = reinterpret_cast<uint32_t *>(w + L.off_irrX), *regX = reinterpret_cast<uint32_t *>(w + L.off_regX),
              *ovfX = reinterpret_cast<uint32_t *>(w + L.off_ovfX), *irrY = reinterpret_cast<uint32_t *>(w + L.off_irrY);
-    uint32_t *start = reinterpret_cast<uint32_t *>(w + L.off_start), *cur = reinterpret_cast<uint32_t *>(w + L.off_cur),
-             *bsum = reinterpret_cast<uint32_t *>(w + L.off_bsum);
+    uint32_t *start = reinterpret_cast<uint32_t *>(w + L.off_start),
+             *gcount = reinterpret_cast<uint32_t *>(w + L.off_gcount),
+             *cstart = reinterpret_cast<uint32_t *>(w + L.off_cstart), *gcur = reinterpret_cast<uint32_t *>(w + L.off_gcur);
+    uint2 *citems = reinterpret_cast<uint2 *>(w + L.off_citems);
     uint2 *items = reinterpret_cast<uint2 *>(w + L.off_items);
 
     // header, flags and the histogram start at zero; so do the counts (rowjoin stores only non-zero cells)
     PH_HIP(hipMemsetAsync(w, 0, L.off_irrX, st));
-    PH_HIP(hipMemsetAsync(start, 0, ((size_t)L.nbk + 1) * 4, st));
+    PH_HIP(hipMemsetAsync(gcount, 0, (size_t)L.nc * 4, st));
     if (ld == ny) {
         PH_HIP(hipMemsetAsync(d_counts, 0, nx * ny * 2, st));
     } else {
@@ -555,23 +612,27 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
     const unsigned gx = (unsigned)nx, gy = (unsigned)ny; // one block per sketch
     hipLaunchKernelGGL(k2::check_kernel, dim3(gx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0);
     hipLaunchKernelGGL(k2::check_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1);
-    uint32_t nbk_log2 = 0;
-    while ((1u << nbk_log2) < L.nbk)
-        ++nbk_log2;
     const uint64_t nmax = std::max(nx, ny);
     hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nmax + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
-                       flagsX, nx, flagsY, ny, irrX, regX, irrY, hdr, nbk_log2);
-    hipLaunchKernelGGL(k2::hist_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, start);
+                       flagsX, nx, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2);
+    // ---- inverted index of the Y side: two-level partition by value
+    {
+        const uint32_t per_batch = std::max<uint32_t>(1u, k2::BATCH_ITEMS / sy);
+        const unsigned batches = (unsigned)((ny + per_batch - 1) / per_batch);
+        hipLaunchKernelGGL(k2::coarse_count_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy, flagsY,
+                           hdr, L.fpc_log2, L.nc, per_batch, gcount);
+        hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, gcount, L.nc, cstart, gcur, start, L.nbk);
+        hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
+                           flagsY, hdr, L.fpc_log2, L.nc, per_batch, gcur, citems);
+        hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(L.nc, 256u * 8u)), dim3(k2::THREADS), 0, st, citems, cstart,
+                           L.nc, L.fpc_log2, hdr, start, items);
+    }
     // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
     // value with its whole bucket: about (nx*sx/(ny*sy)) * sum_b cntY_b^2 compares when X is
     // distributed like Y (exact for the all-vs-all).  The join only loses on huge buckets.
     const double est_scale = ((double)nx * sx) / ((double)ny * sy);
     const double generic_cost = (double)nx * (double)ny * (double)(sx + sy) * 4.0;
-    hipLaunchKernelGGL(k2::scan_sums_kernel, dim3(L.nscan), dim3(k2::THREADS), 0, st, start, bsum, hdr);
-    hipLaunchKernelGGL(k2::scan_top_kernel, dim3(1), dim3(1024), 0, st, bsum, L.nscan, start, L.nbk, hdr, est_scale,
-                       generic_cost);
-    hipLaunchKernelGGL(k2::scan_chunks_kernel, dim3(L.nscan), dim3(k2::THREADS), 0, st, start, cur, bsum);
-    hipLaunchKernelGGL(k2::scatter_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, cur, items);
+    hipLaunchKernelGGL(k2::decide_kernel, dim3(1), dim3(1), 0, st, hdr, est_scale, generic_cost);
     if (!force) {
         const size_t smem = (size_t)sx * 20;
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_kernel),
