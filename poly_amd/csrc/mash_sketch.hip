@@ -267,7 +267,7 @@ template <int KS> struct Stager {
     }
 };
 
-// ---- one staged wave tile: premix, then hash; `emit(window_in_tile, h)` consumes the hashes ----
+// ---- one staged wave tile: premix, then hash; `emit(w0, h[4])` consumes a lane's 4 hashes ----
 template <int KS, class Emit>
 __device__ __forceinline__ void tile_compute(const uint32_t *__restrict__ seqb, uint32_t *__restrict__ P,
                                              const uint32_t *__restrict__ lut, uint32_t k, Emit emit)
@@ -337,15 +337,16 @@ __device__ __forceinline__ void tile_compute(const uint32_t *__restrict__ seqb, 
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            emit(4u * (uint32_t)wq + (uint32_t)c, PH_ABL == 3 ? h[c] : fmix32(h[c]));
+            h[c] = PH_ABL == 3 ? h[c] : fmix32(h[c]);
+        emit(4u * (uint32_t)wq, h); // windows w0 .. w0+3 of the tile
     }
     wave_sync(); // seqb / P are rewritten by this wave's next tile
 }
 
 // All tiles of one sequence; wave w takes tiles w, w + WAVES, ...  LOCKSTEP: the workgroup
 // meets at `before(T0)` (block-uniform hook; the general pass shrinks there) before every round
-// of WAVES tiles; otherwise the waves run free.  emit_full(t0, w, h) for tiles whose WTW windows
-// all exist, emit_part(t0, w, h) (already bounds-checked) for the last one.
+// of WAVES tiles; otherwise the waves run free.  emit_full / emit_part(t0, w0, h[4], nvalid): a lane's
+// 4 consecutive hashes; nvalid == 4 always for emit_full (tiles whose WTW windows all exist).
 template <int KS, bool LOCKSTEP, class Before, class EmitFull, class EmitPart>
 __device__ __forceinline__ void run_tiles(const Smem &sm, const uint32_t *__restrict__ gdw, uint32_t gsh,
                                           int64_t gbytes, int64_t nwin, uint32_t k, uint32_t n_seq_dw, uint32_t n_P_w,
@@ -371,15 +372,49 @@ __device__ __forceinline__ void run_tiles(const Smem &sm, const uint32_t *__rest
         wave_sync();
         if (t0 + TW < nwin)
             st.load(gdw, gsh, gbytes, t0 + TW, n_seq_dw, is_full(t0 + TW));
+        // emit(t0, w0, h[4], nvalid): the lane's 4 hashes of windows t0 + w0 ..; the first nvalid exist
         if (full) {
-            tile_compute<KS>(seqb, P, sm.lut, k, [&](uint32_t w, uint32_t h) { emit_full(t0, w, h); });
+            tile_compute<KS>(seqb, P, sm.lut, k, [&](uint32_t w0, const uint32_t(&h)[4]) { emit_full(t0, w0, h, 4u); });
         } else {
             const uint32_t wl = (uint32_t)((nwin - t0) < (int64_t)WTW ? (nwin - t0) : (int64_t)WTW);
-            tile_compute<KS>(seqb, P, sm.lut, k, [&](uint32_t w, uint32_t h) {
-                if (w < wl)
-                    emit_part(t0, w, h);
+            tile_compute<KS>(seqb, P, sm.lut, k, [&](uint32_t w0, const uint32_t(&h)[4]) {
+                emit_part(t0, w0, h, w0 >= wl ? 0u : (wl - w0 < 4u ? wl - w0 : 4u));
             });
         }
+    }
+}
+
+// Append the lane's hashes h[c] (c < nvalid, h[c] <= tau) to cand[]: ONE LDS atomic per wave for
+// the whole quad (4 ballots, scalar popcounts), then every survivor stores at base + its rank.
+// Slots beyond `cap` are dropped (the caller sees the total in *counter and redoes the sequence).
+__device__ __forceinline__ void append4(uint32_t *__restrict__ counter, uint32_t *__restrict__ cand, uint32_t cap,
+                                        const uint32_t (&h)[4], uint32_t nvalid, uint32_t tau)
+{
+    bool a[4];
+    uint64_t m[4];
+    uint32_t cnt[4], total = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] = (PH_ABL == 4 ? h[c] == 12345u : h[c] <= tau) && (uint32_t)c < nvalid;
+        m[c] = __ballot(a[c]);
+        cnt[c] = (uint32_t)__popcll(m[c]);
+        total += cnt[c];
+    }
+    if (total == 0) // wave-uniform
+        return;
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 0)
+        base = atomicAdd(counter, total);
+    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (a[c]) {
+            const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m[c] >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)m[c], 0u));
+            if (idx < cap)
+                cand[idx] = h[c];
+        }
+        base += cnt[c];
     }
 }
 
@@ -506,7 +541,12 @@ __global__ __launch_bounds__(THREADS) void sketch_fast_kernel(const uint8_t *__r
         // ---- mash.go:81-84: fewer windows than SketchSize -> positional, unsorted, tail untouched
         if (rv.nwin < (int64_t)s) {
             __syncthreads();
-            auto put = [&](int64_t t0, uint32_t w, uint32_t h) { outp[t0 + w] = h; };
+            auto put = [&](int64_t t0, uint32_t w0, const uint32_t(&h)[4], uint32_t nvalid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if ((uint32_t)c < nvalid)
+                        outp[t0 + w0 + c] = h[c];
+            };
             run_tiles<KS, false>(sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w, nothing, put, put);
             continue;
         }
@@ -525,12 +565,8 @@ __global__ __launch_bounds__(THREADS) void sketch_fast_kernel(const uint8_t *__r
         __syncthreads();
         uint32_t C = 0;
         if (ok) {
-            auto keep = [&](int64_t, uint32_t, uint32_t h) {
-                if (PH_ABL == 4 ? h == 12345u : h <= tau0) {
-                    const uint32_t idx = atomicAdd(&sm.misc[0], 1u); // hipcc aggregates this per wave
-                    if (idx < capf)
-                        sm.cand[idx] = h;
-                }
+            auto keep = [&](int64_t, uint32_t, const uint32_t(&h)[4], uint32_t nvalid) {
+                append4(&sm.misc[0], sm.cand, capf, h, nvalid, tau0);
             };
             run_tiles<KS, false>(sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w, nothing, keep, keep);
             __syncthreads();
@@ -591,9 +627,8 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
                     f(sm.cand[i]);
             });
         };
-        auto append = [&](int64_t, uint32_t, uint32_t h) {
-            if (h <= sm.misc[1])
-                sm.cand[atomicAdd(&sm.misc[0], 1u)] = h;
+        auto append = [&](int64_t, uint32_t, const uint32_t(&h)[4], uint32_t nvalid) {
+            append4(&sm.misc[0], sm.cand, cap, h, nvalid, sm.misc[1]);
         };
         run_tiles<KS, true>(
             sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w,
