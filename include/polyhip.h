@@ -355,6 +355,30 @@ int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets,
                           uint64_t n, int seq_type, int circular,
                           int double_stranded, char *out, uint32_t *err);
 
+/* ---- read feeder: io/fastq (*Parser).ParseNext / ParseN  (io/fastq/fastq.go:84-216) ---- */
+/*
+ * A FASTQ file image (d_file, nbytes) becomes the packed batch the kernels above take:
+ * d_seqs = the Sequence of every record back to back, d_offsets[0..n] (n+1 entries),
+ * d_rec_start[i] (optional) = byte offset of record i's identifier line, for the host to
+ * slice identifiers lazily.  Records are four '\n'-terminated lines; a '\r' is not stripped;
+ * parsing stops at the first bad record and the records before it are kept (ParseN).
+ * d_result[0] = n records, [1] = error code (0 none; 1 no '@' (fastq.go:203), 2 empty
+ * sequence (:176), 3 empty quality (:197), 4 unexpected EOF inside a record / last line
+ * without '\n' (:142-148), 5 empty identifier line and 6 identifier field without '='
+ * (the reference PANICS there, :156 and :163), 7 more records than max_records),
+ * [2] = the line the reference's message names, [3] = total sequence bytes.
+ * Capacities: d_seqs nbytes, d_offsets / d_rec_start nbytes/8 + 2 entries (or max_records + 1).
+ */
+size_t polyhip_fastq_workspace_bytes(uint64_t nbytes);
+int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes,
+                           uint8_t *d_seqs, uint64_t *d_offsets,
+                           uint64_t *d_rec_start, uint64_t max_records,
+                           uint64_t *d_result, void *d_work, size_t work_bytes,
+                           polyhip_stream_t stream);
+int polyhip_fastq_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs,
+                       uint64_t *offsets, uint64_t *rec_start,
+                       uint64_t max_records, uint64_t *result);
+
 #ifdef __cplusplus
 }
 #endif

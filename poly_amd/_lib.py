@@ -70,6 +70,9 @@ SIGNATURES = {
     "polyhip_seqhash_batch_dev": (C.c_int, [_vp, _vp, _u64, _u64, _u64, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp,
                                             C.c_size_t, _vp]),
     "polyhip_seqhash_batch": (C.c_int, [_vp, _vp, _u64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "polyhip_fastq_workspace_bytes": (C.c_size_t, [_u64]),
+    "polyhip_fastq_pack_dev": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, C.c_size_t, _vp]),
+    "polyhip_fastq_pack": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
 }
 
 

@@ -1,0 +1,344 @@
+// fastq_pack.hip -- the read feeder: a FASTQ file image resident in HBM becomes the packed batch
+// (bytes + offsets) the hot-path kernels take, without a host parse and without per-read copies.
+//
+// Follows io/fastq/fastq.go:117-216 ((*Parser).ParseNext) and :84-96 (ParseN): records are exactly
+// four '\n'-terminated lines (identifier, sequence, '+', quality); Sequence is line 2 minus the '\n'
+// (a '\r' is NOT stripped, as in the reference); parsing stops at the first bad record and the records
+// before it are returned (ParseN).  Error conditions, in the order the reference meets them:
+//   5  identifier line is empty                (fastq.go:156 indexes string(line)[0]: the reference panics)
+//   6  an identifier field after a ' ' has no '=' (fastq.go:163 indexes optionalSplits[1]: panics)
+//   2  empty sequence line                     (:176-178)
+//   3  empty quality line                      (:197-199)
+//   1  identifier line does not start with '@' (:203-205; reported after the four lines were read)
+//   4  end of file inside a record, including a last line without '\n' (:142-148: "unexpected EOF")
+//
+// Device algorithm: newline positions by a block-count / scan / ranked-write compaction; one thread
+// per 4-line record validates it and measures its sequence; an exclusive scan of the lengths gives the
+// offsets; one workgroup per record copies the bytes.  Pure byte work, HBM bound: reads the file twice
+// (newlines, gather) and writes the sequences once.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+
+namespace polyhip {
+namespace fq {
+
+constexpr int THREADS = 256;
+constexpr uint32_t PER_BLOCK = THREADS * 16; // bytes a workgroup scans for newlines
+
+enum { R_NREC = 0, R_CODE = 1, R_LINE = 2, R_SEQBYTES = 3, R_NLINES = 4, R_FIRSTBAD = 5, R_WORDS = 8 };
+
+// ---- single-workgroup exclusive scan of u32 counts into u64 offsets (out[n] = total) --------
+// n = n_host, or *n_dev / div when n_dev != NULL (a count that only exists on the device)
+__global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *__restrict__ in, uint64_t n_host,
+                                                       const uint64_t *__restrict__ n_dev, uint64_t div,
+                                                       uint64_t *__restrict__ out)
+{
+    const uint64_t n = n_dev ? *n_dev / div : n_host;
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + tid;
+        const uint64_t v = i < n ? in[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w)
+            pre += wsum[w];
+        if (i < n)
+            out[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0)
+        out[n] = carry;
+}
+
+// newlines per PER_BLOCK bytes
+__global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
+                                                                uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t ws[THREADS / 64];
+    const uint64_t base = (uint64_t)blockIdx.x * PER_BLOCK;
+    uint32_t c = 0;
+    for (uint32_t i = threadIdx.x; i < PER_BLOCK; i += THREADS) {
+        const uint64_t p = base + i;
+        c += (p < nbytes && file[p] == '\n') ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        c += (uint32_t)__shfl_xor((int)c, d, 64);
+    if ((threadIdx.x & 63) == 0)
+        ws[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// line_end[k] = position of the k-th '\n'
+__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
+                                                                const uint64_t *__restrict__ block_off,
+                                                                uint64_t *__restrict__ line_end)
+{
+    __shared__ uint32_t wbase[THREADS / 64];
+    __shared__ uint32_t run;
+    const uint64_t base = (uint64_t)blockIdx.x * PER_BLOCK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        run = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < PER_BLOCK; i0 += THREADS) {
+        const uint64_t p = base + i0 + threadIdx.x;
+        const bool nl = p < nbytes && file[p] == '\n';
+        const uint64_t m = __ballot(nl);
+        if (lane == 0)
+            wbase[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t pre = run;
+        for (int w = 0; w < wave; ++w)
+            pre += wbase[w];
+        if (nl) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            line_end[block_off[blockIdx.x] + pre + rank] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            run += wbase[0] + wbase[1] + wbase[2] + wbase[3];
+        __syncthreads();
+    }
+}
+
+// identifier-line checks of fastq.go:155-167: 0, or 5 (empty line), 6 (field without '=')
+__device__ uint32_t header_panics(const uint8_t *__restrict__ file, uint64_t s, uint64_t e)
+{
+    if (e == s)
+        return 5;
+    // tokens after the first ' ' must each contain '=' (optionalSplits[1])
+    uint64_t p = s;
+    while (p < e && file[p] != ' ')
+        ++p;
+    while (p < e) { // file[p] == ' ': a token starts at p + 1
+        ++p;
+        bool eq = false;
+        while (p < e && file[p] != ' ') {
+            eq |= file[p] == '=';
+            ++p;
+        }
+        if (!eq)
+            return 6;
+    }
+    return 0;
+}
+
+// one thread per complete 4-line record: validate, measure the sequence
+__global__ __launch_bounds__(THREADS) void records_kernel(const uint8_t *__restrict__ file,
+                                                         const uint64_t *__restrict__ line_end,
+                                                         const uint64_t *__restrict__ nlines_dev,
+                                                         uint32_t *__restrict__ seq_len, uint64_t *__restrict__ seq_start,
+                                                         uint64_t *__restrict__ rec_start,
+                                                         unsigned long long *__restrict__ res)
+{
+    const uint64_t nrec = *nlines_dev / 4; // complete 4-line records
+    const uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r >= nrec)
+        return;
+    const uint64_t l0 = r == 0 ? 0 : line_end[4 * r - 1] + 1;
+    const uint64_t e0 = line_end[4 * r], e1 = line_end[4 * r + 1], e2 = line_end[4 * r + 2], e3 = line_end[4 * r + 3];
+    uint32_t code = header_panics(file, l0, e0);
+    if (!code && e1 == e0 + 1)
+        code = 2;
+    if (!code && e3 == e2 + 1)
+        code = 3;
+    if (!code && file[l0] != '@')
+        code = 1;
+    seq_len[r] = (uint32_t)(e1 - e0 - 1);
+    seq_start[r] = e0 + 1;
+    if (rec_start)
+        rec_start[r] = l0;
+    if (code) // the first bad record wins; (record << 8 | code) orders by record
+        atomicMin(&res[R_FIRSTBAD], (unsigned long long)((r << 8) | code));
+}
+
+// n_records, error code / line, and the trailing partial record
+__global__ void finish_kernel(const uint8_t *__restrict__ file, uint64_t nbytes, const uint64_t *__restrict__ line_end,
+                              const uint64_t *__restrict__ nlines_dev, const uint64_t *__restrict__ offsets,
+                              uint64_t max_records, unsigned long long *__restrict__ res)
+{
+    const uint64_t nlines = *nlines_dev;
+    const uint64_t nrec = nlines / 4;
+    uint64_t n = nrec, code = 0, line = 0;
+    const unsigned long long fb = res[R_FIRSTBAD];
+    if (fb != ~0ull) {
+        n = fb >> 8;
+        code = fb & 0xFF;
+        const uint64_t r = n;
+        line = code == 2 ? 4 * r + 2 : (code == 1 || code == 3) ? 4 * r + 4 : 4 * r + 1;
+    } else {
+        // bytes after the last complete record: j complete lines + maybe an unterminated one
+        const uint64_t tail0 = nrec == 0 ? 0 : line_end[4 * nrec - 1] + 1;
+        if (tail0 < nbytes) {
+            const uint64_t j = nlines - 4 * nrec; // 0..3 complete lines
+            const uint64_t e0 = j >= 1 ? line_end[4 * nrec] : nbytes;
+            if (j >= 1)
+                code = header_panics(file, tail0, e0);
+            line = 4 * nrec + 1;
+            if (!code && j >= 2 && line_end[4 * nrec + 1] == e0 + 1) {
+                code = 2;
+                line = 4 * nrec + 2;
+            }
+            if (!code) { // the (j+1)-th ReadSlice hits EOF; the message names parser.line + 1
+                code = 4;
+                line = 4 * nrec + j + 2;
+            }
+        }
+    }
+    if (n > max_records) {
+        n = max_records;
+        code = 7; // caller's buffers hold fewer records than the file
+        line = 0;
+    }
+    res[R_NREC] = n;
+    res[R_CODE] = code;
+    res[R_LINE] = line;
+    res[R_SEQBYTES] = offsets[n];
+    res[R_NLINES] = nlines;
+}
+
+// one workgroup per record (grid-stride): sequence bytes -> packed buffer
+__global__ __launch_bounds__(THREADS) void gather_kernel(const uint8_t *__restrict__ file,
+                                                        const uint64_t *__restrict__ seq_start,
+                                                        const uint64_t *__restrict__ offsets,
+                                                        const unsigned long long *__restrict__ res,
+                                                        uint8_t *__restrict__ seqs)
+{
+    const uint64_t n = res[R_NREC];
+    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
+        const uint64_t src = seq_start[r], dst = offsets[r], len = offsets[r + 1] - dst;
+        for (uint64_t t = threadIdx.x; t < len; t += THREADS)
+            seqs[dst + t] = file[src + t];
+    }
+}
+
+struct Layout {
+    uint64_t nblocks, max_lines;
+    size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, total;
+};
+
+static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static Layout layout(uint64_t nbytes)
+{
+    Layout L;
+    L.nblocks = (nbytes + PER_BLOCK - 1) / PER_BLOCK;
+    if (L.nblocks == 0)
+        L.nblocks = 1;
+    L.max_lines = nbytes; // every byte a newline
+    size_t o = 0;
+    L.off_res = o; o += al(R_WORDS * 8);
+    L.off_counts = o; o += al(L.nblocks * 4);
+    L.off_blockoff = o; o += al((L.nblocks + 1) * 8);
+    L.off_lineend = o; o += al((L.max_lines + 1) * 8);
+    L.off_seqlen = o; o += al((L.max_lines / 4 + 1) * 4);
+    L.off_seqstart = o; o += al((L.max_lines / 4 + 1) * 8);
+    L.total = o;
+    return L;
+}
+
+} // namespace fq
+} // namespace polyhip
+
+using namespace polyhip;
+
+extern "C" {
+
+size_t polyhip_fastq_workspace_bytes(uint64_t nbytes) { return fq::layout(nbytes).total; }
+
+int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_seqs, uint64_t *d_offsets,
+                           uint64_t *d_rec_start, uint64_t max_records, uint64_t *d_result, void *d_work,
+                           size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(d_result && d_offsets && d_work && (d_file || nbytes == 0) && (d_seqs || nbytes == 0),
+               "polyhip_fastq_pack: null pointer");
+    const fq::Layout L = fq::layout(nbytes);
+    PH_REQUIRE(work_bytes >= L.total, "polyhip_fastq_pack: workspace too small (%zu < %zu)", work_bytes, L.total);
+    PH_REQUIRE(L.nblocks < (1ull << 31), "polyhip_fastq_pack: file too large for one call");
+    hipStream_t st = as_stream(stream);
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    unsigned long long *res = reinterpret_cast<unsigned long long *>(w + L.off_res);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(w + L.off_counts);
+    uint64_t *blockoff = reinterpret_cast<uint64_t *>(w + L.off_blockoff);
+    uint64_t *line_end = reinterpret_cast<uint64_t *>(w + L.off_lineend);
+    uint32_t *seq_len = reinterpret_cast<uint32_t *>(w + L.off_seqlen);
+    uint64_t *seq_start = reinterpret_cast<uint64_t *>(w + L.off_seqstart);
+
+    PH_HIP(hipMemsetAsync(res, 0, fq::R_WORDS * 8, st));
+    PH_HIP(hipMemsetAsync(res + fq::R_FIRSTBAD, 0xFF, 8, st));
+    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes, counts);
+    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, counts, L.nblocks, (const uint64_t *)nullptr,
+                       (uint64_t)1, blockoff);
+    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
+                       blockoff, line_end);
+    // The line count exists only on the device (blockoff[nblocks]); the record kernels are launched for
+    // the most records the file could hold ("@\nA\n+\nI\n" = 8 bytes each) and read the real count there.
+    const uint64_t *nlines_dev = blockoff + L.nblocks;
+    const uint64_t most = nbytes / 8 + 1;
+    hipLaunchKernelGGL(fq::records_kernel, dim3((unsigned)((most + fq::THREADS - 1) / fq::THREADS)), dim3(fq::THREADS), 0, st,
+                       d_file, line_end, nlines_dev, seq_len, seq_start, d_rec_start, res);
+    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, seq_len, (uint64_t)0, nlines_dev, (uint64_t)4,
+                       d_offsets);
+    hipLaunchKernelGGL(fq::finish_kernel, dim3(1), dim3(1), 0, st, d_file, nbytes, line_end, nlines_dev, d_offsets,
+                       max_records, res);
+    hipLaunchKernelGGL(fq::gather_kernel, dim3((unsigned)std::min<uint64_t>(most, 256ull * 32ull)), dim3(fq::THREADS), 0, st,
+                       d_file, seq_start, d_offsets, res, d_seqs);
+    PH_HIP(hipGetLastError());
+    PH_HIP(hipMemcpyAsync(d_result, res, 4 * 8, hipMemcpyDeviceToDevice, st));
+    return POLYHIP_OK;
+}
+
+int polyhip_fastq_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs, uint64_t *offsets, uint64_t *rec_start,
+                       uint64_t max_records, uint64_t *result)
+{
+    PH_REQUIRE(result && offsets && (file || nbytes == 0) && (seqs || nbytes == 0), "polyhip_fastq_pack: null pointer");
+    const uint64_t most = nbytes / 8 + 1;
+    DevBuf dfile, dseqs, doffs, drec, dres, dwork;
+    PH_HIP(dfile.alloc(nbytes));
+    PH_HIP(dseqs.alloc(nbytes));
+    PH_HIP(doffs.alloc((most + 1) * 8));
+    PH_HIP(drec.alloc(most * 8));
+    PH_HIP(dres.alloc(4 * 8));
+    const size_t wb = polyhip_fastq_workspace_bytes(nbytes);
+    PH_HIP(dwork.alloc(wb));
+    if (nbytes)
+        PH_HIP(hipMemcpy(dfile.p, file, nbytes, hipMemcpyHostToDevice));
+    int rc = polyhip_fastq_pack_dev(dfile.as<uint8_t>(), nbytes, dseqs.as<uint8_t>(), doffs.as<uint64_t>(),
+                                    drec.as<uint64_t>(), max_records, dres.as<uint64_t>(), dwork.p, wb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(result, dres.p, 4 * 8, hipMemcpyDeviceToHost));
+    const uint64_t n = result[0];
+    PH_HIP(hipMemcpy(offsets, doffs.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    if (rec_start && n)
+        PH_HIP(hipMemcpy(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost));
+    if (result[3])
+        PH_HIP(hipMemcpy(seqs, dseqs.p, result[3], hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+} // extern "C"

@@ -6,6 +6,8 @@ committed so that nothing at test/bench time reads /root/reference.
 
   phix174.seq  <- data/phix174.gb   (BASELINE config 1 input; 5,386 bp, lower case)
   puc19.seq    <- data/puc19.gbk    (seqhash_test.go:68-91 rotation fixture)
+  fastq/*.fastq <- io/fastq/data/*.fastq  (verbatim copies of the reference's own parser fixtures:
+                   fastq_test.go:59-66, example_test.go:16-66)
 
 Extraction follows io/genbank/genbank.go:125,627-633: every line between
 ORIGIN and // with all non-letters removed, case preserved.
@@ -41,5 +43,15 @@ def main() -> int:
     return 0
 
 
+def copy_fastq():
+    import glob
+    import shutil
+    dst = os.path.join(HERE, "fastq")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(glob.glob(os.path.join(REF, "io", "fastq", "data", "*.fastq"))):
+        shutil.copy(f, dst)
+
+
 if __name__ == "__main__":
+    copy_fastq()
     sys.exit(main())

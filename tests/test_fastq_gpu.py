@@ -1,0 +1,97 @@
+"""Read feeder parity: poly_amd.fastq's device packer vs the CPU restatement of
+io/fastq (*Parser).ParseNext / ParseAll (oracle/fastq_ref.py), on the reference's own fixtures
+(io/fastq/data/*.fastq -> tests/golden/fastq/) and on synthetic files: same records, same Sequence bytes,
+same error condition and line; then the packed batch goes straight into K1.
+
+Mirrors io/fastq/fastq_test.go:59-66 and example_test.go:16-66."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from oracle import fastq_ref as fr
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fastq")
+
+
+def _check(data: bytes):
+    from poly_amd import fastq
+    seqs, offs, rec, err = fastq.pack(data)
+    want, code, line = fr.parse_all(data)
+    got = [seqs[int(offs[i]): int(offs[i + 1])].tobytes() for i in range(len(offs) - 1)]
+    assert got == [w[1] for w in want]
+    for i, w in enumerate(want):  # the identifier can be sliced from the image at rec_start
+        start = int(rec[i])
+        assert data[start + 1: start + 1 + len(w[0])] == w[0] or data[start:start + 1] != b"@"
+    if code == 0:
+        assert err is None
+    else:
+        assert err is not None and fastq.ERRORS[code].format(line=line) == str(err), (code, line, err)
+
+
+def test_reference_fixtures():
+    files = sorted(glob.glob(os.path.join(GOLD, "*.fastq")))
+    assert len(files) == 7
+    for f in files:
+        _check(open(f, "rb").read())
+    from poly_amd import fastq
+    s = fastq.sequences(open(os.path.join(GOLD, "nanosavseq.fastq"), "rb").read())
+    assert len(s) == 4 and s[0].startswith(b"GATGTGCGCCGTTCCAGTTGCGACG")
+    for name in ("noseq", "noquality", "noidentifier", "emptyseq", "noplus", "noquality2"):  # fastq_test.go:59-66
+        with pytest.raises(fastq.FastqError):
+            fastq.sequences(open(os.path.join(GOLD, f"nanosavseq_{name}.fastq"), "rb").read())
+
+
+def _record(rng, i, L):
+    seq = bytes(rng.choice(list(b"ACGTN"), L).astype(np.uint8))
+    qual = bytes(rng.integers(33, 74, L, dtype=np.uint8))
+    return b"@read%d ch=%d start=%d\n" % (i, i % 7, i * 3) + seq + b"\n+\n" + qual + b"\n"
+
+
+def test_synthetic_and_malformed():
+    rng = np.random.default_rng(8)
+    good = b"".join(_record(rng, i, int(rng.integers(1, 400))) for i in range(300))
+    _check(good)
+    _check(b"")
+    _check(b"\n")
+    _check(good[:-1])                       # last line without newline: the reference drops that record
+    _check(good + b"@tail\nACGT\n")        # EOF inside a record
+    _check(good + b"@tail\nACGT\n+\n")
+    _check(good + b"@tail")
+    _check(good[:5000] + b"\n" + good[5000:])   # a stray empty line shifts the records
+    _check(good + b"@x desc\nACGT\n+\nIIII\n" + good)   # identifier field without '=': the reference panics
+    _check(good + b"read\nACGT\n+\nIIII\n" + good)      # no '@'
+    _check(good + b"@r\n\n+\nIIII\n" + good)            # empty sequence
+    _check(good + b"@r\nACGT\n+\n\n" + good)            # empty quality
+    _check(b"@r\r\nACGT\r\n+\r\nIIII\r\n")           # CR is kept, as in the reference
+    _check(b"@a k=v  \nAC\n+\nII\n")                   # empty field after a double space
+
+
+def test_packed_batch_feeds_the_sketch_kernel():
+    """file image -> device packer -> K1, no host parse: equals sketching the oracle's records"""
+    import torch
+    from poly_amd import fastq, mash
+    rng = np.random.default_rng(9)
+    data = b"".join(_record(rng, i, int(rng.integers(900, 1400))) for i in range(500))
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev)
+    nb = img.numel()
+    seqs = torch.empty(nb, dtype=torch.uint8, device=dev)
+    offs = torch.zeros(nb // 8 + 2, dtype=torch.int64, device=dev)
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    work = torch.empty(fastq.workspace_bytes(nb), dtype=torch.uint8, device=dev)
+    fastq.pack_dev(img, seqs, offs, None, res, work)
+    n, code, _, total = (int(x) for x in res.cpu())
+    assert (n, code) == (500, 0)
+    sk = torch.zeros((n, 200), dtype=torch.int32, device=dev)
+    mash.sketch_batch_dev(seqs, offs[: n + 1], 21, 200, sk)
+    torch.cuda.synchronize()
+    want_recs, _, _ = fr.parse_all(data)
+    buf = np.frombuffer(b"".join(r[1] for r in want_recs), np.uint8)
+    o = np.zeros(n + 1, np.uint64)
+    o[1:] = np.cumsum([len(r[1]) for r in want_recs])
+    assert total == len(buf)
+    assert (sk.cpu().numpy().view(np.uint32) == orc.mash_sketch_batch(buf, o, 21, 200)).all()

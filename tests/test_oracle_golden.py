@@ -346,3 +346,21 @@ def test_synth_dna_is_position_addressable():
     assert (orc.synth_dna(0xC2, 1000) == a[:1000]).all()
     counts = np.bincount(a, minlength=256)[[65, 67, 71, 84]]
     assert counts.min() > 2300
+
+
+# ------------------------------------------------------------------ io/fastq --
+def test_fastq_reference_fixtures():
+    """io/fastq/fastq_test.go:59-66 (TestParseExceptions: all six files must fail), example_test.go:16-66
+    (first identifier / sequence / quality of nanosavseq.fastq, ExampleParser's four identifiers).
+    Fixtures: tests/golden/fastq/ = io/fastq/data/*.fastq."""
+    from oracle import fastq_ref as fr
+    d = os.path.join(GOLD, "fastq")
+    recs, code, _ = fr.parse_all(open(os.path.join(d, "nanosavseq.fastq"), "rb").read())
+    assert code == 0
+    assert [r[0].decode() for r in recs] == ["e3cc70d5-90ef-49b6-bbe1-cfef99537d73", "92728f25-b658-426c-8cd7-d82dc70dbf71",
+                                            "60907b6b-5e38-498e-9c07-f036ebd8c658", "990e110e-5e50-41a2-8ad5-92044d4465b8"]
+    assert recs[0][1].startswith(b"GATGTGCGCCGTTCCAGTTGCGACGTACTATAATCCCCGGCAACACGGTGCTGATTC") and recs[0][1].endswith(b"CATGAGCAATACGTAACT")
+    assert recs[0][2].startswith(b"$$&%&%#$)*59;/767C378411") and len(recs[0][2]) == len(recs[0][1])
+    for name in ("noseq", "noquality", "noidentifier", "emptyseq", "noplus", "noquality2"):
+        _, code, line = fr.parse_all(open(os.path.join(d, f"nanosavseq_{name}.fastq"), "rb").read())
+        assert code != 0 and line > 0, name
