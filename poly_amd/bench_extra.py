@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from . import align, alphabet, mash, matrix, primers, seqhash
+from . import align, alphabet, fastq, mash, matrix, primers, seqhash
 
 HBM_PEAK_GBS = 8000.0
 
@@ -125,10 +125,41 @@ def rotation(dev, n: int = 100_000, L: int = 5000):
             "algorithmic_GBs": (2 * n * L + 8 * n) / ms * 1e3 / 1e9}
 
 
+def hashing(dev, n: int = 100_000, L: int = 5000):
+    """seqhash.Hash of n circular double-stranded DNA sequences (normalise, revcomp, 2 rotations, choose, BLAKE3)"""
+    seqs = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0x5EED, seqs)
+    offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    out = torch.zeros((n, 72), dtype=torch.uint8, device=dev)
+    err = torch.zeros(n, dtype=torch.int32, device=dev)
+    work = torch.empty(seqhash.seqhash_workspace_bytes(n, n * L, True, True), dtype=torch.uint8, device=dev)
+    ms = _time(lambda: seqhash.seqhash_batch_dev(seqs, offs, n * L, L, 0, True, True, out, err, work), 3)
+    return {"workload": f"seqhash.Hash(DNA, circular, double-stranded) of {n} sequences of {L} bp",
+            "sequences_per_s": n / ms * 1e3, "bases_per_s": n * L / ms * 1e3, "ms": ms}
+
+
+def fastq_feeder(dev, n: int = 200_000, L: int = 1000):
+    """FASTQ image (n records of L bp) -> packed batch, parsed on the device"""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    rec = (b"@r0000000 ch=1 start=2\n" + bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8)) + b"\n+\n" +
+           bytes(rng.integers(33, 74, L, dtype=np.uint8)) + b"\n")
+    img = torch.from_numpy(np.frombuffer(rec * n, np.uint8).copy()).to(dev)
+    nb = img.numel()
+    seqs = torch.empty(nb, dtype=torch.uint8, device=dev)
+    offs = torch.zeros(nb // 8 + 2, dtype=torch.int64, device=dev)
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    work = torch.empty(fastq.workspace_bytes(nb), dtype=torch.uint8, device=dev)
+    ms = _time(lambda: fastq.pack_dev(img, seqs, offs, None, res, work), 5)
+    r = [int(x) for x in res.cpu()]
+    return {"workload": f"FASTQ image of {n} records x {L} bp ({nb} B) -> packed read batch on the device",
+            "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
+
+
 def run(dev) -> dict:
     out = {}
     for name, fn in (("smith_waterman", sw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
-                     ("least_rotation", rotation)):
+                     ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder)):
         try:
             out[name] = fn(dev)
         except Exception as e:  # a secondary number must never take the headline down

@@ -15,10 +15,13 @@ run() { # tag, rocprof args..., -- cmd
   if [ -n "$f" ]; then ( cd $ROOT && python scripts/rocpd_summary.py $f "$tag" > gpurun_out/$tag.md 2>&1 ); else echo "no db for $tag"; tail -5 $out/run.log; fi
 }
 BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
-run ${R}_bench_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_bench_stats -o x -- $BENCH
+# kernel stats of the headline command (default steps/warmup, without the secondary kernels so that the
+# K1 average is the timed region's), and of the full default command
+run ${R}_bench_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_bench_stats -o x -- python bench.py --no-extra --no-cpu-baseline
+run ${R}_bench_full_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_bench_full_stats -o x -- python bench.py --no-cpu-baseline
 run ${R}_bench_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_bench_fetch -o x -- $BENCH
 run ${R}_bench_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_bench_write -o x -- $BENCH
 run ${R}_calib_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_calib_fetch -o x -- scripts/ubench/hbm_calib
 run ${R}_calib_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_calib_write -o x -- scripts/ubench/hbm_calib
-for t in bench_stats bench_fetch bench_write calib_fetch calib_write; do echo "== $t"; grep -E "sketch_fast_kernel|sketch_general|read4|read16|write4|write8|write16|failed" $ROOT/gpurun_out/${R}_$t.md | head -12; done
+for t in bench_stats bench_full_stats bench_fetch bench_write calib_fetch calib_write; do echo "== $t"; grep -E "sketch_fast_kernel|sketch_general|read4|read16|write4|write8|write16|failed" $ROOT/gpurun_out/${R}_$t.md | head -12; done
 rm -rf $ROOT/gpurun_out/prof_${R}_*   # keep the summaries, drop the databases
