@@ -203,6 +203,8 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A,
  *     alignA_p = d_alnA[p*aln_stride + aln_stride - len .. p*aln_stride + aln_stride)
  * (the reference builds them by prepending).  Pairs with err != 0 or score 0
  * get length 0, as the reference returns "".
+ * d_score (the score pass's output; may be NULL) lets each pair shrink its window:
+ * a read that aligns well needs far fewer columns than the batch-wide bound.
  * aln_stride >= polyhip_sw_traceback_stride(sc, max_lenA, lenB).
  * d_work: any size >= 256 pairs' worth; polyhip_sw_traceback_workspace_bytes
  * returns enough for all pairs at once (capped at 8 GiB); smaller workspaces
@@ -218,7 +220,8 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A,
                              uint32_t max_lenA, const uint8_t *d_B,
                              const uint64_t *d_offB, uint64_t lenB,
                              const uint32_t *d_endA, const uint32_t *d_endB,
-                             const uint32_t *d_err, uint8_t *d_alnA,
+                             const uint32_t *d_err, const int64_t *d_score,
+                             uint8_t *d_alnA,
                              uint8_t *d_alnB, uint32_t *d_alnLen,
                              uint32_t aln_stride, void *d_work,
                              size_t work_bytes, polyhip_stream_t stream);

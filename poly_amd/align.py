@@ -187,13 +187,15 @@ def SmithWatermanBatch(reads, ref, scoring: Scoring):
 
 
 def sw_traceback_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, lenB: int, endA_t, endB_t, err_t,
-                     alnA_t, alnB_t, alnLen_t, work_t, stream=None) -> None:
-    """Device-resident traceback on torch CUDA tensors (alnA/alnB: (n, stride) uint8)."""
+                     alnA_t, alnB_t, alnLen_t, work_t, stream=None, score_t=None) -> None:
+    """Device-resident traceback on torch CUDA tensors (alnA/alnB: (n, stride) uint8); score_t (the
+    score pass's int64 output) lets every pair shrink its window."""
     n = offA_t.numel() - 1
     _lib.check(_lib.lib().polyhip_sw_traceback_dev(
         scoring.handle(), A_t.data_ptr(), offA_t.data_ptr(), n, max_lenA, B_t.data_ptr(),
         offB_t.data_ptr() if offB_t is not None else None, lenB, endA_t.data_ptr(), endB_t.data_ptr(),
-        err_t.data_ptr(), alnA_t.data_ptr(), alnB_t.data_ptr(), alnLen_t.data_ptr(), alnA_t.shape[1],
+        err_t.data_ptr(), score_t.data_ptr() if score_t is not None else None, alnA_t.data_ptr(), alnB_t.data_ptr(),
+        alnLen_t.data_ptr(), alnA_t.shape[1],
         work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
 
 

@@ -68,7 +68,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000):
     tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, LA, LB), dtype=torch.uint8, device=dev)
     alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
     alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
-    ms_tb = _time(lambda: align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw), 2)
+    ms_tb = _time(lambda: align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score), 2)
     cells = n * LA * LB
     alg = n * (LA + 8 + 8)  # read + score + end position per pair
     return {

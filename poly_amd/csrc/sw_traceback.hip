@@ -60,6 +60,21 @@ static Window window(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB
     return w;
 }
 
+// Columns THIS pair needs (<= wcols, the batch-wide bound).  With its own end row and score M the
+// walk spans at most endA + (smax*endA - M)/|gap| columns (it gains at most smax per row it climbs
+// and ends up with M), and every cell it looks at -- all in rows <= endA -- depends on at most
+// endA + smax*endA/|gap| columns to its left.
+__device__ __forceinline__ uint32_t pair_window(uint32_t wcols, uint32_t eA, int64_t M, int smax, int gap)
+{
+    if (gap >= 0 || smax <= 0 || M <= 0)
+        return wcols;
+    const uint64_t g = (uint64_t)(-gap), top = (uint64_t)smax * eA;
+    const uint64_t reach = eA + top / g;
+    const uint64_t span = eA + (top > (uint64_t)M ? (top - (uint64_t)M) / g : 0);
+    const uint64_t need = span + reach + 2;
+    return need < wcols ? (uint32_t)need : wcols;
+}
+
 // shared by both kernels: walk the direction bits of one pair (one lane)
 __device__ __forceinline__ uint32_t walk(const uint32_t *__restrict__ dirw, uint32_t nw, uint32_t lane_stride,
                                          const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint32_t eA,
@@ -104,7 +119,8 @@ __global__ __launch_bounds__(THREADS) void tb_kernel(const uint8_t *__restrict__
                                                     const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
                                                     const int32_t *__restrict__ lutcc, int na, int nb, int gap,
                                                     const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
-                                                    const uint32_t *__restrict__ err, uint32_t wcols,
+                                                    const uint32_t *__restrict__ err,
+                                                    const int64_t *__restrict__ score, int smax, uint32_t wcols,
                                                     uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
                                                     uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen,
                                                     uint32_t stride)
@@ -137,7 +153,8 @@ __global__ __launch_bounds__(THREADS) void tb_kernel(const uint8_t *__restrict__
         }
     }
     const bool work = active && eA > 0 && eB > 0 && lenA <= RA;
-    const uint32_t c_s = (work && eB > wcols) ? eB - wcols + 1u : 1u; // first column (1-based) of my window
+    const uint32_t mycols = work ? pair_window(wcols, eA, score ? score[pair] : 0, smax, gap) : 0u;
+    const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u; // first column (1-based) of my window
     const uint32_t ncol = work ? eB - c_s + 1u : 0u;
 
     // row offsets into T (code * nb), two per register; rows >= lenA use the pad row (all zero)
@@ -212,7 +229,8 @@ __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
     const uint8_t *__restrict__ B, const uint64_t *__restrict__ offB, uint64_t lenB_shared,
     const int32_t *__restrict__ lut, int gap, const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
-    const uint32_t *__restrict__ err, uint32_t wcols, uint32_t max_lenA, int32_t *__restrict__ hbuf,
+    const uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax, uint32_t wcols, uint32_t max_lenA,
+    int32_t *__restrict__ hbuf,
     uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB,
     uint32_t *__restrict__ alnLen, uint32_t stride)
 {
@@ -233,7 +251,8 @@ __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
     }
     uint32_t len = 0;
     if (eA > 0 && eB > 0) {
-        const uint32_t c_s = eB > wcols ? eB - wcols + 1u : 1u;
+        const uint32_t mycols = pair_window(wcols, eA, score ? score[pair] : 0, smax, gap);
+        const uint32_t c_s = eB > mycols ? eB - mycols + 1u : 1u;
         const uint32_t ncol = eB - c_s + 1u;
         int32_t *Hc = hbuf + local;
         uint32_t *dirw = dirbuf + local;
@@ -432,7 +451,8 @@ size_t polyhip_sw_traceback_workspace_bytes(const polyhip_scoring *sc, uint64_t 
 
 int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
                              uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
-                             const uint32_t *d_endA, const uint32_t *d_endB, const uint32_t *d_err, uint8_t *d_alnA,
+                             const uint32_t *d_endA, const uint32_t *d_endB, const uint32_t *d_err,
+                             const int64_t *d_score, uint8_t *d_alnA,
                              uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
                              polyhip_stream_t stream)
 {
@@ -461,7 +481,7 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
                                    (int)p.smem));                                                                      \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.smem, st, d_A, d_offA, p0, p1, d_B, d_offB, lenB,  \
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err,         \
-                           p.win.wcols, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);                                 \
+                           d_score, (int)sc->smax, p.win.wcols, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);         \
     } while (0)
         if (p.ra == 64)
             PH_TB_LAUNCH(64);
@@ -474,7 +494,8 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
             int32_t *hbuf = static_cast<int32_t *>(d_work);
             uint32_t *dirg = reinterpret_cast<uint32_t *>(hbuf + nl * max_lenA);
             hipLaunchKernelGGL(k3t::tb_generic_kernel, dim3(blocks), dim3(k3t::THREADS), 0, st, d_A, d_offA, p0, p1, d_B,
-                               d_offB, lenB, sc->d_lut, (int)sc->gap, d_endA, d_endB, d_err, p.win.wcols, max_lenA, hbuf,
+                               d_offB, lenB, sc->d_lut, (int)sc->gap, d_endA, d_endB, d_err, d_score, (int)sc->smax,
+                               p.win.wcols, max_lenA, hbuf,
                                dirg, d_alnA, d_alnB, d_alnLen, aln_stride);
         }
 #undef PH_TB_LAUNCH
@@ -541,8 +562,8 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     PH_HIP(dtb.alloc(tb));
     rc = polyhip_sw_traceback_dev(sc, dA.as<uint8_t>(), doA.as<uint64_t>(), npairs, (uint32_t)maxA, dB.as<uint8_t>(),
                                   offB ? doB.as<uint64_t>() : nullptr, maxB, dea.as<uint32_t>(), deb.as<uint32_t>(),
-                                  derr.as<uint32_t>(), dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(),
-                                  aln_stride, dtb.p, tb, nullptr);
+                                  derr.as<uint32_t>(), dscore.as<int64_t>(), dalA.as<uint8_t>(), dalB.as<uint8_t>(),
+                                  dlen.as<uint32_t>(), aln_stride, dtb.p, tb, nullptr);
     if (rc != POLYHIP_OK)
         return rc;
     PH_HIP(hipStreamSynchronize(nullptr));

@@ -37,7 +37,7 @@ def t(f, R=2):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / R
 ms1 = t(lambda: align.sw_batch_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, work))
-ms2 = t(lambda: align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw))
+ms2 = t(lambda: align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score))
 cells = n * LA * LB
 print(f"K3 score: {ms1:.2f} ms ({cells/ms1*1e3:.3e} CUPS); traceback: {ms2:.2f} ms (workspace {tbw.numel()/2**30:.1f} GiB, stride {stride}); "
       f"both: {cells/(ms1+ms2)*1e3:.3e} CUPS; mean score {float(score.double().mean()):.1f} mean aln len {float(ln.double().mean()):.1f}")

@@ -180,7 +180,7 @@ def test_device_resident_chunked_workspace(al):
     small = torch.empty(full // 5, dtype=torch.uint8, device=dev)  # forces >= 5 chunks
     alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
     alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
-    align.sw_traceback_dev(sc, A, offA, L, B, None, 5000, ea, eb, er, alnA, alnB, ln, small)
+    align.sw_traceback_dev(sc, A, offA, L, B, None, 5000, ea, eb, er, alnA, alnB, ln, small, score_t=score)
     torch.cuda.synchronize()
     a_h, b_h, l_h = alnA.cpu().numpy(), alnB.cpu().numpy(), ln.cpu().numpy()
     for p in range(0, n, 11):
