@@ -382,6 +382,28 @@ int polyhip_fastq_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs,
                        uint64_t *offsets, uint64_t *rec_start,
                        uint64_t max_records, uint64_t *result);
 
+/* ---- read feeder: io/fasta (*Parser).ParseNext / ParseN  (io/fasta/fasta.go:102-238) ---- */
+/*
+ * Same contract as polyhip_fastq_pack for a FASTA image, multi-line records included, with
+ * the reference's rules: empty lines and ';' lines are skipped, lines before the first '>'
+ * are skipped, a '>' line directly after a header is SEQUENCE (fasta.go:197-204 looks at the
+ * next line only after a line has been read), a last record ending in an unterminated line is
+ * dropped (ParseNext returns it with io.EOF).  d_rec_start[i] = byte offset of record i's
+ * header line.  d_result[0] = n records, [1] = error code (0 none; 1 no '>' in a non-empty
+ * file (:223), 2 a header without sequence (:227) -- records before it are kept; 7 more
+ * records than max_records), [2] = total sequence bytes, [3] = header lines seen.
+ * Capacities: d_seqs nbytes; d_offsets / d_rec_start nbytes/2 + 3 entries.
+ */
+size_t polyhip_fasta_workspace_bytes(uint64_t nbytes);
+int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes,
+                           uint8_t *d_seqs, uint64_t *d_offsets,
+                           uint64_t *d_rec_start, uint64_t max_records,
+                           uint64_t *d_result, void *d_work, size_t work_bytes,
+                           polyhip_stream_t stream);
+int polyhip_fasta_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs,
+                       uint64_t *offsets, uint64_t *rec_start,
+                       uint64_t max_records, uint64_t *result);
+
 #ifdef __cplusplus
 }
 #endif

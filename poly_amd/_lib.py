@@ -73,6 +73,9 @@ SIGNATURES = {
     "polyhip_fastq_workspace_bytes": (C.c_size_t, [_u64]),
     "polyhip_fastq_pack_dev": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, C.c_size_t, _vp]),
     "polyhip_fastq_pack": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    "polyhip_fasta_workspace_bytes": (C.c_size_t, [_u64]),
+    "polyhip_fasta_pack_dev": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, C.c_size_t, _vp]),
+    "polyhip_fasta_pack": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
 }
 
 

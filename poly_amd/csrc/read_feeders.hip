@@ -1,6 +1,7 @@
-// fastq_pack.hip -- the read feeder: a FASTQ file image resident in HBM becomes the packed batch
-// (bytes + offsets) the hot-path kernels take, without a host parse and without per-read copies.
+// read_feeders.hip -- the read feeders: a FASTQ or FASTA file image resident in HBM becomes the packed
+// batch (bytes + offsets) the hot-path kernels take, without a host parse and without per-read objects.
 //
+// ---- FASTQ ----
 // Follows io/fastq/fastq.go:117-216 ((*Parser).ParseNext) and :84-96 (ParseN): records are exactly
 // four '\n'-terminated lines (identifier, sequence, '+', quality); Sequence is line 2 minus the '\n'
 // (a '\r' is NOT stripped, as in the reference); parsing stops at the first bad record and the records
@@ -16,6 +17,24 @@
 // per 4-line record validates it and measures its sequence; an exclusive scan of the lengths gives the
 // offsets; one workgroup per record copies the bytes.  Pure byte work, HBM bound: reads the file twice
 // (newlines, gather) and writes the sequences once.
+//
+// ---- FASTA ----
+// Follows io/fasta/fasta.go:102-238 ((*Parser).ParseNext / ParseN), quirks included:
+//   * a line is skipped when it is empty or starts with ';' (:169); lines before the first '>' line are
+//     skipped too (:208-216);
+//   * a record ends when the NEXT line starts with '>' (:197-204) -- the check happens after a line is
+//     read, so a '>' line directly after a header is part of that header's SEQUENCE: in a run of
+//     consecutive '>' lines the 1st, 3rd, ... are headers and the 2nd, 4th, ... sequence lines;
+//   * Sequence is the concatenation of the record's lines without their '\n' (a '\r' stays);
+//   * a header without sequence is an error (code 2, :226-229), the records before it are kept;
+//     a non-empty file without any header is an error (code 1, :223) -- unless its last line is an
+//     unterminated non-skippable one, in which case the error wraps io.EOF and ParseN drops it (:107-110);
+//   * a last record that ends in an unterminated, non-skippable line is returned WITH io.EOF by
+//     ParseNext and therefore dropped by ParseN/ParseAll (fasta_test.go:139-142); an unterminated line of
+//     at most one byte, or one starting with ';', is skippable and changes nothing.
+// Device algorithm: the same newline compaction; one thread per line classifies it (the parity inside a
+// run of '>' lines by walking back over the run); two exclusive scans (header rank, sequence bytes) give
+// every line its record and its destination; one workgroup per line copies it.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -235,9 +254,166 @@ __global__ __launch_bounds__(THREADS) void gather_kernel(const uint8_t *__restri
     }
 }
 
+// ---- FASTA ----------------------------------------------------------------------------------------
+enum { F_NREC = 0, F_CODE = 1, F_SEQBYTES = 2, F_NHEADERS = 3, F_FIRSTEMPTY = 4, F_WORDS = 8 };
+
+// per complete line: is it a header?  how many sequence bytes does it contribute?
+__global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *__restrict__ file,
+                                                                const uint64_t *__restrict__ line_end,
+                                                                const uint64_t *__restrict__ nlines_dev,
+                                                                uint32_t *__restrict__ is_header,
+                                                                uint32_t *__restrict__ seq_len)
+{
+    const uint64_t nl = *nlines_dev;
+    const uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (k >= nl)
+        return;
+    const uint64_t start = k == 0 ? 0 : line_end[k - 1] + 1;
+    const uint64_t len = line_end[k] - start;
+    const uint8_t b = len ? file[start] : 0;
+    bool header = false;
+    if (len && b == '>') {
+        // position inside the run of consecutive '>' lines that ends here: odd = header
+        uint64_t run = 1, j = k;
+        while (j > 0) {
+            const uint64_t ps = j == 1 ? 0 : line_end[j - 2] + 1;
+            const uint64_t pl = line_end[j - 1] - ps;
+            if (pl == 0 || file[ps] != '>')
+                break;
+            ++run;
+            --j;
+        }
+        header = (run & 1) != 0;
+    }
+    const bool skippable = len == 0 || b == ';';
+    is_header[k] = header ? 1u : 0u;
+    seq_len[k] = (!header && !skippable) ? (uint32_t)len : 0u;
+}
+
+// lines before the first header carry no sequence
+__global__ __launch_bounds__(THREADS) void fasta_prefix_kernel(const uint64_t *__restrict__ nlines_dev,
+                                                              const uint64_t *__restrict__ hrank,
+                                                              uint32_t *__restrict__ seq_len)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (k < *nlines_dev && hrank[k] == 0 && seq_len[k]) // hrank = headers strictly before line k
+        seq_len[k] = 0;
+}
+
+// offsets[r] = sequence bytes before record r's header; first record without sequence
+__global__ __launch_bounds__(THREADS) void fasta_offsets_kernel(const uint64_t *__restrict__ nlines_dev,
+                                                               const uint32_t *__restrict__ is_header,
+                                                               const uint64_t *__restrict__ hrank,
+                                                               const uint64_t *__restrict__ dst,
+                                                               const uint64_t *__restrict__ line_end,
+                                                               uint64_t *__restrict__ offsets,
+                                                               uint64_t *__restrict__ rec_start)
+{
+    const uint64_t nl = *nlines_dev;
+    const uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (k >= nl)
+        return;
+    if (is_header[k]) {
+        offsets[hrank[k]] = dst[k];
+        if (rec_start)
+            rec_start[hrank[k]] = k == 0 ? 0 : line_end[k - 1] + 1;
+    }
+    if (k == nl - 1)
+        offsets[hrank[nl]] = dst[nl]; // hrank[nl] = number of headers, dst[nl] = all sequence bytes
+}
+
+__global__ __launch_bounds__(THREADS) void fasta_empty_kernel(const uint64_t *__restrict__ hrank,
+                                                             const uint64_t *__restrict__ nlines_dev,
+                                                             const uint64_t *__restrict__ offsets,
+                                                             unsigned long long *__restrict__ res)
+{
+    const uint64_t H = hrank[*nlines_dev];
+    const uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (r < H && offsets[r + 1] == offsets[r])
+        atomicMin(&res[F_FIRSTEMPTY], (unsigned long long)r);
+}
+
+__global__ void fasta_finish_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
+                                    const uint64_t *__restrict__ line_end, const uint64_t *__restrict__ nlines_dev,
+                                    const uint64_t *__restrict__ hrank, const uint64_t *__restrict__ offsets,
+                                    uint64_t max_records, unsigned long long *__restrict__ res)
+{
+    const uint64_t nl = *nlines_dev;
+    const uint64_t H = nl ? hrank[nl] : 0;
+    // the unterminated tail line, if any: non-skippable = longer than one byte and not a comment (:169)
+    const uint64_t tail0 = nl ? line_end[nl - 1] + 1 : 0;
+    bool tail_counts = nbytes - tail0 > 1 && file[tail0] != ';';
+    const bool tail_nonskippable = tail_counts; // any such tail makes a "no header" error wrap io.EOF
+    bool lone_gt = false; // the tail is the single byte '>' and starts a record of its own
+    if (nbytes > tail0 && file[tail0] == '>') {
+        // a '>' tail line is a (nameless, dropped) NEW record unless it sits at an even position of a
+        // run of '>' lines, where it is sequence of the last record like any other line
+        uint64_t run = 1, j = nl;
+        while (j > 0) {
+            const uint64_t ps = j == 1 ? 0 : line_end[j - 2] + 1;
+            const uint64_t pl = line_end[j - 1] - ps;
+            if (pl == 0 || file[ps] != '>')
+                break;
+            ++run;
+            --j;
+        }
+        if (run & 1) {
+            // The records before it are complete.  A longer tail is read as a sequence line with io.EOF
+            // while still looking for a name: the error wraps EOF and is dropped.  The one-byte tail ">"
+            // is skippable (:169), so the same parse ends with a plain "did not find fasta start" (:223).
+            lone_gt = nbytes - tail0 == 1;
+            tail_counts = false;
+        }
+    }
+    uint64_t n = H, code = 0;
+    unsigned long long fe = res[F_FIRSTEMPTY];
+    if (tail_counts && H > 0 && fe == H - 1)
+        fe = ~0ull; // the tail line is this record's sequence; it is dropped below, not an error
+    if (fe != ~0ull) {
+        n = fe;
+        code = 2;
+    } else if (H == 0) {
+        code = (nbytes > 0 && !tail_nonskippable) ? 1 : 0;
+    } else if (tail_counts) {
+        n = H - 1; // ParseNext returns the last record with io.EOF; ParseN drops it
+    } else if (lone_gt) {
+        code = 1;
+    }
+    if (n > max_records) {
+        n = max_records;
+        code = 7;
+    }
+    res[F_NREC] = n;
+    res[F_CODE] = code;
+    res[F_SEQBYTES] = H ? offsets[n] : 0;
+    res[F_NHEADERS] = H;
+}
+
+// one workgroup per line (grid-stride): sequence lines of the kept records -> packed buffer
+__global__ __launch_bounds__(THREADS) void fasta_gather_kernel(const uint8_t *__restrict__ file,
+                                                              const uint64_t *__restrict__ line_end,
+                                                              const uint64_t *__restrict__ nlines_dev,
+                                                              const uint32_t *__restrict__ seq_len,
+                                                              const uint64_t *__restrict__ dst,
+                                                              const unsigned long long *__restrict__ res,
+                                                              uint8_t *__restrict__ seqs)
+{
+    const uint64_t nl = *nlines_dev;
+    const uint64_t total = res[F_SEQBYTES];
+    for (uint64_t k = blockIdx.x; k < nl; k += gridDim.x) {
+        const uint64_t len = seq_len[k], d = dst[k];
+        if (len == 0 || d >= total)
+            continue;
+        const uint64_t src = k == 0 ? 0 : line_end[k - 1] + 1;
+        for (uint64_t t = threadIdx.x; t < len; t += THREADS)
+            seqs[d + t] = file[src + t];
+    }
+}
+
 struct Layout {
     uint64_t nblocks, max_lines;
     size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, total;
+    size_t off_ishdr, off_hrank, off_dst; // FASTA (per line)
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -256,6 +432,21 @@ static Layout layout(uint64_t nbytes)
     L.off_lineend = o; o += al((L.max_lines + 1) * 8);
     L.off_seqlen = o; o += al((L.max_lines / 4 + 1) * 4);
     L.off_seqstart = o; o += al((L.max_lines / 4 + 1) * 8);
+    L.total = o;
+    L.off_ishdr = L.off_hrank = L.off_dst = 0;
+    return L;
+}
+
+// FASTA needs per-LINE arrays (a line can be as short as one byte)
+static Layout layout_fasta(uint64_t nbytes)
+{
+    Layout L = layout(nbytes);
+    size_t o = L.off_seqlen;
+    L.off_seqlen = o; o += al((L.max_lines + 1) * 4);
+    L.off_ishdr = o; o += al((L.max_lines + 1) * 4);
+    L.off_hrank = o; o += al((L.max_lines + 2) * 8);
+    L.off_dst = o; o += al((L.max_lines + 2) * 8);
+    L.off_seqstart = 0;
     L.total = o;
     return L;
 }
@@ -338,6 +529,87 @@ int polyhip_fastq_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs, uint
         PH_HIP(hipMemcpy(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost));
     if (result[3])
         PH_HIP(hipMemcpy(seqs, dseqs.p, result[3], hipMemcpyDeviceToHost));
+    return POLYHIP_OK;
+}
+
+size_t polyhip_fasta_workspace_bytes(uint64_t nbytes) { return fq::layout_fasta(nbytes).total; }
+
+int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_seqs, uint64_t *d_offsets,
+                           uint64_t *d_rec_start, uint64_t max_records, uint64_t *d_result, void *d_work,
+                           size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(d_result && d_offsets && d_work && (d_file || nbytes == 0) && (d_seqs || nbytes == 0),
+               "polyhip_fasta_pack: null pointer");
+    const fq::Layout L = fq::layout_fasta(nbytes);
+    PH_REQUIRE(work_bytes >= L.total, "polyhip_fasta_pack: workspace too small (%zu < %zu)", work_bytes, L.total);
+    PH_REQUIRE(L.nblocks < (1ull << 31) && nbytes < (1ull << 39), "polyhip_fasta_pack: file too large for one call");
+    hipStream_t st = as_stream(stream);
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    unsigned long long *res = reinterpret_cast<unsigned long long *>(w + L.off_res);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(w + L.off_counts);
+    uint64_t *blockoff = reinterpret_cast<uint64_t *>(w + L.off_blockoff);
+    uint64_t *line_end = reinterpret_cast<uint64_t *>(w + L.off_lineend);
+    uint32_t *seq_len = reinterpret_cast<uint32_t *>(w + L.off_seqlen);
+    uint32_t *is_header = reinterpret_cast<uint32_t *>(w + L.off_ishdr);
+    uint64_t *hrank = reinterpret_cast<uint64_t *>(w + L.off_hrank);
+    uint64_t *dst = reinterpret_cast<uint64_t *>(w + L.off_dst);
+
+    PH_HIP(hipMemsetAsync(res, 0, fq::F_WORDS * 8, st));
+    PH_HIP(hipMemsetAsync(res + fq::F_FIRSTEMPTY, 0xFF, 8, st));
+    PH_HIP(hipMemsetAsync(hrank, 0, 16, st));
+    PH_HIP(hipMemsetAsync(dst, 0, 16, st));
+    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes, counts);
+    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, counts, L.nblocks, (const uint64_t *)nullptr,
+                       (uint64_t)1, blockoff);
+    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
+                       blockoff, line_end);
+    const uint64_t *nlines_dev = blockoff + L.nblocks; // the line count exists only on the device
+    const unsigned gl = (unsigned)((nbytes + fq::THREADS - 1) / fq::THREADS + 1); // >= lines
+    hipLaunchKernelGGL(fq::fasta_classify_kernel, dim3(gl), dim3(fq::THREADS), 0, st, d_file, line_end, nlines_dev, is_header,
+                       seq_len);
+    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, is_header, (uint64_t)0, nlines_dev, (uint64_t)1, hrank);
+    hipLaunchKernelGGL(fq::fasta_prefix_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, hrank, seq_len);
+    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, seq_len, (uint64_t)0, nlines_dev, (uint64_t)1, dst);
+    hipLaunchKernelGGL(fq::fasta_offsets_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, is_header, hrank, dst, line_end,
+                       d_offsets, d_rec_start);
+    hipLaunchKernelGGL(fq::fasta_empty_kernel, dim3(gl), dim3(fq::THREADS), 0, st, hrank, nlines_dev, d_offsets, res);
+    hipLaunchKernelGGL(fq::fasta_finish_kernel, dim3(1), dim3(1), 0, st, d_file, nbytes, line_end, nlines_dev, hrank, d_offsets,
+                       max_records, res);
+    hipLaunchKernelGGL(fq::fasta_gather_kernel, dim3((unsigned)std::min<uint64_t>(gl, 256ull * 32ull)), dim3(fq::THREADS), 0, st,
+                       d_file, line_end, nlines_dev, seq_len, dst, res, d_seqs);
+    PH_HIP(hipGetLastError());
+    PH_HIP(hipMemcpyAsync(d_result, res, 4 * 8, hipMemcpyDeviceToDevice, st));
+    return POLYHIP_OK;
+}
+
+int polyhip_fasta_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs, uint64_t *offsets, uint64_t *rec_start,
+                       uint64_t max_records, uint64_t *result)
+{
+    PH_REQUIRE(result && offsets && (file || nbytes == 0) && (seqs || nbytes == 0), "polyhip_fasta_pack: null pointer");
+    const uint64_t most = nbytes / 2 + 2; // ">\n" is the shortest header line
+    DevBuf dfile, dseqs, doffs, drec, dres, dwork;
+    PH_HIP(dfile.alloc(nbytes));
+    PH_HIP(dseqs.alloc(nbytes));
+    PH_HIP(doffs.alloc((most + 1) * 8));
+    PH_HIP(drec.alloc((most + 1) * 8));
+    PH_HIP(dres.alloc(4 * 8));
+    const size_t wb = polyhip_fasta_workspace_bytes(nbytes);
+    PH_HIP(dwork.alloc(wb));
+    if (nbytes)
+        PH_HIP(hipMemcpy(dfile.p, file, nbytes, hipMemcpyHostToDevice));
+    PH_HIP(hipMemset(doffs.p, 0, 16));
+    int rc = polyhip_fasta_pack_dev(dfile.as<uint8_t>(), nbytes, dseqs.as<uint8_t>(), doffs.as<uint64_t>(),
+                                    drec.as<uint64_t>(), max_records, dres.as<uint64_t>(), dwork.p, wb, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(result, dres.p, 4 * 8, hipMemcpyDeviceToHost));
+    const uint64_t n = result[0];
+    PH_HIP(hipMemcpy(offsets, doffs.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    if (rec_start && n)
+        PH_HIP(hipMemcpy(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost));
+    if (result[2])
+        PH_HIP(hipMemcpy(seqs, dseqs.p, result[2], hipMemcpyDeviceToHost));
     return POLYHIP_OK;
 }
 

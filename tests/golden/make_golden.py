@@ -8,6 +8,7 @@ committed so that nothing at test/bench time reads /root/reference.
   puc19.seq    <- data/puc19.gbk    (seqhash_test.go:68-91 rotation fixture)
   fastq/*.fastq <- io/fastq/data/*.fastq  (verbatim copies of the reference's own parser fixtures:
                    fastq_test.go:59-66, example_test.go:16-66)
+  fasta/base.fasta <- io/fasta/data/base.fasta  (example_test.go:18-36,100-114)
 
 Extraction follows io/genbank/genbank.go:125,627-633: every line between
 ORIGIN and // with all non-letters removed, case preserved.
@@ -50,6 +51,8 @@ def copy_fastq():
     os.makedirs(dst, exist_ok=True)
     for f in sorted(glob.glob(os.path.join(REF, "io", "fastq", "data", "*.fastq"))):
         shutil.copy(f, dst)
+    os.makedirs(os.path.join(HERE, "fasta"), exist_ok=True)
+    shutil.copy(os.path.join(REF, "io", "fasta", "data", "base.fasta"), os.path.join(HERE, "fasta"))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,67 @@
+"""FASTA read feeder parity: poly_amd.fasta's device packer vs the CPU restatement of io/fasta
+(*Parser).ParseNext / ParseAll (oracle/fasta_ref.py) -- same records, names, Sequence bytes and error.
+
+Mirrors io/fasta/fasta_test.go:133-241 and example_test.go:18-36."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fasta_ref as fr
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fasta")
+
+
+def _check(data: bytes):
+    from poly_amd import fasta
+    want, code = fr.parse_all(data)
+    raw = bytes(data)
+    seqs, offs, rec, err = fasta.pack(raw)
+    got = []
+    for i in range(len(offs) - 1):
+        start = int(rec[i])
+        end = raw.index(b"\n", start)
+        got.append((raw[start + 1:end], seqs[int(offs[i]): int(offs[i + 1])].tobytes()))
+    assert got == want, (data[:80], got[:3], want[:3])
+    assert (err is None) == (code == 0), (data[:80], err, code)
+    if code:
+        assert str(err) == fasta.ERRORS[code]
+
+
+def test_reference_cases():
+    from poly_amd import fasta
+    _check(b">humen\nGATTACA\nCATGAT")            # fasta_test.go:139-142: EOF-ended fasta not valid
+    _check(b">humen\nGATTACA\nCATGAT\n")
+    _check(b">doggy or something\nGATTACA\n\nCATGAT\n>homunculus\nAAAA\n")
+    _check(b"testing\natagtagtagtagtagatgatgatgatgagatg\n\n\n\n\n\n\n\n\n\n\n")   # :206-215
+    _check(b">OK Fasta\nABGABA\n>NotOKFasta\n")    # :233-241
+    base = open(os.path.join(GOLD, "base.fasta"), "rb").read()
+    _check(base)
+    r = fasta.records(base)
+    assert r[0][0] == b"gi|5524211|gb|AAD44166.1| cytochrome b [Elephas maximus maximus]"   # example_test.go:25-30
+    assert r[1][1].startswith(b"ADQLTEEQIAEFKEAFSLFDKDGDGTITTKELGTVMRSLGQNPTEAELQDMINEVDADGNGTID") and r[1][1].endswith(b"FVQMMTAK*")
+    with pytest.raises(fasta.FastaError):
+        fasta.records(b">OK Fasta\nABGABA\n>NotOKFasta\n")
+
+
+def test_quirks_and_random_files():
+    cases = [b"", b"\n", b"A", b">", b">a", b">a\n", b">a\nA", b">a\nAC", b">a\nAC\n>b", b">a\n>b", b">a\n>b\n", b">a\n>b\n>c\nAC\n",
+             b">a\nAC\n>b\n>c\nGG\n", b">a\n\n>b\nAC\n", b";c\n>a\n;x\nAC\n;y\nGT\n", b"junk\n>a\nAC\n", b">a\r\nAC\r\n",
+             b">a\nAC\n;tail", b">a\nAC\nG", b">a\nAC\n>", b">a\nAC\n>b\n>c", b">a\n>b\n>c", b">>\n>\nA\n", b"AC\nGT", b"AC\nGT\n",
+             b">a\nAC\n\n\n", b">a\n;only\n>b\nAC\n", b">a\nAC\n>b\n;x\n", b">a\nAC\n>b\nG"]
+    for c in cases:
+        _check(c)
+    rng = np.random.default_rng(4)
+    pieces = [b">", b">id", b";c", b"", b"ACGT", b"A", b">x y", b"GG>"]
+    for _ in range(400):
+        n = int(rng.integers(0, 14))
+        lines = [pieces[int(rng.integers(0, len(pieces)))] for _ in range(n)]
+        data = b"\n".join(lines) + (b"\n" if rng.random() < 0.6 and n else b"")
+        _check(data)
+    # a realistic multi-line file
+    recs = []
+    for i in range(200):
+        seq = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 900))).astype(np.uint8))
+        recs.append(b">seq%d desc\n" % i + b"\n".join(seq[j:j + 70] for j in range(0, len(seq), 70)) + b"\n")
+    _check(b"".join(recs))

@@ -364,3 +364,23 @@ def test_fastq_reference_fixtures():
     for name in ("noseq", "noquality", "noidentifier", "emptyseq", "noplus", "noquality2"):
         _, code, line = fr.parse_all(open(os.path.join(d, f"nanosavseq_{name}.fastq"), "rb").read())
         assert code != 0 and line > 0, name
+
+
+# ------------------------------------------------------------------ io/fasta --
+def test_fasta_reference_tests():
+    """io/fasta/fasta_test.go:133-172 (TestParser), :206-215 (TestReadEmptyFasta), :233-241
+    (TestParseEOFAfterName); example_test.go:18-36,100-114 on data/base.fasta (tests/golden/fasta/)."""
+    from oracle import fasta_ref as fr
+    assert fr.parse_all(b">humen\nGATTACA\nCATGAT") == ([], 0)                      # EOF-ended fasta not valid
+    assert fr.parse_all(b">humen\nGATTACA\nCATGAT\n") == ([(b"humen", b"GATTACACATGAT")], 0)
+    assert fr.parse_all(b">doggy or something\nGATTACA\n\nCATGAT\n>homunculus\nAAAA\n") == (
+        [(b"doggy or something", b"GATTACACATGAT"), (b"homunculus", b"AAAA")], 0)
+    recs, code = fr.parse_all(b"testing\natagtagtagtagtagatgatgatgatgagatg\n\n\n\n\n\n\n\n\n\n\n")
+    assert recs == [] and code != 0
+    recs, code = fr.parse_all(b">OK Fasta\nABGABA\n>NotOKFasta\n")
+    assert code != 0
+    recs, code = fr.parse_all(open(os.path.join(GOLD, "fasta", "base.fasta"), "rb").read())
+    assert code == 0 and [r[0] for r in recs] == [b"gi|5524211|gb|AAD44166.1| cytochrome b [Elephas maximus maximus]",
+                                                  b"MCHU - Calmodulin - Human, rabbit, bovine, rat, and chicken"]
+    assert recs[1][1] == (b"ADQLTEEQIAEFKEAFSLFDKDGDGTITTKELGTVMRSLGQNPTEAELQDMINEVDADGNGTIDFPEFLTMMARKMKDTDSEEEIREAFRVFDKDGNGYISAAELRHVMTNLG"
+                          b"EKLTDEEVDEMIREADIDGDGQVNYEEFVQMMTAK*")
