@@ -1,0 +1,79 @@
+"""Host-side mirror of the reference interface (no GPU): alphabet, substitution matrix, Scoring
+flattening, packing, pcr's reverse complement, error classes.
+
+Mirrors alphabet/alphabet_test.go:10-73, search/align/matrix/matrix_test.go:11-49 and the Scoring
+conventions of search/align/align.go:73-95."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from poly_amd import _lib, align, alphabet, matrix, pcr
+from poly_amd.mash import _pack
+
+
+def test_alphabet():
+    """alphabet/alphabet_test.go:10-73"""
+    symbols = ["A", "C", "G", "T"]
+    a = alphabet.NewAlphabet(symbols)
+    for i, s in enumerate(symbols):
+        assert a.Encode(s) == i and a.Decode(i) == s
+    with pytest.raises(alphabet.Error, match="Symbol X not in alphabet"):
+        a.Encode("X")
+    with pytest.raises(alphabet.Error):
+        a.Decode(len(symbols))
+    ext = a.Extend(["N", "-", "*"])
+    assert [ext.Encode(s) for s in symbols] == [0, 1, 2, 3]
+    assert [ext.Encode(s) for s in ["N", "-", "*"]] == [4, 5, 6]
+    assert a.Symbols() == symbols
+    assert alphabet.DNA.Symbols() == ["A", "C", "G", "T"] and alphabet.RNA.Symbols()[-1] == "U"
+    # a repeated symbol keeps its last index (alphabet.go:27-30)
+    assert alphabet.NewAlphabet(["A", "C", "A"]).Encode("A") == 2
+
+
+def test_substitution_matrix():
+    """search/align/matrix/matrix_test.go:11-49"""
+    a1 = alphabet.NewAlphabet(["-", "A", "C", "G", "T"])
+    m = matrix.NewSubstitutionMatrix(a1, alphabet.NewAlphabet(["-", "A", "C", "G", "T"]), matrix.NUC_4)
+    assert [m.Score(x, y) for x, y in (("A", "A"), ("A", "C"), ("C", "T"), ("-", "-"))] == [5, -4, -4, 0]
+    with pytest.raises(alphabet.Error):
+        m.Score("X", "A")
+    with pytest.raises(ValueError):
+        matrix.NewSubstitutionMatrix(a1, a1, [[0, 1], [1, 0]])
+    assert matrix.Default.Score("Q", "Q") == 1 and matrix.Default.Score("Q", "R") == -1  # matrix.go:40-73
+
+
+def test_scoring_flatten_matches_the_oracle_flatten():
+    """the Go wrapper can only see the matrix through Score(): the 256x256 table + valid masks it builds
+    must be what the oracle's restatement of matrix.go:28-38 gives, also for asymmetric two-alphabet matrices"""
+    rows, cols = "ACGT", "ACGTN"
+    scores = [[4, -2, -1, -3, 0], [-2, 5, -3, -1, 0], [-1, -4, 6, -2, 0], [-3, -1, -2, 3, 0]]
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(alphabet.NewAlphabet(list(rows)), alphabet.NewAlphabet(list(cols)),
+                                                       scores), -3)
+    lut, va, vb = sc.flatten()
+    om = orc.SubstitutionMatrix(rows, cols, scores)
+    for a in range(256):
+        for b in range(0, 256, 3):
+            ok_a, ok_b = a < 128 and chr(a) in rows, b < 128 and chr(b) in cols
+            assert va[a] == ok_a and vb[b] == ok_b
+            if ok_a and ok_b:
+                assert lut[a, b] == scores[rows.index(chr(a))][cols.index(chr(b))]
+    assert sc.Score(ord("G"), ord("N")) == 0 and sc.GapPenalty == -3
+    assert align.NewScoring(None, -1).SubstitutionMatrix is matrix.Default  # align.go:80-82
+    _ = om
+
+
+def test_pack_and_revcomp():
+    buf, offs = _pack(["ACGT", b"", "TT", b"\xff\x00"])
+    assert buf.tobytes() == b"ACGTTT\xff\x00" and offs.tolist() == [0, 4, 4, 6, 8]
+    buf, offs = _pack([])
+    assert len(buf) == 0 and offs.tolist() == [0]
+    for s in (b"GATTACA", b"acgtNNRYKM", b"AU-*", b""):
+        assert pcr._revcomp(s) == orc.reverse_complement(s)  # transform.go:15-23,78-109
+
+
+def test_error_classes_and_status_codes():
+    assert issubclass(_lib.GoPanic, _lib.PolyhipError)
+    e = _lib.PolyhipError(-2, "x")
+    assert e.status == -2 and "x" in str(e)
+    # the binding table and the header agree (names + arity are checked against the library in test_abi_cpu)
+    assert "polyhip_fasta_pack_dev" in _lib.SIGNATURES and len(_lib.SIGNATURES) >= 40
