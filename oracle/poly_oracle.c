@@ -509,7 +509,7 @@ void orc_santalucia(const uint8_t *seq_in, size_t n, double primer_conc,
                     double salt_conc, double mg_conc, double *tm, double *dHo,
                     double *dSo)
 {
-    uint8_t *seq = (uint8_t *)malloc(n ? n : 1);
+    uint8_t *seq = (uint8_t *)calloc(n ? n : 1, 1);
     uint8_t *rc = (uint8_t *)malloc(n ? n : 1);
     for (size_t i = 0; i < n; i++)
         seq[i] = ascii_upper(seq_in[i]); /* :71 */
