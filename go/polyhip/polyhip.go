@@ -229,3 +229,32 @@ func SeqhashBatch(seqs []byte, offs []uint64, seqType int, circular, doubleStran
 	}
 	return res, codes[:n], err
 }
+
+// ---- R1: all-gather of per-rank sketches (RCCL over xGMI; one process per GPU) ----
+
+// Comm wraps polyhip_comm.  Rank 0 calls CommUniqueID and ships the 128 bytes to the other ranks.
+type Comm struct{ c *C.polyhip_comm }
+
+func CommUniqueID() ([128]byte, error) {
+	var id [128]byte
+	err := call(func() C.int { return C.polyhip_comm_unique_id((*C.uint8_t)(unsafe.Pointer(&id[0]))) })
+	return id, err
+}
+
+func CommInitRank(id [128]byte, rank, nranks int) (*Comm, error) {
+	cm := &Comm{}
+	err := call(func() C.int {
+		return C.polyhip_comm_init_rank((*C.uint8_t)(unsafe.Pointer(&id[0])), C.int(rank), C.int(nranks), &cm.c)
+	})
+	return cm, err
+}
+
+func (cm *Comm) Close() { C.polyhip_comm_destroy(cm.c); cm.c = nil }
+
+// AllGatherSketches takes DEVICE pointers (the sketches never leave HBM between K1 and K2).
+func (cm *Comm) AllGatherSketches(dLocal unsafe.Pointer, nLocal uint64, s uint32, dAll unsafe.Pointer, stream unsafe.Pointer) error {
+	return call(func() C.int {
+		return C.polyhip_allgather_sketches_dev(cm.c, (*C.uint32_t)(dLocal), C.uint64_t(nLocal), C.uint32_t(s),
+			(*C.uint32_t)(dAll), C.polyhip_stream_t(stream))
+	})
+}

@@ -404,6 +404,27 @@ int polyhip_fasta_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs,
                        uint64_t *offsets, uint64_t *rec_start,
                        uint64_t max_records, uint64_t *result);
 
+/* ---- R1: the path's one collective -- all-gather of per-rank sketches (RCCL over xGMI) ---- */
+/*
+ * For hosts without torch.distributed (the Go/cgo drop-in); one process per GPU.  RCCL is
+ * resolved at run time (dlopen librccl.so.1), so libpolyhip has no link-time dependency on it.
+ * Rank 0 obtains the 128-byte id and passes it to the other ranks by its own channel; every
+ * rank then creates its communicator on its current HIP device.  d_all receives
+ * nranks * n_local sketches in rank order (every rank contributes the same n_local); the call
+ * enqueues one ncclAllGather on `stream`.  Then each rank runs
+ * polyhip_mash_shared_counts_dev(X = its block of d_all, Y = d_all).
+ */
+typedef struct polyhip_comm polyhip_comm;
+int polyhip_comm_unique_id(uint8_t id[128]);
+int polyhip_comm_init_rank(const uint8_t id[128], int rank, int nranks,
+                           polyhip_comm **out);
+int polyhip_comm_destroy(polyhip_comm *c);
+int polyhip_comm_rank(const polyhip_comm *c);
+int polyhip_comm_size(const polyhip_comm *c);
+int polyhip_allgather_sketches_dev(polyhip_comm *c, const uint32_t *d_local,
+                                   uint64_t n_local, uint32_t s,
+                                   uint32_t *d_all, polyhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,12 @@ SIGNATURES = {
     "polyhip_fasta_workspace_bytes": (C.c_size_t, [_u64]),
     "polyhip_fasta_pack_dev": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp, _vp, C.c_size_t, _vp]),
     "polyhip_fasta_pack": (C.c_int, [_vp, _u64, _vp, _vp, _vp, _u64, _vp]),
+    "polyhip_comm_unique_id": (C.c_int, [_vp]),
+    "polyhip_comm_init_rank": (C.c_int, [_vp, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "polyhip_comm_destroy": (C.c_int, [_vp]),
+    "polyhip_comm_rank": (C.c_int, [_vp]),
+    "polyhip_comm_size": (C.c_int, [_vp]),
+    "polyhip_allgather_sketches_dev": (C.c_int, [_vp, _vp, _u64, _u32, _vp, _vp]),
 }
 
 

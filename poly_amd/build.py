@@ -60,7 +60,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                     raise RuntimeError(f"hipcc failed on {cmd[-3]}")
     objs = [s[:-4] + ".o" for s in srcs]
     if force or jobs or _newer(LIB, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode:
             sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)

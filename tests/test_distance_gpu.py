@@ -188,3 +188,23 @@ def test_rows_with_many_relatives_overflow_to_merge(mash):
     rows = list(range(0, 2400, 97)) + [1999, 2000, 2399]
     for i in rows:
         assert (got[i] == _oracle_counts(S[i:i + 1], S)[0]).all()
+
+
+def test_c_abi_allgather_one_rank(mash):
+    """R1 through the C ABI (polyhip_comm_*: RCCL resolved at run time) on a 1-rank communicator"""
+    import ctypes as C
+    import torch
+    from poly_amd import _lib
+    L = _lib.lib()
+    ident = (C.c_uint8 * 128)()
+    _lib.check(L.polyhip_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(L.polyhip_comm_init_rank(ident, 0, 1, C.byref(comm)))
+    assert (L.polyhip_comm_rank(comm), L.polyhip_comm_size(comm)) == (0, 1)
+    dev = torch.device("cuda:0")
+    local = torch.randint(0, 1 << 31, (300, 64), dtype=torch.int32, device=dev)
+    out = torch.zeros_like(local)
+    _lib.check(L.polyhip_allgather_sketches_dev(comm, local.data_ptr(), 300, 64, out.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, local)
+    _lib.check(L.polyhip_comm_destroy(comm))
