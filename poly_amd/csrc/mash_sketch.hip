@@ -84,6 +84,19 @@ __device__ __forceinline__ uint32_t funnel_bytes(uint32_t hi, uint32_t lo, uint3
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
+// Inclusive scan over the 64 lanes of a wave with DPP adds: four row shifts inside each row of 16,
+// then the last lane of rows 0/2 into rows 1/3 and lane 31 into the upper half.
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true); // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true); // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true); // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 struct Smem {
     uint32_t *seqb;   // tile bytes, window 0 at byte 0
     uint32_t *P;      // premixed blocks per byte position; aliased by `bins`
@@ -425,64 +438,97 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
 {
     const int tid = threadIdx.x;
     uint32_t *bins = sm.P;
-    const uint32_t nbf = 1u << nbf_log2;  // 1024 or 2048 bins, whatever fits in the P region
-    const int per = (int)(nbf / THREADS); // 4 or 8 bins per thread
+    const uint32_t nbf = 1u << nbf_log2; // 1024 or 2048 bins, whatever fits in the P region
     const int sig = 32 - __builtin_clz(tau | 1u);
     const int shift = sig > (int)nbf_log2 ? sig - (int)nbf_log2 : 0;
-    for (uint32_t b = tid; b < nbf; b += THREADS) // (the caller's barrier freed P)
-        bins[b] = 0;
+    // a thread owns `per` = 4 or 8 consecutive bins = one or two 16-byte words (the caller's barrier freed P)
+    uint4 *bins4 = reinterpret_cast<uint4 *>(bins);
+    const int q4 = (int)(nbf / (4 * THREADS)); // 1 or 2
+    for (int q = 0; q < q4; ++q)
+        bins4[q4 * tid + q] = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    for (uint32_t i = tid; i < C; i += THREADS)
-        atomicAdd(&bins[sm.cand[i] >> shift], 1u);
+    // the loops over candidates are unrolled by four so that the LDS round trips of a thread's
+    // elements overlap instead of queueing behind each other
+    for (uint32_t i0 = tid; i0 < C; i0 += 4 * THREADS) {
+        uint32_t h[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            h[u] = i0 + u * THREADS < C ? sm.cand[i0 + u * THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * THREADS < C)
+                atomicAdd(&bins[h[u] >> shift], 1u);
+    }
     __syncthreads();
     {
-        uint32_t v[8], sum = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            v[i] = i < per ? bins[per * tid + i] : 0u;
-            sum += v[i];
+        uint4 v[2];
+        uint32_t sum = 0;
+        for (int q = 0; q < 2; ++q) {
+            v[q] = q < q4 ? bins4[q4 * tid + q] : make_uint4(0, 0, 0, 0);
+            sum += v[q].x + v[q].y + v[q].z + v[q].w;
         }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t t = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d)
-                incl += t;
-        }
+        const uint32_t incl = wave_incl_scan(sum);
         if ((tid & 63) == 63)
             sm.misc[4 + (tid >> 6)] = incl;
         __syncthreads();
         uint32_t run = incl - sum;
         for (int w = 0; w < (tid >> 6); ++w)
             run += sm.misc[4 + w];
+        for (int q = 0; q < 2; ++q) {
+            if (q < q4) {
+                uint4 o; // start of each bin
+                o.x = run;
+                o.y = o.x + v[q].x;
+                o.z = o.y + v[q].y;
+                o.w = o.z + v[q].z;
+                run = o.w + v[q].w;
+                bins4[q4 * tid + q] = o;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i0 = tid; i0 < C; i0 += 4 * THREADS) { // afterwards bins[b] = end of bin b
+        uint32_t h[4], at[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < per)
-                bins[per * tid + i] = run; // start of bin
-            run += v[i];
-        }
+        for (int u = 0; u < 4; ++u)
+            h[u] = i0 + u * THREADS < C ? sm.cand[i0 + u * THREADS] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * THREADS < C)
+                at[u] = atomicAdd(&bins[h[u] >> shift], 1u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * THREADS < C)
+                sm.binned[at[u]] = h[u];
     }
     __syncthreads();
-    for (uint32_t i = tid; i < C; i += THREADS) { // afterwards bins[b] = end of bin b
-        const uint32_t h = sm.cand[i];
-        sm.binned[atomicAdd(&bins[h >> shift], 1u)] = h;
-    }
-    __syncthreads();
-    for (uint32_t j = tid; j < C; j += THREADS) {
-        const uint32_t h = sm.binned[j];
-        const uint32_t b = h >> shift;
-        const uint32_t start = b ? bins[b - 1] : 0u;
-        if (start >= s)
-            continue;
-        const uint32_t end = bins[b];
-        uint32_t rank = 0;
-        for (uint32_t x = start; x < end; ++x) {
-            const uint32_t o = sm.binned[x];
-            rank += (o < h) || (o == h && x < j); // duplicates keep distinct ranks
+    for (uint32_t j0 = tid; j0 < C; j0 += 4 * THREADS) {
+        uint32_t h[4], start[4], end[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            h[u] = j0 + u * THREADS < C ? sm.binned[j0 + u * THREADS] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t b = h[u] >> shift;
+            const bool live = j0 + u * THREADS < C;
+            start[u] = live ? (b ? bins[b - 1] : 0u) : s;
+            end[u] = live ? bins[b] : s;
         }
-        const uint32_t pos = start + rank;
-        if (pos < s)
-            outp[pos] = h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (start[u] >= s)
+                continue;
+            const uint32_t j = j0 + u * THREADS;
+            uint32_t pos = start[u];
+            if (end[u] - start[u] > 1u) { // most bins hold one value
+                for (uint32_t x = start[u]; x < end[u]; ++x) {
+                    const uint32_t o = sm.binned[x];
+                    pos += (o < h[u]) || (o == h[u] && x < j); // duplicates keep distinct ranks
+                }
+            }
+            if (pos < s)
+                outp[pos] = h[u];
+        }
     }
 }
 
