@@ -276,6 +276,46 @@ def test_primers_pcr_threshold():
     assert _design_primers(GENE, 55.0) == ("AATAATTACACCGAGATAACACATCATGG", "TTAAGAAAGCGCATTTTCCAGC")
 
 
+def test_pcr_ref_design_primers():
+    """primers/pcr/example_test.go:36-55 through oracle/pcr_ref.py"""
+    from oracle import pcr_ref
+    assert pcr_ref.design_primers(GENE, 55.0) == ("AATAATTACACCGAGATAACACATCATGG", "TTAAGAAAGCGCATTTTCCAGC")
+    assert pcr_ref.design_primers_with_overhangs(GENE, "TTATAGGTCTCATACT", "ATGAAGAGACCATATA", 55.0) == (
+        "TTATAGGTCTCATACTAATAATTACACCGAGATAACACATCATGG", "TATATGGTCTCTTCATTTAAGAAAGCGCATTTTCCAGC")
+
+
+PCR_FRAGMENT = ("TTATAGGTCTCATACT" + GENE.upper() + "ATGAAGAGACCATATA")
+
+
+def test_pcr_ref_simulate_goldens():
+    """primers/pcr/pcr_test.go:14-95, example_test.go:57-66"""
+    from oracle import pcr_ref
+    # ExampleSimulate / TestIssue279PCRBug: the amplicon is overhang + gene + overhang
+    frags, err = pcr_ref.simulate([GENE], 55.0, False, ["TTATAGGTCTCATACTAATAATTACACCGAGATAACACATCATGG",
+                                                      "TATATGGTCTCTTCATTTAAGAAAGCGCATTTTCCAGC"])
+    assert err is None and frags == [PCR_FRAGMENT]
+    frags, err = pcr_ref.simulate([GENE], 55.0, False, ["TATATGGTCTCTTCATTTAAGAAAGCGCATTTTCCAGC",
+                                                      "TTATAGGTCTCATACTAATAATTACACCGAGATAACACATCATGG",
+                                                      "CTGCAGGTCGACTCTAG"])
+    assert err is None and len(frags) == 1 and frags[0] == PCR_FRAGMENT  # TestSimulatePrimerRejection, Issue279
+    # TestSimulateMoreThanOneForward
+    frags, _ = pcr_ref.simulate([GENE], 55.0, False, ["gatactcaaagattctatgaagctatttgaggcacttggtacg",
+                                                    "tatcgctttgtaagcattcaatgcacctttctcttcaagttg",
+                                                    "gtcgttcctcaatctcgcagagaagagctggaaaatg"])
+    assert len(frags) == 1
+    # TestSimulateCircular
+    frags, _ = pcr_ref.simulate([GENE], 55.0, True, ["actctgggctttagaaggagcgataaacggc",
+                                                   "aagtgcctcaaatagcttcatagaatctttgagtatcgg"])
+    assert frags[0] == ("ACTCTGGGCTTTAGAAGGAGCGATAAACGGCACGCACTGGAGCGTCGTTCCTCAATCTCGCAGAGAAGAGCTGGAAAATGCGCTTTCTTAAAATAATTAC"
+                        "ACCGAGATAACACATCATGGATAAACCGATACTCAAAGATTCTATGAAGCTATTTGAGGCACTT")
+    # TestSimulateConcatemerization
+    _, err = pcr_ref.simulate([GENE], 55.0, False, ["AATAATTACACCGAGATAACACATCATGG",
+                                                  "CCATGATGTGTTATCTCGGTGTAATTATTTTAAGAAAGCGCATTTTCCAGC"])
+    assert err == "Concatemerization detected in PCR."
+    # pcr.go:174-178
+    assert pcr_ref.simulate([GENE], 55.0, False, ["ACGT"]) == (None, "Primers are too short.")
+
+
 # -------------------------------------------------------------- transform --
 def test_transform_reverse_complement():
     """transform/transform_test.go:10-80, examples_test.go:9-30"""
