@@ -72,6 +72,67 @@ def cpu_baseline(n_reads: int):
     }
 
 
+def cpu_baseline_extra():
+    """The oracle timed on bounded samples of the secondary workloads (about 2 s each, one host core):
+    what the reference's per-call API costs on the CPU for the same shapes as poly_amd/bench_extra.py."""
+    import numpy as np
+    import oracle as orc
+    out = {}
+
+    def entry(units, unit, dt, sample):
+        return {"value": units / dt, "unit": unit, "cores": 1, "kind": "port", "sample": f"{sample} ({dt:.1f} s)"}
+
+    # SmithWaterman, configs[3] shape: 150 bp reads vs one 5 kb reference, NUC_4, gap -2 (align.go:171-232)
+    ref = bytes(orc.synth_dna(0xC4, 5000))
+    rng = np.random.default_rng(0xC4)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    starts = rng.integers(0, 5000 - 150, size=300)
+    t = time.perf_counter()
+    for a in starts:
+        orc.smith_waterman(ref[a:a + 150], ref, om, -2)
+    out["smith_waterman"] = entry(len(starts) * 150 * 5000, "cell updates/s", time.perf_counter() - t,
+                                  f"{len(starts)} reads of 150 bp vs the 5000 bp reference, orc_smith_waterman "
+                                  "(full int64 matrix + traceback, as align.go:171-232)")
+    # SantaLucia scan, configs[4] shape on a 400 kb slice
+    g = orc.synth_dna(0xC5, 400_000)
+    t = time.perf_counter()
+    orc.santalucia_scan(g, 18, 30, 500e-9, 50e-3, 0.0)
+    nwin = sum(len(g) - L + 1 for L in range(18, 31))
+    out["santalucia_scan"] = entry(nwin, "windows/s", time.perf_counter() - t,
+                                   "all 18..30-mers of a 400000 B genome, one primers.SantaLucia restatement per window")
+    # Distance, configs[2] shape: sorted sketches of s=1000
+    sk = np.sort(rng.integers(0, 1 << 29, size=(600, 1000), dtype=np.uint32), axis=1)
+    t = time.perf_counter()
+    orc.mash_distance_matrix(sk, sk)
+    out["mash_distance"] = entry(600 * 600, "pairs/s", time.perf_counter() - t,
+                                 "600 x 600 sketches of s=1000, (*Mash).Distance restatement per ordered pair")
+    # RotateSequence / Hash of 5 kb circular sequences
+    ns = 8000
+    blob = bytes(orc.synth_dna(0x5EED, ns * 5000))
+    seqs = [blob[i * 5000:(i + 1) * 5000] for i in range(ns)]
+    t = time.perf_counter()
+    for q in seqs:
+        orc.rotate_sequence(q)
+    out["least_rotation"] = entry(ns * 5000, "bases/s", time.perf_counter() - t, f"{ns} sequences of 5000 bp, Booth restatement")
+    t = time.perf_counter()
+    for q in seqs:
+        orc.seqhash(q, "DNA", True, True)
+    out["seqhash"] = entry(ns, "sequences/s", time.perf_counter() - t,
+                           f"{ns} sequences of 5000 bp, seqhash.Hash(DNA, circular, double-stranded) restatement")
+    # FASTQ feeder: the restated io/fastq parser (pure Python, so an upper bound on the gap to Go)
+    from oracle import fastq_ref
+    rec = (b"@r0000000 ch=1 start=2\n" + bytes(rng.choice(list(b"ACGT"), 1000).astype(np.uint8)) + b"\n+\n" +
+           bytes(rng.integers(33, 74, 1000, dtype=np.uint8)) + b"\n")
+    img = rec * 20000
+    t = time.perf_counter()
+    fastq_ref.parse_all(img)
+    e = entry(len(img) / 1e9, "file GB/s", time.perf_counter() - t,
+              "20000 records x 1000 bp through oracle/fastq_ref.py (fastq.go:84-216 restated in Python)")
+    e["kind"] = "port (interpreted Python: not comparable with compiled Go)"
+    out["fastq_feeder"] = e
+    return out
+
+
 def allgather_distance(dev, rank: int, world: int):
     """N = 100k sketches over `world` ranks: each rank sketches its own families, all ranks all-gather
     (one ncclAllGather over xGMI), each computes its row block of the shared-count matrix."""
@@ -229,6 +290,10 @@ def main() -> int:
                 pass
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_reads)
+            if isinstance(line.get("extra"), dict):
+                for name, base in cpu_baseline_extra().items():
+                    if isinstance(line["extra"].get(name), dict):
+                        line["extra"][name]["cpu_baseline"] = base
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -73,6 +73,11 @@ def lib() -> C.CDLL:
         L.orc_santalucia.argtypes = [C.c_void_p, C.c_size_t, C.c_double, C.c_double, C.c_double,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_santalucia.restype = None
+        L.orc_santalucia_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double,
+                                          C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_santalucia_scan.restype = None
+        L.orc_mash_distance_matrix.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        L.orc_mash_distance_matrix.restype = None
         L.orc_marmur_doty.argtypes = [C.c_void_p, C.c_size_t]
         L.orc_marmur_doty.restype = C.c_double
         L.orc_melting_temp.argtypes = [C.c_void_p, C.c_size_t]
@@ -269,6 +274,26 @@ def santalucia(seq, primer_conc: float, salt_conc: float, mg_conc: float):
     lib().orc_santalucia(d, len(d), primer_conc, salt_conc, mg_conc,
                          C.byref(tm), C.byref(dh), C.byref(ds))
     return tm.value, dh.value, ds.value
+
+
+def santalucia_scan(genome, Lmin: int, Lmax: int, primer_conc: float, salt_conc: float, mg_conc: float):
+    """SantaLucia of every genome[i:i+L], L = Lmin..Lmax -> three (Lmax-Lmin+1, n-Lmin+1) planes (NaN-padded)"""
+    g = np.frombuffer(_b(genome), dtype=np.uint8)
+    shape = (Lmax - Lmin + 1, max(0, len(g) - Lmin + 1))
+    tm, dh, ds = (np.full(shape, np.nan) for _ in range(3))
+    lib().orc_santalucia_scan(g.ctypes.data, len(g), Lmin, Lmax, primer_conc, salt_conc, mg_conc,
+                              tm.ctypes.data, dh.ctypes.data, ds.ctypes.data)
+    return tm, dh, ds
+
+
+def mash_distance_matrix(X: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    """(*Mash).Distance (mash.go:138-140) for every ordered pair of the rows of X and Y (sorted sketches)"""
+    X = np.ascontiguousarray(X, dtype=np.uint32)
+    Y = np.ascontiguousarray(Y, dtype=np.uint32)
+    assert X.shape[1] == Y.shape[1]
+    out = np.empty((X.shape[0], Y.shape[0]), dtype=np.float64)
+    lib().orc_mash_distance_matrix(X.ctypes.data, X.shape[0], Y.ctypes.data, Y.shape[0], X.shape[1], out.ctypes.data)
+    return out
 
 
 def marmur_doty(seq) -> float:

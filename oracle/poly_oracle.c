@@ -569,6 +569,30 @@ double orc_melting_temp(const uint8_t *seq, size_t n)
     return tm;
 }
 
+/* What a caller of the reference does for BASELINE configs[4]: primers.SantaLucia on every substring
+ * genome[i:i+L], L = Lmin..Lmax (primers.go:70-105 per call).  Output layout as polyhip_santalucia_scan:
+ * plane (L - Lmin) holds n - L + 1 values; planes are nwin0 = n - Lmin + 1 apart.  Bench/test helper. */
+void orc_santalucia_scan(const uint8_t *genome, size_t n, int Lmin, int Lmax, double primer_conc,
+                         double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+{
+    if (Lmin < 1 || (size_t)Lmin > n)
+        return;
+    const size_t stride = n - (size_t)Lmin + 1;
+    for (int L = Lmin; L <= Lmax && (size_t)L <= n; L++)
+        for (size_t i = 0; i + (size_t)L <= n; i++) {
+            const size_t o = (size_t)(L - Lmin) * stride + i;
+            orc_santalucia(genome + i, (size_t)L, primer_conc, salt_conc, mg_conc, &tm[o], &dH[o], &dS[o]);
+        }
+}
+
+/* (*Mash).Distance (mash.go:107-140) for every ordered pair of two sets of sorted sketches of size s. */
+void orc_mash_distance_matrix(const uint32_t *X, size_t nx, const uint32_t *Y, size_t ny, int s, double *out)
+{
+    for (size_t i = 0; i < nx; i++)
+        for (size_t j = 0; j < ny; j++)
+            out[i * ny + j] = orc_mash_distance(X + i * (size_t)s, s, Y + j * (size_t)s, s);
+}
+
 /* ====================================================================== */
 /* seqhash                                                                 */
 /* ====================================================================== */

@@ -50,6 +50,7 @@ double orc_mash_distance(const uint32_t *a, int sa, const uint32_t *b, int sb);
 /* the integer the similarity is made of (sameHashes, mash.go:121-132),
  * after the early-out of mash.go:117 (which yields 0). */
 int orc_mash_shared(const uint32_t *a, int sa, const uint32_t *b, int sb);
+void orc_mash_distance_matrix(const uint32_t *X, size_t nx, const uint32_t *Y, size_t ny, int s, double *out);
 
 /* ---- search/align + matrix + alphabet --------------------------------- */
 /* A substitution matrix as NewSubstitutionMatrix builds it (matrix.go:20):
@@ -99,6 +100,8 @@ void orc_santalucia(const uint8_t *seq, size_t n, double primer_conc,
                     double salt_conc, double mg_conc, double *tm, double *dH,
                     double *dS);
 /* MarmurDoty, primers.go:108-118; MeltingTemp, primers.go:121-128 */
+void orc_santalucia_scan(const uint8_t *genome, size_t n, int Lmin, int Lmax, double primer_conc,
+                         double salt_conc, double mg_conc, double *tm, double *dH, double *dS);
 double orc_marmur_doty(const uint8_t *seq, size_t n);
 double orc_melting_temp(const uint8_t *seq, size_t n);
 

@@ -424,3 +424,20 @@ def test_fasta_reference_tests():
                                                   b"MCHU - Calmodulin - Human, rabbit, bovine, rat, and chicken"]
     assert recs[1][1] == (b"ADQLTEEQIAEFKEAFSLFDKDGDGTITTKELGTVMRSLGQNPTEAELQDMINEVDADGNGTIDFPEFLTMMARKMKDTDSEEEIREAFRVFDKDGNGYISAAELRHVMTNLG"
                           b"EKLTDEEVDEMIREADIDGDGQVNYEEFVQMMTAK*")
+
+
+# ------------------------------------------------- bench helpers of the oracle --
+def test_oracle_loop_helpers_equal_the_per_call_functions():
+    """orc_santalucia_scan / orc_mash_distance_matrix (bench.py's CPU baselines) are plain loops over the
+    pinned per-call restatements"""
+    g = bytes(orc.synth_dna(7, 300))
+    tm, dh, ds = orc.santalucia_scan(g, 18, 30, 500e-9, 50e-3, 0.0)
+    for L in (18, 25, 30):
+        for i in (0, 17, len(g) - L):
+            assert (tm[L - 18, i], dh[L - 18, i], ds[L - 18, i]) == orc.santalucia(g[i:i + L], 500e-9, 50e-3, 0.0)
+        assert np.isnan(tm[L - 18, len(g) - L + 1:]).all()
+    a, b = orc.Mash(17, 50), orc.Mash(17, 50)
+    a.Sketch(g[:200])
+    b.Sketch(g[100:])
+    d = orc.mash_distance_matrix(np.stack([a.Sketches, b.Sketches]), np.stack([b.Sketches, a.Sketches]))
+    assert d[0, 0] == a.Distance(b) and d[0, 1] == 0.0 and d[1, 0] == 0.0 and d[1, 1] == b.Distance(a)
