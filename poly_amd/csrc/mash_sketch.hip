@@ -34,6 +34,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include <vector>
 
 // PH_ABL != 0 only in scripts/ubench/k1_ablate.hip: knocks out one phase to measure its cost
 // (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage
@@ -808,32 +809,76 @@ int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint
     if (n == 0)
         return POLYHIP_OK;
     PH_REQUIRE(seqs && offsets && out, "polyhip_mash_sketch_batch: null pointer");
-    for (uint64_t i = 0; i < n; ++i)
+    // `out` is in/out: rows of sequences with fewer than s windows keep (part of) the caller's prior
+    // Sketches (mash.go:81-84), so those rows have to travel to the device first; a batch without such
+    // sequences -- the normal case -- skips that upload.
+    bool need_prior = false;
+    for (uint64_t i = 0; i < n; ++i) {
         PH_REQUIRE(offsets[i] <= offsets[i + 1], "polyhip_mash_sketch_batch: offsets not ascending at %llu",
                    (unsigned long long)i);
-    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
-    DevBuf dseq, doff, dout;
-    PH_HIP(dseq.alloc(nbytes + 16));
-    PH_HIP(doff.alloc((n + 1) * sizeof(uint64_t)));
-    PH_HIP(dout.alloc(n * (uint64_t)s * sizeof(uint32_t)));
-    // offsets rebased so the device copy starts at byte 0
-    {
-        uint64_t *tmp = new uint64_t[n + 1];
-        for (uint64_t i = 0; i <= n; ++i)
-            tmp[i] = offsets[i] - b0;
-        hipError_t e = hipMemcpy(doff.p, tmp, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
-        delete[] tmp;
-        PH_HIP(e);
+        need_prior |= offsets[i + 1] - offsets[i] < (uint64_t)k + s;
     }
-    PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
-    // `out` is in/out (prior Sketches survive where the reference leaves them)
-    PH_HIP(hipMemcpy(dout.p, out, n * (uint64_t)s * sizeof(uint32_t), hipMemcpyHostToDevice));
-    int rc = polyhip_mash_sketch_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, k, s, dout.as<uint32_t>(),
-                                           nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(out, dout.p, n * (uint64_t)s * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // Chunks of about 256 MB (sequence bytes + sketch bytes) through two slots, each with its own stream:
+    // the upload and the kernel of chunk c overlap the download of chunk c-1.
+    const uint64_t CHUNK = 256ull << 20, row = (uint64_t)s * sizeof(uint32_t);
+    std::vector<uint64_t> cut{0};
+    uint64_t max_bytes = 0, max_reads = 0;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i, sz = 0;
+        do {
+            sz += offsets[j + 1] - offsets[j] + row;
+            ++j;
+        } while (j < n && sz < CHUNK);
+        cut.push_back(j);
+        max_bytes = std::max(max_bytes, offsets[j] - offsets[i]);
+        max_reads = std::max(max_reads, j - i);
+        i = j;
+    }
+    struct Slot {
+        DevBuf dseq, doff, dout;
+        hipStream_t st = nullptr;
+        std::vector<uint64_t> hoff;
+        ~Slot()
+        {
+            if (st) {
+                (void)hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+            }
+        }
+    } slot[2];
+    const size_t nchunks = cut.size() - 1;
+    for (size_t q = 0; q < std::min<size_t>(2, nchunks); ++q) {
+        PH_HIP(slot[q].dseq.alloc(max_bytes + 16));
+        PH_HIP(slot[q].doff.alloc((max_reads + 1) * sizeof(uint64_t)));
+        PH_HIP(slot[q].dout.alloc(max_reads * row));
+        PH_HIP(hipStreamCreateWithFlags(&slot[q].st, hipStreamNonBlocking));
+        slot[q].hoff.resize(max_reads + 1);
+    }
+    auto download = [&](size_t c) -> hipError_t {
+        Slot &S = slot[c & 1];
+        return hipMemcpyAsync(out + cut[c] * (uint64_t)s, S.dout.p, (cut[c + 1] - cut[c]) * row,
+                              hipMemcpyDeviceToHost, S.st);
+    };
+    for (size_t c = 0; c < nchunks; ++c) {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = cut[c], m = cut[c + 1] - i0, b0 = offsets[i0];
+        PH_HIP(hipStreamSynchronize(S.st)); // chunk c-2 has left this slot (its hoff included)
+        for (uint64_t i = 0; i <= m; ++i)
+            S.hoff[i] = offsets[i0 + i] - b0; // rebased: the device copy starts at byte 0
+        PH_HIP(hipMemcpyAsync(S.doff.p, S.hoff.data(), (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, S.st));
+        PH_HIP(hipMemcpyAsync(S.dseq.p, seqs + b0, offsets[i0 + m] - b0, hipMemcpyHostToDevice, S.st));
+        if (need_prior)
+            PH_HIP(hipMemcpyAsync(S.dout.p, out + i0 * (uint64_t)s, m * row, hipMemcpyHostToDevice, S.st));
+        const int rc = polyhip_mash_sketch_batch_dev(S.dseq.as<uint8_t>(), S.doff.as<uint64_t>(), m, k, s,
+                                                     S.dout.as<uint32_t>(), S.st);
+        if (rc != POLYHIP_OK)
+            return rc;
+        if (c > 0)
+            PH_HIP(download(c - 1));
+    }
+    PH_HIP(download(nchunks - 1));
+    for (size_t q = 0; q < std::min<size_t>(2, nchunks); ++q)
+        PH_HIP(hipStreamSynchronize(slot[q].st));
     return POLYHIP_OK;
 }
 

@@ -83,3 +83,33 @@ def test_rotation_and_hash_mixed():
     rot = seqhash.RotateBatch([s.decode("latin-1") for s in seqs])
     for s_, r in zip(seqs, rot):
         assert r.encode("latin-1") == orc.rotate_sequence(s_)
+
+
+@pytest.mark.parametrize("short_reads", [False, True])
+def test_sketch_host_flavour_pipelines_chunks(short_reads):
+    """polyhip_mash_sketch_batch (host pointers) streams a batch larger than its 256 MB chunk through two
+    slots; every row equals the device flavour's, and rows the reference leaves (partly) untouched keep the
+    caller's prior Sketches -- with short reads in the batch the prior rows are uploaded, without them not."""
+    import torch
+    from poly_amd import mash
+    n, L, k, s = 72_000, 10_000, 21, 1000  # 720 MB of reads + 288 MB of sketches: 4 chunks
+    dev = torch.device("cuda:0")
+    seqs_t = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0x51, seqs_t)
+    seqs = seqs_t.cpu().numpy()
+    lens = np.full(n, L, np.uint64)
+    if short_reads:
+        lens[[5, 30_000, n - 1]] = [500, 10, 1020]  # positional / untouched / exactly k + s - 1
+    # ragged offsets into the same byte stream (reads simply start where the previous one ended)
+    offs = np.zeros(n + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    prior = np.full((n, s), 0xABCD0000, np.uint32) + np.arange(s, dtype=np.uint32)
+    got = mash.sketch_batch_packed(seqs, offs, k, s, out=prior.copy())
+    want_t = torch.from_numpy(prior.view(np.int32).copy()).to(dev)
+    mash.sketch_batch_dev(seqs_t, torch.from_numpy(offs.view(np.int64)).to(dev), k, s, want_t)
+    want = want_t.cpu().numpy().view(np.uint32)
+    assert (got == want).all()
+    for r in (0, 5, 30_000, n - 1):  # and against the oracle on the special rows
+        one = np.ascontiguousarray(seqs[int(offs[r]):int(offs[r + 1])])
+        ref = orc.mash_sketch_batch(one, np.array([0, len(one)], np.uint64), k, s, out=prior[r:r + 1].copy())
+        assert (got[r] == ref[0]).all(), r
