@@ -264,6 +264,9 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
 /* which kernel family the last polyhip_sw_batch*_dev call on this thread
  * used: 1 = register-tiled shared-B kernel, 2 = generic kernel (tests). */
 int polyhip_sw_last_path(void);
+/* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
+ * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel (tests). */
+int polyhip_sw_traceback_last_path(void);
 
 /* ---- K4: primers SantaLucia / MarmurDoty / MeltingTemp  (primers/primers.go:70-128) */
 /*

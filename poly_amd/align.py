@@ -129,6 +129,11 @@ def last_path() -> int:
     return int(_lib.lib().polyhip_sw_last_path())
 
 
+def sw_traceback_last_path() -> int:
+    """1 = byte-profile traceback kernel, 2 = register-tiled table kernel, 3 = generic (tests)"""
+    return int(_lib.lib().polyhip_sw_traceback_last_path())
+
+
 # ---- full SmithWaterman: score pass + traceback (align.go:171-232) -------------------
 
 def sw_align_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.ndarray,

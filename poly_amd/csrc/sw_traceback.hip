@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -39,6 +40,8 @@ namespace polyhip {
 namespace k3t {
 
 constexpr int THREADS = 256;
+
+static thread_local int g_tb_last_path = 0;
 
 struct Window {
     uint32_t wcols;   // columns of the re-run DP (<= lenB)
@@ -60,18 +63,27 @@ static Window window(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB
     return w;
 }
 
-// Columns THIS pair needs (<= wcols, the batch-wide bound).  With its own end row and score M the
-// walk spans at most endA + (smax*endA - M)/|gap| columns (it gains at most smax per row it climbs
-// and ends up with M), and every cell it looks at -- all in rows <= endA -- depends on at most
-// endA + smax*endA/|gap| columns to its left.
-__device__ __forceinline__ uint32_t pair_window(uint32_t wcols, uint32_t eA, int64_t M, int smax, int gap)
+// Columns THIS pair needs (<= wcols, the batch-wide bound), from its own end row eA and score M.
+//  * The walk spans at most  span = eA + (smax*eA - M)/|gap|  columns: it climbs at most eA rows,
+//    gains at most smax per row and ends up with M, so that is all it can pay for left moves.
+//  * A windowed H never exceeds the true H (fewer paths), and equals it when an optimal path into the
+//    cell lies inside the window.  At a walk cell (row i, value h >= M - smax*(eA - i), since walking
+//    back one row loses at most smax) the decision -- which candidate equals h first -- only needs
+//    the candidates that reach h to be exact; a smaller one may be underestimated without changing
+//    it.  Such a predecessor holds H' >= h - smax at a row i' <= i, so every path achieving it has at
+//    most (smax*i' - H')/|gap| <= (smax*eA - M + smax)/|gap| left moves and i' other moves:
+//    cand = eA + (smax*eA + smax - M)/|gap| columns to its left are enough.
+//  `wide` (POLYHIP_TB_WIDE=1, a testing aid) replaces cand by the bound that makes EVERY cell of the
+//  rows <= eA exact, eA + smax*eA/|gap|; tests check both give the same alignments.
+__device__ __forceinline__ uint32_t pair_window(uint32_t wcols, uint32_t eA, int64_t M, int smax, int gap, int wide)
 {
     if (gap >= 0 || smax <= 0 || M <= 0)
         return wcols;
     const uint64_t g = (uint64_t)(-gap), top = (uint64_t)smax * eA;
-    const uint64_t reach = eA + top / g;
     const uint64_t span = eA + (top > (uint64_t)M ? (top - (uint64_t)M) / g : 0);
-    const uint64_t need = span + reach + 2;
+    const uint64_t over = top + (uint64_t)smax > (uint64_t)M ? (top + (uint64_t)smax - (uint64_t)M) / g + 1 : 0;
+    const uint64_t cand = eA + (wide ? top / g : std::min<uint64_t>(over, top / g));
+    const uint64_t need = span + cand + 2;
     return need < wcols ? (uint32_t)need : wcols;
 }
 
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(THREADS) void tb_kernel(const uint8_t *__restrict__
                                                     const int32_t *__restrict__ lutcc, int na, int nb, int gap,
                                                     const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
                                                     const uint32_t *__restrict__ err,
-                                                    const int64_t *__restrict__ score, int smax, uint32_t wcols,
+                                                    const int64_t *__restrict__ score, int smax, uint32_t wcols, int wide,
                                                     uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
                                                     uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen,
                                                     uint32_t stride)
@@ -153,7 +165,7 @@ __global__ __launch_bounds__(THREADS) void tb_kernel(const uint8_t *__restrict__
         }
     }
     const bool work = active && eA > 0 && eB > 0 && lenA <= RA;
-    const uint32_t mycols = work ? pair_window(wcols, eA, score ? score[pair] : 0, smax, gap) : 0u;
+    const uint32_t mycols = work ? pair_window(wcols, eA, score ? score[pair] : 0, smax, gap, wide) : 0u;
     const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u; // first column (1-based) of my window
     const uint32_t ncol = work ? eB - c_s + 1u : 0u;
 
@@ -224,13 +236,255 @@ __global__ __launch_bounds__(THREADS) void tb_kernel(const uint8_t *__restrict__
     alnLen[pair] = (active && eA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
 }
 
+// ---- shared-reference traceback on the byte profile (the hot one: BASELINE config 4) ----------------
+// Same window, one pair per lane and H column in registers as tb_kernel, but built like the score
+// pass (sw_batch.hip): the reference's profile prof[j/4][code][j%4] = S(sym(code), b_j) (int8) sits
+// WHOLE in LDS, a lane sweeps its own window in blocks of 4 columns, a row of a block costs one
+// ds_read_b32 (the lane's own block address + its row's code byte, one SDWA add), and a cell is
+//     d0 = max(diag + s, 0)   t = max(up, left) + gap   h = max(d0, t)
+// plus two recorded bits, each the carry of one compare shifted into a word by v_addc_co_u32:
+//     G = t > d0     the cell was reached by a gap move (never set where the diagonal ties: the
+//                    reference tests the diagonal first, align.go:215)
+//     L = left > up  ... and that gap move is "left" (only on a strict win: "up" is tested first, :220)
+// The "H is 0" case needs no bit: the walk carries the running score, starting from the score
+// pass's maximum and subtracting what each move contributed (H of the predecessor, exactly), and
+// stops when it reaches 0 -- the reference's `for H[i][j] > 0`.
+// Words: per column and group of 32 rows one G word and one L word (row r of the group at bit
+// rows_in_group-1-r), stored lane-interleaved like tb_kernel's.
+constexpr int TBU = 4; // columns per block
+
+__global__ __launch_bounds__(256) void tb_profile_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t lenB_pad,
+                                                        const int8_t *__restrict__ lutc, int ncodes, int cp,
+                                                        int8_t *__restrict__ prof)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= lenB_pad)
+        return;
+    int8_t *col = prof + (size_t)(j >> 2) * cp * 4 + (j & 3);
+    const int live = j < lenB ? ncodes : 0; // pad columns / pad codes: -128 keeps every H at 0
+    const uint8_t b = j < lenB ? B[j] : 0;
+    for (int c = 0; c < cp; ++c)
+        col[c * 4] = c < live ? lutc[c * 256 + b] : (int8_t)-128;
+}
+
+#define PH_TB_ADDR(dst, pk, SEL)                                                                           \
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                 : "=v"(dst)                                                                               \
+                 : "v"(blk), "v"(pk))
+#define PH_TB_ISSUE(pk, w0, w1, w2, w3)                           \
+    do {                                                          \
+        uint32_t a0_, a1_, a2_, a3_;                              \
+        PH_TB_ADDR(a0_, pk, "BYTE_0");                            \
+        PH_TB_ADDR(a1_, pk, "BYTE_1");                            \
+        PH_TB_ADDR(a2_, pk, "BYTE_2");                            \
+        PH_TB_ADDR(a3_, pk, "BYTE_3");                            \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_)); \
+    } while (0)
+// w = 2 * w + (x > y)
+#define PH_TB_BIT(w, x, y)                                                                  \
+    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"     \
+                 : "+v"(w)                                                                  \
+                 : "v"(x), "v"(y)                                                           \
+                 : "vcc")
+#define PH_TB_CELL(S, DIAG, UP, LEFT, HOUT, C)         \
+    do {                                               \
+        const int up_ = (UP), left_ = (LEFT);          \
+        const int d0_ = max((DIAG) + (S), 0);          \
+        const int t_ = max(up_, left_) + gap;          \
+        HOUT = max(d0_, t_);                           \
+        PH_TB_BIT(wG[C], t_, d0_);                     \
+        PH_TB_BIT(wL[C], left_, up_);                  \
+    } while (0)
+#define PH_TB_ROW(I, W)                                         \
+    do {                                                        \
+        const int i_ = (I);                                     \
+        const uint32_t w_ = (W);                                \
+        const int s0 = (int)(int8_t)(w_);                       \
+        const int s1 = (int)(int8_t)(w_ >> 8);                  \
+        const int s2 = (int)(int8_t)(w_ >> 16);                 \
+        const int s3 = (int)w_ >> 24;                           \
+        const int left = H[i_];                                 \
+        int h0, h1, h2, h3;                                     \
+        PH_TB_CELL(s0, pdiag, pr0, left, h0, 0);                \
+        PH_TB_CELL(s1, pr0, pr1, h0, h1, 1);                    \
+        PH_TB_CELL(s2, pr1, pr2, h1, h2, 2);                    \
+        PH_TB_CELL(s3, pr2, pr3, h2, h3, 3);                    \
+        pdiag = left;                                           \
+        pr0 = h0;                                               \
+        pr1 = h1;                                               \
+        pr2 = h2;                                               \
+        pr3 = h3;                                               \
+        H[i_] = h3;                                             \
+        if ((i_ & 31) == 31 || i_ == RA - 1) {                  \
+            uint32_t *o_ = dirw + ((size_t)t * TBU * NG + (i_ >> 5)) * 2 * 64; \
+            _Pragma("unroll") for (int c_ = 0; c_ < TBU; ++c_)  \
+            {                                                   \
+                o_[((size_t)c_ * NG * 2 + 0) * 64] = wG[c_];    \
+                o_[((size_t)c_ * NG * 2 + 1) * 64] = wL[c_];    \
+            }                                                   \
+        }                                                       \
+    } while (0)
+
+template <int RA, int CP>
+__global__ __launch_bounds__(THREADS) void tb_prof_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ B, uint32_t lenB_pad, const int8_t *__restrict__ prof,
+    const uint8_t *__restrict__ codeA, int ncodes, int gap, const uint32_t *__restrict__ endA,
+    const uint32_t *__restrict__ endB, const uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
+    uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
+    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    static_assert(RA % 4 == 0 && RA <= 256, "RA");
+    constexpr int NG = (RA + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) int8_t lds_tb[];
+    int8_t *P = lds_tb;
+    uint8_t *codeL = reinterpret_cast<uint8_t *>(lds_tb + (size_t)lenB_pad * CP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(prof);
+        uint4 *dst = reinterpret_cast<uint4 *>(P);
+        const uint32_t nvec = lenB_pad * CP / 16; // lenB_pad % 4 == 0 and CP % 8 == 0
+        for (uint32_t v = tid; v < nvec; v += THREADS)
+            dst[v] = src[v];
+    }
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    const uint64_t pair = pair0 + (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < pair1;
+    uint32_t lenA = 0, eA = 0, eB = 0;
+    int64_t M = 0;
+    const uint8_t *ap = A;
+    if (active) {
+        const uint64_t o0 = offA[pair];
+        lenA = (uint32_t)(offA[pair + 1] - o0);
+        ap = A + o0;
+        if (err[pair] == 0u) {
+            eA = endA[pair];
+            eB = endB[pair];
+            M = score[pair];
+        }
+    }
+    const bool work = active && eA > 0 && eB > 0 && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? pair_window(wcols, eA, M, smax, gap, wide) : 0u;
+    const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u; // first column (1-based) of my window
+    const uint32_t jb0 = (c_s - 1u) & ~3u;                               // 0-based, on a block boundary
+    const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u;        // <= nblk_alloc
+
+    // packed byte offsets (code * 4) of my rows inside a profile block; rows >= lenA use the pad code
+    uint32_t apk[RA / 4];
+#pragma unroll
+    for (int w = 0; w < RA / 4; ++w) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = 4 * w + b;
+            uint32_t code = (uint32_t)ncodes;
+            if (work && (uint32_t)i < lenA) {
+                const uint32_t c = codeL[ap[i]];
+                code = c == 0xFFu ? (uint32_t)ncodes : c;
+            }
+            pk |= (code * 4u) << (8 * b);
+        }
+        apk[w] = pk;
+    }
+
+    int H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
+
+    for (uint32_t t = 0; t < nblk_alloc; ++t) {
+        if (!__any(t < nblk))
+            break;
+        if (t < nblk) {
+            const uint32_t blk = lds_base + ((jb0 >> 2) + t) * (CP * 4);
+            int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
+            uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
+            uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+            PH_TB_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+#pragma unroll
+            for (int g = 0; g < RA / 4; ++g) {
+                if (g + 1 < RA / 4) {
+                    PH_TB_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+                }
+                PH_TB_ROW(4 * g + 0, wa0);
+                PH_TB_ROW(4 * g + 1, wa1);
+                PH_TB_ROW(4 * g + 2, wa2);
+                PH_TB_ROW(4 * g + 3, wa3);
+                wa0 = wb0;
+                wa1 = wb1;
+                wa2 = wb2;
+                wa3 = wb3;
+            }
+        }
+    }
+
+    if (!active)
+        return;
+    uint32_t len = 0;
+    if (work) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
+        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+        uint32_t i = eA, j = eB;
+        int h = (int)M;
+        while (h > 0 && i > 0 && j > jb0 && len < stride) {
+            const uint32_t jj = j - 1u, rel = jj - jb0, r = i - 1u, g = r >> 5;
+            const uint32_t rows = min(32u, (uint32_t)RA - 32u * g);
+            const uint32_t bit = rows - 1u - (r & 31u);
+            const uint32_t *wp = dirw + ((size_t)rel * NG + g) * 2 * 64;
+            // L2-served loads: the words were stored by this same lane a moment ago
+            const uint32_t wg = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wl = __hip_atomic_load(wp + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint8_t sa = ap[r], sb = B[jj];
+            uint8_t ca, cb;
+            if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
+                h -= (int)P[((size_t)(jj >> 2) * CP + codeL[sa]) * 4 + (jj & 3u)];
+                ca = sa;
+                cb = sb;
+                --i;
+                --j;
+            } else if (((wl >> bit) & 1u) == 0u) { // :220-223
+                h -= gap;
+                ca = sa;
+                cb = '-';
+                --i;
+            } else { // :224-227
+                h -= gap;
+                ca = '-';
+                cb = sb;
+                --j;
+            }
+            outA[stride - 1 - len] = ca; // strings are built by prepending: fill from the back
+            outB[stride - 1 - len] = cb;
+            ++len;
+        }
+    }
+    alnLen[pair] = (active && eA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
+}
+#undef PH_TB_ROW
+#undef PH_TB_CELL
+#undef PH_TB_BIT
+#undef PH_TB_ISSUE
+#undef PH_TB_ADDR
+
 // any lenA: H column and direction words in global scratch, lane-interleaved
 __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
     const uint8_t *__restrict__ B, const uint64_t *__restrict__ offB, uint64_t lenB_shared,
     const int32_t *__restrict__ lut, int gap, const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
-    const uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax, uint32_t wcols, uint32_t max_lenA,
-    int32_t *__restrict__ hbuf,
+    const uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax, uint32_t wcols, int wide,
+    uint32_t max_lenA, int32_t *__restrict__ hbuf,
     uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB,
     uint32_t *__restrict__ alnLen, uint32_t stride)
 {
@@ -251,7 +505,7 @@ __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
     }
     uint32_t len = 0;
     if (eA > 0 && eB > 0) {
-        const uint32_t mycols = pair_window(wcols, eA, score ? score[pair] : 0, smax, gap);
+        const uint32_t mycols = pair_window(wcols, eA, score ? score[pair] : 0, smax, gap, wide);
         const uint32_t c_s = eB > mycols ? eB - mycols + 1u : 1u;
         const uint32_t ncol = eB - c_s + 1u;
         int32_t *Hc = hbuf + local;
@@ -395,13 +649,20 @@ __global__ __launch_bounds__(THREADS) void nw_kernel(const uint8_t *__restrict__
 struct Plan {
     int ra;            // 0 = generic
     Window win;
-    size_t per_pair;   // workspace bytes per pair
+    size_t per_pair;   // workspace bytes per pair (the larger of the two register-tiled layouts)
     size_t smem;
+    // profile variant (shared reference, score known): tb_prof_kernel
+    bool prof_ok;
+    int cp;
+    uint32_t lenB_pad, nblk_alloc;
+    size_t prof_bytes, prof_smem;
 };
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
 {
-    Plan p;
+    Plan p{};
     p.win = window(sc, max_lenA, lenB);
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     p.smem = (size_t)na * nb * 4 + 512;
@@ -415,6 +676,18 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
     }
     if (p.per_pair == 0)
         p.per_pair = 4;
+    p.cp = sc->cp <= 8 ? 8 : 32;
+    p.lenB_pad = (uint32_t)align_up((size_t)std::min<uint64_t>(lenB, 1u << 30), TBU);
+    p.prof_smem = (size_t)p.lenB_pad * p.cp + 256;
+    p.prof_ok = reg && sc->int8_ok && sc->gap <= -1 && sc->smax > 0 && sc->cp <= 32 && lenB > 0 && lenB < (1u << 30) &&
+                p.prof_smem <= 64 * 1024 && (uint64_t)sc->smax * max_lenA < (1ull << 30);
+    if (p.prof_ok) {
+        // a lane's window starts on a block boundary (up to 3 columns early) and ends inside a block
+        p.nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 1;
+        p.prof_bytes = align_up((size_t)p.lenB_pad * p.cp, 256);
+        const size_t per = (size_t)p.nblk_alloc * TBU * ((p.ra + 31) / 32) * 2 * 4;
+        p.per_pair = std::max(p.per_pair, per);
+    }
     return p;
 }
 
@@ -424,6 +697,8 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
 using namespace polyhip;
 
 extern "C" {
+
+int polyhip_sw_traceback_last_path(void) { return k3t::g_tb_last_path; }
 
 uint32_t polyhip_sw_traceback_stride(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
 {
@@ -446,7 +721,7 @@ size_t polyhip_sw_traceback_workspace_bytes(const polyhip_scoring *sc, uint64_t 
         want = cap / floor_ * floor_;
     if (want < floor_)
         want = floor_;
-    return (size_t)want + 256;
+    return (size_t)want + 256 + p.prof_bytes;
 }
 
 int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
@@ -464,16 +739,54 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
     const k3t::Plan p = k3t::plan(sc, max_lenA, lenB);
     PH_REQUIRE(aln_stride >= p.win.stride, "polyhip_sw_traceback: aln_stride %u < %u (polyhip_sw_traceback_stride)",
                aln_stride, p.win.stride);
-    const size_t usable = work_bytes & ~(size_t)255;
+    const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr;
+    k3t::g_tb_last_path = use_prof ? 1 : (p.ra ? 2 : 3);
+    const char *wide_env = getenv("POLYHIP_TB_WIDE");
+    const int wide = wide_env && wide_env[0] == '1';
+    PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
+    const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     const uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
     PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_sw_traceback: workspace too small (%zu B; %zu B per pair, >= %d pairs)",
                work_bytes, p.per_pair, k3t::THREADS);
     hipStream_t st = as_stream(stream);
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+    int8_t *prof = static_cast<int8_t *>(d_work);
+    void *d_dir = static_cast<uint8_t *>(d_work) + p.prof_bytes;
+    if (use_prof) {
+        hipLaunchKernelGGL(k3t::tb_profile_kernel, dim3((p.lenB_pad + 255) / 256), dim3(256), 0, st, d_B, (uint32_t)lenB,
+                           p.lenB_pad, sc->d_lutc, sc->ncodes, p.cp, prof);
+        PH_HIP(hipGetLastError());
+    }
     for (uint64_t p0 = 0; p0 < npairs; p0 += chunk) {
         const uint64_t p1 = std::min(npairs, p0 + chunk);
         const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
-        uint32_t *dirbuf = static_cast<uint32_t *>(d_work);
+        uint32_t *dirbuf = static_cast<uint32_t *>(d_dir);
+        if (use_prof) {
+#define PH_TBP_LAUNCH(RA_, CP_)                                                                                        \
+    do {                                                                                                               \
+        auto kern = k3t::tb_prof_kernel<RA_, CP_>;                                                                     \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                   (int)p.prof_smem));                                                                 \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.prof_smem, st, d_A, d_offA, p0, p1, d_B,           \
+                           p.lenB_pad, prof, sc->d_codeA, sc->ncodes, (int)sc->gap, d_endA, d_endB, d_err, d_score,    \
+                           (int)sc->smax, p.win.wcols, wide, p.nblk_alloc, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);     \
+    } while (0)
+            if (p.ra == 64 && p.cp == 8)
+                PH_TBP_LAUNCH(64, 8);
+            else if (p.ra == 64)
+                PH_TBP_LAUNCH(64, 32);
+            else if (p.ra == 152 && p.cp == 8)
+                PH_TBP_LAUNCH(152, 8);
+            else if (p.ra == 152)
+                PH_TBP_LAUNCH(152, 32);
+            else if (p.cp == 8)
+                PH_TBP_LAUNCH(256, 8);
+            else
+                PH_TBP_LAUNCH(256, 32);
+#undef PH_TBP_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
+        }
 #define PH_TB_LAUNCH(RA_)                                                                                              \
     do {                                                                                                               \
         auto kern = k3t::tb_kernel<RA_>;                                                                               \
@@ -481,7 +794,7 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
                                    (int)p.smem));                                                                      \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.smem, st, d_A, d_offA, p0, p1, d_B, d_offB, lenB,  \
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err,         \
-                           d_score, (int)sc->smax, p.win.wcols, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);         \
+                           d_score, (int)sc->smax, p.win.wcols, wide, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);   \
     } while (0)
         if (p.ra == 64)
             PH_TB_LAUNCH(64);
@@ -491,11 +804,11 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
             PH_TB_LAUNCH(256);
         else {
             const size_t nl = (size_t)blocks * k3t::THREADS;
-            int32_t *hbuf = static_cast<int32_t *>(d_work);
+            int32_t *hbuf = static_cast<int32_t *>(d_dir);
             uint32_t *dirg = reinterpret_cast<uint32_t *>(hbuf + nl * max_lenA);
             hipLaunchKernelGGL(k3t::tb_generic_kernel, dim3(blocks), dim3(k3t::THREADS), 0, st, d_A, d_offA, p0, p1, d_B,
                                d_offB, lenB, sc->d_lut, (int)sc->gap, d_endA, d_endB, d_err, d_score, (int)sc->smax,
-                               p.win.wcols, max_lenA, hbuf,
+                               p.win.wcols, wide, max_lenA, hbuf,
                                dirg, d_alnA, d_alnB, d_alnLen, aln_stride);
         }
 #undef PH_TB_LAUNCH

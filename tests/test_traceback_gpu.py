@@ -189,3 +189,69 @@ def test_device_resident_chunked_workspace(al):
         sb = sb if isinstance(sb, bytes) else sb.encode()
         assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb
         assert int(score[p]) == s
+
+
+@pytest.mark.parametrize("gap", [-2, -7])
+def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap):
+    """(gap -2: even unrelated reads score > 300, the linear phase of local alignment; gap -7: scores fall
+    to the noise floor, so the per-pair windows range from the tightest to the batch-wide bound.)  200k reads at 0..90 % substitutions + 0..12 % indels (scores from 750 down to the noise floor)
+    against one 5 kb reference.  The byte-profile kernel (score given), the table kernel (no score: the
+    batch-wide window) and the byte-profile kernel with the conservative per-pair window
+    (POLYHIP_TB_WIDE=1) must write identical alignments; a sample is checked against the oracle."""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    n, L, LB = 200_000, 150, 5000
+    ref = orc.synth_dna(0xC4, LB)
+    B = torch.from_numpy(ref.copy()).to(dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    starts = torch.randint(0, LB - L, (n,), device=dev, generator=gen)
+    A = B[starts[:, None] + torch.arange(L, device=dev)[None, :]]
+    rate = torch.linspace(0.0, 0.9, n, device=dev)[:, None]
+    hit = torch.rand(A.shape, device=dev, generator=gen) < rate
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    A[hit] = lut[torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)]
+    # indels: rotate a random suffix by one base (deletion + insertion at the end keeps the length)
+    cut = torch.randint(1, L, (n,), device=dev, generator=gen)
+    shift = (torch.rand(n, device=dev, generator=gen) < rate[:, 0] / 7.5)
+    idx = torch.arange(L, device=dev)[None, :].expand(n, L)
+    src = torch.where(shift[:, None] & (idx >= cut[:, None]), (idx + 1).clamp(max=L - 1), idx)
+    A = torch.gather(A, 1, src).reshape(-1).contiguous()
+    offA = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, gap)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, work)
+    stride = align.sw_traceback_stride(sc, L, LB)
+    tbw = torch.empty(min(align.sw_traceback_workspace_bytes(sc, n, L, LB), 3 << 30), dtype=torch.uint8, device=dev)
+
+    def run(score_t, wide):
+        if wide:
+            monkeypatch.setenv("POLYHIP_TB_WIDE", "1")
+        else:
+            monkeypatch.delenv("POLYHIP_TB_WIDE", raising=False)
+        a = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        b = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        ln = torch.zeros(n, dtype=torch.int32, device=dev)
+        align.sw_traceback_dev(sc, A, offA, L, B, None, LB, ea, eb, er, a, b, ln, tbw, score_t=score_t)
+        torch.cuda.synchronize()
+        return a, b, ln, align.sw_traceback_last_path()
+
+    a1, b1, l1, path1 = run(score, False)
+    a2, b2, l2, path2 = run(None, False)
+    a3, b3, l3, path3 = run(score, True)
+    assert (path1, path2, path3) == (1, 2, 1)
+    assert int(score.min()) < (100 if gap == -7 else 400) and int(score.max()) == 750
+    for a, b, ln in ((a2, b2, l2), (a3, b3, l3)):
+        assert torch.equal(l1, ln) and torch.equal(a1, a) and torch.equal(b1, b)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    A_h, a_h, b_h, l_h, s_h = A.cpu().numpy().reshape(n, L), a1.cpu().numpy(), b1.cpu().numpy(), l1.cpu().numpy(), score.cpu().numpy()
+    refb = ref.tobytes()
+    for p in range(0, n, 997):
+        s, sa, sb, _, _ = orc.smith_waterman(A_h[p].tobytes(), refb, om, gap)
+        sa = sa if isinstance(sa, bytes) else sa.encode()
+        sb = sb if isinstance(sb, bytes) else sb.encode()
+        assert int(s_h[p]) == s
+        assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, p
