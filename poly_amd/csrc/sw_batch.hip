@@ -47,6 +47,7 @@ constexpr int THREADS = 256;
 constexpr int U = 4;          // columns per unrolled block
 constexpr int JC_MAX = 1024;  // columns per LDS chunk (10 key bits)
 constexpr int SCORE_LIMIT = 1 << 14;
+constexpr uint64_t WAVE_BATCH = 32768; // below this many pairs the one-wave-per-pair kernel (1.7e12 cell updates/s flat) beats the ~16 ms floor of one lane-per-pair wave
 
 static thread_local int g_last_path = 0;
 
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(THREADS) void sw_shared_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
     uint32_t lenB, uint32_t lenB_pad, const int8_t *__restrict__ prof, uint32_t jc_max,
     const uint8_t *__restrict__ codeA, const uint32_t *__restrict__ binfo, int ncodes, int gap,
-    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err,
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ count)
 {
     static_assert(RA % 4 == 0 && RA <= 256, "RA");
     extern __shared__ __attribute__((aligned(16))) int8_t lds[];
@@ -136,8 +138,16 @@ __global__ __launch_bounds__(THREADS) void sw_shared_kernel(
     uint8_t *codeL = reinterpret_cast<uint8_t *>(lds + (size_t)jc_max * CP);
 
     const int tid = threadIdx.x;
-    const uint64_t pair = (uint64_t)blockIdx.x * THREADS + tid;
-    const bool active = pair < npairs;
+    // either pairs [0, npairs) in order, or the pairs on `list` (the packed pass's ties, sw_packed.hip)
+    uint64_t pair = (uint64_t)blockIdx.x * THREADS + tid;
+    bool active = pair < npairs;
+    if (list) {
+        const uint32_t cnt = *count;
+        if ((uint64_t)blockIdx.x * THREADS >= cnt)
+            return; // whole workgroup: before any barrier
+        active = pair < cnt;
+        pair = active ? list[pair] : 0;
+    }
     codeL[tid] = codeA[tid];
     __syncthreads();
 
@@ -326,10 +336,12 @@ __global__ __launch_bounds__(256) void sw_generic_kernel(
 }
 
 struct Plan {
-    int path;      // 1 fast, 2 generic
+    int path;      // 1 fast, 2 generic, 3 packed (sw_packed.hip) + wave kernel for its ties, 4 wave kernel (small batch)
     int ra, cp;    // fast: template parameters
     uint32_t lenB_pad, jc_max;
     size_t work_bytes, smem_bytes;
+    size_t fast_bytes; // path 3: where the packed pass's workspace starts
+    k3p::PackedPlan pk;
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -350,6 +362,15 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
             p.jc_max = std::max<uint32_t>(p.lenB_pad, U);
         p.smem_bytes = (size_t)p.jc_max * p.cp + 256;
         p.work_bytes = 256 + align_up((size_t)p.lenB_pad * p.cp, 256);
+        p.fast_bytes = p.work_bytes;
+        const bool wave_ok = (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024;
+        const char *wenv = getenv("POLYHIP_SW_WAVE");
+        if (wave_ok && npairs < WAVE_BATCH && !(wenv && wenv[0] == '0')) {
+            p.path = 4; // too few pairs to fill the chip one per lane: one wave per pair (sw_wave.hip)
+        } else if (wave_ok && k3p::packed_plan(sc, npairs, max_lenA, lenB, &p.pk) && p.pk.ra == p.ra && p.cp == 8) {
+            p.path = 3;
+            p.work_bytes += p.pk.work_bytes;
+        }
     } else {
         p.path = 2;
         p.work_bytes = align_up((size_t)npairs * (lenB + 1) * sizeof(int32_t), 256);
@@ -360,7 +381,8 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
 template <int RA, int CP>
 static int launch_fast(const polyhip_scoring *sc, const Plan &p, const uint8_t *d_A, const uint64_t *d_offA,
                        uint64_t npairs, const uint8_t *d_B, uint32_t lenB, int8_t *prof, uint32_t *binfo,
-                       int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
+                       int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st,
+                       const uint32_t *list = nullptr, const uint32_t *count = nullptr)
 {
     auto kern = sw_shared_kernel<RA, CP>;
     if (p.smem_bytes > 48 * 1024)
@@ -369,7 +391,7 @@ static int launch_fast(const polyhip_scoring *sc, const Plan &p, const uint8_t *
     const uint64_t blocks = (npairs + THREADS - 1) / THREADS;
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.smem_bytes, st, d_A, d_offA, npairs, d_B, lenB,
                        p.lenB_pad, prof, p.jc_max, sc->d_codeA, binfo, sc->ncodes, (int)sc->gap, d_score, d_endA,
-                       d_endB, d_err);
+                       d_endB, d_err, list, count);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
@@ -532,7 +554,7 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
                p.work_bytes);
     hipStream_t st = as_stream(stream);
     k3::g_last_path = p.path;
-    if (p.path == 1) {
+    if (p.path == 1 || p.path == 3 || p.path == 4) {
         uint32_t *binfo = static_cast<uint32_t *>(d_work);
         int8_t *prof = static_cast<int8_t *>(d_work) + 256;
         PH_HIP(hipMemsetAsync(binfo, 0xFF, 256, st));
@@ -540,6 +562,21 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
             hipLaunchKernelGGL(k3::profile_kernel, dim3((p.lenB_pad + 255) / 256), dim3(256), 0, st, d_B,
                                (uint32_t)lenB, p.lenB_pad, sc->d_lutc, sc->ncodes, p.cp, sc->d_validB, prof, binfo);
             PH_HIP(hipGetLastError());
+        }
+        if (p.path == 4)
+            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, (uint32_t)lenB, binfo, nullptr, nullptr, npairs,
+                                 d_score, d_endA, d_endB, d_err, st);
+        // packed pass first (two pairs per lane); the few pairs it leaves on its tie list go through the
+        // exact one-wave-per-pair kernel (a lane-per-pair kernel would take a full DP's time for them)
+        if (p.path == 3) {
+            uint32_t *list = nullptr, *count = nullptr;
+            const int rc = k3p::packed_run(sc, p.pk, d_A, d_offA, npairs, d_B, (uint32_t)lenB, prof, binfo,
+                                           static_cast<uint8_t *>(d_work) + p.fast_bytes, d_score, d_endA, d_endB, d_err,
+                                           &list, &count, st);
+            if (rc != POLYHIP_OK)
+                return rc;
+            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, (uint32_t)lenB, binfo, list, count, npairs,
+                                 d_score, d_endA, d_endB, d_err, st);
         }
 #define PH_SW_CASE(RA_, CP_)                                                                                       \
     if (p.ra == RA_ && p.cp == CP_)                                                                                \

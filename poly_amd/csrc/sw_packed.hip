@@ -1,0 +1,527 @@
+// sw_packed.hip -- K3, packed variant of the Smith-Waterman score pass for gfx950.
+//
+// Same job as sw_shared_kernel (sw_batch.hip): fill + argmax of align.SmithWaterman
+// (search/align/align.go:171-203) for many reads against ONE shared reference -- but every lane carries
+// TWO pairs, one in each 16-bit half of its registers, and a cell of both costs four packed
+// instructions instead of five 32-bit ones:
+//     d = v_pk_add_i16(diag, s)            s = (S(a0_i, b_j), S(a1_i, b_j)) straight from LDS
+//     m = v_pk_max_i16(up, left)
+//     t = v_pk_sub_u16(m, |gap|) clamp     = max(0, m + gap): the recurrence's zero comes for free
+//     h = v_pk_max_i16(d, t)
+// plus one v_pk_max_i16 for the running maximum of the 4-column block.  The per-cell (row, column)
+// key of sw_shared_kernel does not fit 16 bits, so the position is found differently:
+//   1. sw_pk_kernel keeps, per pair, the maximum M, the FIRST 4-column block that reaches it and
+//      whether a later block reaches it again (a tie);
+//   2. sw_locate_kernel re-runs the recurrence (32-bit, one pair per lane, the lane's own columns,
+//      byte profile whole in LDS like the traceback) on the few columns that can feed a cell worth M
+//      in that block -- lenA + (smax*lenA - M)/|gap| of them -- and takes the first cell equal to M in
+//      row-major order (align.go:197-201, strict `>`).  A windowed H never exceeds the true H and equals
+//      it wherever the true value is M (all paths of that score fit the window), so the cell is exact;
+//   3. pairs with a tie (the row-major-first maximum may sit in a later block with a smaller row)
+//      go on a list that sw_shared_kernel, the exact 32-bit kernel, works off afterwards.
+//
+// The combined profile prof2[j/4][code0 * ncp + code1][j%4] holds both pairs' scores as packed
+// int16, 16 bytes per (block, code pair): one ds_read_b128 per row and block, address = block base +
+// a 16-bit offset picked from the packed row registers by one SDWA add.  It is streamed through LDS in
+// chunks of 64 blocks (36 KB for the 6 codes of {-,A,C,G,T} + pad).
+//
+// Conditions (plan below): what sw_shared_kernel needs, plus <= 7 symbols in FirstAlphabet, scores
+// below 2^15 with headroom, and a reference whose byte profile fits LDS for step 2.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+
+#include "common.h"
+#include "sw_scoring.h"
+
+namespace polyhip {
+namespace k3p {
+
+constexpr int THREADS = 256;
+constexpr int PADS = -1024; // score of a pad row / pad column: keeps d far below every real value
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// prof2 entry (q, cidx) = 4 dwords, one per column of block q: lo half = S(sym(code0), b_j), hi = S(sym(code1), b_j)
+__global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t nq,
+                                                      const int8_t *__restrict__ lutc, int ncodes, int ncp,
+                                                      uint32_t *__restrict__ prof2)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // one (block, code pair) each
+    const uint32_t ncc = (uint32_t)(ncp * ncp);
+    if (e >= nq * ncc)
+        return;
+    const uint32_t q = e / ncc, cidx = e % ncc;
+    const int c0 = (int)(cidx / (uint32_t)ncp), c1 = (int)(cidx % (uint32_t)ncp);
+    uint32_t w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t j = 4 * q + c;
+        int s0 = PADS, s1 = PADS;
+        if (j < lenB) {
+            const uint8_t b = B[j];
+            if (c0 < ncodes)
+                s0 = lutc[c0 * 256 + b];
+            if (c1 < ncodes)
+                s1 = lutc[c1 * 256 + b];
+        }
+        w[c] = ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 << 16);
+    }
+    reinterpret_cast<uint4 *>(prof2)[e] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// address of a row's table entry = (block base / 16 + code-pair index) * 16: the index is a byte of the
+// packed row registers (SDWA add), the shift restores bytes
+#define PH_PK_ISSUE(dst, rp, SEL)                                                                                  \
+    do {                                                                                                           \
+        uint32_t ad_;                                                                                              \
+        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL  \
+                     "\n\tv_lshlrev_b32_e32 %0, 4, %0"                                                             \
+                     : "=&v"(ad_)                                                                                  \
+                     : "v"(blk16), "v"(rp));                                                                       \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ad_));                                                \
+    } while (0)
+#define PH_PK_ROW(I, W)                                    \
+    do {                                                   \
+        const int i_ = (I);                                \
+        const uint32_t left = H[i_];                       \
+        const uint32_t h0 = pk_max(pk_add(pdiag, (W).x), pk_subsat(pk_max(pr0, left), gap2)); \
+        const uint32_t h1 = pk_max(pk_add(pr0, (W).y), pk_subsat(pk_max(pr1, h0), gap2));     \
+        const uint32_t h2 = pk_max(pk_add(pr1, (W).z), pk_subsat(pk_max(pr2, h1), gap2));     \
+        const uint32_t h3 = pk_max(pk_add(pr2, (W).w), pk_subsat(pk_max(pr3, h2), gap2));     \
+        bm = pk_max(pk_max(bm, h0), pk_max(h1, pk_max(h2, h3)));                              \
+        pdiag = left;                                      \
+        pr0 = h0;                                          \
+        pr1 = h1;                                          \
+        pr2 = h2;                                          \
+        pr3 = h3;                                          \
+        H[i_] = h3;                                        \
+    } while (0)
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// byte code of A[i] of one pair, pad code where the pair has no such row or the byte is not in FirstAlphabet
+__device__ __forceinline__ uint32_t row_code(const uint8_t *__restrict__ ap, uint32_t lenA, int i,
+                                             const uint8_t *__restrict__ codeL, uint32_t pad)
+{
+    if ((uint32_t)i >= lenA)
+        return pad;
+    const uint32_t c = codeL[ap[i]];
+    return c == 0xFFu ? pad : c;
+}
+
+template <int RA>
+__global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                       uint64_t npairs, const uint32_t *__restrict__ prof2,
+                                                       uint32_t nq, uint32_t jcb, uint32_t tab_bytes, int ncp,
+                                                       const uint8_t *__restrict__ codeA, int ncodes, int gapabs,
+                                                       uint32_t *__restrict__ infoM, uint32_t *__restrict__ infoQ)
+{
+    static_assert(RA % 4 == 0 && RA <= 152, "RA"); // two workgroups per CU: 256 VGPRs hold H[RA] + RA/4 code registers
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_pk[];
+    uint8_t *codeL = lds_pk + (size_t)jcb * tab_bytes;
+    const int tid = threadIdx.x;
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    // my two pairs
+    const uint64_t base = (uint64_t)blockIdx.x * (2 * THREADS);
+    const uint64_t p0 = base + tid, p1 = base + THREADS + tid;
+    const uint8_t *ap0 = A, *ap1 = A;
+    uint32_t len0 = 0, len1 = 0;
+    if (p0 < npairs) {
+        const uint64_t o = offA[p0], l = offA[p0 + 1] - o;
+        ap0 = A + o;
+        len0 = l > (uint64_t)RA ? 0u : (uint32_t)l; // too long: no score here, the locate kernel reports it
+    }
+    if (p1 < npairs) {
+        const uint64_t o = offA[p1], l = offA[p1 + 1] - o;
+        ap1 = A + o;
+        len1 = l > (uint64_t)RA ? 0u : (uint32_t)l;
+    }
+    // index of row i's code pair inside a block's table, four rows per register
+    uint32_t rpk[RA / 4];
+#pragma unroll
+    for (int w = 0; w < RA / 4; ++w) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int i = 4 * w + h;
+            const uint32_t c0 = row_code(ap0, len0, i, codeL, (uint32_t)ncodes);
+            const uint32_t c1 = row_code(ap1, len1, i, codeL, (uint32_t)ncodes);
+            pk |= (c0 * (uint32_t)ncp + c1) << (8 * h);
+        }
+        rpk[w] = pk;
+    }
+
+    uint32_t H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+    const uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
+    uint32_t best = 0, bestq = 0, ties = 0; // packed halves: maximum, its first block, bit 0 / bit 16 = tie
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk));
+
+    for (uint32_t q0 = 0; q0 < nq; q0 += jcb) {
+        const uint32_t nb = min(jcb, nq - q0);
+        __syncthreads(); // previous chunk fully consumed
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(prof2) + (size_t)q0 * tab_bytes);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds_pk);
+            const uint32_t nvec = nb * tab_bytes / 16;
+            for (uint32_t v = tid; v < nvec; v += THREADS)
+                dst[v] = src[v];
+        }
+        __syncthreads();
+        for (uint32_t t = 0; t < nb; ++t) {
+            const uint32_t blk16 = (lds_base + t * tab_bytes) >> 4; // lds_pk and tab_bytes are multiples of 16
+            uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0, bm = 0;
+            u32x4 wa, wb;
+            PH_PK_ISSUE(wa, rpk[0], "BYTE_0");
+#pragma unroll
+            for (int g = 0; g < RA / 4; ++g) {
+                PH_PK_ISSUE(wb, rpk[g], "BYTE_1");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PK_ROW(4 * g, wa);
+                PH_PK_ISSUE(wa, rpk[g], "BYTE_2");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                PH_PK_ROW(4 * g + 1, wb);
+                PH_PK_ISSUE(wb, rpk[g], "BYTE_3");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PK_ROW(4 * g + 2, wa);
+                if (g + 1 < RA / 4) {
+                    PH_PK_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                }
+                PH_PK_ROW(4 * g + 3, wb);
+            }
+            // block maximum against the running one, per half; a block reaching the maximum AGAIN is a tie
+            const uint32_t q = q0 + t;
+            const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
+            if (blo > mlo) {
+                best = (best & 0xFFFF0000u) | blo;
+                bestq = (bestq & 0xFFFF0000u) | q;
+                ties &= ~1u;
+            } else if (blo == mlo && blo != 0u) {
+                ties |= 1u;
+            }
+            if (bhi > mhi) {
+                best = (best & 0xFFFFu) | (bhi << 16);
+                bestq = (bestq & 0xFFFFu) | (q << 16);
+                ties &= ~0x10000u;
+            } else if (bhi == mhi && bhi != 0u) {
+                ties |= 0x10000u;
+            }
+        }
+    }
+    if (p0 < npairs) {
+        infoM[p0] = best & 0xFFFFu;
+        infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+    }
+    if (p1 < npairs) {
+        infoM[p1] = best >> 16;
+        infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+    }
+}
+#undef PH_PK_ROW
+#undef PH_PK_ISSUE
+
+// ---- step 2: the cell.  One pair per lane, 32-bit, the lane's own window of 4-column blocks -----------
+#define PH_LC_ADDR(dst, pk, SEL)                                                                           \
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                 : "=v"(dst)                                                                               \
+                 : "v"(blk), "v"(pk))
+#define PH_LC_ISSUE(pk, w0, w1, w2, w3)                           \
+    do {                                                          \
+        uint32_t a0_, a1_, a2_, a3_;                              \
+        PH_LC_ADDR(a0_, pk, "BYTE_0");                            \
+        PH_LC_ADDR(a1_, pk, "BYTE_1");                            \
+        PH_LC_ADDR(a2_, pk, "BYTE_2");                            \
+        PH_LC_ADDR(a3_, pk, "BYTE_3");                            \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_)); \
+    } while (0)
+#define PH_LC_CELL(S, DIAG, UP, LEFT, HOUT, C)                                    \
+    do {                                                                          \
+        HOUT = max(max((DIAG) + (S), 0), max((UP), (LEFT)) + gap);                \
+        key = min(key, HOUT == M ? (uint32_t)((i_ << 2) | (C)) : 0xFFFFFFFFu);    \
+    } while (0)
+#define PH_LC_ROW(I, W)                                   \
+    do {                                                  \
+        const int i_ = (I);                               \
+        const uint32_t w_ = (W);                          \
+        const int s0 = (int)(int8_t)(w_);                 \
+        const int s1 = (int)(int8_t)(w_ >> 8);            \
+        const int s2 = (int)(int8_t)(w_ >> 16);           \
+        const int s3 = (int)w_ >> 24;                     \
+        const int left = H[i_];                           \
+        int h0, h1, h2, h3;                               \
+        PH_LC_CELL(s0, pdiag, pr0, left, h0, 0);          \
+        PH_LC_CELL(s1, pr0, pr1, h0, h1, 1);              \
+        PH_LC_CELL(s2, pr1, pr2, h1, h2, 2);              \
+        PH_LC_CELL(s3, pr2, pr3, h2, h3, 3);              \
+        pdiag = left;                                     \
+        pr0 = h0;                                         \
+        pr1 = h1;                                         \
+        pr2 = h2;                                         \
+        pr3 = h3;                                         \
+        H[i_] = h3;                                       \
+    } while (0)
+
+template <int RA, int CP>
+__global__ __launch_bounds__(THREADS) void sw_locate_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    uint32_t lenB, uint32_t lenB_pad, const int8_t *__restrict__ prof, const uint8_t *__restrict__ codeA,
+    const uint32_t *__restrict__ binfo, int ncodes, int gap, int smax, const uint32_t *__restrict__ infoM,
+    const uint32_t *__restrict__ infoQ, uint32_t *__restrict__ list, uint32_t *__restrict__ count,
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+{
+    static_assert(RA % 4 == 0 && RA <= 256, "RA");
+    extern __shared__ __attribute__((aligned(16))) int8_t lds_lc[];
+    int8_t *P = lds_lc;
+    uint8_t *codeL = reinterpret_cast<uint8_t *>(lds_lc + (size_t)lenB_pad * CP);
+    const int tid = threadIdx.x;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(prof);
+        uint4 *dst = reinterpret_cast<uint4 *>(P);
+        const uint32_t nvec = lenB_pad * CP / 16;
+        for (uint32_t v = tid; v < nvec; v += THREADS)
+            dst[v] = src[v];
+    }
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    const uint64_t pair = (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < npairs;
+    uint64_t o0 = 0;
+    uint32_t lenA = 0;
+    if (active) {
+        o0 = offA[pair];
+        const uint64_t l = offA[pair + 1] - o0;
+        lenA = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+    }
+    const bool too_long = lenA > RA;
+    if (too_long)
+        lenA = 0;
+    const uint8_t *ap = A + o0;
+    // packed row codes (as sw_shared_kernel) and the first byte of A outside FirstAlphabet
+    uint32_t apk[RA / 4];
+    int firstbad = -1;
+    uint32_t badsym = 0, a0sym = 0;
+#pragma unroll
+    for (int w = 0; w < RA / 4; ++w) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = 4 * w + b;
+            uint32_t code = (uint32_t)ncodes;
+            if ((uint32_t)i < lenA) {
+                const uint32_t sym = ap[i];
+                if (i == 0)
+                    a0sym = sym;
+                code = codeL[sym];
+                if (code == 0xFFu) {
+                    if (firstbad < 0) {
+                        firstbad = i;
+                        badsym = sym;
+                    }
+                    code = (uint32_t)ncodes;
+                }
+            }
+            pk |= (code * 4u) << (8 * b);
+        }
+        apk[w] = pk;
+    }
+    uint32_t e = 0;
+    if (too_long) {
+        e = 0xFFFFFFFFu;
+    } else if (lenA > 0 && lenB > 0) { // align.go:189-191 + matrix.go:29-36: row-major first failing cell
+        const uint32_t bbad = binfo[0];
+        if (firstbad == 0)
+            e = (1u << 8) | a0sym;
+        else if (bbad != 0xFFFFFFFFu)
+            e = (2u << 8) | B[bbad];
+        else if (firstbad > 0)
+            e = (1u << 8) | badsym;
+    }
+    const int M = active ? (int)infoM[pair] : 0;
+    const uint32_t iq = active ? infoQ[pair] : 0u;
+    const bool tie = (iq >> 31) != 0u;
+    const uint32_t q = iq & 0x7FFFFFFFu;
+    const bool work = active && e == 0u && M > 0 && !tie;
+
+    // columns that can feed a cell worth M in block q: lenA + (smax*lenA - M)/|gap| before its last column
+    uint32_t jb0 = 0, nblk = 0;
+    if (work) {
+        const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
+        const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u;
+        const uint32_t jend = 4u * q + 4u; // one past the block's last column
+        jb0 = (jend > need ? jend - need : 0u) & ~3u;
+        nblk = (jend - jb0) >> 2;
+    }
+
+    int H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+    uint32_t key = 0xFFFFFFFFu;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
+    for (uint32_t t = 0;; ++t) {
+        if (!__any(t < nblk))
+            break;
+        if (t < nblk) {
+            const uint32_t blk = lds_base + ((jb0 >> 2) + t) * (CP * 4);
+            int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
+            uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+            PH_LC_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+#pragma unroll
+            for (int g = 0; g < RA / 4; ++g) {
+                if (g + 1 < RA / 4) {
+                    PH_LC_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+                }
+                PH_LC_ROW(4 * g + 0, wa0);
+                PH_LC_ROW(4 * g + 1, wa1);
+                PH_LC_ROW(4 * g + 2, wa2);
+                PH_LC_ROW(4 * g + 3, wa3);
+                wa0 = wb0;
+                wa1 = wb1;
+                wa2 = wb2;
+                wa3 = wb3;
+            }
+            if (t + 1 < nblk)
+                key = 0xFFFFFFFFu; // only the last block can hold M (earlier ones stayed below it)
+        }
+    }
+
+    if (!active)
+        return;
+    // a tie, or (never expected) no cell found: the exact kernel decides
+    if (e == 0u && M > 0 && (tie || key == 0xFFFFFFFFu)) {
+        list[atomicAdd(count, 1u)] = (uint32_t)pair;
+        return;
+    }
+    const bool hit = e == 0u && M > 0;
+    score[pair] = hit ? (int64_t)M : 0;
+    endA[pair] = hit ? (key >> 2) + 1u : 0u;
+    endB[pair] = hit ? 4u * q + (key & 3u) + 1u : 0u;
+    err[pair] = e;
+}
+#undef PH_LC_ROW
+#undef PH_LC_CELL
+#undef PH_LC_ISSUE
+#undef PH_LC_ADDR
+
+// ---- host side ---------------------------------------------------------------------------------------
+bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, PackedPlan *out)
+{
+    PackedPlan p{};
+    const char *env = getenv("POLYHIP_SW_PACKED");
+    if (env && env[0] == '0')
+        return false;
+    const uint64_t minlen = std::min<uint64_t>(max_lenA, lenB);
+    if (!(sc->int8_ok && sc->gap <= -1 && -sc->gap < 16384 && sc->smax > 0 && sc->cp <= 8 &&
+          lenB > 0 && lenB < (1ull << 18) && (uint64_t)sc->smax * minlen < 30000ull))
+        return false;
+    if (max_lenA > 152 || npairs >= (1ull << 32))
+        return false;
+    p.ra = max_lenA <= 64 ? 64 : 152;
+    p.ncp = sc->ncodes + 1;
+    p.tab_bytes = (uint32_t)(p.ncp * p.ncp * 16);
+    p.lenB_pad = (uint32_t)align_up(lenB, 4);
+    p.nq = p.lenB_pad / 4;
+    p.jcb = std::max<uint32_t>(1, std::min<uint32_t>(64, 36864u / p.tab_bytes));
+    p.pk_smem = (size_t)p.jcb * p.tab_bytes + 256;
+    p.locate_smem = (size_t)p.lenB_pad * 8 + 256;
+    if (p.locate_smem > 64 * 1024)
+        return false; // the byte profile of the reference has to sit whole in LDS for step 2
+    p.prof2_bytes = align_up((size_t)p.nq * p.tab_bytes, 256);
+    p.info_bytes = align_up((size_t)npairs * 4, 256);
+    p.work_bytes = p.prof2_bytes + 3 * p.info_bytes + 256;
+    *out = p;
+    return true;
+}
+
+template <int RA>
+static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
+                         uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
+                         uint32_t *prof2, uint32_t *infoM, uint32_t *infoQ, uint32_t *list, uint32_t *count,
+                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
+{
+    {
+        const uint32_t n = p.nq * (uint32_t)(p.ncp * p.ncp);
+        hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, p.nq, sc->d_lutc,
+                           sc->ncodes, p.ncp, prof2);
+        PH_HIP(hipGetLastError());
+    }
+    {
+        auto kern = sw_pk_kernel<RA>;
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.pk_smem));
+        const uint64_t blocks = (npairs + 2 * THREADS - 1) / (2 * THREADS);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.pk_smem, st, d_A, d_offA, npairs, prof2, p.nq,
+                           p.jcb, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
+        PH_HIP(hipGetLastError());
+    }
+    {
+        auto kern = sw_locate_kernel<RA, 8>;
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.locate_smem));
+        const uint64_t blocks = (npairs + THREADS - 1) / THREADS;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.locate_smem, st, d_A, d_offA, npairs, d_B, lenB,
+                           p.lenB_pad, prof, sc->d_codeA, binfo, sc->ncodes, (int)sc->gap, (int)sc->smax, infoM, infoQ,
+                           list, count, d_score, d_endA, d_endB, d_err);
+        PH_HIP(hipGetLastError());
+    }
+    return POLYHIP_OK;
+}
+
+int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
+               uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
+               void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
+               uint32_t **list_out, uint32_t **count_out, hipStream_t st)
+{
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    uint32_t *count = reinterpret_cast<uint32_t *>(w);
+    uint32_t *prof2 = reinterpret_cast<uint32_t *>(w + 256);
+    uint32_t *infoM = reinterpret_cast<uint32_t *>(w + 256 + p.prof2_bytes);
+    uint32_t *infoQ = reinterpret_cast<uint32_t *>(w + 256 + p.prof2_bytes + p.info_bytes);
+    uint32_t *list = reinterpret_cast<uint32_t *>(w + 256 + p.prof2_bytes + 2 * p.info_bytes);
+    PH_HIP(hipMemsetAsync(count, 0, 256, st));
+    *list_out = list;
+    *count_out = count;
+    if (p.ra == 64)
+        return launch_packed<64>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
+                                 d_score, d_endA, d_endB, d_err, st);
+    return launch_packed<152>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
+                              d_score, d_endA, d_endB, d_err, st);
+}
+
+} // namespace k3p
+} // namespace polyhip

@@ -25,3 +25,43 @@ struct polyhip_scoring {
     int32_t *d_lut;      // [256][256]
     uint8_t *d_validA, *d_validB;
 };
+
+// ---- packed score pass (sw_packed.hip), driven from polyhip_sw_batch_dev (sw_batch.hip) ----------------
+#include <hip/hip_runtime.h>
+
+namespace polyhip {
+namespace k3p {
+
+struct PackedPlan {
+    int ra, ncp;                    // rows per lane (template), codes incl. pad
+    uint32_t tab_bytes;             // bytes of one block's table: ncp * ncp * 16
+    uint32_t lenB_pad, nq, jcb;     // columns (multiple of 4), 4-column blocks, blocks per LDS chunk
+    size_t pk_smem, locate_smem;
+    size_t prof2_bytes, info_bytes; // workspace pieces
+    size_t work_bytes;              // 256 (tie counter) + prof2 + infoM + infoQ + tie list
+};
+
+// false: the batch does not qualify (see sw_packed.hip) or POLYHIP_SW_PACKED=0
+bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, PackedPlan *out);
+
+// profile2 + packed pass + locate.  Pairs the exact kernel has to redo (ties) are left on *list_out
+// (count at *count_out, both inside d_work); every other pair has its four outputs written.
+int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
+               uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
+               void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
+               uint32_t **list_out, uint32_t **count_out, hipStream_t st);
+
+} // namespace k3p
+} // namespace polyhip
+
+// ---- one-wave-per-pair exact score pass (sw_wave.hip): the packed pass's tie list and small batches ----
+namespace polyhip {
+namespace k3w {
+
+// pairs [0, npairs) if list == nullptr, else the *count pairs on `list`; max_items bounds the grid
+int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
+             const uint8_t *d_B, uint32_t lenB, const uint32_t *binfo, const uint32_t *list, const uint32_t *count,
+             uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st);
+
+} // namespace k3w
+} // namespace polyhip

@@ -1,0 +1,198 @@
+// sw_wave.hip -- K3, low-latency exact Smith-Waterman score pass: ONE WAVE PER PAIR.
+//
+// The lane-per-pair kernels (sw_batch.hip, sw_packed.hip) need thousands of pairs to fill the chip and
+// take the time of one full DP (10-20 ms at 150 x 5000) no matter how few pairs there are.  This kernel
+// serves the other end: the handful of pairs the packed pass leaves on its tie list, and small batches
+// (a single align.SmithWaterman call is a batch of one).  Same recurrence and argmax as
+// search/align/align.go:171-203, same outputs as sw_shared_kernel.
+//
+// Systolic sweep: lane l owns rows [l*R, l*R + R) of the pair (R = 1..4 for lenA <= 64..256) and
+// works on column j = s - l in step s, so the row above its first row (lane l-1's last row, same
+// column) was finished one step earlier and arrives, together with that column's B code, by one
+// lane shift per step.  lenB + 63 steps of R cells per lane; S(a, b) from the compact int32 table in LDS.
+// Argmax: per lane the best (h, then smaller row, then smaller column), folded across lanes at the
+// end -- the first maximum in row-major order (align.go:197-201, strict `>`).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "common.h"
+#include "sw_scoring.h"
+
+namespace polyhip {
+namespace k3w {
+
+constexpr int THREADS = 256; // 4 waves = 4 pairs per workgroup
+
+template <int R>
+__global__ __launch_bounds__(THREADS) void sw_wave_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    uint32_t lenB, const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
+    const int32_t *__restrict__ lutcc, int na, int nb, int gap, const uint32_t *__restrict__ binfo,
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, int64_t *__restrict__ score,
+    uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb] (last row / column: pad, zeros), codeA, codeB
+    uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < na * nb; t += THREADS)
+        T[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+
+    const uint64_t total = list ? (uint64_t)*count : npairs;
+    // grid-stride over work items, one per wave (wave-uniform control flow, no barrier below)
+    for (uint64_t w = (uint64_t)blockIdx.x * (THREADS / 64) + (tid >> 6); w < total;
+         w += (uint64_t)gridDim.x * (THREADS / 64)) {
+    const uint64_t pair = list ? (uint64_t)list[w] : w;
+
+    const uint64_t o0 = offA[pair];
+    const uint64_t l64 = offA[pair + 1] - o0;
+    const bool too_long = l64 > (uint64_t)(64 * R);
+    const uint32_t lenA = too_long ? 0u : (uint32_t)l64;
+    const uint8_t *ap = A + o0;
+
+    // my rows' table offsets (code * nb); the first byte outside FirstAlphabet, wave-wide
+    uint32_t ro[R];
+    uint32_t mybad = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t r = (uint32_t)lane * R + k;
+        uint32_t code = (uint32_t)(na - 1);
+        if (r < lenA) {
+            const uint32_t c = cA[ap[r]];
+            if (c == 0xFFu)
+                mybad = min(mybad, r);
+            else
+                code = c;
+        }
+        ro[k] = code * (uint32_t)nb;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        mybad = min(mybad, (uint32_t)__shfl_xor((int)mybad, d, 64));
+    uint32_t e = 0;
+    if (too_long) {
+        e = 0xFFFFFFFFu;
+    } else if (lenA > 0 && lenB > 0) { // align.go:189-191 + matrix.go:29-36: row-major first failing cell
+        const uint32_t bbad = binfo[0];
+        if (mybad == 0u)
+            e = (1u << 8) | ap[0];
+        else if (bbad != 0xFFFFFFFFu)
+            e = (2u << 8) | B[bbad];
+        else if (mybad != 0xFFFFFFFFu)
+            e = (1u << 8) | ap[mybad];
+    }
+
+    int Hrow[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        Hrow[k] = 0;
+    int topprev = 0, last_h = 0;
+    uint32_t last_b = (uint32_t)(nb - 1);
+    int besth = 0;
+    uint32_t besti = 0, bestj = 0;
+    const uint32_t steps = (e == 0u && lenA > 0 && lenB > 0) ? lenB + 63u : 0u;
+    // B codes enter at lane 0, 64 columns per coalesced load, the next chunk in flight while this one is used
+    auto load_chunk = [&](uint32_t s0) -> uint32_t {
+        uint32_t c = (uint32_t)(nb - 1);
+        if (s0 + (uint32_t)lane < lenB) {
+            const uint32_t cc = cB[B[s0 + (uint32_t)lane]];
+            c = cc == 0xFFu ? (uint32_t)(nb - 1) : cc;
+        }
+        return c;
+    };
+    uint32_t chunk = steps ? load_chunk(0) : 0u, next_chunk = 0u;
+    for (uint32_t s = 0; s < steps; ++s) {
+        if ((s & 63u) == 0u) {
+            if (s)
+                chunk = next_chunk;
+            next_chunk = load_chunk(s + 64u);
+        }
+        int top_in = __shfl_up(last_h, 1, 64);
+        uint32_t b_in = (uint32_t)__shfl_up((int)last_b, 1, 64);
+        const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
+        if (lane == 0) {
+            top_in = 0;
+            b_in = b_new;
+        }
+        const uint32_t j = s - (uint32_t)lane; // wraps for lanes that have not started: not < lenB
+        const bool valid = j < lenB;
+        int diag = topprev, up = top_in;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int left = Hrow[k];
+            const int sc = T[ro[k] + b_in];
+            int h = max(max(diag + sc, 0), max(up, left) + gap);
+            h = valid ? h : 0;
+            const uint32_t r = (uint32_t)lane * R + k;
+            // first maximum in row-major order: higher h, else smaller row (columns come in order)
+            if (r < lenA && (h > besth || (h == besth && h > 0 && r < besti))) {
+                besth = h;
+                besti = r;
+                bestj = j;
+            }
+            diag = left;
+            up = h;
+            Hrow[k] = h;
+        }
+        topprev = valid ? top_in : 0;
+        last_h = Hrow[R - 1];
+        last_b = b_in;
+    }
+    // fold the lanes: max h, then min row, then min column
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int oh = __shfl_xor(besth, d, 64);
+        const uint32_t oi = (uint32_t)__shfl_xor((int)besti, d, 64), oj = (uint32_t)__shfl_xor((int)bestj, d, 64);
+        if (oh > besth || (oh == besth && (oi < besti || (oi == besti && oj < bestj)))) {
+            besth = oh;
+            besti = oi;
+            bestj = oj;
+        }
+    }
+    if (lane == 0) {
+        const bool hit = e == 0u && besth > 0;
+        score[pair] = hit ? (int64_t)besth : 0;
+        endA[pair] = hit ? besti + 1u : 0u;
+        endB[pair] = hit ? bestj + 1u : 0u;
+        err[pair] = e;
+    }
+    } // work items
+}
+
+int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
+             const uint8_t *d_B, uint32_t lenB, const uint32_t *binfo, const uint32_t *list, const uint32_t *count,
+             uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
+{
+    const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+    const size_t smem = (size_t)na * nb * 4 + 512;
+    const uint64_t blocks = std::min<uint64_t>((max_items + THREADS / 64 - 1) / (THREADS / 64), 4096);
+    if (blocks == 0)
+        return POLYHIP_OK;
+#define PH_WAVE_LAUNCH(R_)                                                                                            \
+    do {                                                                                                              \
+        auto kern = sw_wave_kernel<R_>;                                                                               \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)smem));                                                                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem, st, d_A, d_offA, npairs, d_B, lenB,     \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, binfo, list, count, d_score,  \
+                           d_endA, d_endB, d_err);                                                                    \
+    } while (0)
+    if (max_lenA <= 64)
+        PH_WAVE_LAUNCH(1);
+    else if (max_lenA <= 128)
+        PH_WAVE_LAUNCH(2);
+    else if (max_lenA <= 192)
+        PH_WAVE_LAUNCH(3);
+    else
+        PH_WAVE_LAUNCH(4);
+#undef PH_WAVE_LAUNCH
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+} // namespace k3w
+} // namespace polyhip

@@ -47,21 +47,39 @@ def _in(alpha, ch):
 
 
 def _check(al, scoring, omat, gap, reads, ref=None, refs=None, expect_path=None):
+    """expect_path 1 = "a shared-reference fast path": the batch is run through every variant that
+    qualifies -- one wave per pair (4, small batches), packed (3), lane per pair (1) -- by switching the
+    others off with POLYHIP_SW_WAVE / POLYHIP_SW_PACKED, and each must equal the oracle."""
+    import os
     align = al[0]
     A, offA = _pack(reads)
     if refs is None:
-        B, _ = _pack([ref])
-        got = align.sw_batch_packed(scoring, A, offA, B, None)
+        B, offB = _pack([ref])[0], None
         want = _oracle_batch(reads, [ref] * len(reads), omat, gap)
     else:
         B, offB = _pack(refs)
-        got = align.sw_batch_packed(scoring, A, offA, B, offB)
         want = _oracle_batch(reads, refs, omat, gap)
-    if expect_path is not None:
-        assert align.last_path() == expect_path
-    for p, w in enumerate(want):
-        g = (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p]))
-        assert g == w, f"pair {p}: got {g} want {w} (lenA {len(reads[p])})"
+    variants = [({}, None)] if expect_path != 1 else [({}, (1, 3, 4)), ({"POLYHIP_SW_WAVE": "0"}, (1, 3)),
+                                                      ({"POLYHIP_SW_WAVE": "0", "POLYHIP_SW_PACKED": "0"}, (1,))]
+    for env, paths in variants:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            got = align.sw_batch_packed(scoring, A, offA, B, offB)
+            path = align.last_path()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        if paths is not None:
+            assert path in paths, (path, paths)
+        elif expect_path is not None:
+            assert path == expect_path
+        for p, w in enumerate(want):
+            g = (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p]))
+            assert g == w, f"path {path} pair {p}: got {g} want {w} (lenA {len(reads[p])})"
 
 
 def _mutate(rng, seq: bytes, sub=0.05, indel=0.01) -> bytes:
@@ -226,7 +244,7 @@ def test_device_resident_config4_sample(al):
     work = torch.empty(align.sw_workspace_bytes(sc, n, L, 5000), dtype=torch.uint8, device=dev)
     align.sw_batch_dev(sc, A, offA, L, B, None, 5000, score, ea, eb, er, work)
     torch.cuda.synchronize()
-    assert align.last_path() == 1
+    assert align.last_path() in (1, 3, 4)
     assert (score.cpu().numpy() == 5 * L).all()
     assert (ea.cpu().numpy() == L).all()
     assert (er.cpu().numpy() == 0).all()
@@ -234,3 +252,75 @@ def test_device_resident_config4_sample(al):
     refb = ref.tobytes()
     first = np.array([refb.find(reads[i].tobytes()) + L for i in range(n)])
     assert (eb.cpu().numpy() == first).all()
+
+
+@pytest.mark.parametrize("kind", ["random", "repeats", "short_ref", "bad_symbols"])
+def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
+    """The packed two-pairs-per-lane pass + locate + tie list (path 3) against the exact 32-bit kernel alone
+    (POLYHIP_SW_PACKED=0, path 1) on 120k ragged reads at 0..90 % substitutions: score, endA, endB and err
+    of every pair are equal.  `repeats`: the reference is a 16-fold tandem repeat with a few point changes,
+    so most maxima occur in several blocks (ties -> the exact kernel decides which is first in row-major
+    order); `short_ref`: fewer columns than one LDS chunk; `bad_symbols`: reads and reference with bytes
+    outside the alphabets.  A sample is also checked against the oracle."""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(11)
+    LB = {"random": 5000, "repeats": 4800, "short_ref": 37, "bad_symbols": 2000}[kind]
+    ref = orc.synth_dna(0xC4, LB).copy()
+    if kind == "repeats":
+        unit = ref[:300].copy()
+        ref = np.tile(unit, 16)
+        ref[rng.integers(0, LB, 12)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 12)]
+    n, L = 120_000, 152
+    starts = rng.integers(0, max(1, LB - L), n)
+    idx = (starts[:, None] + np.arange(L)[None, :]) % LB
+    reads = ref[idx]
+    rate = np.linspace(0.0, 0.9, n)[:, None]
+    hit = rng.random((n, L)) < rate
+    reads[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    lens = rng.integers(0, L + 1, n)
+    lens[rng.random(n) < 0.5] = 150
+    if kind == "bad_symbols":
+        bad = rng.random(n) < 0.02
+        reads[bad, rng.integers(0, 20, int(bad.sum()))] = ord("N")
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)]) if n else np.zeros(0, np.uint8)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    A = torch.from_numpy(flat.copy()).to(dev)
+    offA = torch.from_numpy(offs).to(dev)
+
+    def run(refarr, packed):
+        if packed:
+            monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        B = torch.from_numpy(refarr.copy()).to(dev)
+        score = torch.full((n,), -7, dtype=torch.int64, device=dev)
+        ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+        work = torch.empty(align.sw_workspace_bytes(sc, n, L, len(refarr)), dtype=torch.uint8, device=dev)
+        align.sw_batch_dev(sc, A, offA, L, B, None, len(refarr), score, ea, eb, er, work)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path()
+
+    refs = [ref]
+    if kind == "bad_symbols":
+        r2 = ref.copy()
+        r2[1234] = ord("N")
+        refs.append(r2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    for refarr in refs:
+        got, path = run(refarr, True)
+        want, path0 = run(refarr, False)
+        assert (path, path0) == (3, 1)
+        for g, w in zip(got, want):
+            assert (g == w).all()
+        refb = refarr.tobytes()
+        for p in range(0, n, 1501):
+            a = flat[offs[p]:offs[p + 1]].tobytes()
+            try:
+                s, _, _, ea_, eb_ = orc.smith_waterman(a, refb, om, -2)
+                assert (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p])) == (s, ea_, eb_, 0), p
+            except orc.AlphabetError:
+                assert int(got[3][p]) != 0 and int(got[0][p]) == 0
