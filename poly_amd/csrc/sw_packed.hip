@@ -459,7 +459,7 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     p.jcb = std::max<uint32_t>(1, std::min<uint32_t>(64, 36864u / p.tab_bytes));
     p.pk_smem = (size_t)p.jcb * p.tab_bytes + 256;
     p.locate_smem = (size_t)p.lenB_pad * 8 + 256;
-    if (p.locate_smem > 64 * 1024)
+    if (p.locate_smem > 160 * 1024)
         return false; // the byte profile of the reference has to sit whole in LDS for step 2
     p.prof2_bytes = align_up((size_t)p.nq * p.tab_bytes, 256);
     p.info_bytes = align_up((size_t)npairs * 4, 256);

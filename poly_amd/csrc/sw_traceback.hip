@@ -680,7 +680,7 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
     p.lenB_pad = (uint32_t)align_up((size_t)std::min<uint64_t>(lenB, 1u << 30), TBU);
     p.prof_smem = (size_t)p.lenB_pad * p.cp + 256;
     p.prof_ok = reg && sc->int8_ok && sc->gap <= -1 && sc->smax > 0 && sc->cp <= 32 && lenB > 0 && lenB < (1u << 30) &&
-                p.prof_smem <= 64 * 1024 && (uint64_t)sc->smax * max_lenA < (1ull << 30);
+                p.prof_smem <= 160 * 1024 && (uint64_t)sc->smax * max_lenA < (1ull << 30);
     if (p.prof_ok) {
         // a lane's window starts on a block boundary (up to 3 columns early) and ends inside a block
         p.nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 1;

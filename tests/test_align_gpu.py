@@ -254,25 +254,26 @@ def test_device_resident_config4_sample(al):
     assert (eb.cpu().numpy() == first).all()
 
 
-@pytest.mark.parametrize("kind", ["random", "repeats", "short_ref", "bad_symbols"])
+@pytest.mark.parametrize("kind", ["random", "repeats", "short_ref", "bad_symbols", "long_ref"])
 def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
     """The packed two-pairs-per-lane pass + locate + tie list (path 3) against the exact 32-bit kernel alone
     (POLYHIP_SW_PACKED=0, path 1) on 120k ragged reads at 0..90 % substitutions: score, endA, endB and err
     of every pair are equal.  `repeats`: the reference is a 16-fold tandem repeat with a few point changes,
     so most maxima occur in several blocks (ties -> the exact kernel decides which is first in row-major
     order); `short_ref`: fewer columns than one LDS chunk; `bad_symbols`: reads and reference with bytes
-    outside the alphabets.  A sample is also checked against the oracle."""
+    outside the alphabets; `long_ref`: a 15 kb reference (the locate kernel's byte profile takes 120 KB of LDS).
+    A sample is also checked against the oracle."""
     import torch
     align = al[0]
     dev = torch.device("cuda:0")
     rng = np.random.default_rng(11)
-    LB = {"random": 5000, "repeats": 4800, "short_ref": 37, "bad_symbols": 2000}[kind]
+    LB = {"random": 5000, "repeats": 4800, "short_ref": 37, "bad_symbols": 2000, "long_ref": 15000}[kind]  # long_ref: 120 KB of LDS
     ref = orc.synth_dna(0xC4, LB).copy()
     if kind == "repeats":
         unit = ref[:300].copy()
         ref = np.tile(unit, 16)
         ref[rng.integers(0, LB, 12)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 12)]
-    n, L = 120_000, 152
+    n, L = (40_000 if kind == "long_ref" else 120_000), 152
     starts = rng.integers(0, max(1, LB - L), n)
     idx = (starts[:, None] + np.arange(L)[None, :]) % LB
     reads = ref[idx]

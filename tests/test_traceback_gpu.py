@@ -191,8 +191,8 @@ def test_device_resident_chunked_workspace(al):
         assert int(score[p]) == s
 
 
-@pytest.mark.parametrize("gap", [-2, -7])
-def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap):
+@pytest.mark.parametrize("gap,LB", [(-2, 5000), (-7, 5000), (-2, 15000)])
+def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB):
     """(gap -2: even unrelated reads score > 300, the linear phase of local alignment; gap -7: scores fall
     to the noise floor, so the per-pair windows range from the tightest to the batch-wide bound.)  200k reads at 0..90 % substitutions + 0..12 % indels (scores from 750 down to the noise floor)
     against one 5 kb reference.  The byte-profile kernel (score given), the table kernel (no score: the
@@ -201,7 +201,7 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap):
     import torch
     align = al[0]
     dev = torch.device("cuda:0")
-    n, L, LB = 200_000, 150, 5000
+    n, L = (200_000 if LB == 5000 else 60_000), 150  # 15 kb: the profile takes 120 KB of LDS
     ref = orc.synth_dna(0xC4, LB)
     B = torch.from_numpy(ref.copy()).to(dev)
     gen = torch.Generator(device=dev)
