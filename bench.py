@@ -93,6 +93,12 @@ def cpu_baseline_extra():
     out["smith_waterman"] = entry(len(starts) * 150 * 5000, "cell updates/s", time.perf_counter() - t,
                                   f"{len(starts)} reads of 150 bp vs the 5000 bp reference, orc_smith_waterman "
                                   "(full int64 matrix + traceback, as align.go:171-232)")
+    pairs = [(ref[a:a + 150], bytes(orc.synth_dna(int(a) + 7919 * r, 150))) for r in range(15) for a in starts]
+    t = time.perf_counter()
+    for x, y in pairs:
+        orc.needleman_wunsch(x, y, om, -2)
+    out["needleman_wunsch"] = entry(len(pairs) * 150 * 150, "cell updates/s", time.perf_counter() - t,
+                                    f"{len(pairs)} pairs of 150 x 150 bp, orc_needleman_wunsch (align.go:100-166)")
     # SantaLucia scan, configs[4] shape on a 400 kb slice
     g = orc.synth_dna(0xC5, 400_000)
     t = time.perf_counter()

@@ -269,6 +269,9 @@ int polyhip_sw_last_path(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel (tests). */
 int polyhip_sw_traceback_last_path(void);
+/* ... and the last polyhip_nw_align_batch_dev call: 1 = register-tiled kernel, 2 = generic kernel
+ * (POLYHIP_NW_GENERIC=1 forces it; tests). */
+int polyhip_nw_last_path(void);
 
 /* ---- K4: primers SantaLucia / MarmurDoty / MeltingTemp  (primers/primers.go:70-128) */
 /*

@@ -134,6 +134,11 @@ def sw_traceback_last_path() -> int:
     return int(_lib.lib().polyhip_sw_traceback_last_path())
 
 
+def nw_last_path() -> int:
+    """1 = register-tiled NeedlemanWunsch kernel, 2 = generic (tests)"""
+    return int(_lib.lib().polyhip_nw_last_path())
+
+
 # ---- full SmithWaterman: score pass + traceback (align.go:171-232) -------------------
 
 def sw_align_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.ndarray,
@@ -237,6 +242,22 @@ def nw_align_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.nda
     sa = [alnA[p, stride - int(alen[p]):].tobytes() for p in range(n)]
     sb = [alnB[p, stride - int(alen[p]):].tobytes() for p in range(n)]
     return score, err, sa, sb
+
+
+def nw_workspace_bytes(npairs: int, max_lenA: int, max_lenB: int) -> int:
+    return int(_lib.lib().polyhip_nw_workspace_bytes(npairs, max_lenA, max_lenB))
+
+
+def nw_align_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, lenB: int, score_t, err_t, alnA_t, alnB_t,
+                 alnLen_t, work_t, stream=None) -> None:
+    """Device-resident NeedlemanWunsch on torch CUDA tensors (alnA/alnB: (n, stride >= max_lenA + lenB) uint8,
+    strings right-aligned in their slots); lenB = the longest B (or the shared B's length when offB_t is None)."""
+    n = offA_t.numel() - 1
+    _lib.check(_lib.lib().polyhip_nw_align_batch_dev(
+        scoring.handle(), A_t.data_ptr(), offA_t.data_ptr(), n, max_lenA, B_t.data_ptr(),
+        offB_t.data_ptr() if offB_t is not None else None, lenB, score_t.data_ptr(), err_t.data_ptr(),
+        alnA_t.data_ptr(), alnB_t.data_ptr(), alnLen_t.data_ptr(), alnA_t.shape[1], work_t.data_ptr(),
+        work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
 
 
 def NeedlemanWunsch(stringA, stringB, scoring: Scoring):

@@ -156,9 +156,34 @@ def fastq_feeder(dev, n: int = 200_000, L: int = 1000):
             "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
 
 
+def nw(dev, n: int = 200_000, L: int = 150):
+    """global alignment of n pairs of L bp reads (B = A with 5 % substitutions), NUC_4, gap -2"""
+    a = alphabet.NewAlphabet(list("-ACGT"))
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
+    A = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xA1, A)
+    B = A.clone().view(n, L)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xA1)
+    hit = torch.rand(B.shape, device=dev, generator=gen) < 0.05
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    B[hit] = lut[torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)]
+    B = B.reshape(-1).contiguous()
+    off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    err, ln = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(2))
+    alnA = torch.zeros((n, 2 * L), dtype=torch.uint8, device=dev)
+    alnB = torch.zeros((n, 2 * L), dtype=torch.uint8, device=dev)
+    work = torch.empty(align.nw_workspace_bytes(n, L, L), dtype=torch.uint8, device=dev)
+    ms = _time(lambda: align.nw_align_dev(sc, A, off, L, B, off, L, score, err, alnA, alnB, ln, work), 3)
+    return {"workload": f"NeedlemanWunsch (score + aligned strings) of {n} pairs of {L} x {L} bp, NUC_4, gap -2",
+            "cell_updates_per_s": n * L * L / ms * 1e3, "ms": ms, "mean_score": float(score.double().mean()),
+            "mean_alignment_len": float(ln.double().mean())}
+
+
 def run(dev) -> dict:
     out = {}
-    for name, fn in (("smith_waterman", sw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
+    for name, fn in (("smith_waterman", sw), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder)):
         try:
             out[name] = fn(dev)

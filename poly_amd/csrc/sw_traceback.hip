@@ -42,6 +42,7 @@ namespace k3t {
 constexpr int THREADS = 256;
 
 static thread_local int g_tb_last_path = 0;
+static thread_local int g_nw_last_path = 0;
 
 struct Window {
     uint32_t wcols;   // columns of the re-run DP (<= lenB)
@@ -646,6 +647,166 @@ __global__ __launch_bounds__(THREADS) void nw_kernel(const uint8_t *__restrict__
     alnLen[pair] = len;
 }
 
+// ---- NeedlemanWunsch, register-tiled (lenA <= 256, compact table in LDS) -------------------------
+// Same cell and bit recording as tb_prof_kernel minus the zero: d = diag + s, t = max(up, left) + gap,
+// h = max(d, t), G = t > d (the diagonal wins ties, align.go:146), L = left > up ("up" is tested before the
+// final else, :150-158); boundary column H[i][0] = i*gap in the registers, boundary row carried in `top`.
+// Per-pair B: every lane looks its own column's symbol up in the table (one ds_read per cell).
+#define PH_NW_BIT(w, x, y)                                                              \
+    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
+                 : "+v"(w)                                                              \
+                 : "v"(x), "v"(y)                                                       \
+                 : "vcc")
+
+template <int RA>
+__global__ __launch_bounds__(THREADS) void nw_reg_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                        uint64_t pair0, uint64_t pair1, const uint8_t *__restrict__ B,
+                                                        const uint64_t *__restrict__ offB, uint64_t lenB_shared,
+                                                        const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
+                                                        const int32_t *__restrict__ lutcc, int na, int nb, int gap,
+                                                        uint32_t max_lenB, uint32_t *__restrict__ dirbuf,
+                                                        int64_t *__restrict__ score, uint32_t *__restrict__ err,
+                                                        uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB,
+                                                        uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    constexpr int NG = (RA + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb] then codeA[256], codeB[256]
+    uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < na * nb; t += THREADS)
+        T[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+
+    const uint64_t pair = pair0 + (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < pair1;
+    uint32_t m = 0, n = 0;
+    const uint8_t *a = A, *b = B;
+    if (active) {
+        const uint64_t o0 = offA[pair];
+        m = (uint32_t)(offA[pair + 1] - o0);
+        a = A + o0;
+        b = offB ? B + offB[pair] : B;
+        n = (uint32_t)(offB ? offB[pair + 1] - offB[pair] : lenB_shared);
+    }
+    // align.go:126-129 + matrix.go:29-36: the first failing Score() in row-major order
+    uint32_t e = 0;
+    if (m > 0 && n > 0) {
+        if (cA[a[0]] == 0xFFu) {
+            e = (1u << 8) | a[0];
+        } else {
+            for (uint32_t j = 0; j < n && !e; ++j)
+                if (cB[b[j]] == 0xFFu)
+                    e = (2u << 8) | b[j];
+            for (uint32_t i = 1; i < m && !e; ++i)
+                if (cA[a[i]] == 0xFFu)
+                    e = (1u << 8) | a[i];
+        }
+    }
+    const bool work = active && e == 0u && m > 0 && n > 0 && m <= RA;
+
+    uint32_t aoff[RA / 2]; // row offsets into T (code * nb), two per register; rows >= m use the pad row
+#pragma unroll
+    for (int r = 0; r < RA / 2; ++r) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * r + h;
+            uint32_t code = (uint32_t)(na - 1);
+            if (work && (uint32_t)i < m)
+                code = cA[a[i]];
+            pk |= (code * (uint32_t)nb) << (16 * h);
+        }
+        aoff[r] = pk;
+    }
+    int H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = (i + 1) * gap; // H[i+1][0], align.go:112-115
+
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)max_lenB * NG * 2 * 64) + lane;
+    const uint32_t ncol = work ? n : 0u;
+    int top = 0; // H[0][j-1]
+    for (uint32_t jr = 0; jr < max_lenB; ++jr) {
+        if (!__any(jr < ncol))
+            break;
+        if (jr < ncol) {
+            const uint32_t cb = cB[b[jr]];
+            int diag = top, up = top + gap; // H[0][j-1], H[0][j] (:117-120)
+            top = up;
+            uint32_t wG = 0, wL = 0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                const uint32_t ro = (aoff[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const int s = T[ro + cb];
+                const int left = H[i];
+                const int d = diag + s;
+                const int t = max(up, left) + gap;
+                const int h = max(d, t);
+                PH_NW_BIT(wG, t, d);
+                PH_NW_BIT(wL, left, up);
+                diag = left;
+                up = h;
+                H[i] = h;
+                if ((i & 31) == 31 || i == RA - 1) {
+                    dirw[(((size_t)jr * NG + (i >> 5)) * 2 + 0) * 64] = wG;
+                    dirw[(((size_t)jr * NG + (i >> 5)) * 2 + 1) * 64] = wL;
+                }
+            }
+        }
+    }
+    if (!active)
+        return;
+    err[pair] = e;
+    if (e || m > RA) {
+        score[pair] = 0;
+        alnLen[pair] = m > RA && !e ? 0xFFFFFFFFu : 0u;
+        return;
+    }
+    int last = 0; // H[m][n]
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        last = (uint32_t)i + 1u == m ? H[i] : last;
+    score[pair] = m == 0 ? (int64_t)n * gap : (n == 0 ? (int64_t)m * gap : (int64_t)last);
+    uint32_t len = 0;
+    if (work) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
+        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+        uint32_t i = m, j = n;
+        while (i > 0 && j > 0 && len < stride) { // :141: stops as soon as EITHER index reaches 0
+            const uint32_t r = i - 1u, g = r >> 5;
+            const uint32_t rows = min(32u, (uint32_t)RA - 32u * g);
+            const uint32_t bit = rows - 1u - (r & 31u);
+            const uint32_t *wp = dirw + ((size_t)(j - 1u) * NG + g) * 2 * 64;
+            const uint32_t wg = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wl = __hip_atomic_load(wp + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint8_t ca, cb;
+            if (((wg >> bit) & 1u) == 0u) {
+                ca = a[i - 1];
+                cb = b[j - 1];
+                --i;
+                --j;
+            } else if (((wl >> bit) & 1u) == 0u) {
+                ca = a[i - 1];
+                cb = '-';
+                --i;
+            } else {
+                ca = '-';
+                cb = b[j - 1];
+                --j;
+            }
+            outA[stride - 1 - len] = ca;
+            outB[stride - 1 - len] = cb;
+            ++len;
+        }
+    }
+    alnLen[pair] = len;
+}
+#undef PH_NW_BIT
+
 struct Plan {
     int ra;            // 0 = generic
     Window win;
@@ -689,6 +850,17 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
         p.per_pair = std::max(p.per_pair, per);
     }
     return p;
+}
+
+// NW workspace per pair: the larger of the generic layout (2-bit codes + the H column) and the
+// register-tiled one (G and L words per 32 rows of RA)
+static inline int nw_ra(uint32_t max_lenA) { return max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : max_lenA <= 256 ? 256 : 0; }
+static uint64_t nw_per_pair(uint32_t max_lenA, uint64_t max_lenB)
+{
+    const uint64_t generic = max_lenB * ((max_lenA + 15) / 16) * 4 + (uint64_t)max_lenA * 4 + 8;
+    const int ra = nw_ra(max_lenA);
+    const uint64_t reg = ra ? max_lenB * (uint64_t)((ra + 31) / 32) * 8 : 0;
+    return std::max<uint64_t>(std::max(generic, reg), 8);
 }
 
 } // namespace k3t
@@ -894,9 +1066,11 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
 
 extern "C" {
 
+int polyhip_nw_last_path(void) { return k3t::g_nw_last_path; }
+
 size_t polyhip_nw_workspace_bytes(uint64_t npairs, uint32_t max_lenA, uint64_t max_lenB)
 {
-    const uint64_t per_pair = (uint64_t)max_lenB * ((max_lenA + 15) / 16) * 4 + (uint64_t)max_lenA * 4 + 8;
+    const uint64_t per_pair = k3t::nw_per_pair(max_lenA, max_lenB);
     const uint64_t padded = (npairs + k3t::THREADS - 1) / k3t::THREADS * k3t::THREADS;
     uint64_t want = padded * per_pair;
     const uint64_t cap = 8ull << 30, floor_ = (uint64_t)k3t::THREADS * per_pair;
@@ -918,14 +1092,43 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
                "polyhip_nw_align_batch: aln_stride %u < max_lenA + lenB", aln_stride);
     if ((int64_t)sc->absmax * (int64_t)((uint64_t)max_lenA + lenB) >= (1ll << 31))
         return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_nw_align_batch: scores could overflow int32");
-    const uint64_t per_pair = (uint64_t)lenB * ((max_lenA + 15) / 16) * 4 + (uint64_t)max_lenA * 4 + 8;
+    const uint64_t per_pair = k3t::nw_per_pair(max_lenA, lenB);
     const uint64_t chunk = (work_bytes & ~(size_t)255) / per_pair / k3t::THREADS * k3t::THREADS;
     PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_nw_align_batch: workspace too small (%zu B; %llu B per pair, >= %d pairs)",
                work_bytes, (unsigned long long)per_pair, k3t::THREADS);
     hipStream_t st = as_stream(stream);
+    // register-tiled kernel: lenA <= 256, the compact table fits LDS, columns below 2^31; else the generic one
+    const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+    const size_t reg_smem = (size_t)na * nb * 4 + 512;
+    const char *nw_env = getenv("POLYHIP_NW_GENERIC"); // testing aid: force the generic kernel
+    const int reg_ra = (reg_smem <= 60 * 1024 && (size_t)na * nb < 65536 && lenB < (1ull << 31) && max_lenA > 0 &&
+                        lenB > 0 && !(nw_env && nw_env[0] == '1'))
+                           ? k3t::nw_ra(max_lenA)
+                           : 0;
+    k3t::g_nw_last_path = reg_ra ? 1 : 2;
     for (uint64_t p0 = 0; p0 < npairs; p0 += chunk) {
         const uint64_t p1 = std::min(npairs, p0 + chunk);
         const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
+        if (reg_ra) {
+#define PH_NW_LAUNCH(RA_)                                                                                             \
+    do {                                                                                                              \
+        auto kern = k3t::nw_reg_kernel<RA_>;                                                                          \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)reg_smem));                                                                   \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), reg_smem, st, d_A, d_offA, p0, p1, d_B, d_offB, lenB, \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, (uint32_t)lenB,               \
+                           static_cast<uint32_t *>(d_work), d_score, d_err, d_alnA, d_alnB, d_alnLen, aln_stride);    \
+    } while (0)
+            if (reg_ra == 64)
+                PH_NW_LAUNCH(64);
+            else if (reg_ra == 152)
+                PH_NW_LAUNCH(152);
+            else
+                PH_NW_LAUNCH(256);
+#undef PH_NW_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
+        }
         const size_t nl = (size_t)blocks * k3t::THREADS;
         int32_t *hbuf = static_cast<int32_t *>(d_work);
         uint32_t *dirg = reinterpret_cast<uint32_t *>(hbuf + nl * (max_lenA ? max_lenA : 1));

@@ -48,13 +48,18 @@ def test_TestNeedlemanWunsch(al):
         align.NeedlemanWunsch("GAXTACA", "GCATGCU", sc)
 
 
-def test_batch_matches_oracle(al):
+@pytest.mark.parametrize("maxlen,generic", [(60, False), (150, False), (150, True), (250, False), (300, False)])
+def test_batch_matches_oracle(al, monkeypatch, maxlen, generic):
+    """ragged batches against the oracle: the register-tiled kernel (lenA <= 64 / 152 / 256 rows) and the generic
+    one (longer A, or POLYHIP_NW_GENERIC=1); invalid symbols; per-pair and shared B"""
+    if generic:
+        monkeypatch.setenv("POLYHIP_NW_GENERIC", "1")
     rng = np.random.default_rng(5)
     mat = [[0, 0, 0, 0, 0], [0, 3, -3, -3, -3], [0, -3, 3, -3, -3], [0, -3, -3, 3, -3], [0, -3, -3, -3, 3]]
     for gap in (-2, -1, 0, 1):
         sc = _scoring(al, "-ACGT", mat, gap)
         om = orc.SubstitutionMatrix("-ACGT", "-ACGT", mat)
-        A = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(0, 90))).astype(np.uint8)) for _ in range(300)]
+        A = [bytes(rng.choice(list(b"ACGT"), int(rng.integers(0, min(maxlen, 160)))).astype(np.uint8)) for _ in range(300)]
         B = []
         for a in A:
             b = bytearray(a)
@@ -64,13 +69,20 @@ def test_batch_matches_oracle(al):
                 else:
                     b.insert(int(rng.integers(0, len(b) + 1)), int(rng.choice(list(b"ACGT"))))
             B.append(bytes(b))
-        A += [b"ACGT" * 70, b"A" * 300]
-        B += [b"ACGA" * 65, b"A" * 17]
+        A += [(b"ACGT" * 70)[:maxlen], b"A" * maxlen, b"ACNT", b"ACGT", b"TTTT"]
+        B += [b"ACGA" * 65, b"A" * 17, b"ACGT", b"ACXT", b""]
         pa, oa = _pack(A)
         pb, ob = _pack(B)
         score, err, sa, sb = al[0].nw_align_packed(sc, pa, oa, pb, ob)
+        assert al[0].nw_last_path() == (1 if maxlen <= 256 and not generic else 2)
         for p, (a, b) in enumerate(zip(A, B)):
-            w = orc.needleman_wunsch(a, b, om, gap)
+            try:
+                w = orc.needleman_wunsch(a, b, om, gap)
+            except orc.AlphabetError as ex:
+                sym = str(ex).split(" ")[1]
+                assert int(err[p]) & 0xFF == ord(sym) and int(score[p]) == 0 and sa[p] == b"" and sb[p] == b""
+                continue
+            assert int(err[p]) == 0
             wa = w[1] if isinstance(w[1], bytes) else w[1].encode()
             wb = w[2] if isinstance(w[2], bytes) else w[2].encode()
             assert (int(score[p]), sa[p], sb[p]) == (w[0], wa, wb), (p, gap, a, b)
