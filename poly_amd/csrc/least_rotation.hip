@@ -33,7 +33,7 @@ namespace polyhip {
 namespace k5 {
 
 constexpr int THREADS = 256;
-constexpr uint32_t LIST_CAP = 4096;      // candidates kept in LDS
+constexpr uint32_t LIST_CAP = 1024;      // candidates kept in LDS (random DNA: ~n/256 after the first word)
 constexpr uint32_t MAX_ROUNDS = 64;      // 4 bytes per round before the serial fallback
 constexpr uint32_t LDS_SEQ_MAX = 120 * 1024;
 
@@ -89,6 +89,15 @@ template <class Ptr> __device__ uint64_t two_pointer_wave(Ptr s, uint64_t n)
     return i < j ? i : j;
 }
 
+// 4 bytes of an LDS-staged sequence at byte position p as a big-endian word: two aligned dwords, a
+// funnel shift and a byte swap (the staged copy carries 8 wrapped bytes behind s[n-1])
+__device__ __forceinline__ uint32_t word_lds(const uint32_t *__restrict__ L, uint32_t p)
+{
+    const uint32_t d0 = L[p >> 2], d1 = L[(p >> 2) + 1];
+    const uint32_t le = __builtin_amdgcn_alignbyte(d1, d0, p & 3u);
+    return __builtin_bswap32(le);
+}
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *__restrict__ seqs,
                                                                 const uint64_t *__restrict__ offs, uint64_t nseq,
@@ -101,6 +110,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
     __shared__ uint32_t cnt;
     __shared__ uint64_t answer;
     const int tid = threadIdx.x;
+    uint32_t *L = reinterpret_cast<uint32_t *>(lds);
 
     for (uint64_t q = blockIdx.x; q < nseq; q += gridDim.x) {
         const uint64_t o0 = offs[q];
@@ -113,16 +123,28 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                 rotated[o0] = g[0];
             continue;
         }
-        if (IN_LDS && n + 4 > lds_seq_bytes)
+        if (IN_LDS && n + 8 > lds_seq_bytes)
             continue; // the global-memory launch handles this one
-        if (!IN_LDS && n + 4 <= lds_seq_bytes)
+        if (!IN_LDS && n + 8 <= lds_seq_bytes)
             continue;
 
-        // ---- stage the sequence (+ 4 wrapped bytes so a word never wraps)
+        // ---- stage the sequence (+ 8 wrapped bytes so a word never wraps), a dword per thread and step:
+        // aligned global dwords funnelled to the sequence's own alignment; the last dword index is clamped
+        // (the bytes it would add lie behind the sequence)
         __syncthreads();
         if (IN_LDS) {
-            for (uint64_t t = tid; t < n + 4; t += THREADS)
-                lds[t] = g[t < n ? t : (t - n) % n];
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(g);
+            const uint32_t sh = (uint32_t)(addr & 3u);
+            const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+            const uint64_t last_dw = (sh + n - 1) >> 2; // dword holding s[n-1]
+            const uint64_t ndw = (n + 3) >> 2;
+            for (uint64_t t = tid; t < ndw; t += THREADS) {
+                const uint32_t d0 = gd[t], d1 = gd[t + 1 <= last_dw ? t + 1 : last_dw];
+                L[t] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            }
+            __syncthreads();
+            if (tid < 8) // s[0..7] again behind s[n-1] (n may be tiny: cyclic)
+                lds[n + tid] = lds[(uint64_t)tid % n];
         }
         if (tid == 0) {
             cnt = 0;
@@ -131,29 +153,57 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         __syncthreads();
 
         auto byte_at = [&](uint64_t p) -> uint32_t { // cyclic position p < 2n
-            return IN_LDS ? lds[p] : g[p >= n ? p - n : p];
+            return IN_LDS ? lds[p >= n ? p - n : p] : g[p >= n ? p - n : p];
         };
         auto word = [&](uint64_t p) -> uint32_t { // big-endian 4 bytes at cyclic position p < 2n
             p -= p >= n ? n : 0;
-            if (IN_LDS)
-                return word_at(lds, p);
+            if (IN_LDS) {
+                if (n >= 4)
+                    return word_lds(L, (uint32_t)p);
+                return word_at(lds, p); // n = 2, 3: the 8 wrapped bytes cover it
+            }
             return ((uint32_t)g[p] << 24) | ((uint32_t)g[(p + 1) % n] << 16) | ((uint32_t)g[(p + 2) % n] << 8) |
                    (uint32_t)g[(p + 3) % n];
         };
 
-        // ---- 1. least first word
+        // ---- 1. least first word (LDS: a thread takes 4 neighbouring positions from two dwords)
         uint32_t m = 0xFFFFFFFFu;
-        for (uint64_t p = tid; p < n; p += THREADS)
-            m = min(m, word(p));
-        m = block_min(m, red);
         bool serial = false;
-        for (uint64_t p0 = 0; p0 < n; p0 += THREADS) {
-            const uint64_t p = p0 + tid;
-            const bool is = p < n && word(p) == m;
-            if (is) {
-                const uint32_t slot = atomicAdd(&cnt, 1u);
-                if (slot < LIST_CAP)
-                    listA[slot] = (uint32_t)p;
+        if (IN_LDS && n >= 8) {
+            const uint64_t nquad = (n + 3) >> 2;
+            for (uint64_t t = tid; t < nquad; t += THREADS) {
+                const uint32_t d0 = L[t], d1 = L[t + 1];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (4 * t + k < n)
+                        m = min(m, __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, k)));
+            }
+            m = block_min(m, red);
+            for (uint64_t t0 = 0; t0 < nquad; t0 += THREADS) {
+                const uint64_t t = t0 + tid;
+                if (t < nquad) {
+                    const uint32_t d0 = L[t], d1 = L[t + 1];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; ++k)
+                        if (4 * t + k < n && __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, k)) == m) {
+                            const uint32_t slot = atomicAdd(&cnt, 1u);
+                            if (slot < LIST_CAP)
+                                listA[slot] = (uint32_t)(4 * t + k);
+                        }
+                }
+            }
+        } else {
+            for (uint64_t p = tid; p < n; p += THREADS)
+                m = min(m, word(p));
+            m = block_min(m, red);
+            for (uint64_t p0 = 0; p0 < n; p0 += THREADS) {
+                const uint64_t p = p0 + tid;
+                const bool is = p < n && word(p) == m;
+                if (is) {
+                    const uint32_t slot = atomicAdd(&cnt, 1u);
+                    if (slot < LIST_CAP)
+                        listA[slot] = (uint32_t)p;
+                }
             }
         }
         __syncthreads();
@@ -215,10 +265,30 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         if (tid == 0)
             rot[q] = r;
         if (rotated) { // RotateSequence: (s + s)[r : r + n], seqhash.go:131-137
-            for (uint64_t t = tid; t < n; t += THREADS) {
-                uint64_t p = t + r;
-                p -= p >= n ? n : 0;
-                rotated[o0 + t] = (uint8_t)byte_at(p);
+            uint8_t *out = rotated + o0;
+            if (IN_LDS && n >= 8) {
+                // bytes up to the first aligned output dword and behind the last one singly, whole dwords between
+                const uint64_t head = (4 - (reinterpret_cast<uintptr_t>(out) & 3u)) & 3u;
+                const uint64_t nd = (n - head) >> 2, tail0 = head + 4 * nd;
+                if ((uint64_t)tid < head)
+                    out[tid] = (uint8_t)byte_at((uint64_t)tid + r);
+                if ((uint64_t)tid < n - tail0)
+                    out[tail0 + tid] = (uint8_t)byte_at(tail0 + tid + r);
+                uint32_t *od = reinterpret_cast<uint32_t *>(out + head);
+                for (uint64_t t = tid; t < nd; t += THREADS) {
+                    uint64_t p = head + 4 * t + r;
+                    p -= p >= n ? n : 0;
+                    // p + 3 may run past s[n-1]: the wrapped bytes behind it continue with s[0..]
+                    const uint32_t d0 = L[p >> 2], d1 = L[(p >> 2) + 1];
+                    const uint32_t w = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(p & 3u));
+                    od[t] = w;
+                }
+            } else {
+                for (uint64_t t = tid; t < n; t += THREADS) {
+                    uint64_t p = t + r;
+                    p -= p >= n ? n : 0;
+                    out[t] = (uint8_t)byte_at(p);
+                }
             }
         }
     }
@@ -239,7 +309,7 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
     PH_REQUIRE(d_seqs && d_offsets && d_rot_index, "polyhip_least_rotation_batch: null pointer");
     hipStream_t st = as_stream(stream);
     // LDS holds sequences up to LDS_SEQ_MAX; size the allocation to the batch's longest
-    uint64_t lds_seq = max_len + 4;
+    uint64_t lds_seq = max_len + 8;
     if (lds_seq > k5::LDS_SEQ_MAX)
         lds_seq = k5::LDS_SEQ_MAX;
     lds_seq = (lds_seq + 15) & ~15ull;
@@ -250,7 +320,7 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
     hipLaunchKernelGGL(kl, dim3(blocks), dim3(k5::THREADS), lds_seq, st, d_seqs, d_offsets, n, lds_seq, d_rot_index,
                        d_rotated);
     PH_HIP(hipGetLastError());
-    if (max_len + 4 > lds_seq) {
+    if (max_len + 8 > lds_seq) {
         hipLaunchKernelGGL((k5::least_rotation_kernel<false>), dim3(blocks), dim3(k5::THREADS), 0, st, d_seqs, d_offsets,
                            n, lds_seq, d_rot_index, d_rotated);
         PH_HIP(hipGetLastError());
