@@ -102,16 +102,32 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
         const uint64_t off = base + (uint64_t)b * 64;
         const uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
         uint32_t w[16];
+        if (blen == 64) {
+            // a full block: aligned dwords funnelled to the data's own alignment (the 17th dword is only
+            // touched when it holds bytes of this block)
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(data + off);
+            const uint32_t sh = (uint32_t)(addr & 3u);
+            const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+            uint32_t d[17];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            uint32_t x = 0;
+            for (int i = 0; i < 16; ++i)
+                d[i] = gd[i];
+            d[16] = sh ? gd[16] : 0u;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t p = 4 * i + j;
-                if (p < blen)
-                    x |= (uint32_t)data[off + p] << (8 * j);
+            for (int i = 0; i < 16; ++i)
+                w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                uint32_t x = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t p = 4 * i + j;
+                    if (p < blen)
+                        x |= (uint32_t)data[off + p] << (8 * j);
+                }
+                w[i] = x;
             }
-            w[i] = x;
         }
         uint32_t flags = 0;
         if (b == 0)
@@ -162,29 +178,100 @@ __device__ __forceinline__ bool in_set(uint32_t c, const char *set)
     return false;
 }
 
-// normalise + validate (+ reverse complement).  err[q] = 0 or (code << 8) | first offending letter
+// 4 bytes at an arbitrary address: one or two aligned dwords and a funnel shift (the second dword is
+// only touched when it holds some of the 4 bytes)
+__device__ __forceinline__ uint32_t load4(const uint8_t *p)
+{
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = (uint32_t)(addr & 3u);
+    const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+    const uint32_t d0 = gd[0], d1 = sh ? gd[1] : 0u;
+    return __builtin_amdgcn_alignbyte(d1, d0, sh);
+}
+
+// normalise + validate (+ reverse complement).  err[q] = 0 or (code << 8) | first offending letter.
+// Byte maps live in LDS (normalised letter, its complement, membership in the alphabet); the sequence is
+// walked in whole OUTPUT dwords (unaligned 4-byte loads on the input side), the few bytes in front of the
+// first and behind the last aligned dword singly.
 __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restrict__ seqs,
                                                          const uint64_t *__restrict__ offs, uint64_t n, int seq_type,
                                                          int want_rc, uint8_t *__restrict__ norm,
                                                          uint8_t *__restrict__ rc, uint32_t *__restrict__ err)
 {
     __shared__ unsigned long long first_bad; // (position << 8) | letter
+    __shared__ uint8_t upL[256], cmpL[256], okL[256];
+    {
+        const uint32_t b = threadIdx.x; // THREADS == 256
+        uint32_t c = ascii_upper(b);
+        if (seq_type == 1 && c == 'U') // seqhash.go:146-148
+            c = 'T';
+        upL[b] = (uint8_t)c;
+        cmpL[b] = (uint8_t)complement_upper(c); // transform.go:15-23, of the normalised letter
+        okL[b] = seq_type == 2 ? in_set(c, "ACDEFGHIKLMNPQRSTVWYUO*BXZ") : in_set(c, "ATUGCYRSWKMBDHVNZ");
+    }
     for (uint64_t q = blockIdx.x; q < n; q += gridDim.x) {
         const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
+        const uint8_t *src = seqs + o0;
         __syncthreads();
         if (threadIdx.x == 0)
             first_bad = ~0ull;
         __syncthreads();
-        for (uint64_t t = threadIdx.x; t < len; t += THREADS) {
-            uint32_t c = ascii_upper(seqs[o0 + t]);
-            if (seq_type == 1 && c == 'U') // seqhash.go:146-148
-                c = 'T';
-            const bool good = seq_type == 2 ? in_set(c, "ACDEFGHIKLMNPQRSTVWYUO*BXZ") : in_set(c, "ATUGCYRSWKMBDHVNZ");
-            if (!good)
+        auto one = [&](uint64_t t) { // byte t of the sequence -> norm[t], rc[len-1-t]
+            const uint32_t b = src[t], c = upL[b];
+            if (!okL[b])
                 atomicMin(&first_bad, ((unsigned long long)t << 8) | c);
             norm[o0 + t] = (uint8_t)c;
             if (want_rc)
-                rc[o0 + (len - 1 - t)] = (uint8_t)complement_upper(c); // transform.go:15-23
+                rc[o0 + (len - 1 - t)] = cmpL[b];
+        };
+        if (len < 16) {
+            for (uint64_t t = threadIdx.x; t < len; t += THREADS)
+                one(t);
+        } else {
+            // norm: aligned output dwords [head, head + 4*nd)
+            {
+                uint8_t *dst = norm + o0;
+                const uint64_t head = (4 - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
+                const uint64_t nd = (len - head) >> 2, tail0 = head + 4 * nd;
+                if (threadIdx.x < head || (threadIdx.x >= 4 && threadIdx.x - 4 < len - tail0)) {
+                    const uint64_t t = threadIdx.x < 4 ? threadIdx.x : tail0 + (threadIdx.x - 4);
+                    const uint32_t b = src[t];
+                    if (!okL[b])
+                        atomicMin(&first_bad, ((unsigned long long)t << 8) | upL[b]);
+                    dst[t] = upL[b];
+                }
+                uint32_t *od = reinterpret_cast<uint32_t *>(dst + head);
+                for (uint64_t d = threadIdx.x; d < nd; d += THREADS) {
+                    const uint64_t t = head + 4 * d;
+                    const uint32_t w = load4(src + t);
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t b = (w >> (8 * k)) & 0xFFu;
+                        if (!okL[b])
+                            atomicMin(&first_bad, ((unsigned long long)(t + k) << 8) | upL[b]);
+                        o |= (uint32_t)upL[b] << (8 * k);
+                    }
+                    od[d] = o;
+                }
+            }
+            // reverse complement: output byte u is the complement of input byte len-1-u
+            if (want_rc) {
+                uint8_t *dst = rc + o0;
+                const uint64_t head = (4 - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
+                const uint64_t nd = (len - head) >> 2, tail0 = head + 4 * nd;
+                if (threadIdx.x < head || (threadIdx.x >= 4 && threadIdx.x - 4 < len - tail0)) {
+                    const uint64_t u = threadIdx.x < 4 ? threadIdx.x : tail0 + (threadIdx.x - 4);
+                    dst[u] = cmpL[src[len - 1 - u]];
+                }
+                uint32_t *od = reinterpret_cast<uint32_t *>(dst + head);
+                for (uint64_t d = threadIdx.x; d < nd; d += THREADS) {
+                    const uint64_t u = head + 4 * d;           // output bytes u .. u+3
+                    const uint32_t w = load4(src + (len - 4 - u)); // input bytes len-4-u .. len-1-u, to be reversed
+                    od[d] = (uint32_t)cmpL[w >> 24] | ((uint32_t)cmpL[(w >> 16) & 0xFFu] << 8) |
+                            ((uint32_t)cmpL[(w >> 8) & 0xFFu] << 16) | ((uint32_t)cmpL[w & 0xFFu] << 24);
+                }
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0)
@@ -192,15 +279,77 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
     }
 }
 
+// sort.Strings(...)[0] (seqhash.go:180-193): sel[q] = 1 when the second candidate is the bytewise smaller one.
+// One wave per sequence, 64 bytes per step, out at the first difference.
+__global__ __launch_bounds__(THREADS) void select_kernel(const uint8_t *__restrict__ cand0,
+                                                        const uint8_t *__restrict__ cand1,
+                                                        const uint64_t *__restrict__ offs, uint64_t n,
+                                                        uint32_t *__restrict__ sel)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t nw = (uint64_t)gridDim.x * (THREADS / 64);
+    for (uint64_t q = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); q < n; q += nw) {
+        const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
+        uint32_t pick = 0;
+        for (uint64_t t0 = 0; t0 < len; t0 += 64) {
+            const uint64_t t = t0 + lane;
+            const uint32_t a = t < len ? cand0[o0 + t] : 0u, b = t < len ? cand1[o0 + t] : 0u;
+            const uint64_t ne = __ballot(a != b);
+            if (ne) {
+                const int f = __builtin_ctzll(ne);
+                pick = (uint32_t)__builtin_amdgcn_readlane((int)b, f) < (uint32_t)__builtin_amdgcn_readlane((int)a, f);
+                break;
+            }
+        }
+        if (lane == 0)
+            sel[q] = pick;
+    }
+}
+
+// chaining values of every chunk of every multi-chunk sequence, ONE THREAD PER CHUNK over the whole batch
+// (a chunk's 16 blocks chain, so the chunk is the unit of parallelism): chunk g belongs to the sequence q
+// with cvoff[q] <= g < cvoff[q + 1] (binary search), its value goes to level A of that sequence's tree.
+__global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restrict__ cand0,
+                                                       const uint8_t *__restrict__ cand1,
+                                                       const uint64_t *__restrict__ offs, uint64_t n,
+                                                       const uint64_t *__restrict__ cvoff, uint64_t max_chunks,
+                                                       const uint32_t *__restrict__ sel, const uint32_t *__restrict__ err,
+                                                       uint32_t *__restrict__ cvbuf)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (g >= max_chunks)
+        return;
+    uint64_t lo = 0, hi = n; // last q with cvoff[q] <= g
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (cvoff[mid] <= g)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    const uint64_t q = lo, o0 = offs[q], len = offs[q + 1] - o0;
+    const uint64_t nchunks = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
+    const uint64_t c = g - cvoff[q];
+    if (c >= nchunks || nchunks == 1 || err[q] != 0u)
+        return; // behind the batch's last chunk; single-chunk sequences are the root compression's business
+    const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
+    uint32_t cv[8];
+    chunk_cv(data, len, c, false, cv);
+    uint32_t *A = cvbuf + cvoff[q] * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        A[c * 8 + i] = cv[i];
+}
+
 // choose the bytewise smaller candidate (sort.Strings), BLAKE3 it, format the seqhash
 __global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restrict__ cand0,
                                                        const uint8_t *__restrict__ cand1,
                                                        const uint64_t *__restrict__ offs, uint64_t n,
                                                        const uint64_t *__restrict__ cvoff, uint32_t *__restrict__ cvbuf,
+                                                       const uint32_t *__restrict__ sel,
                                                        const uint32_t *__restrict__ err, uint32_t prefix_letters,
                                                        char *__restrict__ out)
 {
-    __shared__ unsigned long long first_diff;
     const int tid = threadIdx.x;
     for (uint64_t q = blockIdx.x; q < n; q += gridDim.x) {
         char *o = out + q * 72;
@@ -210,26 +359,7 @@ __global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restric
             continue;
         }
         const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
-        const uint8_t *data = cand0 + o0;
-        if (cand1) { // first differing byte decides
-            __syncthreads();
-            if (tid == 0)
-                first_diff = ~0ull;
-            __syncthreads();
-            for (uint64_t t0 = 0; t0 < len; t0 += BTHREADS) {
-                const uint64_t t = t0 + tid;
-                if (t < len && cand0[o0 + t] != cand1[o0 + t])
-                    atomicMin(&first_diff, (unsigned long long)t);
-                __syncthreads();
-                if (first_diff != ~0ull)
-                    break;
-                __syncthreads();
-            }
-            __syncthreads();
-            const unsigned long long d = first_diff;
-            if (d != ~0ull && cand1[o0 + d] < cand0[o0 + d])
-                data = cand1 + o0;
-        }
+        const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
         const uint64_t nchunks = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
         uint32_t *A = cvbuf + cvoff[q] * 16, *B = A + nchunks * 8; // two levels of chaining values
         uint32_t root[8];
@@ -237,13 +367,7 @@ __global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restric
             if (tid == 0)
                 chunk_cv(data, len, 0, true, root);
         } else {
-            for (uint64_t c = tid; c < nchunks; c += BTHREADS) {
-                uint32_t cv[8];
-                chunk_cv(data, len, c, false, cv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    A[c * 8 + i] = cv[i];
-            }
+            // level A was filled by chunk_kernel
             uint64_t m = nchunks;
             uint32_t *src = A, *dst = B;
             while (m > 2) {
@@ -344,7 +468,7 @@ __global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__rest
 }
 
 struct Layout {
-    size_t off_norm, off_rc, off_rot0, off_rot1, off_rotidx, off_cvoff, off_cv, total;
+    size_t off_norm, off_rc, off_rot0, off_rot1, off_rotidx, off_cvoff, off_sel, off_cv, total;
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -358,7 +482,8 @@ static Layout layout(uint64_t n, uint64_t total_bytes, int circular, int ds)
     L.off_rot0 = o; o += circular ? al(total_bytes + 16) : 0;
     L.off_rot1 = o; o += (circular && ds) ? al(total_bytes + 16) : 0;
     L.off_rotidx = o; o += circular ? al(n * 8) : 0;
-    L.off_cvoff = o; o += al(n * 8);
+    L.off_cvoff = o; o += al((n + 1) * 8);
+    L.off_sel = o; o += al(n * 4);
     // two levels of 8-word chaining values per chunk; chunks <= total_bytes / 1024 + n
     L.off_cv = o; o += al((total_bytes / s2::CHUNK + n + 1) * 16 * 4);
     L.total = o;
@@ -399,6 +524,7 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     uint64_t *rotidx = reinterpret_cast<uint64_t *>(w + L.off_rotidx);
     uint64_t *cvoff = reinterpret_cast<uint64_t *>(w + L.off_cvoff);
     uint32_t *cvbuf = reinterpret_cast<uint32_t *>(w + L.off_cv);
+    uint32_t *sel = reinterpret_cast<uint32_t *>(w + L.off_sel);
 
     const unsigned blocks = (unsigned)std::min<uint64_t>(n, 256ull * 32ull);
     hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type,
@@ -420,8 +546,17 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     hipLaunchKernelGGL(s2::chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d_offsets, n, cvoff);
     const uint32_t letters = (uint32_t)(seq_type == 0 ? 'D' : seq_type == 1 ? 'R' : 'P') |
                              ((uint32_t)(circular ? 'C' : 'L') << 8) | ((uint32_t)(double_stranded ? 'D' : 'S') << 16);
-    hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvoff, cvbuf, d_err,
-                       letters, d_out);
+    if (c1) {
+        const unsigned sblocks = (unsigned)std::min<uint64_t>((n + 3) / 4, 256ull * 32ull);
+        hipLaunchKernelGGL(s2::select_kernel, dim3(sblocks), dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, sel);
+    }
+    {
+        const uint64_t max_chunks = total_bytes / s2::CHUNK + n + 1; // >= the batch's chunk count
+        hipLaunchKernelGGL(s2::chunk_kernel, dim3((unsigned)((max_chunks + s2::THREADS - 1) / s2::THREADS)),
+                           dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, cvoff, max_chunks, sel, d_err, cvbuf);
+    }
+    hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvoff, cvbuf, sel,
+                       d_err, letters, d_out);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
