@@ -23,5 +23,8 @@ run ${R}_bench_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${
 run ${R}_bench_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_bench_write -o x -- $BENCH
 run ${R}_calib_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_calib_fetch -o x -- scripts/ubench/hbm_calib
 run ${R}_calib_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_calib_write -o x -- scripts/ubench/hbm_calib
-for t in bench_stats bench_full_stats bench_fetch bench_write calib_fetch calib_write; do echo "== $t"; grep -E "sketch_fast_kernel|sketch_general|read4|read16|write4|write8|write16|failed" $ROOT/gpurun_out/${R}_$t.md | head -12; done
+# K3 (co-headline): kernel stats of score pass + traceback at config 4, and the issue counters of the packed pass
+run ${R}_k3_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_k3_stats -o x -- python scripts/quick_k3tb.py
+run ${R}_k3_pmc --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k3_pmc -o x -- python scripts/quick_k3tb.py 262144
+for t in bench_stats bench_full_stats bench_fetch bench_write calib_fetch calib_write k3_stats k3_pmc; do echo "== $t"; grep -E "sketch_fast_kernel|sketch_general|read4|read16|write4|write8|write16|failed|sw_pk|sw_locate|sw_wave|tb_prof" $ROOT/gpurun_out/${R}_$t.md | head -12; done
 rm -rf $ROOT/gpurun_out/prof_${R}_*   # keep the summaries, drop the databases
