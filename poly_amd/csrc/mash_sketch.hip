@@ -38,6 +38,9 @@
 
 // PH_ABL != 0 only in scripts/ubench/k1_ablate.hip: knocks out one phase to measure its cost
 // (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage
+#ifndef PH_WPE
+#define PH_WPE 6 // waves per SIMD the fast kernel is register-allocated for (6 workgroups per CU fit its LDS)
+#endif
 #ifndef PH_ABL
 #define PH_ABL 0
 #endif
@@ -558,7 +561,7 @@ __device__ __forceinline__ ReadView view(const uint8_t *__restrict__ seqs, const
 // Persistent workgroups: each one walks the batch with stride gridDim.x.  Sequences the fast
 // pass cannot finish exactly are appended to `redo` for the general kernel.
 template <int KS>
-__global__ __launch_bounds__(THREADS) void sketch_fast_kernel(const uint8_t *__restrict__ seqs,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE, 8))) void sketch_fast_kernel(const uint8_t *__restrict__ seqs,
                                                              const uint64_t *__restrict__ offs, uint64_t nseq,
                                                              uint32_t k_rt, uint32_t s, uint32_t *__restrict__ out,
                                                              uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P,
