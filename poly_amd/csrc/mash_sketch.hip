@@ -41,6 +41,9 @@
 #ifndef PH_WPE
 #define PH_WPE 6 // waves per SIMD the fast kernel is register-allocated for (6 workgroups per CU fit its LDS)
 #endif
+#ifndef PH_CAPK
+#define PH_CAPK 12u // candidate buffer of the fast pass: s + PH_CAPK * sqrt(s) + 64 entries
+#endif
 #ifndef PH_ABL
 #define PH_ABL 0
 #endif
@@ -718,7 +721,7 @@ static Launch plan(uint32_t k, uint32_t s)
     uint32_t rt = 1;
     while ((uint64_t)rt * rt < s)
         ++rt;
-    L.capf = (s4 + 12u * rt + 64u + 63u) & ~63u;
+    L.capf = (s4 + PH_CAPK * rt + 64u + 63u) & ~63u;
     L.cap = s4 + TW + 64u; // general pass: shrink to s, then one more round always fits
     const size_t common = (size_t)WAVES * L.n_seq_dw + L.n_P + 16 + 256;
     L.smem_fast = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + 2 * (size_t)L.capf) * 4;
