@@ -1,0 +1,106 @@
+"""Randomised cross-check of the Smith-Waterman paths (not part of the test suite; run on the GPU box):
+random substitution matrices / gaps / lengths / alphabets; every pair: packed pass (3) == exact lane-per-pair
+kernel (1) == wave kernel (4, on a slice); traceback: profile kernel == table kernel; a sample == oracle."""
+import os, sys, time
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+import oracle as orc
+from poly_amd import align, alphabet, matrix
+dev = torch.device('cuda:0')
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+t_end = time.time() + budget
+it = 0
+while time.time() < t_end:
+    rng = np.random.default_rng(seed0 + it)
+    it += 1
+    nsym = int(rng.integers(2, 7))
+    syms = "ACGTNR"[:nsym]
+    style = int(rng.integers(0, 3))
+    if style == 0:
+        mat = rng.integers(-9, 10, (nsym, nsym))
+    elif style == 1:
+        ma, mi = int(rng.integers(1, 12)), -int(rng.integers(0, 12))
+        mat = np.full((nsym, nsym), mi); np.fill_diagonal(mat, ma)
+    else:
+        mat = rng.integers(-3, 4, (nsym, nsym))
+    mat = mat.astype(int).tolist()
+    gap = -int(rng.integers(1, 10))
+    a = alphabet.NewAlphabet(list(syms))
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, mat), gap)
+    om = orc.SubstitutionMatrix(syms, syms, mat)
+    LB = int(rng.choice([7, 60, 333, 1000, 5000, 9000]))
+    L = int(rng.choice([5, 40, 64, 100, 150, 152]))
+    n = 40_000
+    symb = np.frombuffer(syms.encode(), np.uint8)
+    ref = symb[rng.integers(0, nsym, LB)]
+    if rng.random() < 0.3:  # repeats: many ties
+        unit = ref[: max(3, LB // 9)]
+        ref = np.tile(unit, LB // len(unit) + 1)[:LB].copy()
+    starts = rng.integers(0, max(1, LB - L + 1), n)
+    reads = ref[(starts[:, None] + np.arange(L)[None, :]) % LB]
+    rate = rng.random(n)[:, None] * float(rng.choice([0.1, 0.5, 1.0]))
+    hit = rng.random((n, L)) < rate
+    reads[hit] = symb[rng.integers(0, nsym, int(hit.sum()))]
+    lens = rng.integers(0, L + 1, n)
+    lens[rng.random(n) < 0.6] = L
+    offs = np.zeros(n + 1, np.int64); offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)])
+    A = torch.from_numpy(flat.copy()).to(dev); offA = torch.from_numpy(offs).to(dev)
+    B = torch.from_numpy(ref.copy()).to(dev)
+
+    def score_pass(env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            score = torch.full((n,), -7, dtype=torch.int64, device=dev)
+            ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+            work = torch.empty(align.sw_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
+            align.sw_batch_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, work)
+            torch.cuda.synchronize()
+            return (score, ea, eb, er), align.last_path()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    got3, p3 = score_pass({})
+    got1, p1 = score_pass({"POLYHIP_SW_PACKED": "0"})
+    for x, y in zip(got3, got1):
+        assert torch.equal(x, y), ("packed vs exact", it, syms, mat, gap, LB, L, p3, p1)
+    # wave kernel on the first 3000 pairs
+    m = 3000
+    sw = torch.full((m,), -7, dtype=torch.int64, device=dev)
+    wa, wb, we = (torch.full((m,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+    work = torch.empty(align.sw_workspace_bytes(sc, m, L, LB), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, A, offA[: m + 1].contiguous(), L, B, None, LB, sw, wa, wb, we, work)
+    torch.cuda.synchronize()
+    p4 = align.last_path()
+    for x, y in zip((sw, wa, wb, we), got1):
+        assert torch.equal(x, y[:m]), ("wave vs exact", it, syms, mat, gap, LB, L, p4)
+    # traceback: profile kernel (score given) vs table kernel (no score)
+    score, ea, eb, er = got1
+    stride = align.sw_traceback_stride(sc, L, LB)
+    tbw = torch.empty(min(align.sw_traceback_workspace_bytes(sc, n, L, LB), 2 << 30), dtype=torch.uint8, device=dev)
+    outs = []
+    for st in (score, None):
+        aa = torch.zeros((n, stride), dtype=torch.uint8, device=dev); bb = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        ln = torch.zeros(n, dtype=torch.int32, device=dev)
+        align.sw_traceback_dev(sc, A, offA, L, B, None, LB, ea, eb, er, aa, bb, ln, tbw, score_t=st)
+        torch.cuda.synchronize()
+        outs.append((aa, bb, ln, align.sw_traceback_last_path()))
+    assert torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), \
+        ("traceback kernels", it, syms, mat, gap, LB, L, outs[0][3], outs[1][3])
+    # oracle sample
+    s_h, ea_h, eb_h = score.cpu().numpy(), ea.cpu().numpy(), eb.cpu().numpy()
+    a_h, b_h, l_h = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), outs[0][2].cpu().numpy()
+    refb = ref.tobytes()
+    step = max(1, n // max(4, int(2e6 // max(1, L * LB))))
+    for p in range(0, n, step):
+        rd = flat[offs[p]:offs[p + 1]].tobytes()
+        s, sa, sb, oa, ob = orc.smith_waterman(rd, refb, om, gap)
+        sa = sa if isinstance(sa, bytes) else sa.encode(); sb = sb if isinstance(sb, bytes) else sb.encode()
+        assert (int(s_h[p]), int(ea_h[p]), int(eb_h[p])) == (s, oa, ob), ("oracle score", it, p, syms, mat, gap, LB, L)
+        assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, ("oracle strings", it, p, syms, mat, gap, LB, L)
+    print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} paths {p3}/{p1}/{p4} tb {outs[0][3]}/{outs[1][3]} max score {int(score.max())} ok", flush=True)
+print("fuzz done", it, "iterations")
