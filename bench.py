@@ -285,8 +285,26 @@ def main() -> int:
             line_extra = allgather_distance(dev, rank, world)
         except Exception as e:
             line_extra = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE configs[3] sharded: every rank aligns its own 1M reads against the shared reference
+        # (pairs split N/G, no collective); the slowest rank sets the time
+        r, sw_err = None, None
+        try:
+            from poly_amd import bench_extra
+            r = bench_extra.sw(dev, shard=rank)
+            times = [r["score_pass_ms"], r["score_pass_ms"] + r["traceback_ms"]]
+        except Exception as e:  # the collective below must still be entered by every rank
+            sw_err, times = f"{type(e).__name__}: {e}", [float("inf"), float("inf")]
+        t = torch.tensor(times, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if sw_err is None and bool(torch.isfinite(t).all()):
+            cells = world * 1_000_000 * 150 * 5000
+            sw_extra = {"workload": f"{world} x (" + r["workload"] + "), reads sharded over the GPUs",
+                        "cell_updates_per_s": cells / float(t[0].item()) * 1e3, "score_pass_ms": float(t[0].item()),
+                        "cell_updates_per_s_with_traceback": cells / float(t[1].item()) * 1e3}
+        else:
+            sw_extra = {"error": sw_err or "another rank failed"}
         if rank == 0:
-            line["extra"] = {"mash_distance_allgather": line_extra}
+            line["extra"] = {"mash_distance_allgather": line_extra, "smith_waterman": sw_extra}
     if rank == 0 and world == 1:
         if not args.no_extra:
             try:

@@ -45,14 +45,15 @@ def family_sketches(dev, nfam: int, copies: int, L: int, k: int, s: int, seed: i
     return sk
 
 
-def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000):
-    """config 4: n reads of LA bp (substrings of the reference, 5 % substitutions) vs one LB reference, NUC_4, gap -2"""
+def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
+    """config 4: n reads of LA bp (substrings of the reference, 5 % substitutions) vs one LB reference, NUC_4, gap -2;
+    `shard` picks this rank's reads when the pairs are split over GPUs (the reference is the same everywhere)"""
     a = alphabet.NewAlphabet(list("-ACGT"))
     sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
     B = torch.empty(LB, dtype=torch.uint8, device=dev)
     mash.synth_dna_dev(0xC4, B)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(0xC4 + 1)
+    gen.manual_seed(0xC4 + 1 + 7919 * shard)
     starts = torch.randint(0, LB - LA, (n,), device=dev, generator=gen)
     A = B[starts[:, None] + torch.arange(LA, device=dev)[None, :]]
     hit = torch.rand(A.shape, device=dev, generator=gen) < 0.05
