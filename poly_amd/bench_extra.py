@@ -157,6 +157,36 @@ def fastq_feeder(dev, n: int = 200_000, L: int = 1000):
             "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
 
 
+def sw_pairs(dev, n: int = 200_000, L: int = 150):
+    """reads against reads: n pairs of L x L (B = A with 5 % substitutions), every pair its own B"""
+    a = alphabet.NewAlphabet(list("-ACGT"))
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
+    A = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xA2, A)
+    B = A.clone().view(n, L)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0xA2)
+    hit = torch.rand(B.shape, device=dev, generator=gen) < 0.05
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    B[hit] = lut[torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)]
+    B = B.reshape(-1).contiguous()
+    off = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er, ln = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, L, L, False), dtype=torch.uint8, device=dev)
+    ms_score = _time(lambda: align.sw_batch_dev(sc, A, off, L, B, off, L, score, ea, eb, er, work), 3)
+    stride = align.sw_traceback_stride(sc, L, L)
+    tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, L, L), dtype=torch.uint8, device=dev)
+    alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    ms_tb = _time(lambda: align.sw_traceback_dev(sc, A, off, L, B, off, L, ea, eb, er, alnA, alnB, ln, tbw, score_t=score), 2)
+    cells = n * L * L
+    return {"workload": f"{n} pairs of {L} x {L} bp, each with its own B, NUC_4, gap -2",
+            "cell_updates_per_s": cells / ms_score * 1e3, "score_pass_ms": ms_score,
+            "cell_updates_per_s_with_traceback": cells / (ms_score + ms_tb) * 1e3, "traceback_ms": ms_tb,
+            "mean_score": float(score.double().mean())}
+
+
 def nw(dev, n: int = 200_000, L: int = 150):
     """global alignment of n pairs of L bp reads (B = A with 5 % substitutions), NUC_4, gap -2"""
     a = alphabet.NewAlphabet(list("-ACGT"))
@@ -184,7 +214,7 @@ def nw(dev, n: int = 200_000, L: int = 150):
 
 def run(dev) -> dict:
     out = {}
-    for name, fn in (("smith_waterman", sw), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
+    for name, fn in (("smith_waterman", sw), ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder)):
         try:
             out[name] = fn(dev)

@@ -275,6 +275,121 @@ __global__ __launch_bounds__(THREADS) void sw_shared_kernel(
     err[pair] = e;
 }
 
+// ---- per-pair B (reads against reads), register-tiled --------------------------------------------------
+// One pair per lane, H column (RA rows) in VGPRs like sw_shared_kernel, but every lane walks its OWN
+// B: the score of a cell is a lookup in the compact int32 table T[codeA][codeB] in LDS (row offset
+// from the packed row registers, column offset from the lane's current B symbol).  Same key trick for
+// the row-major-first argmax, columns folded in chunks of 1024.
+template <int RA>
+__global__ __launch_bounds__(THREADS) void sw_pair_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    const uint64_t *__restrict__ offB, uint32_t max_lenB, const uint8_t *__restrict__ codeA,
+    const uint8_t *__restrict__ codeB, const int32_t *__restrict__ lutcc, int na, int nb, int gap,
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t Tp[]; // [na][nb] then codeA[256], codeB[256]
+    uint8_t *cA = reinterpret_cast<uint8_t *>(Tp + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x;
+    for (int t = tid; t < na * nb; t += THREADS)
+        Tp[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+
+    const uint64_t pair = (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < npairs;
+    uint32_t m = 0, n = 0;
+    const uint8_t *a = A, *b = B;
+    bool too_long = false;
+    if (active) {
+        const uint64_t o0 = offA[pair], l = offA[pair + 1] - o0;
+        too_long = l > (uint64_t)RA;
+        m = too_long ? 0u : (uint32_t)l;
+        a = A + o0;
+        b = B + offB[pair];
+        n = (uint32_t)(offB[pair + 1] - offB[pair]);
+    }
+    // align.go:189-191 + matrix.go:29-36: the first failing Score() in row-major order
+    uint32_t e = too_long ? 0xFFFFFFFFu : 0u;
+    if (m > 0 && n > 0) {
+        if (cA[a[0]] == 0xFFu) {
+            e = (1u << 8) | a[0];
+        } else {
+            for (uint32_t j = 0; j < n && !e; ++j)
+                if (cB[b[j]] == 0xFFu)
+                    e = (2u << 8) | b[j];
+            for (uint32_t i = 1; i < m && !e; ++i)
+                if (cA[a[i]] == 0xFFu)
+                    e = (1u << 8) | a[i];
+        }
+    }
+    const bool work = active && e == 0u && m > 0 && n > 0;
+
+    uint32_t aoff[RA / 2]; // row offsets into T (code * nb), two per register; rows >= m use the pad row (zeros)
+#pragma unroll
+    for (int r = 0; r < RA / 2; ++r) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = 2 * r + h;
+            uint32_t code = (uint32_t)(na - 1);
+            if (work && (uint32_t)i < m)
+                code = cA[a[i]];
+            pk |= (code * (uint32_t)nb) << (16 * h);
+        }
+        aoff[r] = pk;
+    }
+    int H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+    uint32_t gbest = 0, gbestj = 0; // gbest = h << 8 | (255 - i)
+    const uint32_t ncol = work ? n : 0u;
+    for (uint32_t c0 = 0; c0 < max_lenB; c0 += JC_MAX) {
+        if (!__any(c0 < ncol))
+            break;
+        uint32_t best = 0;
+        const uint32_t jc = min((uint32_t)JC_MAX, max_lenB - c0);
+        for (uint32_t jr = 0; jr < jc; ++jr) {
+            if (!__any(c0 + jr < ncol))
+                break;
+            if (c0 + jr < ncol) {
+                const uint32_t cb = cB[b[c0 + jr]];
+                const uint32_t sj = 1023u - jr;
+                int diag = 0, up = 0;
+#pragma unroll
+                for (int i = 0; i < RA; ++i) {
+                    const uint32_t ro = (aoff[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                    const int sc = Tp[ro + cb];
+                    const int left = H[i];
+                    const int h = max(max(diag + sc, max(up, left) + gap), 0);
+                    // rows >= m sit on the pad row of T (zeros): whatever they hold is below the row above
+                    // them by at least |gap| ... unless gap >= 0, so they are kept out of the argmax by value 0
+                    const uint32_t hv = (uint32_t)i < m ? (uint32_t)h : 0u;
+                    best = max(best, (hv << 18) | ((uint32_t)((255 - i) << 10) | sj));
+                    diag = left;
+                    up = h;
+                    H[i] = h;
+                }
+            }
+        }
+        const uint32_t si = best >> 10;
+        if (si > gbest) { // strict: an earlier chunk (smaller j) wins ties on (h, i)
+            gbest = si;
+            gbestj = c0 + (1023u - (best & 1023u));
+        }
+    }
+    if (!active)
+        return;
+    const uint32_t sc = gbest >> 8;
+    const bool hit = e == 0u && sc > 0u;
+    score[pair] = hit ? (int64_t)sc : 0;
+    endA[pair] = hit ? (255u - (gbest & 255u)) + 1u : 0u;
+    endB[pair] = hit ? gbestj + 1u : 0u;
+    err[pair] = e;
+}
+
 // The reference's loop nest, one pair per lane; previous row in global scratch
 // laid out [j][pair] so a wave's accesses coalesce.
 __global__ __launch_bounds__(256) void sw_generic_kernel(
@@ -346,6 +461,12 @@ struct Plan {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+static bool pair_kernel_off()
+{
+    const char *e = getenv("POLYHIP_SW_PAIR"); // testing aid: POLYHIP_SW_PAIR=0 -> generic kernel
+    return e && e[0] == '0';
+}
+
 static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, bool shared)
 {
     Plan p{};
@@ -371,6 +492,13 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
             p.path = 3;
             p.work_bytes += p.pk.work_bytes;
         }
+    } else if (!shared && max_lenA <= 256 && max_lenA > 0 && lenB > 0 && lenB < (1ull << 31) &&
+               (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 &&
+               (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) < 65536 &&
+               (uint64_t)std::max(sc->smax, 0) * minlen < (uint64_t)SCORE_LIMIT && !pair_kernel_off()) {
+        p.path = 5; // per-pair B, register-tiled (sw_pair_kernel)
+        p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
+        p.work_bytes = 256;
     } else {
         p.path = 2;
         p.work_bytes = align_up((size_t)npairs * (lenB + 1) * sizeof(int32_t), 256);
@@ -588,6 +716,29 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
         PH_SW_FAST_LIST(PH_SW_CASE)
 #undef PH_SW_CASE
         return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_sw_batch: no kernel for RA=%d CP=%d", p.ra, p.cp);
+    }
+    if (p.path == 5) {
+        const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+        const size_t smem = (size_t)na * nb * 4 + 512;
+        const uint64_t nblk = (npairs + k3::THREADS - 1) / k3::THREADS;
+#define PH_SW_PAIR(RA_)                                                                                               \
+    do {                                                                                                              \
+        auto kern = k3::sw_pair_kernel<RA_>;                                                                          \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)smem));                                                                       \
+        hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(k3::THREADS), smem, st, d_A, d_offA, npairs, d_B, d_offB,  \
+                           (uint32_t)lenB, sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_score,      \
+                           d_endA, d_endB, d_err);                                                                    \
+    } while (0)
+        if (p.ra == 64)
+            PH_SW_PAIR(64);
+        else if (p.ra == 152)
+            PH_SW_PAIR(152);
+        else
+            PH_SW_PAIR(256);
+#undef PH_SW_PAIR
+        PH_HIP(hipGetLastError());
+        return POLYHIP_OK;
     }
     const uint64_t blocks = (npairs + 255) / 256;
     hipLaunchKernelGGL(k3::sw_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, d_A, d_offA, npairs, d_B, d_offB,

@@ -102,5 +102,40 @@ while time.time() < t_end:
         sa = sa if isinstance(sa, bytes) else sa.encode(); sb = sb if isinstance(sb, bytes) else sb.encode()
         assert (int(s_h[p]), int(ea_h[p]), int(eb_h[p])) == (s, oa, ob), ("oracle score", it, p, syms, mat, gap, LB, L)
         assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, ("oracle strings", it, p, syms, mat, gap, LB, L)
-    print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} paths {p3}/{p1}/{p4} tb {outs[0][3]}/{outs[1][3]} max score {int(score.max())} ok", flush=True)
+    # per-pair B: register-tiled kernel (5) vs generic (2), any gap sign
+    npp = 4000
+    gap2 = int(rng.integers(-9, 3))
+    sc2 = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, mat), gap2)
+    LBp = int(rng.choice([1, 9, 70, 200, 300]))
+    lb = rng.integers(0, LBp + 1, npp)
+    offb = np.zeros(npp + 1, np.int64); offb[1:] = np.cumsum(lb)
+    Bp = symb[rng.integers(0, nsym, int(offb[-1]) + 1)]
+    # make most B's related to their A: copy a prefix of the read
+    for q in range(0, npp, 3):
+        w = min(int(lb[q]), int(lens[q]))
+        Bp[offb[q]:offb[q] + w] = flat[offs[q]:offs[q] + w]
+    Bt = torch.from_numpy(Bp.copy()).to(dev); offBt = torch.from_numpy(offb).to(dev)
+    offAp = offA[: npp + 1].contiguous()
+    res = []
+    for env in ({}, {"POLYHIP_SW_PAIR": "0"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            sco = torch.full((npp,), -7, dtype=torch.int64, device=dev)
+            xa, xb, xe = (torch.full((npp,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+            wk = torch.empty(align.sw_workspace_bytes(sc2, npp, L, LBp, False), dtype=torch.uint8, device=dev)
+            align.sw_batch_dev(sc2, A, offAp, L, Bt, offBt, LBp, sco, xa, xb, xe, wk)
+            torch.cuda.synchronize()
+            res.append(((sco, xa, xb, xe), align.last_path()))
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    for x, y in zip(res[0][0], res[1][0]):
+        assert torch.equal(x, y), ("pair kernel vs generic", it, syms, mat, gap2, LBp, L, res[0][1], res[1][1])
+    om2 = orc.SubstitutionMatrix(syms, syms, mat)
+    sh, ah, bh = (t.cpu().numpy() for t in res[0][0][:3])
+    for q in range(0, npp, 97):
+        s_, _, _, oa, ob = orc.smith_waterman(flat[offs[q]:offs[q + 1]].tobytes(), Bp[offb[q]:offb[q + 1]].tobytes(), om2, gap2)
+        assert (int(sh[q]), int(ah[q]), int(bh[q])) == (s_, oa, ob), ("pair oracle", it, q, syms, mat, gap2)
+    print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} pp {res[0][1]}/{res[1][1]} gap2 {gap2} paths {p3}/{p1}/{p4} tb {outs[0][3]}/{outs[1][3]} max score {int(score.max())} ok", flush=True)
 print("fuzz done", it, "iterations")
