@@ -52,7 +52,7 @@ constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
 constexpr uint32_t TAB = 2048;        // LDS hash accumulator slots per row
 constexpr uint32_t TAB_LIMIT = 1536;  // distinct columns a row may hit before it goes to the merge
 constexpr uint32_t S_MAX = 8192;      // X SketchSize rowjoin stages in LDS
-constexpr int JOIN_U = 4;             // buckets a wave keeps in flight
+constexpr int JOIN_U = 8;             // buckets a wave keeps in flight
 
 enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_pad, H_EST_LO, H_EST_HI, H_WORDS = 16 };
 enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
