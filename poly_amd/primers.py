@@ -79,7 +79,7 @@ def santalucia_scan_dev(seq_t, length: int, start0: int, nstarts: int, minLen: i
                         stream=None) -> None:
     """Device-resident scan on torch CUDA tensors (uint8 genome, float64 planes)."""
     assert seq_t.is_cuda and tm_t.is_cuda and dH_t.is_cuda and dS_t.is_cuda
-    need = (maxLen - minLen + 1) * ld
+    need = (maxLen - minLen) * ld + nstarts  # the last plane only has to hold its nstarts values
     assert tm_t.numel() >= need and dH_t.numel() >= need and dS_t.numel() >= need
     assert tm_t.element_size() == 8 and seq_t.element_size() == 1 and seq_t.numel() >= length
     _lib.check(_lib.lib().polyhip_santalucia_scan_dev(

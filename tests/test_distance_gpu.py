@@ -208,3 +208,40 @@ def test_c_abi_allgather_one_rank(mash):
     torch.cuda.synchronize()
     assert torch.equal(out, local)
     _lib.check(L.polyhip_comm_destroy(comm))
+
+
+def test_full_size_config3_row_block_properties(mash):
+    """BASELINE configs[2] at FULL size for one rank of 8: a 12,500 x 100,000 row block of the all-vs-all over
+    100,000 sketches of s = 1000 (1000 families x 100 copies at 1 % substitution, sketched by K1).  Properties of
+    the whole block: the diagonal shares all s hashes; the block is symmetric where it overlaps its own rows;
+    counts never exceed s; 300 sampled cells (in-family and out) equal the reference's merge; distances are
+    exactly 1 - count/s in fp64."""
+    import torch
+    from poly_amd import bench_extra
+    dev = torch.device("cuda:0")
+    s = 1000
+    sk = bench_extra.family_sketches(dev, 1000, 100, 10_000, 21, s, seed=0xC3)
+    N, nrows = sk.shape[0], sk.shape[0] // 8
+    X = sk[:nrows]
+    counts = torch.empty((nrows, N), dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(nrows, s, N, s), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(X, sk, counts, work)
+    torch.cuda.synchronize()
+    c = counts.to(torch.int32)
+    assert bool((c.diagonal() == s).all())
+    assert bool((c >= 0).all()) and bool((c <= s).all())
+    assert torch.equal(c[:, :nrows], c[:, :nrows].T)
+    rng = np.random.default_rng(9)
+    sk_h = sk[: nrows].cpu().numpy().view(np.uint32)
+    for _ in range(300):
+        i = int(rng.integers(0, nrows))
+        j = int(rng.integers(0, nrows)) if rng.random() < 0.5 else (i // 100) * 100 + int(rng.integers(0, 100))
+        assert int(c[i, j]) == orc.mash_shared(sk_h[i], sk_h[j]), (i, j)
+    dist = torch.empty((nrows, N), dtype=torch.float64, device=dev)
+    mash.distance_from_counts_dev(counts, s, s, dist)
+    # exactly mash.go:134,139 -- 1 - float64(same)/float64(size), IEEE division (numpy; torch's scalar divide on the
+    # GPU multiplies by the reciprocal, which differs in the last bit)
+    rows = rng.choice(nrows, 64, replace=False)
+    want = 1.0 - c[torch.from_numpy(rows).to(dev)].cpu().numpy().astype(np.float64) / np.float64(s)
+    assert (dist[torch.from_numpy(rows).to(dev)].cpu().numpy() == want).all()
+    assert bool((dist[c == 0] == 1.0).all()) and bool((dist.diagonal() == 0.0).all())

@@ -146,3 +146,36 @@ def test_error_paths(mash):
         mash.New(21, 1).Sketch("ACGT" * 100)
     with pytest.raises(_lib.GoPanic):
         mash.New(21, 0).Sketch("ACGT" * 100)
+
+
+def test_full_size_config2_properties(mash):
+    """BASELINE configs[1] at FULL size (1,000,000 reads x 10 kb, k=21, s=1000; 14 GB resident): size-independent
+    properties of the whole output -- every row strictly usable by Distance (ascending), every row independent
+    of its batch (equal to the same read sketched in a batch of 64), 16 sampled rows equal to the oracle, and
+    the second run bit-identical (no leftover state)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, L, k, s = 1_000_000, 10_000, 21, 1000
+    seqs = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC2, seqs)
+    offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    out = torch.zeros((n, s), dtype=torch.int32, device=dev)
+    mash.sketch_batch_dev(seqs, offs, k, s, out)
+    torch.cuda.synchronize()
+    # hashes are unsigned: compare through int64
+    step = 100_000
+    for r0 in range(0, n, step):
+        blk = out[r0:r0 + step].to(torch.int64) & 0xFFFFFFFF
+        assert bool((blk[:, 1:] >= blk[:, :-1]).all()), r0
+    rng = np.random.default_rng(2)
+    pick = np.sort(rng.choice(n, 64, replace=False))
+    sub = torch.cat([seqs[int(r) * L:(int(r) + 1) * L] for r in pick])
+    sub_out = torch.zeros((64, s), dtype=torch.int32, device=dev)
+    mash.sketch_batch_dev(sub, offs[:65].contiguous(), k, s, sub_out)
+    assert torch.equal(sub_out, out[torch.from_numpy(pick).to(dev)])
+    host = sub[:16 * L].cpu().numpy()
+    want = orc.mash_sketch_batch(host, np.arange(0, 17 * L, L, dtype=np.uint64), k, s)
+    assert (sub_out[:16].cpu().numpy().view(np.uint32) == want).all()
+    again = torch.zeros((n, s), dtype=torch.int32, device=dev)
+    mash.sketch_batch_dev(seqs, offs, k, s, again)
+    assert torch.equal(out, again)

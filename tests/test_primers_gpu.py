@@ -127,3 +127,44 @@ def test_errors(pr):
     with pytest.raises(_lib.PolyhipError):
         pr.SantaLucia(b"AC\xc3\xa9GT", 500e-9, 50e-3, 0)
     assert pr.MarmurDoty("") == -7.0
+
+
+def test_full_size_config5_properties(pr):
+    """BASELINE configs[4] at FULL size: all 18..30-mers of a 5,000,000 B genome (64,999,701 windows, 1.56 GB of
+    output).  Properties of the whole output: the scan in one piece equals the scan of two parts glued at an
+    arbitrary cut (windows are independent: the multi-GPU partition); every window that fits has a finite Tm and
+    the ones running off the end are NaN; 200 sampled windows equal the oracle bit for bit."""
+    import torch
+    from poly_amd import mash
+    dev = torch.device("cuda:0")
+    n, Lmin, Lmax = 5_000_000, 18, 30
+    g = torch.empty(n, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC5, g)
+    ld = n - Lmin + 1
+    nl = Lmax - Lmin + 1
+    tm, dh, ds = (torch.full((nl * ld,), float("nan"), dtype=torch.float64, device=dev) for _ in range(3))
+    pr.santalucia_scan_dev(g, n, 0, ld, Lmin, Lmax, 500e-9, 50e-3, 0.0, tm, dh, ds, ld)
+    # two halves with a cut that is no multiple of anything
+    cut = 2_345_671
+    tm2, dh2, ds2 = (torch.full((nl * ld,), float("nan"), dtype=torch.float64, device=dev) for _ in range(3))
+    pr.santalucia_scan_dev(g, n, 0, cut, Lmin, Lmax, 500e-9, 50e-3, 0.0, tm2, dh2, ds2, ld)
+    for L in range(Lmin, Lmax + 1):  # the second half writes plane by plane behind the first
+        o = (L - Lmin) * ld + cut
+        pr.santalucia_scan_dev(g, n, cut, ld - cut, L, L, 500e-9, 50e-3, 0.0, tm2[o:], dh2[o:], ds2[o:], ld)
+    torch.cuda.synchronize()
+    for a, b in ((tm, tm2), (dh, dh2), (ds, ds2)):
+        assert torch.equal(torch.nan_to_num(a, nan=-1e300), torch.nan_to_num(b, nan=-1e300))
+    # every window that fits has a finite Tm; the ones running off the end are NaN
+    for L in (Lmin, Lmax):
+        p = tm[(L - Lmin) * ld:(L - Lmin + 1) * ld]
+        assert bool(torch.isfinite(p[: n - L + 1]).all()) and bool(torch.isnan(p[n - L + 1:]).all())
+    host = g.cpu().numpy()
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        L = int(rng.integers(Lmin, Lmax + 1))
+        i = int(rng.integers(0, n - L + 1))
+        want = orc.santalucia(host[i:i + L].tobytes(), 500e-9, 50e-3, 0.0)
+        o = (L - Lmin) * ld + i
+        got = (float(tm[o]), float(dh[o]), float(ds[o]))
+        assert _bits(got[0]) == _bits(want[0]) and _bits(got[1]) == _bits(want[1]) and _bits(got[2]) == _bits(want[2])
+        assert abs(got[0] - want[0]) <= 1e-6  # the north star's tolerance
