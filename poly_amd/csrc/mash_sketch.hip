@@ -118,6 +118,56 @@ struct Smem {
 // Returns (block-uniform) the number T of values <= tau.  If T >= s and T <= binned_cap:
 // cand[0..s) = the s smallest ascending, misc[0] = s, misc[1] = cand[s-1].
 // If T < s (and keep_partial): cand[0..T) = those values (any order), misc[0] = T.
+// ---- bins that hold many values ------------------------------------------------------------------
+// Repeated k-mers (tandem repeats, homopolymers, poly-A tails) put hundreds of EQUAL hashes into one bin of
+// the counting sort, and ranking every element against its whole bin is quadratic in the bin size.  Bins
+// with more than BIG_BIN values are therefore left out of the per-element ranking and handled by whole
+// waves: the smallest not-yet-placed value of the bin (wave min), then every copy of it in index order
+// (ballot prefix), and so on -- one pass per DISTINCT value, which is what such a bin has few of.
+constexpr uint32_t BIG_BIN = 32;
+constexpr uint32_t BIG_LIST_CAP = 512; // the list lives in seqb (>= WAVES * WTW / 4 dwords); more big bins than that: per-element ranking
+
+template <class Emit>
+__device__ __forceinline__ void rank_big_bins(const uint32_t *__restrict__ binned, const uint32_t *__restrict__ bins,
+                                              const uint32_t *__restrict__ biglist, uint32_t nbig, uint32_t s, Emit emit)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (uint32_t q = wave; q < nbig; q += WAVES) {
+        const uint32_t b = biglist[q];
+        const uint32_t st = b ? bins[b - 1] : 0u, en = bins[b]; // after the scatter bins[b] is the END of bin b
+        uint32_t base = st, lastv = 0;
+        bool first = true;
+        while (base < s && base < en) {
+            uint32_t m = 0xFFFFFFFFu;
+            bool has = false;
+            for (uint32_t x = st + lane; x < en; x += 64) {
+                const uint32_t o = binned[x];
+                if (first || o > lastv) {
+                    m = min(m, o);
+                    has = true;
+                }
+            }
+            if (__ballot(has) == 0ull)
+                break;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1)
+                m = min(m, (uint32_t)__shfl_xor((int)m, d, 64));
+            for (uint32_t x0 = st; x0 < en; x0 += 64) {
+                const uint32_t x = x0 + lane;
+                const bool eq = x < en && binned[x] == m;
+                const uint64_t mask = __ballot(eq);
+                const uint32_t pos = base + (uint32_t)__builtin_popcountll(mask & below);
+                if (eq && pos < s)
+                    emit(pos, m);
+                base += (uint32_t)__builtin_popcountll(mask);
+            }
+            lastv = m;
+            first = false;
+        }
+    }
+}
+
 template <class ForEach>
 __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t binned_cap, bool keep_partial,
                              ForEach for_each)
@@ -131,6 +181,8 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
 
     for (int b = tid; b < NB; b += THREADS)
         bins[b] = 0;
+    if (tid == 0)
+        sm.misc[8] = 0; // bins with more than BIG_BIN values
     __syncthreads();
     for_each([&](uint32_t h) {
         if (h <= tau)
@@ -163,6 +215,11 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
         for (int i = 0; i < 8; ++i) {
             bins[8 * tid + i] = run; // start of bin
             run += v[i];
+            if (v[i] > BIG_BIN) { // seqb is idle while the candidates are sorted: it holds the list
+                const uint32_t slot = atomicAdd(&sm.misc[8], 1u);
+                if (slot < BIG_LIST_CAP)
+                    sm.seqb[slot] = (uint32_t)(8 * tid + i);
+            }
         }
         if (tid == THREADS - 1)
             sm.misc[3] = run; // T
@@ -187,6 +244,8 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
         return T;
     }
     // rank inside the bin; ties broken by slot so duplicates get distinct ranks
+    const uint32_t nbig = sm.misc[8];
+    const bool by_waves = nbig <= BIG_LIST_CAP; // else the list is incomplete: rank every element the slow way
     for (uint32_t j = tid; j < T; j += THREADS) {
         const uint32_t h = sm.binned[j];
         const uint32_t b = h >> shift;
@@ -194,6 +253,8 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
         if (start >= s)
             continue;
         const uint32_t end = bins[b];
+        if (by_waves && end - start > BIG_BIN)
+            continue; // a whole wave places this bin's values (rank_big_bins)
         uint32_t rank = 0;
         for (uint32_t x = start; x < end; ++x) {
             const uint32_t o = sm.binned[x];
@@ -203,6 +264,8 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
         if (pos < s)
             sm.cand[pos] = h;
     }
+    if (by_waves)
+        rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [&](uint32_t pos, uint32_t h) { sm.cand[pos] = h; });
     __syncthreads();
     if (tid == 0) {
         sm.misc[0] = s;
@@ -453,6 +516,8 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
     const int q4 = (int)(nbf / (4 * THREADS)); // 1 or 2
     for (int q = 0; q < q4; ++q)
         bins4[q4 * tid + q] = make_uint4(0, 0, 0, 0);
+    if (tid == 0)
+        sm.misc[8] = 0; // bins with more than BIG_BIN values
     __syncthreads();
     // the loops over candidates are unrolled by four so that the LDS round trips of a thread's
     // elements overlap instead of queueing behind each other
@@ -490,6 +555,16 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
                 o.w = o.z + v[q].z;
                 run = o.w + v[q].w;
                 bins4[q4 * tid + q] = o;
+                if (max(max(v[q].x, v[q].y), max(v[q].z, v[q].w)) > BIG_BIN) { // rare: repeated k-mers
+                    const uint32_t cnt4[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (cnt4[c] > BIG_BIN) {
+                            const uint32_t slot = atomicAdd(&sm.misc[8], 1u);
+                            if (slot < BIG_LIST_CAP)
+                                sm.seqb[slot] = (uint32_t)(4 * (q4 * tid + q) + c);
+                        }
+                }
             }
         }
     }
@@ -509,6 +584,8 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
                 sm.binned[at[u]] = h[u];
     }
     __syncthreads();
+    const uint32_t nbig = sm.misc[8];
+    const bool by_waves = nbig <= BIG_LIST_CAP; // else the list is incomplete: rank every element the slow way
     for (uint32_t j0 = tid; j0 < C; j0 += 4 * THREADS) {
         uint32_t h[4], start[4], end[4];
 #pragma unroll
@@ -527,6 +604,8 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
                 continue;
             const uint32_t j = j0 + u * THREADS;
             uint32_t pos = start[u];
+            if (by_waves && end[u] - start[u] > BIG_BIN)
+                continue; // a whole wave places this bin's values (rank_big_bins)
             if (end[u] - start[u] > 1u) { // most bins hold one value
                 for (uint32_t x = start[u]; x < end[u]; ++x) {
                     const uint32_t o = sm.binned[x];
@@ -537,6 +616,8 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
                 outp[pos] = h[u];
         }
     }
+    if (by_waves)
+        rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [&](uint32_t pos, uint32_t hv) { outp[pos] = hv; });
 }
 
 struct ReadView {

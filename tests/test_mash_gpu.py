@@ -179,3 +179,27 @@ def test_full_size_config2_properties(mash):
     again = torch.zeros((n, s), dtype=torch.int32, device=dev)
     mash.sketch_batch_dev(seqs, offs, k, s, again)
     assert torch.equal(out, again)
+
+
+def test_repeated_kmers_big_bins(mash):
+    """reads with a random part and a tandem-repeated part (copy numbers around and above the 32-value bin
+    limit): the threshold pass still succeeds, but its counting sort meets bins holding dozens of EQUAL hashes,
+    which whole waves place (rank_big_bins); plus pure repeats / homopolymers / poly-A tails that go to the
+    general kernel.  Every sketch equals the oracle's (duplicates kept, as the reference keeps them)."""
+    rng = np.random.default_rng(33)
+    reads = []
+    for copies in (20, 31, 32, 33, 40, 64, 100, 300):
+        for unit_len in (37, 200, 410):
+            unit = bytes(rng.choice(list(b"ACGT"), unit_len).astype(np.uint8))
+            rep = unit * copies
+            for rnd_len in (0, 1500, 6000):
+                rnd = bytes(rng.choice(list(b"ACGT"), rnd_len).astype(np.uint8))
+                reads.append((rnd + rep)[:12000])
+                reads.append((rep[: len(rep) // 2] + rnd + rep[len(rep) // 2:])[:12000])
+    reads += [b"A" * 10000, b"AC" * 5000, bytes(rng.choice(list(b"ACGT"), 5000).astype(np.uint8)) + b"A" * 5000]
+    buf, offs = _pack(reads)
+    for k, s in ((21, 1000), (17, 200), (31, 2000)):
+        got = mash.sketch_batch_packed(buf, offs, k, s)
+        want = orc.mash_sketch_batch(buf, offs, k, s)
+        bad = np.nonzero((got != want).any(axis=1))[0]
+        assert len(bad) == 0, (k, s, bad[:8], [len(reads[b]) for b in bad[:8]])
