@@ -167,8 +167,12 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         };
 
         // ---- 1. least first word (LDS: a thread takes 4 neighbouring positions from two dwords)
+        // A least word made of one byte (aaaa) comes in runs: a position whose predecessor also starts with
+        // aaaa loses to it (the byte behind the run is larger than a, else a smaller word would exist), so only
+        // the first position of each run is a candidate -- a poly-A tail is ONE candidate, not thousands.
+        // A sequence that is nothing but that byte leaves no candidate at all: every rotation is equal, index 0.
         uint32_t m = 0xFFFFFFFFu;
-        bool serial = false;
+        bool serial = false, homo = false;
         if (IN_LDS && n >= 8) {
             const uint64_t nquad = (n + 3) >> 2;
             for (uint64_t t = tid; t < nquad; t += THREADS) {
@@ -179,6 +183,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                         m = min(m, __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, k)));
             }
             m = block_min(m, red);
+            homo = n >= 4 && (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
             for (uint64_t t0 = 0; t0 < nquad; t0 += THREADS) {
                 const uint64_t t = t0 + tid;
                 if (t < nquad) {
@@ -186,9 +191,12 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
 #pragma unroll
                     for (uint32_t k = 0; k < 4; ++k)
                         if (4 * t + k < n && __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, k)) == m) {
+                            const uint64_t p = 4 * t + k;
+                            if (homo && word(p ? p - 1 : n - 1) == m)
+                                continue; // inside a run of the least byte: the run's first position beats it
                             const uint32_t slot = atomicAdd(&cnt, 1u);
                             if (slot < LIST_CAP)
-                                listA[slot] = (uint32_t)(4 * t + k);
+                                listA[slot] = (uint32_t)p;
                         }
                 }
             }
@@ -196,9 +204,10 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
             for (uint64_t p = tid; p < n; p += THREADS)
                 m = min(m, word(p));
             m = block_min(m, red);
+            homo = n >= 4 && (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
             for (uint64_t p0 = 0; p0 < n; p0 += THREADS) {
                 const uint64_t p = p0 + tid;
-                const bool is = p < n && word(p) == m;
+                const bool is = p < n && word(p) == m && !(homo && word(p ? p - 1 : n - 1) == m);
                 if (is) {
                     const uint32_t slot = atomicAdd(&cnt, 1u);
                     if (slot < LIST_CAP)
@@ -210,6 +219,12 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         uint32_t c = cnt;
         if (c > LIST_CAP || n > 0xFFFFFFFFull)
             serial = true;
+        if (c == 0) { // homopolymer: all rotations equal, the smallest index is 0
+            if (tid == 0)
+                listA[0] = 0;
+            c = 1;
+            __syncthreads();
+        }
 
         // ---- 2. rounds of 4 more bytes
         uint32_t *cur = listA, *nxt = listB;

@@ -139,3 +139,31 @@ def test_hash_batch_matches_oracle(sh, stype, circular, ds):
             assert isinstance(g, ValueError) and str(g) == str(e), (s[:20], g, e)
             continue
         assert g == want, (s[:30], len(s))
+
+
+def test_runs_of_the_least_byte():
+    """poly-A style inputs: long runs of the smallest byte (one candidate per run instead of one per position),
+    runs that wrap around the origin, several runs of equal and different lengths, runs of a byte that is NOT
+    the smallest, and sequences that are nothing but one byte -- index and rotated bytes equal Booth's."""
+    from poly_amd import seqhash as sh
+    rng = np.random.default_rng(77)
+    seqs = []
+    for _ in range(60):
+        n = int(rng.integers(5, 3000))
+        body = bytearray(rng.choice(list(b"ACGT"), n).astype(np.uint8))
+        for _ in range(int(rng.integers(1, 4))):
+            run = int(rng.integers(4, max(5, n // 2)))
+            at = int(rng.integers(0, n))
+            byte = int(rng.choice(list(b"AAAC")))  # mostly the least byte
+            for t in range(run):
+                body[(at + t) % n] = byte  # may wrap around the origin
+        seqs.append(bytes(body))
+    seqs += [b"A" * 7, b"A" * 1000, b"C" * 33, b"AAAAC", b"CAAAA", b"AACAA", b"AAAACAAAAC", b"AAAACAAAAAC" * 40,
+             b"A" * 500 + b"C" + b"A" * 500, b"A" * 499 + b"C" + b"A" * 500, b"T" * 100 + b"A" * 100 + b"T" * 100 + b"A" * 100]
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(q) for q in seqs])
+    buf = np.frombuffer(b"".join(seqs), np.uint8).copy()
+    rot, out = sh.least_rotation_batch_packed(buf, offs, True)
+    for i, q in enumerate(seqs):
+        assert int(rot[i]) == orc.booth_least_rotation(q), (i, q[:30], len(q))
+        assert out[int(offs[i]): int(offs[i + 1])].tobytes() == orc.rotate_sequence(q), i
