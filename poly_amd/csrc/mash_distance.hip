@@ -471,6 +471,85 @@ __global__ __launch_bounds__(THREADS) void rowjoin_kernel(const uint32_t *__rest
     }
 }
 
+constexpr int DENSE_THREADS = 1024; // one workgroup per CU (its LDS is the whole CU's): 16 waves keep the bucket loads coming
+
+// ---- rows whose LDS hash table overflowed (thousands of relatives) ----------------------------------
+// Same bucket walk as rowjoin_kernel, but the accumulator is a DENSE array of 16-bit counters in LDS, one
+// per column of a stripe of 2 * W columns (two counters per dword, bumped with one 32-bit LDS atomic: a count
+// never exceeds the sketch size, so the halves cannot carry into each other).  ceil(ny / 2W) stripes per
+// row; each stripe is flushed whole, zeros included.  Work follows the shared hashes, like the sparse join --
+// the reference's two-pointer merge for such a row would be ny * (sx + sy) steps.
+__global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint32_t *__restrict__ X, uint32_t sx,
+                                                               const uint32_t *__restrict__ start,
+                                                               const uint2 *__restrict__ items, uint32_t nbk,
+                                                               const uint32_t *__restrict__ hdr,
+                                                               const uint32_t *__restrict__ ovfX, uint64_t ny,
+                                                               uint32_t w_log2, uint16_t *__restrict__ counts,
+                                                               uint64_t ld)
+{
+    if (hdr[H_MODE] != MODE_SPARSE)
+        return;
+    extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
+    uint32_t *xv = dyn, *dval = dyn + sx, *dmul = dyn + 2 * (size_t)sx, *dbeg = dyn + 3 * (size_t)sx,
+             *dend = dyn + 4 * (size_t)sx, *dense = dyn + 5 * (size_t)sx;
+    __shared__ uint32_t ndist;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t shift = hdr[H_SHIFT], W = 1u << w_log2, novf = hdr[H_NOVF];
+    for (uint32_t r = blockIdx.x; r < novf; r += gridDim.x) {
+        const uint64_t i = ovfX[r];
+        __syncthreads();
+        if (tid == 0)
+            ndist = 0;
+        const uint32_t *xp = X + i * sx;
+        for (uint32_t p = tid; p < sx; p += DENSE_THREADS)
+            xv[p] = xp[p];
+        __syncthreads();
+        for (uint32_t p = tid; p < sx; p += DENSE_THREADS) { // distinct values of the row and their buckets
+            const uint32_t v = xv[p];
+            if (p != 0 && xv[p - 1] == v)
+                continue;
+            const uint32_t b = v >> shift;
+            if (b >= nbk)
+                continue;
+            const uint32_t bs = start[b], be = start[b + 1];
+            if (be == bs)
+                continue;
+            uint32_t a = 1;
+            while (p + a < sx && xv[p + a] == v)
+                ++a;
+            const uint32_t slot = atomicAdd(&ndist, 1u);
+            dval[slot] = v;
+            dmul[slot] = a;
+            dbeg[slot] = bs;
+            dend[slot] = be;
+        }
+        __syncthreads();
+        const uint32_t nd = ndist;
+        for (uint64_t c0 = 0; c0 < ny; c0 += 2ull * W) {
+            for (uint32_t t = tid; t < W; t += DENSE_THREADS)
+                dense[t] = 0;
+            __syncthreads();
+            const uint32_t stripe = (uint32_t)(c0 >> (w_log2 + 1));
+            for (uint32_t d = wave; d < nd; d += DENSE_THREADS / 64) {
+                const uint32_t v = dval[d], a = dmul[d];
+                for (uint32_t t = dbeg[d] + lane; t < dend[d]; t += 64) {
+                    const uint2 it = items[t];
+                    const uint32_t id = it.y & ID_MASK;
+                    if (it.x == v && (it.y >> ID_BITS) < a && (id >> (w_log2 + 1)) == stripe)
+                        atomicAdd(&dense[(id & (2u * W - 1u)) >> 1], 1u << (16u * (id & 1u)));
+                }
+            }
+            __syncthreads();
+            for (uint32_t t = tid; t < 2u * W; t += DENSE_THREADS) {
+                const uint64_t col = c0 + t;
+                if (col < ny)
+                    counts[i * ld + col] = (uint16_t)(dense[t >> 1] >> (16u * (t & 1u)));
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // mash.go:107-135 for one pair, receiver = X_i
 __device__ uint32_t similarity_count(const uint32_t *__restrict__ x, uint32_t sx, const uint32_t *__restrict__ y,
                                      uint32_t sy)
@@ -515,14 +594,14 @@ __global__ __launch_bounds__(THREADS) void generic_kernel(const uint32_t *__rest
                                                          const uint32_t *__restrict__ irrX,
                                                          const uint32_t *__restrict__ regX,
                                                          const uint32_t *__restrict__ irrY,
-                                                         const uint32_t *__restrict__ ovfX,
+                                                         const uint32_t *__restrict__ ovfX, int ovf_done,
                                                          uint16_t *__restrict__ counts, uint64_t ld)
 {
     const bool all = hdr[H_MODE] == MODE_GENERIC;
     const uint64_t nIrrX = hdr[H_NIRRX], nIrrY = hdr[H_NIRRY], nRegX = hdr[H_NREGX], nOvf = hdr[H_NOVF];
     const uint64_t partA = all ? nx * ny : nIrrX * ny; // (irregular row) x (every column)
     const uint64_t partB = all ? 0 : nRegX * nIrrY;    // (regular row) x (irregular column)
-    const uint64_t partC = all ? 0 : nOvf * ny;        // (overflowed row) x (every column)
+    const uint64_t partC = (all || ovf_done) ? 0 : nOvf * ny; // (overflowed row) x (every column), unless the dense join took them
     const uint64_t total = partA + partB + partC;
     for (uint64_t p = (uint64_t)blockIdx.x * THREADS + threadIdx.x; p < total; p += (uint64_t)gridDim.x * THREADS) {
         uint64_t i, j;
@@ -641,11 +720,29 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
         hipLaunchKernelGGL(k2::rowjoin_kernel, dim3(blocks), dim3(k2::THREADS), smem, st, d_X, nx, sx, flagsX, start, items,
                            L.nbk, hdr, ovfX, d_counts, ld);
     }
+    // rows that overflowed their hash table: dense 16-bit counters per column stripe, as many columns per
+    // stripe as LDS holds next to the row's own arrays (a power of two of dwords, two columns each)
+    int ovf_done = 0;
+    if (!force) {
+        const size_t row_bytes = (size_t)sx * 20, avail = 158 * 1024 > row_bytes ? 158 * 1024 - row_bytes : 0;
+        uint32_t w_log2 = 0;
+        while (w_log2 < 15 && ((size_t)4 << (w_log2 + 1)) <= avail)
+            ++w_log2;
+        if (((size_t)4 << w_log2) <= avail && w_log2 >= 12) { // at least 8192 columns per stripe
+            const size_t smem = row_bytes + ((size_t)4 << w_log2);
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull);
+            hipLaunchKernelGGL(k2::rowjoin_dense_kernel, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, sx, start, items,
+                               L.nbk, hdr, ovfX, ny, w_log2, d_counts, ld);
+            ovf_done = 1;
+        }
+    }
     {
         const uint64_t pairs = nx * ny;
         const unsigned blocks = (unsigned)std::min<uint64_t>((pairs + k2::THREADS - 1) / k2::THREADS, 256ull * 16ull);
         hipLaunchKernelGGL(k2::generic_kernel, dim3(blocks), dim3(k2::THREADS), 0, st, d_X, nx, sx, d_Y, ny, sy, hdr, irrX,
-                           regX, irrY, ovfX, d_counts, ld);
+                           regX, irrY, ovfX, ovf_done, d_counts, ld);
     }
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;

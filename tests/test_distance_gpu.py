@@ -169,7 +169,8 @@ def test_errors(mash):
 
 
 def test_rows_with_many_relatives_overflow_to_merge(mash):
-    """a row related to more sketches than the join's LDS table holds is merged instead"""
+    """a row related to more sketches than the join's LDS hash table holds goes to the dense join (16-bit
+    counters per column in LDS) -- same counts as the reference's merge"""
     import torch
     rng = np.random.default_rng(13)
     base = np.sort(rng.choice(1 << 31, 64, replace=False).astype(np.uint32))
@@ -245,3 +246,32 @@ def test_full_size_config3_row_block_properties(mash):
     want = 1.0 - c[torch.from_numpy(rows).to(dev)].cpu().numpy().astype(np.float64) / np.float64(s)
     assert (dist[torch.from_numpy(rows).to(dev)].cpu().numpy() == want).all()
     assert bool((dist[c == 0] == 1.0).all()) and bool((dist.diagonal() == 0.0).all())
+
+
+def test_dense_rows_over_several_column_stripes(mash):
+    """70,000 columns need two stripes of the dense join's LDS counters (65,536 columns each); rows with thousands
+    of relatives on both sides of the stripe border, duplicates inside sketches (multiset semantics), a few
+    irregular (unsorted) Y sketches in between (those pairs take the reference's own loop)."""
+    import torch
+    rng = np.random.default_rng(17)
+    ny, s = 70_000, 16
+    Y = np.sort(rng.integers(0, 1 << 31, (ny, s), dtype=np.uint32), axis=1)
+    base = np.sort(rng.choice(1 << 31, 6, replace=False).astype(np.uint32))
+    rel = rng.choice(ny, 9000, replace=False)            # relatives spread over both stripes
+    Y[rel, :4] = base[:4]
+    Y[rel[:3000], 4] = base[3]                           # a duplicated value in 3000 of them
+    Y = np.sort(Y, axis=1)
+    Y[[5, 40_000, 69_999]] = Y[[5, 40_000, 69_999]][:, ::-1]  # irregular: descending
+    X = Y[np.concatenate([rel[:40], rng.choice(ny, 24, replace=False)])].copy()
+    X[3, :5] = base[3]                                   # X row with a 5-fold duplicate
+    X = np.sort(X, axis=1)
+    dev = torch.device("cuda:0")
+    Xt, Yt = (torch.from_numpy(a.view(np.int32).copy()).to(dev) for a in (X, Y))
+    ct = torch.full((len(X), ny), -1, dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(len(X), s, ny, s), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(Xt, Yt, ct, work)
+    torch.cuda.synchronize()
+    mode, ix, iy, ovf, est = mash.shared_counts_mode(work)
+    assert mode == 0 and ovf >= 40 and iy == 3
+    got = ct.cpu().numpy().view(np.uint16)
+    assert (got == _oracle_counts(X, Y)).all()
