@@ -264,11 +264,13 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
 /* which kernel family the last polyhip_sw_batch*_dev call on this thread used (tests):
  * 1 = lane-per-pair register-tiled shared-B kernel, 2 = generic kernel, 3 = packed two-pairs-per-lane
  * pass + locate + one-wave-per-pair kernel for its ties, 4 = one-wave-per-pair kernel (small batches),
- * 5 = register-tiled kernel for per-pair B.  POLYHIP_SW_WAVE=0 / POLYHIP_SW_PACKED=0 / POLYHIP_SW_PAIR=0
- * in the environment switch 4 / 3 / 5 off (testing aids). */
+ * 5 = register-tiled kernel for per-pair B, 6 = one-wave-per-pair kernel for what those cannot take (reads of
+ * 257..4096 symbols, gap >= 0, scores beyond int8; shared or per-pair B).  POLYHIP_SW_WAVE=0 /
+ * POLYHIP_SW_PACKED=0 / POLYHIP_SW_PAIR=0 in the environment switch 4 and 6 / 3 / 5 off (testing aids). */
 int polyhip_sw_last_path(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
- * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel (tests). */
+ * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
+ * kernel for reads of 257..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off). */
 int polyhip_sw_traceback_last_path(void);
 /* ... and the last polyhip_nw_align_batch_dev call: 1 = register-tiled kernel, 2 = generic kernel
  * (POLYHIP_NW_GENERIC=1 forces it; tests). */

@@ -451,7 +451,8 @@ __global__ __launch_bounds__(256) void sw_generic_kernel(
 }
 
 struct Plan {
-    int path;      // 1 fast, 2 generic, 3 packed (sw_packed.hip) + wave kernel for its ties, 4 wave kernel (small batch)
+    int path;      // 1 fast, 2 generic, 3 packed (sw_packed.hip) + wave kernel for its ties, 4 wave kernel (small batch),
+                   // 5 per-pair B register-tiled, 6 wave kernel for what the others cannot take (long reads, ...)
     int ra, cp;    // fast: template parameters
     uint32_t lenB_pad, jc_max;
     size_t work_bytes, smem_bytes;
@@ -460,6 +461,12 @@ struct Plan {
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static bool wave_kernel_off()
+{
+    const char *e = getenv("POLYHIP_SW_WAVE"); // testing aid: POLYHIP_SW_WAVE=0 -> no one-wave-per-pair kernel
+    return e && e[0] == '0';
+}
 
 static bool pair_kernel_off()
 {
@@ -485,8 +492,7 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
         p.work_bytes = 256 + align_up((size_t)p.lenB_pad * p.cp, 256);
         p.fast_bytes = p.work_bytes;
         const bool wave_ok = (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024;
-        const char *wenv = getenv("POLYHIP_SW_WAVE");
-        if (wave_ok && npairs < WAVE_BATCH && !(wenv && wenv[0] == '0')) {
+        if (wave_ok && npairs < WAVE_BATCH && !wave_kernel_off()) {
             p.path = 4; // too few pairs to fill the chip one per lane: one wave per pair (sw_wave.hip)
         } else if (wave_ok && k3p::packed_plan(sc, npairs, max_lenA, lenB, &p.pk) && p.pk.ra == p.ra && p.cp == 8) {
             p.path = 3;
@@ -498,6 +504,12 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
                (uint64_t)std::max(sc->smax, 0) * minlen < (uint64_t)SCORE_LIMIT && !pair_kernel_off()) {
         p.path = 5; // per-pair B, register-tiled (sw_pair_kernel)
         p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
+        p.work_bytes = 256;
+    } else if (max_lenA > 0 && max_lenA <= k3w::WAVE_MAX_LENA && lenB > 0 && lenB < (1ull << 31) - 64 &&
+               (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 && !wave_kernel_off()) {
+        // whatever the lane-per-pair kernels cannot take (reads longer than 256, gap >= 0, wide scores), shared or
+        // per-pair B: one wave per pair, plain int32, up to 4096 rows (sw_wave.hip)
+        p.path = 6;
         p.work_bytes = 256;
     } else {
         p.path = 2;
@@ -692,8 +704,8 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
             PH_HIP(hipGetLastError());
         }
         if (p.path == 4)
-            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, (uint32_t)lenB, binfo, nullptr, nullptr, npairs,
-                                 d_score, d_endA, d_endB, d_err, st);
+            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, nullptr, nullptr,
+                                 npairs, d_score, d_endA, d_endB, d_err, st);
         // packed pass first (two pairs per lane); the few pairs it leaves on its tie list go through the
         // exact one-wave-per-pair kernel (a lane-per-pair kernel would take a full DP's time for them)
         if (p.path == 3) {
@@ -703,8 +715,8 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
                                            &list, &count, st);
             if (rc != POLYHIP_OK)
                 return rc;
-            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, (uint32_t)lenB, binfo, list, count, npairs,
-                                 d_score, d_endA, d_endB, d_err, st);
+            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count,
+                                 npairs, d_score, d_endA, d_endB, d_err, st);
         }
 #define PH_SW_CASE(RA_, CP_)                                                                                       \
     if (p.ra == RA_ && p.cp == CP_)                                                                                \
@@ -717,6 +729,9 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
 #undef PH_SW_CASE
         return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_sw_batch: no kernel for RA=%d CP=%d", p.ra, p.cp);
     }
+    if (p.path == 6)
+        return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, (uint32_t)lenB, nullptr, nullptr, nullptr,
+                             npairs, d_score, d_endA, d_endB, d_err, st);
     if (p.path == 5) {
         const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
         const size_t smem = (size_t)na * nb * 4 + 512;

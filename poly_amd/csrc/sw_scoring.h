@@ -58,9 +58,12 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
 namespace polyhip {
 namespace k3w {
 
-// pairs [0, npairs) if list == nullptr, else the *count pairs on `list`; max_items bounds the grid
+// pairs [0, npairs) if list == nullptr, else the *count pairs on `list`; max_items bounds the grid;
+// d_offB == nullptr: one shared B of lenB bytes (binfo = its first invalid byte), else per-pair B
+constexpr uint32_t WAVE_MAX_LENA = 4096; // 64 lanes x 64 rows
 int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
-             const uint8_t *d_B, uint32_t lenB, const uint32_t *binfo, const uint32_t *list, const uint32_t *count,
+             const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
+             const uint32_t *count,
              uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st);
 
 } // namespace k3w

@@ -479,6 +479,187 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
 #undef PH_TB_ISSUE
 #undef PH_TB_ADDR
 
+// ---- reads longer than the 256 rows a lane can hold: ONE WAVE PER PAIR (like sw_wave.hip) ---------------
+// Lane l owns rows [l*R, l*R + R) and works on column s - l of the pair's window in step s; the row above
+// its first row and the column's B code arrive by one lane shift per step.  Same G / L bits as
+// tb_prof_kernel, one word set per (step, lane) so a wave stores contiguously; the walk (all lanes in step,
+// lane 0 writes) carries the running score down from the score pass's maximum.
+#define PH_TBW_BIT(w, x, y)                                                             \
+    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
+                 : "+v"(w)                                                              \
+                 : "v"(x), "v"(y)                                                       \
+                 : "vcc")
+
+template <int R>
+__global__ __launch_bounds__(THREADS) void tb_wave_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ Bbase, const uint64_t *__restrict__ offB, const uint8_t *__restrict__ codeA,
+    const uint8_t *__restrict__ codeB, const int32_t *__restrict__ lutcc, int na, int nb, int gap,
+    const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB, const uint32_t *__restrict__ err,
+    const int64_t *__restrict__ score, int smax, uint32_t wcols, int wide, uint32_t *__restrict__ dirbuf,
+    uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    constexpr int NG = (R + 31) / 32;            // 32-row groups per lane
+    constexpr int NWL = R <= 16 ? 1 : 2 * NG;    // words per (step, lane): G | L << 16, or NG words of each
+    extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb] then codeA[256], codeB[256]
+    uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < na * nb; t += THREADS)
+        T[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+    const uint64_t wslot = (uint64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
+    const uint64_t pair = pair0 + wslot;
+    if (pair >= pair1)
+        return; // wave-uniform, no barrier below
+    const uint64_t o0 = offA[pair];
+    const uint32_t lenA = (uint32_t)(offA[pair + 1] - o0);
+    const uint8_t *ap = A + o0;
+    const uint8_t *B = offB ? Bbase + offB[pair] : Bbase;
+    uint32_t eA = 0, eB = 0;
+    int64_t M = 0;
+    if (err[pair] == 0u) {
+        eA = endA[pair];
+        eB = endB[pair];
+        M = score[pair];
+    }
+    uint32_t len = 0;
+    if (eA > 0 && eB > 0 && M > 0 && lenA <= 64u * R) {
+        const uint32_t mycols = pair_window(wcols, eA, M, smax, gap, wide);
+        const uint32_t c_s = eB > mycols ? eB - mycols + 1u : 1u; // first column (1-based) of the window
+        const uint32_t ncol = eB - c_s + 1u;
+        uint32_t ro[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint32_t r = (uint32_t)lane * R + k;
+            uint32_t code = (uint32_t)(na - 1);
+            if (r < lenA) {
+                const uint32_t c = cA[ap[r]];
+                code = c == 0xFFu ? (uint32_t)(na - 1) : c;
+            }
+            ro[k] = code * (uint32_t)nb;
+        }
+        uint32_t *dirw = dirbuf + wslot * ((size_t)(wcols + 63u) * 64 * NWL) + (size_t)lane * NWL;
+        int Hrow[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            Hrow[k] = 0;
+        int topprev = 0, last_h = 0;
+        uint32_t last_b = (uint32_t)(nb - 1);
+        auto load_chunk = [&](uint32_t s0) -> uint32_t { // B codes of window columns s0 + lane
+            uint32_t c = (uint32_t)(nb - 1);
+            if (s0 + (uint32_t)lane < ncol) {
+                const uint32_t cc = cB[B[c_s - 1u + s0 + (uint32_t)lane]];
+                c = cc == 0xFFu ? (uint32_t)(nb - 1) : cc;
+            }
+            return c;
+        };
+        uint32_t chunk = load_chunk(0), next_chunk = 0u;
+        const uint32_t steps = ncol + 63u;
+        for (uint32_t s = 0; s < steps; ++s) {
+            if ((s & 63u) == 0u) {
+                if (s)
+                    chunk = next_chunk;
+                next_chunk = load_chunk(s + 64u);
+            }
+            int top_in = __shfl_up(last_h, 1, 64);
+            uint32_t b_in = (uint32_t)__shfl_up((int)last_b, 1, 64);
+            const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
+            if (lane == 0) {
+                top_in = 0;
+                b_in = b_new;
+            }
+            const uint32_t jr = s - (uint32_t)lane; // wraps for lanes that have not started
+            const bool valid = jr < ncol;
+            int diag = topprev, up = top_in;
+            uint32_t gw[NG], lw[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                gw[g] = lw[g] = 0u;
+#pragma unroll
+            for (int k = 0; k < R; ++k) {
+                const int left = Hrow[k];
+                const int sc = T[ro[k] + b_in];
+                const int d0 = max(diag + sc, 0);
+                const int t = max(up, left) + gap;
+                int h = max(d0, t);
+                PH_TBW_BIT(gw[k >> 5], t, d0);
+                PH_TBW_BIT(lw[k >> 5], left, up);
+                h = valid ? h : 0;
+                diag = left;
+                up = h;
+                Hrow[k] = h;
+            }
+            topprev = valid ? top_in : 0;
+            last_h = Hrow[R - 1];
+            last_b = b_in;
+            if (valid) {
+                uint32_t *o = dirw + (size_t)s * 64 * NWL;
+                if (R <= 16) {
+                    o[0] = gw[0] | (lw[0] << 16);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        o[g] = gw[g];
+                        o[NG + g] = lw[g];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // ---- walk (uniform over the wave; lane 0 writes)
+        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+        uint32_t i = eA, j = eB;
+        int h = (int)M;
+        const uint32_t *dbase = dirbuf + wslot * ((size_t)(wcols + 63u) * 64 * NWL);
+        while (h > 0 && i > 0 && j >= c_s && len < stride) {
+            const uint32_t r = i - 1u, l = r / R, k = r % R;
+            const uint32_t s = (j - c_s) + l;
+            const uint32_t *wp = dbase + ((size_t)s * 64 + l) * NWL;
+            uint32_t gbit, lbit;
+            if (R <= 16) {
+                const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gbit = (w >> (R - 1 - k)) & 1u;
+                lbit = (w >> (16 + R - 1 - k)) & 1u;
+            } else {
+                const uint32_t g = k >> 5, bit = 31u - (k & 31u);
+                gbit = (__hip_atomic_load(wp + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> bit) & 1u;
+                lbit = (__hip_atomic_load(wp + NG + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> bit) & 1u;
+            }
+            const uint8_t sa = ap[r], sb = B[j - 1u];
+            uint8_t ca, cb;
+            if (gbit == 0u) { // align.go:215-219
+                const uint32_t ka = cA[sa], kb = cB[sb];
+                h -= T[(ka == 0xFFu ? (uint32_t)(na - 1) : ka) * (uint32_t)nb + (kb == 0xFFu ? (uint32_t)(nb - 1) : kb)];
+                ca = sa;
+                cb = sb;
+                --i;
+                --j;
+            } else if (lbit == 0u) { // :220-223
+                h -= gap;
+                ca = sa;
+                cb = '-';
+                --i;
+            } else { // :224-227
+                h -= gap;
+                ca = '-';
+                cb = sb;
+                --j;
+            }
+            if (lane == 0) {
+                outA[stride - 1 - len] = ca;
+                outB[stride - 1 - len] = cb;
+            }
+            ++len;
+        }
+    }
+    if (lane == 0)
+        alnLen[pair] = (eA > 0 && lenA > 64u * R) ? 0xFFFFFFFFu : len;
+}
+#undef PH_TBW_BIT
+
 // any lenA: H column and direction words in global scratch, lane-interleaved
 __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
@@ -817,6 +998,9 @@ struct Plan {
     int cp;
     uint32_t lenB_pad, nblk_alloc;
     size_t prof_bytes, prof_smem;
+    // one wave per pair for 256 < lenA <= 4096 (score known): tb_wave_kernel
+    int wave_r;            // 0 = not applicable
+    size_t wave_per_pair;
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -837,6 +1021,13 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
     }
     if (p.per_pair == 0)
         p.per_pair = 4;
+    p.wave_r = 0;
+    if (max_lenA > 256 && max_lenA <= 4096 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536) {
+        p.wave_r = max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : 64;
+        const size_t nwl = p.wave_r <= 16 ? 1 : 2 * ((p.wave_r + 31) / 32);
+        p.wave_per_pair = ((size_t)p.win.wcols + 63) * 64 * nwl * 4;
+        p.per_pair = std::max(p.per_pair, p.wave_per_pair);
+    }
     p.cp = sc->cp <= 8 ? 8 : 32;
     p.lenB_pad = (uint32_t)align_up((size_t)std::min<uint64_t>(lenB, 1u << 30), TBU);
     p.prof_smem = (size_t)p.lenB_pad * p.cp + 256;
@@ -912,7 +1103,10 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
     PH_REQUIRE(aln_stride >= p.win.stride, "polyhip_sw_traceback: aln_stride %u < %u (polyhip_sw_traceback_stride)",
                aln_stride, p.win.stride);
     const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr;
-    k3t::g_tb_last_path = use_prof ? 1 : (p.ra ? 2 : 3);
+    const char *tbw_env = getenv("POLYHIP_TB_WAVE"); // testing aid: POLYHIP_TB_WAVE=0 -> generic kernel for long reads
+    const bool use_wave = !use_prof && p.ra == 0 && p.wave_r != 0 && d_score != nullptr && d_B != nullptr &&
+                          !(tbw_env && tbw_env[0] == '0');
+    k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
     const char *wide_env = getenv("POLYHIP_TB_WIDE");
     const int wide = wide_env && wide_env[0] == '1';
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
@@ -933,6 +1127,29 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
         const uint64_t p1 = std::min(npairs, p0 + chunk);
         const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
         uint32_t *dirbuf = static_cast<uint32_t *>(d_dir);
+        if (use_wave) {
+            const unsigned wblocks = (unsigned)((p1 - p0 + k3t::THREADS / 64 - 1) / (k3t::THREADS / 64));
+#define PH_TBW_LAUNCH(R_)                                                                                             \
+    do {                                                                                                              \
+        auto kern = k3t::tb_wave_kernel<R_>;                                                                          \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)p.smem));                                                                     \
+        hipLaunchKernelGGL(kern, dim3(wblocks), dim3(k3t::THREADS), p.smem, st, d_A, d_offA, p0, p1, d_B, d_offB,     \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err, d_score, \
+                           (int)sc->smax, p.win.wcols, wide, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);           \
+    } while (0)
+            if (p.wave_r == 8)
+                PH_TBW_LAUNCH(8);
+            else if (p.wave_r == 16)
+                PH_TBW_LAUNCH(16);
+            else if (p.wave_r == 32)
+                PH_TBW_LAUNCH(32);
+            else
+                PH_TBW_LAUNCH(64);
+#undef PH_TBW_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
+        }
         if (use_prof) {
 #define PH_TBP_LAUNCH(RA_, CP_)                                                                                        \
     do {                                                                                                               \

@@ -2,11 +2,12 @@
 //
 // The lane-per-pair kernels (sw_batch.hip, sw_packed.hip) need thousands of pairs to fill the chip and
 // take the time of one full DP (10-20 ms at 150 x 5000) no matter how few pairs there are.  This kernel
-// serves the other end: the handful of pairs the packed pass leaves on its tie list, and small batches
-// (a single align.SmithWaterman call is a batch of one).  Same recurrence and argmax as
+// serves the other end: the handful of pairs the packed pass leaves on its tie list, small batches (a single
+// align.SmithWaterman call is a batch of one), reads longer than the 256 rows a lane can hold in registers
+// (up to 4096, shared or per-pair B).  Same recurrence and argmax as
 // search/align/align.go:171-203, same outputs as sw_shared_kernel.
 //
-// Systolic sweep: lane l owns rows [l*R, l*R + R) of the pair (R = 1..4 for lenA <= 64..256) and
+// Systolic sweep: lane l owns rows [l*R, l*R + R) of the pair (R = 1..64 for lenA <= 64..4096) and
 // works on column j = s - l in step s, so the row above its first row (lane l-1's last row, same
 // column) was finished one step earlier and arrives, together with that column's B code, by one
 // lane shift per step.  lenB + 63 steps of R cells per lane; S(a, b) from the compact int32 table in LDS.
@@ -26,8 +27,9 @@ constexpr int THREADS = 256; // 4 waves = 4 pairs per workgroup
 
 template <int R>
 __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
-    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
-    uint32_t lenB, const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ Bbase,
+    const uint64_t *__restrict__ offB, uint32_t lenB_shared, const uint8_t *__restrict__ codeA,
+    const uint8_t *__restrict__ codeB,
     const int32_t *__restrict__ lutcc, int na, int nb, int gap, const uint32_t *__restrict__ binfo,
     const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, int64_t *__restrict__ score,
     uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
@@ -48,6 +50,9 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
          w += (uint64_t)gridDim.x * (THREADS / 64)) {
     const uint64_t pair = list ? (uint64_t)list[w] : w;
 
+    // shared reference, or this pair's own B
+    const uint8_t *B = offB ? Bbase + offB[pair] : Bbase;
+    const uint32_t lenB = offB ? (uint32_t)(offB[pair + 1] - offB[pair]) : lenB_shared;
     const uint64_t o0 = offA[pair];
     const uint64_t l64 = offA[pair + 1] - o0;
     const bool too_long = l64 > (uint64_t)(64 * R);
@@ -77,7 +82,17 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     if (too_long) {
         e = 0xFFFFFFFFu;
     } else if (lenA > 0 && lenB > 0) { // align.go:189-191 + matrix.go:29-36: row-major first failing cell
-        const uint32_t bbad = binfo[0];
+        uint32_t bbad = 0xFFFFFFFFu; // first byte of B outside SecondAlphabet
+        if (offB || !binfo) {
+            for (uint32_t j0 = 0; j0 < lenB && bbad == 0xFFFFFFFFu; j0 += 64) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const uint64_t bad = __ballot(j < lenB && cB[B[j]] == 0xFFu);
+                if (bad)
+                    bbad = j0 + (uint32_t)__builtin_ctzll(bad);
+            }
+        } else {
+            bbad = binfo[0];
+        }
         if (mybad == 0u)
             e = (1u << 8) | ap[0];
         else if (bbad != 0xFFFFFFFFu)
@@ -164,7 +179,8 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
 }
 
 int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
-             const uint8_t *d_B, uint32_t lenB, const uint32_t *binfo, const uint32_t *list, const uint32_t *count,
+             const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
+             const uint32_t *count,
              uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
 {
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
@@ -177,7 +193,7 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
         auto kern = sw_wave_kernel<R_>;                                                                               \
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                    (int)smem));                                                                       \
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem, st, d_A, d_offA, npairs, d_B, lenB,     \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem, st, d_A, d_offA, npairs, d_B, d_offB, lenB, \
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, binfo, list, count, d_score,  \
                            d_endA, d_endB, d_err);                                                                    \
     } while (0)
@@ -187,8 +203,16 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
         PH_WAVE_LAUNCH(2);
     else if (max_lenA <= 192)
         PH_WAVE_LAUNCH(3);
-    else
+    else if (max_lenA <= 256)
         PH_WAVE_LAUNCH(4);
+    else if (max_lenA <= 512)
+        PH_WAVE_LAUNCH(8);
+    else if (max_lenA <= 1024)
+        PH_WAVE_LAUNCH(16);
+    else if (max_lenA <= 2048)
+        PH_WAVE_LAUNCH(32);
+    else
+        PH_WAVE_LAUNCH(64); // up to WAVE_MAX_LENA rows
 #undef PH_WAVE_LAUNCH
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;

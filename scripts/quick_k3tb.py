@@ -6,7 +6,8 @@ sys.path.insert(0, '.')
 from poly_amd import align, alphabet, matrix, mash
 dev = torch.device('cuda:0')
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-LA, LB = 150, 5000
+LA = int(sys.argv[2]) if len(sys.argv) > 2 else 150
+LB = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 a = alphabet.NewAlphabet(list("-ACGT"))
 sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
 B = torch.empty(LB, dtype=torch.uint8, device=dev)

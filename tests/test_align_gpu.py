@@ -50,7 +50,8 @@ def _check(al, scoring, omat, gap, reads, ref=None, refs=None, expect_path=None)
     """expect_path 1 = "a shared-reference fast path": the batch is run through every variant that
     qualifies -- one wave per pair (4, small batches), packed (3), lane per pair (1) -- by switching the
     others off with POLYHIP_SW_WAVE / POLYHIP_SW_PACKED, and each must equal the oracle.  expect_path 2 =
-    everything else: the per-pair-B register-tiled kernel (5) where it qualifies, and the generic kernel."""
+    everything else: the per-pair-B register-tiled kernel (5) or the one-wave-per-pair kernel (6: long reads, gap >= 0,
+    wide scores) where they qualify, and the generic kernel."""
     import os
     align = al[0]
     A, offA = _pack(reads)
@@ -65,7 +66,7 @@ def _check(al, scoring, omat, gap, reads, ref=None, refs=None, expect_path=None)
         variants = [({}, (1, 3, 4)), ({"POLYHIP_SW_WAVE": "0"}, (1, 3)),
                     ({"POLYHIP_SW_WAVE": "0", "POLYHIP_SW_PACKED": "0"}, (1,))]
     elif expect_path == 2:  # "not a shared-reference fast path": per-pair register-tiled kernel (5) or generic (2)
-        variants = [({}, (2, 5)), ({"POLYHIP_SW_PAIR": "0"}, (2,))]
+        variants = [({}, (2, 5, 6)), ({"POLYHIP_SW_PAIR": "0"}, (2, 6)), ({"POLYHIP_SW_PAIR": "0", "POLYHIP_SW_WAVE": "0"}, (2,))]
     for env, paths in variants:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)

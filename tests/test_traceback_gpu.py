@@ -255,3 +255,47 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB):
         sb = sb if isinstance(sb, bytes) else sb.encode()
         assert int(s_h[p]) == s
         assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, p
+
+
+@pytest.mark.parametrize("maxA,LB,shared", [(300, 900, True), (700, 1500, True), (1200, 1300, False), (2600, 700, True), (4096, 300, False)])
+def test_long_reads_wave_kernels(al, monkeypatch, maxA, LB, shared):
+    """reads longer than the 256 rows a lane holds (257..4096): the one-wave-per-pair score kernel (path 6) and
+    traceback kernel (path 4) against the generic kernels (POLYHIP_SW_WAVE=0 / POLYHIP_TB_WAVE=0) on every pair and
+    against the oracle on a sample; shared and per-pair B, ragged lengths."""
+    align = al[0]
+    rng = np.random.default_rng(maxA)
+    n = 48
+    ref = orc.synth_dna(0xC4, LB).tobytes()
+    reads, refs = [], []
+    for p in range(n):
+        L = int(rng.integers(maxA // 2, maxA + 1)) if p else maxA
+        if shared:
+            src = (ref * (L // LB + 2))
+            at = int(rng.integers(0, LB))
+            reads.append(_mutate(rng, src[at:at + L], sub=0.08, indel=0.02)[:maxA])
+            refs.append(ref)
+        else:
+            b = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, LB + 1))).astype(np.uint8))
+            reads.append(_mutate(rng, (b * (L // len(b) + 2))[:L], sub=0.1, indel=0.03)[:maxA])
+            refs.append(b)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    A, offA = _pack(reads)
+    if shared:
+        B, offB = _pack([ref])[0], None
+    else:
+        B, offB = _pack(refs)
+    got = align.sw_align_packed(sc, A, offA, B, offB)
+    assert (align.last_path(), align.sw_traceback_last_path()) == (6, 4)
+    monkeypatch.setenv("POLYHIP_SW_WAVE", "0")
+    monkeypatch.setenv("POLYHIP_TB_WAVE", "0")
+    base = align.sw_align_packed(sc, A, offA, B, offB)
+    assert (align.last_path(), align.sw_traceback_last_path()) == (2, 3)
+    for g, w in zip(got[:4], base[:4]):
+        assert (np.asarray(g) == np.asarray(w)).all()
+    assert got[4] == base[4] and got[5] == base[5]
+    for p in range(0, n, 9):
+        s, sa, sb, ea, eb = orc.smith_waterman(reads[p], refs[p], om, -2)
+        sa = sa if isinstance(sa, bytes) else sa.encode()
+        sb = sb if isinstance(sb, bytes) else sb.encode()
+        assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s, ea, eb) and got[4][p] == sa and got[5][p] == sb, p
