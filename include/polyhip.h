@@ -272,8 +272,8 @@ int polyhip_sw_last_path(void);
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
  * kernel for reads of 257..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off). */
 int polyhip_sw_traceback_last_path(void);
-/* ... and the last polyhip_nw_align_batch_dev call: 1 = register-tiled kernel, 2 = generic kernel
- * (POLYHIP_NW_GENERIC=1 forces it; tests). */
+/* ... and the last polyhip_nw_align_batch_dev call: 1 = register-tiled kernel (lenA <= 256), 2 = generic kernel
+ * (POLYHIP_NW_GENERIC=1 forces it), 3 = one-wave-per-pair kernel (lenA 257..4096); tests. */
 int polyhip_nw_last_path(void);
 
 /* ---- K4: primers SantaLucia / MarmurDoty / MeltingTemp  (primers/primers.go:70-128) */

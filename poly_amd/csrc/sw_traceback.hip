@@ -988,6 +988,193 @@ __global__ __launch_bounds__(THREADS) void nw_reg_kernel(const uint8_t *__restri
 }
 #undef PH_NW_BIT
 
+// ---- NeedlemanWunsch for 256 < lenA <= 4096: one wave per pair (same sweep as tb_wave_kernel) ----------
+// Boundaries H[i][0] = i*gap (the lanes' initial registers), H[0][j] = j*gap (fed to lane 0); the whole matrix's
+// G / L bits are kept (no window in a global alignment); the walk stops when either index reaches 0 (align.go:141).
+#define PH_NWW_BIT(w, x, y)                                                             \
+    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
+                 : "+v"(w)                                                              \
+                 : "v"(x), "v"(y)                                                       \
+                 : "vcc")
+
+template <int R>
+__global__ __launch_bounds__(THREADS) void nw_wave_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ Bbase, const uint64_t *__restrict__ offB, uint64_t lenB_shared,
+    const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB, const int32_t *__restrict__ lutcc, int na,
+    int nb, int gap, uint32_t max_lenB, uint32_t *__restrict__ dirbuf, int64_t *__restrict__ score,
+    uint32_t *__restrict__ err, uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen,
+    uint32_t stride)
+{
+    constexpr int NG = (R + 31) / 32;
+    constexpr int NWL = R <= 16 ? 1 : 2 * NG;
+    extern __shared__ __attribute__((aligned(16))) int32_t T[];
+    uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < na * nb; t += THREADS)
+        T[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+    const uint64_t wslot = (uint64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
+    const uint64_t pair = pair0 + wslot;
+    if (pair >= pair1)
+        return; // wave-uniform
+    const uint64_t o0 = offA[pair];
+    const uint32_t m = (uint32_t)(offA[pair + 1] - o0);
+    const uint8_t *a = A + o0;
+    const uint8_t *b = offB ? Bbase + offB[pair] : Bbase;
+    const uint32_t n = (uint32_t)(offB ? offB[pair + 1] - offB[pair] : lenB_shared);
+    // align.go:126-129 + matrix.go:29-36: the first failing Score() in row-major order, found by the wave
+    uint32_t e = 0;
+    if (m > 0 && n > 0) {
+        uint32_t abad = 0xFFFFFFFFu, bbad = 0xFFFFFFFFu;
+        for (uint32_t i0 = 0; i0 < m && abad == 0xFFFFFFFFu; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            const uint64_t bad = __ballot(i < m && cA[a[i]] == 0xFFu);
+            if (bad)
+                abad = i0 + (uint32_t)__builtin_ctzll(bad);
+        }
+        for (uint32_t j0 = 0; j0 < n && bbad == 0xFFFFFFFFu; j0 += 64) {
+            const uint32_t j = j0 + (uint32_t)lane;
+            const uint64_t bad = __ballot(j < n && cB[b[j]] == 0xFFu);
+            if (bad)
+                bbad = j0 + (uint32_t)__builtin_ctzll(bad);
+        }
+        if (abad == 0u)
+            e = (1u << 8) | a[0];
+        else if (bbad != 0xFFFFFFFFu)
+            e = (2u << 8) | b[bbad];
+        else if (abad != 0xFFFFFFFFu)
+            e = (1u << 8) | a[abad];
+    }
+    if (e || m == 0 || n == 0 || m > 64u * R) {
+        if (lane == 0) {
+            err[pair] = e;
+            score[pair] = e ? 0 : (m == 0 ? (int64_t)n * gap : (int64_t)m * gap);
+            alnLen[pair] = (!e && m > 64u * R) ? 0xFFFFFFFFu : 0u;
+        }
+        return;
+    }
+    uint32_t ro[R];
+    int Hrow[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const uint32_t r = (uint32_t)lane * R + k;
+        ro[k] = (r < m ? (uint32_t)cA[a[r]] : (uint32_t)(na - 1)) * (uint32_t)nb;
+        Hrow[k] = (int)(r + 1u) * gap; // H[r+1][0], align.go:112-115
+    }
+    uint32_t *dirw = dirbuf + wslot * ((size_t)(max_lenB + 63u) * 64 * NWL) + (size_t)lane * NWL;
+    int topprev = (int)((uint32_t)lane * R) * gap; // H[l*R][0]: the diagonal of my first row in column 1
+    int last_h = 0;
+    uint32_t last_b = (uint32_t)(nb - 1);
+    auto load_chunk = [&](uint32_t s0) -> uint32_t {
+        return s0 + (uint32_t)lane < n ? (uint32_t)cB[b[s0 + (uint32_t)lane]] : (uint32_t)(nb - 1);
+    };
+    uint32_t chunk = load_chunk(0), next_chunk = 0u;
+    const uint32_t steps = n + 63u;
+    for (uint32_t s = 0; s < steps; ++s) {
+        if ((s & 63u) == 0u) {
+            if (s)
+                chunk = next_chunk;
+            next_chunk = load_chunk(s + 64u);
+        }
+        int top_in = __shfl_up(last_h, 1, 64);
+        uint32_t b_in = (uint32_t)__shfl_up((int)last_b, 1, 64);
+        const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
+        const uint32_t jr = s - (uint32_t)lane; // 0-based column; wraps for lanes that have not started
+        const bool valid = jr < n;
+        if (lane == 0) {
+            top_in = (int)(jr + 1u) * gap; // H[0][j], :117-120
+            b_in = b_new;
+        }
+        int diag = topprev, up = top_in;
+        uint32_t gw[NG], lw[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            gw[g] = lw[g] = 0u;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int left = Hrow[k];
+            const int sc = T[ro[k] + b_in];
+            const int d = diag + sc;
+            const int t = max(up, left) + gap;
+            const int h = max(d, t);
+            PH_NWW_BIT(gw[k >> 5], t, d);
+            PH_NWW_BIT(lw[k >> 5], left, up);
+            diag = left;
+            up = valid ? h : left;          // lanes outside the matrix keep their boundary column
+            Hrow[k] = valid ? h : left;
+        }
+        if (valid) {
+            topprev = top_in;
+            last_h = Hrow[R - 1];
+            uint32_t *o = dirw + (size_t)s * 64 * NWL;
+            if (R <= 16) {
+                o[0] = gw[0] | (lw[0] << 16);
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    o[g] = gw[g];
+                    o[NG + g] = lw[g];
+                }
+            }
+        }
+        last_b = b_in;
+    }
+    // H[m][n] sits in the lane that owns row m-1
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+        mine = (uint32_t)lane * R + k + 1u == m ? Hrow[k] : mine;
+    const int total = __shfl(mine, (int)((m - 1u) / R), 64);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+    const uint32_t *dbase = dirbuf + wslot * ((size_t)(max_lenB + 63u) * 64 * NWL);
+    uint32_t i = m, j = n, len = 0;
+    while (i > 0 && j > 0 && len < stride) { // :141: stops as soon as EITHER index reaches 0
+        const uint32_t r = i - 1u, l = r / R, k = r % R;
+        const uint32_t *wp = dbase + ((size_t)((j - 1u) + l) * 64 + l) * NWL;
+        uint32_t gbit, lbit;
+        if (R <= 16) {
+            const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gbit = (w >> (R - 1 - k)) & 1u;
+            lbit = (w >> (16 + R - 1 - k)) & 1u;
+        } else {
+            const uint32_t g = k >> 5, bit = 31u - (k & 31u);
+            gbit = (__hip_atomic_load(wp + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> bit) & 1u;
+            lbit = (__hip_atomic_load(wp + NG + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> bit) & 1u;
+        }
+        uint8_t ca, cb;
+        if (gbit == 0u) {
+            ca = a[i - 1];
+            cb = b[j - 1];
+            --i;
+            --j;
+        } else if (lbit == 0u) {
+            ca = a[i - 1];
+            cb = '-';
+            --i;
+        } else {
+            ca = '-';
+            cb = b[j - 1];
+            --j;
+        }
+        if (lane == 0) {
+            outA[stride - 1 - len] = ca;
+            outB[stride - 1 - len] = cb;
+        }
+        ++len;
+    }
+    if (lane == 0) {
+        err[pair] = 0;
+        score[pair] = (int64_t)total;
+        alnLen[pair] = len;
+    }
+}
+#undef PH_NWW_BIT
+
 struct Plan {
     int ra;            // 0 = generic
     Window win;
@@ -1046,12 +1233,18 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
 // NW workspace per pair: the larger of the generic layout (2-bit codes + the H column) and the
 // register-tiled one (G and L words per 32 rows of RA)
 static inline int nw_ra(uint32_t max_lenA) { return max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : max_lenA <= 256 ? 256 : 0; }
+static inline int nw_wave_r(uint32_t max_lenA)
+{
+    return max_lenA <= 256 ? 0 : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : max_lenA <= 4096 ? 64 : 0;
+}
 static uint64_t nw_per_pair(uint32_t max_lenA, uint64_t max_lenB)
 {
     const uint64_t generic = max_lenB * ((max_lenA + 15) / 16) * 4 + (uint64_t)max_lenA * 4 + 8;
     const int ra = nw_ra(max_lenA);
     const uint64_t reg = ra ? max_lenB * (uint64_t)((ra + 31) / 32) * 8 : 0;
-    return std::max<uint64_t>(std::max(generic, reg), 8);
+    const int wr = nw_wave_r(max_lenA);
+    const uint64_t wave = wr ? (max_lenB + 63) * 64 * (uint64_t)(wr <= 16 ? 1 : 2 * ((wr + 31) / 32)) * 4 : 0;
+    return std::max<uint64_t>(std::max(std::max(generic, reg), wave), 8);
 }
 
 } // namespace k3t
@@ -1322,10 +1515,37 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
                         lenB > 0 && !(nw_env && nw_env[0] == '1'))
                            ? k3t::nw_ra(max_lenA)
                            : 0;
-    k3t::g_nw_last_path = reg_ra ? 1 : 2;
+    const int wave_r = (reg_ra == 0 && reg_smem <= 60 * 1024 && (size_t)na * nb < 65536 && lenB > 0 &&
+                        lenB < (1ull << 31) - 64 && !(nw_env && nw_env[0] == '1'))
+                           ? k3t::nw_wave_r(max_lenA)
+                           : 0;
+    k3t::g_nw_last_path = reg_ra ? 1 : wave_r ? 3 : 2;
     for (uint64_t p0 = 0; p0 < npairs; p0 += chunk) {
         const uint64_t p1 = std::min(npairs, p0 + chunk);
         const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
+        if (wave_r) {
+            const unsigned wblocks = (unsigned)((p1 - p0 + k3t::THREADS / 64 - 1) / (k3t::THREADS / 64));
+#define PH_NWW_LAUNCH(R_)                                                                                             \
+    do {                                                                                                              \
+        auto kern = k3t::nw_wave_kernel<R_>;                                                                          \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)reg_smem));                                                                   \
+        hipLaunchKernelGGL(kern, dim3(wblocks), dim3(k3t::THREADS), reg_smem, st, d_A, d_offA, p0, p1, d_B, d_offB, lenB, \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, (uint32_t)lenB,               \
+                           static_cast<uint32_t *>(d_work), d_score, d_err, d_alnA, d_alnB, d_alnLen, aln_stride);    \
+    } while (0)
+            if (wave_r == 8)
+                PH_NWW_LAUNCH(8);
+            else if (wave_r == 16)
+                PH_NWW_LAUNCH(16);
+            else if (wave_r == 32)
+                PH_NWW_LAUNCH(32);
+            else
+                PH_NWW_LAUNCH(64);
+#undef PH_NWW_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
+        }
         if (reg_ra) {
 #define PH_NW_LAUNCH(RA_)                                                                                             \
     do {                                                                                                              \

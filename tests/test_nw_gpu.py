@@ -48,10 +48,12 @@ def test_TestNeedlemanWunsch(al):
         align.NeedlemanWunsch("GAXTACA", "GCATGCU", sc)
 
 
-@pytest.mark.parametrize("maxlen,generic", [(60, False), (150, False), (150, True), (250, False), (300, False)])
+@pytest.mark.parametrize("maxlen,generic", [(60, False), (150, False), (150, True), (250, False), (300, False), (300, True),
+                                            (700, False), (1500, False), (3000, False), (4500, False)])
 def test_batch_matches_oracle(al, monkeypatch, maxlen, generic):
-    """ragged batches against the oracle: the register-tiled kernel (lenA <= 64 / 152 / 256 rows) and the generic
-    one (longer A, or POLYHIP_NW_GENERIC=1); invalid symbols; per-pair and shared B"""
+    """ragged batches against the oracle: the register-tiled kernel (lenA <= 64 / 152 / 256 rows), the
+    one-wave-per-pair kernel (257..4096) and the generic one (longer A, or POLYHIP_NW_GENERIC=1); invalid symbols;
+    per-pair and shared B"""
     if generic:
         monkeypatch.setenv("POLYHIP_NW_GENERIC", "1")
     rng = np.random.default_rng(5)
@@ -69,12 +71,17 @@ def test_batch_matches_oracle(al, monkeypatch, maxlen, generic):
                 else:
                     b.insert(int(rng.integers(0, len(b) + 1)), int(rng.choice(list(b"ACGT"))))
             B.append(bytes(b))
-        A += [(b"ACGT" * 70)[:maxlen], b"A" * maxlen, b"ACNT", b"ACGT", b"TTTT"]
-        B += [b"ACGA" * 65, b"A" * 17, b"ACGT", b"ACXT", b""]
+        long_a = bytes(rng.choice(list(b"ACGT"), maxlen).astype(np.uint8))
+        long_b = bytearray(long_a)
+        for _ in range(maxlen // 25):
+            long_b[int(rng.integers(0, len(long_b)))] = int(rng.choice(list(b"ACGT")))
+        del long_b[maxlen // 3: maxlen // 3 + 7]
+        A += [(b"ACGT" * 1200)[:maxlen], b"A" * maxlen, b"ACNT", b"ACGT", b"TTTT", long_a, long_a[: maxlen // 2], long_a]
+        B += [b"ACGA" * 65, b"A" * 17, b"ACGT", b"ACXT", b"", bytes(long_b), bytes(long_b), long_a[::-1]]
         pa, oa = _pack(A)
         pb, ob = _pack(B)
         score, err, sa, sb = al[0].nw_align_packed(sc, pa, oa, pb, ob)
-        assert al[0].nw_last_path() == (1 if maxlen <= 256 and not generic else 2)
+        assert al[0].nw_last_path() == (2 if generic or maxlen > 4096 else 1 if maxlen <= 256 else 3)
         for p, (a, b) in enumerate(zip(A, B)):
             try:
                 w = orc.needleman_wunsch(a, b, om, gap)
