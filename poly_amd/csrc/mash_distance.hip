@@ -46,9 +46,12 @@ namespace polyhip {
 namespace k2 {
 
 constexpr int THREADS = 256;
-constexpr uint32_t MAX_OCC = 255; // occurrence number packed above the sketch id
-constexpr uint32_t ID_BITS = 24;
-constexpr uint32_t ID_MASK = (1u << ID_BITS) - 1u;
+// An index item is (value, sketch id | occurrence number << id_bits): id_bits = ceil(log2(ny)) (<= ID_BITS_MAX),
+// the rest of the dword counts the copies of the value inside one sketch, so that the join can apply the merge's
+// multiset semantics (occ < multiplicity in the row).  With 100k sketches that leaves 15 bits: a sketch made of
+// one repeated hash (a homopolymer read) is an ordinary citizen, not an "irregular" one that drags every pair it
+// is part of through the reference's merge loop.
+constexpr uint32_t ID_BITS_MAX = 24;
 constexpr uint32_t TAB = 2048;        // LDS hash accumulator slots per row
 constexpr uint32_t TAB_LIMIT = 1536;  // distinct columns a row may hit before it goes to the merge
 constexpr uint32_t S_MAX = 8192;      // X SketchSize rowjoin stages in LDS
@@ -102,7 +105,7 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
 // ---- check: ascending? occurrence number representable? max value.  One block per sketch.
 __global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restrict__ sk, uint32_t s,
                                                        uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
-                                                       int force_irregular, int track_max)
+                                                       int force_irregular, int track_max, uint32_t max_occ)
 {
     const uint64_t q = blockIdx.x;
     const uint32_t *p = sk + q * s;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restri
         v = max(v, x);
         if (e + 1 < s && x > p[e + 1])
             bad = true;
-        if (e >= MAX_OCC + 1 && p[e - (MAX_OCC + 1)] == x) // > 256 equal values in one sketch
+        if (e > max_occ && p[e - max_occ - 1u] == x) // more equal values in one sketch than an item can number
             bad = true;
     }
     if (bad)
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(1024) void coarse_scan_kernel(const uint32_t *__res
 __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
                                                                 const uint8_t *__restrict__ flags,
                                                                 const uint32_t *__restrict__ hdr, uint32_t cshift_extra,
-                                                                uint32_t nc, uint32_t per_batch,
+                                                                uint32_t nc, uint32_t per_batch, uint32_t id_bits,
                                                                 uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
 {
     extern __shared__ uint32_t lh[]; // count[nc] then base[nc]
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
             while (occ < e && p[e - occ - 1] == v)
                 ++occ;
             const uint32_t c = v >> cshift;
-            citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << ID_BITS));
+            citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
         }
     }
 }
@@ -376,12 +379,13 @@ __device__ __forceinline__ bool table_add(uint32_t *__restrict__ keys, uint32_t 
 __global__ __launch_bounds__(THREADS) void rowjoin_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
                                                          const uint8_t *__restrict__ flagsX,
                                                          const uint32_t *__restrict__ start,
-                                                         const uint2 *__restrict__ items, uint32_t nbk,
+                                                         const uint2 *__restrict__ items, uint32_t nbk, uint32_t id_bits,
                                                          uint32_t *__restrict__ hdr, uint32_t *__restrict__ ovfX,
                                                          uint16_t *__restrict__ counts, uint64_t ld)
 {
     if (hdr[H_MODE] != MODE_SPARSE)
         return;
+    const uint32_t id_mask = (1u << id_bits) - 1u;
     // per distinct value d of the row: dval, dmul (multiplicity), dbeg/dend (its bucket in `items`)
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     uint32_t *xv = dyn, *dval = dyn + sx, *dmul = dyn + 2 * (size_t)sx, *dbeg = dyn + 3 * (size_t)sx,
@@ -447,12 +451,12 @@ __global__ __launch_bounds__(THREADS) void rowjoin_kernel(const uint32_t *__rest
                 if (d >= nd)
                     break;
                 const uint32_t v = dval[d], a = dmul[d];
-                if (it[u].y != 0xFFFFFFFFu && it[u].x == v && (it[u].y >> ID_BITS) < a)
-                    ok &= table_add(keys, cnts, &nkeys, it[u].y & ID_MASK);
+                if (it[u].y != 0xFFFFFFFFu && it[u].x == v && (it[u].y >> id_bits) < a)
+                    ok &= table_add(keys, cnts, &nkeys, it[u].y & id_mask);
                 for (uint32_t t = dbeg[d] + 64 + lane; t < dend[d]; t += 64) { // rest of a long bucket
                     const uint2 r = items[t];
-                    if (r.x == v && (r.y >> ID_BITS) < a)
-                        ok &= table_add(keys, cnts, &nkeys, r.y & ID_MASK);
+                    if (r.x == v && (r.y >> id_bits) < a)
+                        ok &= table_add(keys, cnts, &nkeys, r.y & id_mask);
                 }
             }
             if (nkeys > TAB_LIMIT)
@@ -484,8 +488,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                                                                const uint2 *__restrict__ items, uint32_t nbk,
                                                                const uint32_t *__restrict__ hdr,
                                                                const uint32_t *__restrict__ ovfX, uint64_t ny,
-                                                               uint32_t w_log2, uint16_t *__restrict__ counts,
-                                                               uint64_t ld)
+                                                               uint32_t w_log2, uint32_t id_bits,
+                                                               uint16_t *__restrict__ counts, uint64_t ld)
 {
     if (hdr[H_MODE] != MODE_SPARSE)
         return;
@@ -534,8 +538,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 const uint32_t v = dval[d], a = dmul[d];
                 for (uint32_t t = dbeg[d] + lane; t < dend[d]; t += 64) {
                     const uint2 it = items[t];
-                    const uint32_t id = it.y & ID_MASK;
-                    if (it.x == v && (it.y >> ID_BITS) < a && (id >> (w_log2 + 1)) == stripe)
+                    const uint32_t id = it.y & ((1u << id_bits) - 1u);
+                    if (it.x == v && (it.y >> id_bits) < a && (id >> (w_log2 + 1)) == stripe)
                         atomicAdd(&dense[(id & (2u * W - 1u)) >> 1], 1u << (16u * (id & 1u)));
                 }
             }
@@ -687,10 +691,14 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
     }
 
     // the join packs the Y sketch id into 24 bits and stages an X row in LDS
-    const int force = (ny > k2::ID_MASK + 1ull || sx > k2::S_MAX) ? 1 : 0;
+    const int force = (ny > (1ull << k2::ID_BITS_MAX) || sx > k2::S_MAX) ? 1 : 0;
+    uint32_t id_bits = 1; // bits of a Y sketch id; the rest of an item's second dword numbers the copies of a value
+    while ((1ull << id_bits) < ny && id_bits < k2::ID_BITS_MAX)
+        ++id_bits;
+    const uint32_t max_occ = (1u << (32 - id_bits)) - 2u; // all-ones stays free (the join's "no item" marker)
     const unsigned gx = (unsigned)nx, gy = (unsigned)ny; // one block per sketch
-    hipLaunchKernelGGL(k2::check_kernel, dim3(gx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0);
-    hipLaunchKernelGGL(k2::check_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1);
+    hipLaunchKernelGGL(k2::check_kernel, dim3(gx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0, 0xFFFFFFFEu);
+    hipLaunchKernelGGL(k2::check_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1, max_occ);
     const uint64_t nmax = std::max(nx, ny);
     hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nmax + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                        flagsX, nx, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2);
@@ -702,7 +710,7 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
                            hdr, L.fpc_log2, L.nc, per_batch, gcount);
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, gcount, L.nc, cstart, gcur, start, L.nbk);
         hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
-                           flagsY, hdr, L.fpc_log2, L.nc, per_batch, gcur, citems);
+                           flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, gcur, citems);
         hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(L.nc, 256u * 8u)), dim3(k2::THREADS), 0, st, citems, cstart,
                            L.nc, L.fpc_log2, hdr, start, items);
     }
@@ -718,7 +726,7 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull * 16ull);
         hipLaunchKernelGGL(k2::rowjoin_kernel, dim3(blocks), dim3(k2::THREADS), smem, st, d_X, nx, sx, flagsX, start, items,
-                           L.nbk, hdr, ovfX, d_counts, ld);
+                           L.nbk, id_bits, hdr, ovfX, d_counts, ld);
     }
     // rows that overflowed their hash table: dense 16-bit counters per column stripe, as many columns per
     // stripe as LDS holds next to the row's own arrays (a power of two of dwords, two columns each)
@@ -734,7 +742,7 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull);
             hipLaunchKernelGGL(k2::rowjoin_dense_kernel, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, sx, start, items,
-                               L.nbk, hdr, ovfX, ny, w_log2, d_counts, ld);
+                               L.nbk, hdr, ovfX, ny, w_log2, id_bits, d_counts, ld);
             ovf_done = 1;
         }
     }

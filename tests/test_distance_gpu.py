@@ -275,3 +275,32 @@ def test_dense_rows_over_several_column_stripes(mash):
     assert mode == 0 and ovf >= 40 and iy == 3
     got = ct.cpu().numpy().view(np.uint16)
     assert (got == _oracle_counts(X, Y)).all()
+
+
+def test_sketches_made_of_repeated_hashes_stay_in_the_join(mash):
+    """homopolymer / tandem-repeat reads sketch to a few hashes repeated hundreds of times (the reference keeps
+    duplicates).  Such sketches are regular for the join (the occurrence number has 32 - ceil(log2(ny)) bits), and
+    min(multiplicity in X, multiplicity in Y) per shared value is what the reference's merge counts."""
+    import torch
+    rng = np.random.default_rng(23)
+    s, ny = 1000, 300
+    Y = np.sort(rng.integers(0, 1 << 30, (ny, s), dtype=np.uint32), axis=1)
+    h1, h2, h3 = 12345, 777777, 900000001
+    Y[0, :] = h1                                  # 1000 copies of one hash
+    Y[1, :600] = h1; Y[1, 600:] = h2              # 600 + 400
+    Y[2, :300] = h1; Y[2, 300:650] = h2; Y[2, 650:] = h3
+    Y[3, :257] = h2                               # just above the old 256 limit
+    Y[4, :5] = h3
+    Y = np.sort(Y, axis=1)
+    X = Y[[0, 1, 2, 3, 4, 50, 51]].copy()
+    dev = torch.device("cuda:0")
+    Xt, Yt = (torch.from_numpy(a.view(np.int32).copy()).to(dev) for a in (X, Y))
+    ct = torch.full((len(X), ny), -1, dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(len(X), s, ny, s), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(Xt, Yt, ct, work)
+    torch.cuda.synchronize()
+    mode, ix, iy, ovf, est = mash.shared_counts_mode(work)
+    assert (mode, ix, iy) == (0, 0, 0)
+    got = ct.cpu().numpy().view(np.uint16)
+    assert (got == _oracle_counts(X, Y)).all()
+    assert got[0, 0] == 1000 and got[0, 1] == 600 and got[1, 2] == 300 + 350
