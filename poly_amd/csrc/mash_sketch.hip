@@ -128,7 +128,7 @@ constexpr uint32_t BIG_BIN = 32;
 constexpr uint32_t BIG_LIST_CAP = 512; // the list lives in seqb (>= WAVES * WTW / 4 dwords); more big bins than that: per-element ranking
 
 template <class Emit>
-__device__ __forceinline__ void rank_big_bins(const uint32_t *__restrict__ binned, const uint32_t *__restrict__ bins,
+__device__ __attribute__((noinline)) void rank_big_bins(const uint32_t *__restrict__ binned, const uint32_t *__restrict__ bins,
                                               const uint32_t *__restrict__ biglist, uint32_t nbig, uint32_t s, Emit emit)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -264,7 +264,7 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
         if (pos < s)
             sm.cand[pos] = h;
     }
-    if (by_waves)
+    if (by_waves && nbig)
         rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [&](uint32_t pos, uint32_t h) { sm.cand[pos] = h; });
     __syncthreads();
     if (tid == 0) {
@@ -616,7 +616,7 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
                 outp[pos] = h[u];
         }
     }
-    if (by_waves)
+    if (by_waves && nbig) // rare: keep it out of line (and out of the common path's register budget)
         rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [&](uint32_t pos, uint32_t hv) { outp[pos] = hv; });
 }
 
