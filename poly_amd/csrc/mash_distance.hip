@@ -27,10 +27,12 @@
 //            global atomics); then flush the table's entries to counts[i][*].
 //            "occ < a" makes a value that is a times in X_i and b times in Y_j
 //            count min(a, b) times: what the reference's two-pointer merge counts.
+//   dense    rows whose hash table overflows (thousands of related sketches): the
+//            same bucket walk with DENSE 16-bit counters in LDS, one per column of
+//            a 65,536-column stripe (rowjoin_dense_kernel)
 //   generic  the reference's own loop, one pair per lane, for every pair that
 //            involves an irregular sketch (the range early-out of mash.go:117
-//            and the merge both read unsorted data there), for rows whose table
-//            overflows (thousands of related sketches), and for ALL pairs when
+//            and the merge both read unsorted data there), and for ALL pairs when
 //            the index says the input is dense (huge buckets: many near-identical
 //            sketches), where merging is cheaper than joining.
 //

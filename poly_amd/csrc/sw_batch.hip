@@ -6,9 +6,11 @@
 // linear gap, arbitrary (possibly asymmetric) substitution matrix, argmax =
 // first maximum in row-major order (i over A outer, j over B inner).
 //
-// Two kernel families:
+// This file holds the entry points, the plan that picks a path (polyhip_sw_last_path), and three kernels; the
+// packed two-pairs-per-lane pass (the default at BASELINE config 4) lives in sw_packed.hip, the one-wave-per-pair
+// kernel (small batches, ties of the packed pass, reads of 257..4096 symbols) in sw_wave.hip.
 //
-//  sw_shared_kernel<RA, CP>  -- the hot one (BASELINE config 4: 1M x 150 bp
+//  sw_shared_kernel<RA, CP>  -- 32-bit lane-per-pair kernel (BASELINE config 4: 1M x 150 bp
 //    reads against ONE shared 5 kb reference).  Inter-sequence parallel: one
 //    pair per lane, all 64 lanes of a wave walk the SAME column b_j.  The whole
 //    H column of the pair (RA rows, int32) lives in VGPRs; the reference is
@@ -22,7 +24,10 @@
 //    Conditions: shared B, lenA <= 256, scores in int8, gap <= -1,
 //    maxS * min(lenA, lenB) < 2^14.
 //
-//  sw_generic_kernel -- everything else (per-pair B, long A, odd scoring):
+//  sw_pair_kernel<RA> -- per-pair B (reads against reads), lenA <= 256: the same register tiling with the score
+//    looked up in the compact int32 table in LDS by the lane's own B symbol.
+//
+//  sw_generic_kernel -- the last resort (A beyond 4096 symbols, tables too large for LDS):
 //    one pair per lane, the reference's own loop nest with the previous row in
 //    a lane-interleaved global scratch.  Correct for any input; not tuned.
 //
