@@ -77,6 +77,10 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         "cell_updates_per_s": cells / ms_score * 1e3, "score_pass_ms": ms_score,
         "cell_updates_per_s_with_traceback": cells / (ms_score + ms_tb) * 1e3, "traceback_ms": ms_tb,
         "algorithmic_GBs_score_pass": alg / ms_score * 1e3 / 1e9,
+        # the bound that matters for K3: VALU issue.  The packed kernel spends 22 half-rate instructions
+        # (88 cycles) per 512 cells (64 lanes x 2 pairs x 4 columns); 1024 SIMDs at ~2.4 GHz.
+        "valu_issue_ceiling_cell_updates_per_s": 1024 * 2.4e9 * 512 / 88,
+        "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / (1024 * 2.4e9 * 512 / 88),
         "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
     }
 
