@@ -9,6 +9,8 @@ committed so that nothing at test/bench time reads /root/reference.
   fastq/*.fastq <- io/fastq/data/*.fastq  (verbatim copies of the reference's own parser fixtures:
                    fastq_test.go:59-66, example_test.go:16-66)
   fasta/base.fasta <- io/fasta/data/base.fasta  (example_test.go:18-36,100-114)
+  clone_goldengate_rotated.seq <- the `// Output:` line of clone/example_test.go:11-31 (ExampleGoldenGate prints
+                   seqhash.RotateSequence(Clones[0])): a 4.4 kb circular construct already at its least rotation
 
 Extraction follows io/genbank/genbank.go:125,627-633: every line between
 ORIGIN and // with all non-letters removed, case preserved.
@@ -55,6 +57,18 @@ def copy_fastq():
     shutil.copy(os.path.join(REF, "io", "fasta", "data", "base.fasta"), os.path.join(HERE, "fasta"))
 
 
+def clone_example_output():
+    """the expected output of ExampleGoldenGate (clone/example_test.go:30-31)"""
+    with open(os.path.join(REF, "clone", "example_test.go")) as f:
+        src = f.read()
+    at = src.index("fmt.Println(seqhash.RotateSequence(Clones[0]))")
+    out = re.search(r"// Output: ([A-Za-z]+)", src[at:]).group(1)
+    with open(os.path.join(HERE, "clone_goldengate_rotated.seq"), "w") as f:
+        f.write(out + "\n")
+    print("clone_goldengate_rotated.seq", len(out))
+
+
 if __name__ == "__main__":
     copy_fastq()
+    clone_example_output()
     sys.exit(main())

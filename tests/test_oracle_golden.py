@@ -370,6 +370,12 @@ def test_seqhash_rotation():
     assert want[:30] == b"aaaaaaaccaccgctaccagcggtggtttg"
     for r in range(0, len(puc), 1):
         assert orc.rotate_sequence(puc[r:] + puc[:r]) == want
+    # clone/example_test.go:30-31: ExampleGoldenGate prints RotateSequence(construct) -- a reference-held
+    # 3.7 kb least rotation: it rotates to itself, and so does every rotation of it
+    gg = _read("clone_goldengate_rotated.seq")
+    assert len(gg) == 3662 and orc.booth_least_rotation(gg) == 0 and orc.rotate_sequence(gg) == gg.encode()
+    for r in range(1, len(gg), 37):
+        assert orc.rotate_sequence(gg[r:] + gg[:r]) == gg.encode()
     # Booth == naive minimum over random strings, incl. periodic ones
     rng = np.random.default_rng(3)
     for _ in range(300):

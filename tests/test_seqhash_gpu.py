@@ -167,3 +167,14 @@ def test_runs_of_the_least_byte():
     for i, q in enumerate(seqs):
         assert int(rot[i]) == orc.booth_least_rotation(q), (i, q[:30], len(q))
         assert out[int(offs[i]): int(offs[i + 1])].tobytes() == orc.rotate_sequence(q), i
+
+
+def test_clone_example_golden():
+    """clone/example_test.go:30-31: the reference's ExampleGoldenGate prints RotateSequence of a 3.7 kb circular
+    construct; that string is a reference-held least rotation -- it and every rotation of it rotate to it."""
+    import os
+    from poly_amd import seqhash as sh
+    gg = open(os.path.join(os.path.dirname(__file__), "golden", "clone_goldengate_rotated.seq")).read().strip()
+    assert sh.RotateSequence(gg) == gg
+    rots = [gg[r:] + gg[:r] for r in range(0, len(gg), 11)]
+    assert set(sh.RotateBatch(rots) if hasattr(sh, "RotateBatch") else [sh.RotateSequence(x) for x in rots]) == {gg}
