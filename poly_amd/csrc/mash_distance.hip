@@ -165,7 +165,7 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
 // LDS histogram + scan, writes start[] and the final item order.
 
 constexpr uint32_t FPC_MAX = 2048;   // fine buckets per coarse bucket (nbk <= 2^23)
-constexpr uint32_t BATCH_ITEMS = 16384; // items a level-1 workgroup takes at a time
+constexpr uint32_t BATCH_ITEMS = 65536; // items a level-1 workgroup takes at a time
 
 // coarse histogram: gcount[c] += items of my batch in coarse bucket c
 __global__ __launch_bounds__(THREADS) void coarse_count_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
