@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import torch
 
-from . import align, alphabet, fastq, mash, matrix, primers, seqhash
+from . import align, alphabet, fasta, fastq, mash, matrix, primers, seqhash
 
 HBM_PEAK_GBS = 8000.0
 
@@ -216,10 +216,29 @@ def nw(dev, n: int = 200_000, L: int = 150):
             "mean_alignment_len": float(ln.double().mean())}
 
 
+def fasta_feeder(dev, n: int = 100_000, L: int = 4000, width: int = 80):
+    """FASTA image (n records of L bp in lines of `width`) -> packed batch, parsed on the device"""
+    import numpy as np
+    rng = np.random.default_rng(2)
+    body = bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+    rec = b">seq0000000 some description\n" + b"\n".join(body[i:i + width] for i in range(0, L, width)) + b"\n"
+    img = torch.from_numpy(np.frombuffer(rec * n, np.uint8).copy()).to(dev)
+    nb = img.numel()
+    seqs = torch.empty(nb, dtype=torch.uint8, device=dev)
+    offs = torch.zeros(nb // 8 + 2, dtype=torch.int64, device=dev)
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    work = torch.empty(fasta.workspace_bytes(nb), dtype=torch.uint8, device=dev)
+    ms = _time(lambda: fasta.pack_dev(img, seqs, offs, None, res, work), 5)
+    r = [int(x) for x in res.cpu()]
+    return {"workload": f"FASTA image of {n} records x {L} bp in {width}-column lines ({nb} B) -> packed batch on the device",
+            "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
+
+
 def run(dev) -> dict:
     out = {}
     for name, fn in (("smith_waterman", sw), ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
-                     ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder)):
+                     ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder),
+                     ("fasta_feeder", fasta_feeder)):
         try:
             out[name] = fn(dev)
         except Exception as e:  # a secondary number must never take the headline down

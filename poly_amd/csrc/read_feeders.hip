@@ -89,6 +89,105 @@ __global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *__restri
         out[n] = carry;
 }
 
+// ---- the same scan over SCAN_SEGS workgroups for long inputs (millions of lines): per-segment sums, a scan of
+// the sums, then every workgroup scans its own segment from its offset.  n may exist only on the device.
+constexpr int SCAN_SEGS = 512;
+
+__device__ __forceinline__ void scan_segment(uint64_t n, uint64_t &lo, uint64_t &hi)
+{
+    const uint64_t per = ((n + SCAN_SEGS - 1) / SCAN_SEGS + 1023) / 1024 * 1024; // whole 1024-element chunks
+    lo = min(n, (uint64_t)blockIdx.x * per);
+    hi = min(n, lo + per);
+}
+
+__global__ __launch_bounds__(1024) void scan_sums_kernel(const uint32_t *__restrict__ in, uint64_t n_host,
+                                                        const uint64_t *__restrict__ n_dev, uint64_t div,
+                                                        uint64_t *__restrict__ partial)
+{
+    const uint64_t n = n_dev ? *n_dev / div : n_host;
+    uint64_t lo, hi;
+    scan_segment(n, lo, hi);
+    __shared__ uint64_t ws[16];
+    uint64_t sum = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024)
+        sum += in[i];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        sum += __shfl_xor(sum, d, 64);
+    if ((threadIdx.x & 63) == 0)
+        ws[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < 16; ++w)
+            t += ws[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_SEGS) void scan_offsets_kernel(uint64_t *__restrict__ partial, uint64_t n_host,
+                                                                const uint64_t *__restrict__ n_dev, uint64_t div,
+                                                                uint64_t *__restrict__ out)
+{
+    __shared__ uint64_t ws[SCAN_SEGS / 64];
+    const int tid = threadIdx.x;
+    const uint64_t v = partial[tid];
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d)
+            incl += t;
+    }
+    if ((tid & 63) == 63)
+        ws[tid >> 6] = incl;
+    __syncthreads();
+    uint64_t pre = 0;
+    for (int w = 0; w < (tid >> 6); ++w)
+        pre += ws[w];
+    partial[tid] = pre + incl - v; // exclusive: where segment tid starts
+    if (tid == SCAN_SEGS - 1)
+        out[n_dev ? *n_dev / div : n_host] = pre + incl;
+}
+
+__global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *__restrict__ in, uint64_t n_host,
+                                                         const uint64_t *__restrict__ n_dev, uint64_t div,
+                                                         const uint64_t *__restrict__ partial, uint64_t *__restrict__ out)
+{
+    const uint64_t n = n_dev ? *n_dev / div : n_host;
+    uint64_t lo, hi;
+    scan_segment(n, lo, hi);
+    __shared__ uint64_t wsum[16];
+    __shared__ uint64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        carry = partial[blockIdx.x];
+    __syncthreads();
+    for (uint64_t base = lo; base < hi; base += 1024) {
+        const uint64_t i = base + tid;
+        const uint64_t v = i < hi ? in[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w)
+            pre += wsum[w];
+        if (i < hi)
+            out[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry = pre + incl;
+        __syncthreads();
+    }
+}
+
 // newlines per PER_BLOCK bytes
 __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
                                                                 uint32_t *__restrict__ counts)
@@ -456,6 +555,24 @@ static Layout layout_fasta(uint64_t nbytes)
 
 using namespace polyhip;
 
+// exclusive scan of `in` (n = n_host, or *n_dev / div) into out[0..n]; `upper` bounds n on the host: long
+// inputs go through SCAN_SEGS workgroups (its partial sums live in a stream-ordered scratch allocation)
+static int scan_u32(const uint32_t *in, uint64_t n_host, const uint64_t *n_dev, uint64_t div, uint64_t upper,
+                    uint64_t *out, hipStream_t st)
+{
+    if (upper <= 262144) {
+        hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, n_host, n_dev, div, out);
+        return POLYHIP_OK;
+    }
+    uint64_t *partial = nullptr;
+    PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), fq::SCAN_SEGS * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(fq::scan_sums_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial);
+    hipLaunchKernelGGL(fq::scan_offsets_kernel, dim3(1), dim3(fq::SCAN_SEGS), 0, st, partial, n_host, n_dev, div, out);
+    hipLaunchKernelGGL(fq::scan_apply_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial, out);
+    PH_HIP(hipFreeAsync(partial, st));
+    return POLYHIP_OK;
+}
+
 extern "C" {
 
 size_t polyhip_fastq_workspace_bytes(uint64_t nbytes) { return fq::layout(nbytes).total; }
@@ -481,8 +598,8 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(res, 0, fq::R_WORDS * 8, st));
     PH_HIP(hipMemsetAsync(res + fq::R_FIRSTBAD, 0xFF, 8, st));
     hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes, counts);
-    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, counts, L.nblocks, (const uint64_t *)nullptr,
-                       (uint64_t)1, blockoff);
+    if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, st))
+        return rc;
     hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
                        blockoff, line_end);
     // The line count exists only on the device (blockoff[nblocks]); the record kernels are launched for
@@ -491,8 +608,8 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     const uint64_t most = nbytes / 8 + 1;
     hipLaunchKernelGGL(fq::records_kernel, dim3((unsigned)((most + fq::THREADS - 1) / fq::THREADS)), dim3(fq::THREADS), 0, st,
                        d_file, line_end, nlines_dev, seq_len, seq_start, d_rec_start, res);
-    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, seq_len, (uint64_t)0, nlines_dev, (uint64_t)4,
-                       d_offsets);
+    if (int rc = scan_u32(seq_len, 0, nlines_dev, 4, nbytes / 8 + 1, d_offsets, st))
+        return rc;
     hipLaunchKernelGGL(fq::finish_kernel, dim3(1), dim3(1), 0, st, d_file, nbytes, line_end, nlines_dev, d_offsets,
                        max_records, res);
     hipLaunchKernelGGL(fq::gather_kernel, dim3((unsigned)std::min<uint64_t>(most, 256ull * 32ull)), dim3(fq::THREADS), 0, st,
@@ -559,17 +676,19 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(hrank, 0, 16, st));
     PH_HIP(hipMemsetAsync(dst, 0, 16, st));
     hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes, counts);
-    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, counts, L.nblocks, (const uint64_t *)nullptr,
-                       (uint64_t)1, blockoff);
+    if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, st))
+        return rc;
     hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
                        blockoff, line_end);
     const uint64_t *nlines_dev = blockoff + L.nblocks; // the line count exists only on the device
     const unsigned gl = (unsigned)((nbytes + fq::THREADS - 1) / fq::THREADS + 1); // >= lines
     hipLaunchKernelGGL(fq::fasta_classify_kernel, dim3(gl), dim3(fq::THREADS), 0, st, d_file, line_end, nlines_dev, is_header,
                        seq_len);
-    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, is_header, (uint64_t)0, nlines_dev, (uint64_t)1, hrank);
+    if (int rc = scan_u32(is_header, 0, nlines_dev, 1, nbytes + 1, hrank, st))
+        return rc;
     hipLaunchKernelGGL(fq::fasta_prefix_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, hrank, seq_len);
-    hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, seq_len, (uint64_t)0, nlines_dev, (uint64_t)1, dst);
+    if (int rc = scan_u32(seq_len, 0, nlines_dev, 1, nbytes + 1, dst, st))
+        return rc;
     hipLaunchKernelGGL(fq::fasta_offsets_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, is_header, hrank, dst, line_end,
                        d_offsets, d_rec_start);
     hipLaunchKernelGGL(fq::fasta_empty_kernel, dim3(gl), dim3(fq::THREADS), 0, st, hrank, nlines_dev, d_offsets, res);

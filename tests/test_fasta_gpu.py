@@ -65,3 +65,23 @@ def test_quirks_and_random_files():
         seq = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 900))).astype(np.uint8))
         recs.append(b">seq%d desc\n" % i + b"\n".join(seq[j:j + 70] for j in range(0, len(seq), 70)) + b"\n")
     _check(b"".join(recs))
+
+
+def test_large_file_goes_through_the_multi_workgroup_scan():
+    """a ~1 MB FASTA image (tens of thousands of lines: past the single-workgroup scan's limit) with ragged line
+    widths, comment lines and empty lines: same records as the restated parser"""
+    rng = np.random.default_rng(31)
+    parts = []
+    for i in range(2500):
+        L = int(rng.integers(1, 700))
+        body = bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+        w = int(rng.integers(20, 90))
+        parts.append(b">rec%d some words\n" % i + b"\n".join(body[j:j + w] for j in range(0, L, w)) + b"\n")
+        if i % 97 == 0:
+            parts.append(b";a comment line\n")
+        if i % 131 == 0:
+            parts.append(b"\n")
+    data = b"".join(parts)
+    assert len(data) > 600_000
+    _check(data)
+    _check(data[:-1])      # EOF right behind the last sequence line

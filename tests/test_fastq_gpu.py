@@ -95,3 +95,13 @@ def test_packed_batch_feeds_the_sketch_kernel():
     o[1:] = np.cumsum([len(r[1]) for r in want_recs])
     assert total == len(buf)
     assert (sk.cpu().numpy().view(np.uint32) == orc.mash_sketch_batch(buf, o, 21, 200)).all()
+
+
+def test_large_file_goes_through_the_multi_workgroup_scan():
+    """a 2.5 MB FASTQ image (more records than the single-workgroup scan takes): same records as the restated parser,
+    also with a malformed record deep inside"""
+    rng = np.random.default_rng(32)
+    good = b"".join(_record(rng, i, int(rng.integers(1, 120))) for i in range(24000))
+    assert len(good) > 2_200_000
+    _check(good)
+    _check(good[:1_500_000] + b"@r\nACGT\n+\n\n" + good[1_500_000:])
