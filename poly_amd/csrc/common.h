@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -45,6 +47,14 @@ struct DevBuf {
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
+
+// Testing aids: NAME=0 (or =1) in the environment, read per call, switches one kernel variant off (or on) so that
+// the parity tests can cross-check the variants; never needed in production.
+inline bool env_is(const char *name, char value)
+{
+    const char *e = getenv(name);
+    return e && e[0] == value;
+}
 
 inline hipStream_t as_stream(polyhip_stream_t s) { return static_cast<hipStream_t>(s); }
 

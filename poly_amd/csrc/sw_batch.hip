@@ -469,14 +469,12 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 
 static bool wave_kernel_off()
 {
-    const char *e = getenv("POLYHIP_SW_WAVE"); // testing aid: POLYHIP_SW_WAVE=0 -> no one-wave-per-pair kernel
-    return e && e[0] == '0';
+    return env_is("POLYHIP_SW_WAVE", '0'); // testing aid: no one-wave-per-pair kernel
 }
 
 static bool pair_kernel_off()
 {
-    const char *e = getenv("POLYHIP_SW_PAIR"); // testing aid: POLYHIP_SW_PAIR=0 -> generic kernel
-    return e && e[0] == '0';
+    return env_is("POLYHIP_SW_PAIR", '0'); // testing aid: generic kernel for per-pair B
 }
 
 static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, bool shared)

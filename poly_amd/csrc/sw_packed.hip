@@ -442,8 +442,7 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
 bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, PackedPlan *out)
 {
     PackedPlan p{};
-    const char *env = getenv("POLYHIP_SW_PACKED");
-    if (env && env[0] == '0')
+    if (env_is("POLYHIP_SW_PACKED", '0')) // testing aid
         return false;
     const uint64_t minlen = std::min<uint64_t>(max_lenA, lenB);
     if (!(sc->int8_ok && sc->gap <= -1 && -sc->gap < 16384 && sc->smax > 0 && sc->cp <= 8 &&

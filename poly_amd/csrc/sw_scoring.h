@@ -2,6 +2,13 @@
 // (sw_batch.hip) and the traceback (sw_traceback.hip).
 #pragma once
 
+// w = 2 * w + (x > y): the compare's carry shifted into a word (direction bits of the tracebacks; two instructions)
+#define PH_CARRY_BIT(w, x, y)                                                           \
+    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
+                 : "+v"(w)                                                              \
+                 : "v"(x), "v"(y)                                                       \
+                 : "vcc")
+
 #include <cstdint>
 
 struct polyhip_scoring {

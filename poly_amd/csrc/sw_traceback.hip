@@ -285,19 +285,14 @@ __global__ __launch_bounds__(256) void tb_profile_kernel(const uint8_t *__restri
         asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_)); \
     } while (0)
 // w = 2 * w + (x > y)
-#define PH_TB_BIT(w, x, y)                                                                  \
-    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"     \
-                 : "+v"(w)                                                                  \
-                 : "v"(x), "v"(y)                                                           \
-                 : "vcc")
 #define PH_TB_CELL(S, DIAG, UP, LEFT, HOUT, C)         \
     do {                                               \
         const int up_ = (UP), left_ = (LEFT);          \
         const int d0_ = max((DIAG) + (S), 0);          \
         const int t_ = max(up_, left_) + gap;          \
         HOUT = max(d0_, t_);                           \
-        PH_TB_BIT(wG[C], t_, d0_);                     \
-        PH_TB_BIT(wL[C], left_, up_);                  \
+        PH_CARRY_BIT(wG[C], t_, d0_);                     \
+        PH_CARRY_BIT(wL[C], left_, up_);                  \
     } while (0)
 #define PH_TB_ROW(I, W)                                         \
     do {                                                        \
@@ -475,7 +470,6 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
 }
 #undef PH_TB_ROW
 #undef PH_TB_CELL
-#undef PH_TB_BIT
 #undef PH_TB_ISSUE
 #undef PH_TB_ADDR
 
@@ -484,11 +478,6 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
 // its first row and the column's B code arrive by one lane shift per step.  Same G / L bits as
 // tb_prof_kernel, one word set per (step, lane) so a wave stores contiguously; the walk (all lanes in step,
 // lane 0 writes) carries the running score down from the score pass's maximum.
-#define PH_TBW_BIT(w, x, y)                                                             \
-    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
-                 : "+v"(w)                                                              \
-                 : "v"(x), "v"(y)                                                       \
-                 : "vcc")
 
 template <int R>
 __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
@@ -585,8 +574,8 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
                 const int d0 = max(diag + sc, 0);
                 const int t = max(up, left) + gap;
                 int h = max(d0, t);
-                PH_TBW_BIT(gw[k >> 5], t, d0);
-                PH_TBW_BIT(lw[k >> 5], left, up);
+                PH_CARRY_BIT(gw[k >> 5], t, d0);
+                PH_CARRY_BIT(lw[k >> 5], left, up);
                 h = valid ? h : 0;
                 diag = left;
                 up = h;
@@ -658,7 +647,6 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     if (lane == 0)
         alnLen[pair] = (eA > 0 && lenA > 64u * R) ? 0xFFFFFFFFu : len;
 }
-#undef PH_TBW_BIT
 
 // any lenA: H column and direction words in global scratch, lane-interleaved
 __global__ __launch_bounds__(THREADS) void tb_generic_kernel(
@@ -833,11 +821,6 @@ __global__ __launch_bounds__(THREADS) void nw_kernel(const uint8_t *__restrict__
 // h = max(d, t), G = t > d (the diagonal wins ties, align.go:146), L = left > up ("up" is tested before the
 // final else, :150-158); boundary column H[i][0] = i*gap in the registers, boundary row carried in `top`.
 // Per-pair B: every lane looks its own column's symbol up in the table (one ds_read per cell).
-#define PH_NW_BIT(w, x, y)                                                              \
-    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
-                 : "+v"(w)                                                              \
-                 : "v"(x), "v"(y)                                                       \
-                 : "vcc")
 
 template <int RA>
 __global__ __launch_bounds__(THREADS) void nw_reg_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
@@ -927,8 +910,8 @@ __global__ __launch_bounds__(THREADS) void nw_reg_kernel(const uint8_t *__restri
                 const int d = diag + s;
                 const int t = max(up, left) + gap;
                 const int h = max(d, t);
-                PH_NW_BIT(wG, t, d);
-                PH_NW_BIT(wL, left, up);
+                PH_CARRY_BIT(wG, t, d);
+                PH_CARRY_BIT(wL, left, up);
                 diag = left;
                 up = h;
                 H[i] = h;
@@ -986,16 +969,10 @@ __global__ __launch_bounds__(THREADS) void nw_reg_kernel(const uint8_t *__restri
     }
     alnLen[pair] = len;
 }
-#undef PH_NW_BIT
 
 // ---- NeedlemanWunsch for 256 < lenA <= 4096: one wave per pair (same sweep as tb_wave_kernel) ----------
 // Boundaries H[i][0] = i*gap (the lanes' initial registers), H[0][j] = j*gap (fed to lane 0); the whole matrix's
 // G / L bits are kept (no window in a global alignment); the walk stops when either index reaches 0 (align.go:141).
-#define PH_NWW_BIT(w, x, y)                                                             \
-    asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \
-                 : "+v"(w)                                                              \
-                 : "v"(x), "v"(y)                                                       \
-                 : "vcc")
 
 template <int R>
 __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
@@ -1101,8 +1078,8 @@ __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
             const int d = diag + sc;
             const int t = max(up, left) + gap;
             const int h = max(d, t);
-            PH_NWW_BIT(gw[k >> 5], t, d);
-            PH_NWW_BIT(lw[k >> 5], left, up);
+            PH_CARRY_BIT(gw[k >> 5], t, d);
+            PH_CARRY_BIT(lw[k >> 5], left, up);
             diag = left;
             up = valid ? h : left;          // lanes outside the matrix keep their boundary column
             Hrow[k] = valid ? h : left;
@@ -1173,7 +1150,6 @@ __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
         alnLen[pair] = len;
     }
 }
-#undef PH_NWW_BIT
 
 struct Plan {
     int ra;            // 0 = generic
@@ -1296,12 +1272,10 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
     PH_REQUIRE(aln_stride >= p.win.stride, "polyhip_sw_traceback: aln_stride %u < %u (polyhip_sw_traceback_stride)",
                aln_stride, p.win.stride);
     const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr;
-    const char *tbw_env = getenv("POLYHIP_TB_WAVE"); // testing aid: POLYHIP_TB_WAVE=0 -> generic kernel for long reads
     const bool use_wave = !use_prof && p.ra == 0 && p.wave_r != 0 && d_score != nullptr && d_B != nullptr &&
-                          !(tbw_env && tbw_env[0] == '0');
+                          !env_is("POLYHIP_TB_WAVE", '0'); // testing aid: generic kernel for long reads
     k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
-    const char *wide_env = getenv("POLYHIP_TB_WIDE");
-    const int wide = wide_env && wide_env[0] == '1';
+    const int wide = env_is("POLYHIP_TB_WIDE", '1'); // testing aid: the conservative per-pair window
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     const uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
@@ -1510,13 +1484,13 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
     // register-tiled kernel: lenA <= 256, the compact table fits LDS, columns below 2^31; else the generic one
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     const size_t reg_smem = (size_t)na * nb * 4 + 512;
-    const char *nw_env = getenv("POLYHIP_NW_GENERIC"); // testing aid: force the generic kernel
+    const bool nw_generic = env_is("POLYHIP_NW_GENERIC", '1'); // testing aid: force the generic kernel
     const int reg_ra = (reg_smem <= 60 * 1024 && (size_t)na * nb < 65536 && lenB < (1ull << 31) && max_lenA > 0 &&
-                        lenB > 0 && !(nw_env && nw_env[0] == '1'))
+                        lenB > 0 && !nw_generic)
                            ? k3t::nw_ra(max_lenA)
                            : 0;
     const int wave_r = (reg_ra == 0 && reg_smem <= 60 * 1024 && (size_t)na * nb < 65536 && lenB > 0 &&
-                        lenB < (1ull << 31) - 64 && !(nw_env && nw_env[0] == '1'))
+                        lenB < (1ull << 31) - 64 && !nw_generic)
                            ? k3t::nw_wave_r(max_lenA)
                            : 0;
     k3t::g_nw_last_path = reg_ra ? 1 : wave_r ? 3 : 2;
