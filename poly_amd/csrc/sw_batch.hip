@@ -83,23 +83,6 @@ __global__ __launch_bounds__(256) void profile_kernel(const uint8_t *__restrict_
     }
 }
 
-// address of row r's profile dword = block base + (code * 4), the code byte picked by SDWA
-#define PH_SW_ADDR(dst, pk, SEL)                                                                           \
-    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
-                 : "=v"(dst)                                                                               \
-                 : "v"(blk), "v"(pk))
-#define PH_SW_ISSUE(pk, w0, w1, w2, w3)                                 \
-    do {                                                                \
-        uint32_t a0_, a1_, a2_, a3_;                                    \
-        PH_SW_ADDR(a0_, pk, "BYTE_0");                                  \
-        PH_SW_ADDR(a1_, pk, "BYTE_1");                                  \
-        PH_SW_ADDR(a2_, pk, "BYTE_2");                                  \
-        PH_SW_ADDR(a3_, pk, "BYTE_3");                                  \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_));       \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_));       \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_));       \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_));       \
-    } while (0)
 // one row of the 4-column block (i is a compile-time constant after unrolling)
 #define PH_SW_ROW(I, W)                                                              \
     do {                                                                             \
@@ -231,11 +214,11 @@ __global__ __launch_bounds__(THREADS) void sw_shared_kernel(
             int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0; // H[i-1][jb..jb+3]; row 0 of H is 0
             int pdiag = 0;                          // H[i-1][jb-1]
             uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
-            PH_SW_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+            PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
 #pragma unroll
             for (int g = 0; g < RA / 4; ++g) {
                 if (g + 1 < RA / 4) {
-                    PH_SW_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                    PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
                     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));

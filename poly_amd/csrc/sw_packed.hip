@@ -248,23 +248,6 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
 #undef PH_PK_ROW
 #undef PH_PK_ISSUE
 
-// ---- step 2: the cell.  One pair per lane, 32-bit, the lane's own window of 4-column blocks -----------
-#define PH_LC_ADDR(dst, pk, SEL)                                                                           \
-    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
-                 : "=v"(dst)                                                                               \
-                 : "v"(blk), "v"(pk))
-#define PH_LC_ISSUE(pk, w0, w1, w2, w3)                           \
-    do {                                                          \
-        uint32_t a0_, a1_, a2_, a3_;                              \
-        PH_LC_ADDR(a0_, pk, "BYTE_0");                            \
-        PH_LC_ADDR(a1_, pk, "BYTE_1");                            \
-        PH_LC_ADDR(a2_, pk, "BYTE_2");                            \
-        PH_LC_ADDR(a3_, pk, "BYTE_3");                            \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_)); \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_)); \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_)); \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_)); \
-    } while (0)
 #define PH_LC_CELL(S, DIAG, UP, LEFT, HOUT, C)                                    \
     do {                                                                          \
         HOUT = max(max((DIAG) + (S), 0), max((UP), (LEFT)) + gap);                \
@@ -397,11 +380,11 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
             const uint32_t blk = lds_base + ((jb0 >> 2) + t) * (CP * 4);
             int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
             uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
-            PH_LC_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+            PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
 #pragma unroll
             for (int g = 0; g < RA / 4; ++g) {
                 if (g + 1 < RA / 4) {
-                    PH_LC_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                    PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
                     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
@@ -435,8 +418,6 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
 }
 #undef PH_LC_ROW
 #undef PH_LC_CELL
-#undef PH_LC_ISSUE
-#undef PH_LC_ADDR
 
 // ---- host side ---------------------------------------------------------------------------------------
 bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, PackedPlan *out)

@@ -2,6 +2,26 @@
 // (sw_batch.hip) and the traceback (sw_traceback.hip).
 #pragma once
 
+// The byte-profile kernels (score pass, locate, traceback) fetch the profile dwords of four rows at once: address of
+// row r's dword = block base `blk` (a uint32_t LDS byte address in scope) + code * 4, the code byte picked out of the
+// packed row register by one SDWA add; hand-placed so that the loads run a group of rows ahead of their use.
+#define PH_PROF_ADDR(dst, pk, SEL)                                                                         \
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                 : "=v"(dst)                                                                               \
+                 : "v"(blk), "v"(pk))
+#define PH_PROF_ISSUE(pk, w0, w1, w2, w3)                         \
+    do {                                                          \
+        uint32_t a0_, a1_, a2_, a3_;                              \
+        PH_PROF_ADDR(a0_, pk, "BYTE_0");                          \
+        PH_PROF_ADDR(a1_, pk, "BYTE_1");                          \
+        PH_PROF_ADDR(a2_, pk, "BYTE_2");                          \
+        PH_PROF_ADDR(a3_, pk, "BYTE_3");                          \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_)); \
+        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_)); \
+    } while (0)
+
 // w = 2 * w + (x > y): the compare's carry shifted into a word (direction bits of the tracebacks; two instructions)
 #define PH_CARRY_BIT(w, x, y)                                                           \
     asm volatile("v_cmp_gt_i32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" \

@@ -268,22 +268,6 @@ __global__ __launch_bounds__(256) void tb_profile_kernel(const uint8_t *__restri
         col[c * 4] = c < live ? lutc[c * 256 + b] : (int8_t)-128;
 }
 
-#define PH_TB_ADDR(dst, pk, SEL)                                                                           \
-    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
-                 : "=v"(dst)                                                                               \
-                 : "v"(blk), "v"(pk))
-#define PH_TB_ISSUE(pk, w0, w1, w2, w3)                           \
-    do {                                                          \
-        uint32_t a0_, a1_, a2_, a3_;                              \
-        PH_TB_ADDR(a0_, pk, "BYTE_0");                            \
-        PH_TB_ADDR(a1_, pk, "BYTE_1");                            \
-        PH_TB_ADDR(a2_, pk, "BYTE_2");                            \
-        PH_TB_ADDR(a3_, pk, "BYTE_3");                            \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w0) : "v"(a0_)); \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w1) : "v"(a1_)); \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w2) : "v"(a2_)); \
-        asm volatile("ds_read_b32 %0, %1" : "=v"(w3) : "v"(a3_)); \
-    } while (0)
 // w = 2 * w + (x > y)
 #define PH_TB_CELL(S, DIAG, UP, LEFT, HOUT, C)         \
     do {                                               \
@@ -405,11 +389,11 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
             int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
             uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
             uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
-            PH_TB_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+            PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
 #pragma unroll
             for (int g = 0; g < RA / 4; ++g) {
                 if (g + 1 < RA / 4) {
-                    PH_TB_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                    PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
                     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
@@ -470,8 +454,6 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
 }
 #undef PH_TB_ROW
 #undef PH_TB_CELL
-#undef PH_TB_ISSUE
-#undef PH_TB_ADDR
 
 // ---- reads longer than the 256 rows a lane can hold: ONE WAVE PER PAIR (like sw_wave.hip) ---------------
 // Lane l owns rows [l*R, l*R + R) and works on column s - l of the pair's window in step s; the row above
