@@ -757,46 +757,20 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && endA && endB && err, "polyhip_sw_batch: null pointer");
-    uint64_t maxA = 0, maxB = offB ? 0 : lenB;
-    for (uint64_t i = 0; i < npairs; ++i) {
-        PH_REQUIRE(offA[i] <= offA[i + 1], "polyhip_sw_batch: offA not ascending at %llu", (unsigned long long)i);
-        maxA = std::max(maxA, offA[i + 1] - offA[i]);
-        if (offB) {
-            PH_REQUIRE(offB[i] <= offB[i + 1], "polyhip_sw_batch: offB not ascending at %llu", (unsigned long long)i);
-            maxB = std::max(maxB, offB[i + 1] - offB[i]);
-        }
-    }
-    PH_REQUIRE(maxA < 0xFFFFFFFFull, "polyhip_sw_batch: A longer than 2^32");
-    const uint64_t a0 = offA[0], abytes = offA[npairs] - a0;
-    const uint64_t b0 = offB ? offB[0] : 0, bbytes = offB ? offB[npairs] - b0 : lenB;
-    PH_REQUIRE((A || abytes == 0) && (B || bbytes == 0), "polyhip_sw_batch: null sequence buffer");
-    DevBuf dA, doA, dB, doB, dscore, dea, deb, derr, dwork;
-    PH_HIP(dA.alloc(abytes + 16));
-    PH_HIP(doA.alloc((npairs + 1) * 8));
-    PH_HIP(dB.alloc(bbytes + 16));
+    PairStage in;
+    if (int rc0 = in.load("polyhip_sw_batch", A, offA, npairs, B, offB, lenB))
+        return rc0;
+    const uint64_t maxA = in.maxA, maxB = in.maxB;
+    DevBuf dscore, dea, deb, derr, dwork;
     PH_HIP(dscore.alloc(npairs * 8));
     PH_HIP(dea.alloc(npairs * 4));
     PH_HIP(deb.alloc(npairs * 4));
     PH_HIP(derr.alloc(npairs * 4));
-    std::vector<uint64_t> tmp(npairs + 1);
-    for (uint64_t i = 0; i <= npairs; ++i)
-        tmp[i] = offA[i] - a0;
-    PH_HIP(hipMemcpy(doA.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
-    if (abytes)
-        PH_HIP(hipMemcpy(dA.p, A + a0, abytes, hipMemcpyHostToDevice));
-    if (bbytes)
-        PH_HIP(hipMemcpy(dB.p, B + b0, bbytes, hipMemcpyHostToDevice));
-    if (offB) {
-        PH_HIP(doB.alloc((npairs + 1) * 8));
-        for (uint64_t i = 0; i <= npairs; ++i)
-            tmp[i] = offB[i] - b0;
-        PH_HIP(hipMemcpy(doB.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
-    }
     const size_t wb = polyhip_sw_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB, offB == nullptr);
     PH_HIP(dwork.alloc(wb));
-    int rc = polyhip_sw_batch_dev(sc, dA.as<uint8_t>(), doA.as<uint64_t>(), npairs, (uint32_t)maxA, dB.as<uint8_t>(),
-                                  offB ? doB.as<uint64_t>() : nullptr, maxB, dscore.as<int64_t>(), dea.as<uint32_t>(),
-                                  deb.as<uint32_t>(), derr.as<uint32_t>(), dwork.p, wb, nullptr);
+    int rc = polyhip_sw_batch_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
+                                  dscore.as<int64_t>(), dea.as<uint32_t>(), deb.as<uint32_t>(), derr.as<uint32_t>(), dwork.p,
+                                  wb, nullptr);
     if (rc != POLYHIP_OK)
         return rc;
     PH_HIP(hipStreamSynchronize(nullptr));

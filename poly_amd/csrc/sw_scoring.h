@@ -95,3 +95,64 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
 
 } // namespace k3w
 } // namespace polyhip
+
+// ---- host-pointer flavours: packed A / B batches copied to the device -------------------------------------
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace polyhip {
+
+// Validates a packed batch of pairs (offsets ascending, buffers present), copies it to the device with offsets
+// rebased to 0, and reports the longest A / B.  Shared by polyhip_sw_batch, polyhip_sw_align_batch, polyhip_nw_align_batch.
+struct PairStage {
+    DevBuf dA, doA, dB, doB;
+    uint64_t maxA = 0, maxB = 0;
+    bool per_pair_B = false;
+
+    const uint8_t *A() const { return dA.as<uint8_t>(); }
+    const uint64_t *offA() const { return doA.as<uint64_t>(); }
+    const uint8_t *B() const { return dB.as<uint8_t>(); }
+    const uint64_t *offB() const { return per_pair_B ? doB.as<uint64_t>() : nullptr; }
+
+    int load(const char *who, const uint8_t *A_, const uint64_t *offA_, uint64_t npairs, const uint8_t *B_,
+             const uint64_t *offB_, uint64_t lenB)
+    {
+        per_pair_B = offB_ != nullptr;
+        maxA = 0;
+        maxB = offB_ ? 0 : lenB;
+        for (uint64_t i = 0; i < npairs; ++i) {
+            PH_REQUIRE(offA_[i] <= offA_[i + 1], "%s: offA not ascending at %llu", who, (unsigned long long)i);
+            maxA = std::max(maxA, offA_[i + 1] - offA_[i]);
+            if (offB_) {
+                PH_REQUIRE(offB_[i] <= offB_[i + 1], "%s: offB not ascending at %llu", who, (unsigned long long)i);
+                maxB = std::max(maxB, offB_[i + 1] - offB_[i]);
+            }
+        }
+        PH_REQUIRE(maxA < 0xFFFFFFFFull && maxB < 0xFFFFFFFFFFFFull, "%s: sequence too long", who);
+        const uint64_t a0 = offA_[0], abytes = offA_[npairs] - a0;
+        const uint64_t b0 = offB_ ? offB_[0] : 0, bbytes = offB_ ? offB_[npairs] - b0 : lenB;
+        PH_REQUIRE((A_ || abytes == 0) && (B_ || bbytes == 0), "%s: null sequence buffer", who);
+        PH_HIP(dA.alloc(abytes + 16));
+        PH_HIP(doA.alloc((npairs + 1) * 8));
+        PH_HIP(dB.alloc(bbytes + 16));
+        std::vector<uint64_t> tmp(npairs + 1);
+        for (uint64_t i = 0; i <= npairs; ++i)
+            tmp[i] = offA_[i] - a0;
+        PH_HIP(hipMemcpy(doA.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+        if (abytes)
+            PH_HIP(hipMemcpy(dA.p, A_ + a0, abytes, hipMemcpyHostToDevice));
+        if (bbytes)
+            PH_HIP(hipMemcpy(dB.p, B_ + b0, bbytes, hipMemcpyHostToDevice));
+        if (offB_) {
+            PH_HIP(doB.alloc((npairs + 1) * 8));
+            for (uint64_t i = 0; i <= npairs; ++i)
+                tmp[i] = offB_[i] - b0;
+            PH_HIP(hipMemcpy(doB.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+        }
+        return POLYHIP_OK;
+    }
+};
+
+} // namespace polyhip
