@@ -156,6 +156,47 @@ func (s *Scoring) SWAlignBatch(A []byte, offA []uint64, B []byte, offB []uint64,
 	return res, nil
 }
 
+// NWAlignBatch: align.NeedlemanWunsch (align.go:100-166) for every pair; B shared (offB == nil) or pairwise.
+// EndA / EndB stay 0 (a global alignment has no end cell to report).
+func (s *Scoring) NWAlignBatch(A []byte, offA []uint64, B []byte, offB []uint64, maxLenA int) ([]AlignResult, error) {
+	n := len(offA) - 1
+	lenB := uint64(len(B))
+	var pOffB *C.uint64_t
+	shared := C.uint64_t(len(B))
+	if offB != nil {
+		pOffB = (*C.uint64_t)(unsafe.Pointer(&offB[0]))
+		shared, lenB = 0, 0
+		for i := 0; i < n; i++ {
+			if d := offB[i+1] - offB[i]; d > lenB {
+				lenB = d
+			}
+		}
+	}
+	stride := maxLenA + int(lenB)
+	if stride == 0 {
+		stride = 1
+	}
+	score := make([]int64, n)
+	errs, alen := make([]uint32, n), make([]uint32, n)
+	alnA, alnB := make([]byte, n*stride+1), make([]byte, n*stride+1)
+	err := call(func() C.int {
+		return C.polyhip_nw_align_batch(s.h, (*C.uint8_t)(unsafe.Pointer(&A[0])), (*C.uint64_t)(unsafe.Pointer(&offA[0])),
+			C.uint64_t(n), (*C.uint8_t)(unsafe.Pointer(&B[0])), pOffB, shared, (*C.int64_t)(unsafe.Pointer(&score[0])),
+			(*C.uint32_t)(unsafe.Pointer(&errs[0])), (*C.uint8_t)(unsafe.Pointer(&alnA[0])),
+			(*C.uint8_t)(unsafe.Pointer(&alnB[0])), (*C.uint32_t)(unsafe.Pointer(&alen[0])), C.uint32_t(stride))
+	})
+	if err != nil {
+		return nil, err
+	}
+	res := make([]AlignResult, n)
+	for p := 0; p < n; p++ {
+		hi := (p + 1) * stride
+		lo := hi - int(alen[p])
+		res[p] = AlignResult{Score: score[p], AlignA: string(alnA[lo:hi]), AlignB: string(alnB[lo:hi]), Err: errs[p]}
+	}
+	return res, nil
+}
+
 // SantaLuciaBatch / SantaLuciaScan / MarmurDotyBatch / LeastRotationBatch follow the same pattern:
 
 func SantaLuciaBatch(seqs []byte, offs []uint64, conc, na, mg float64) (tm, dH, dS []float64, err error) {

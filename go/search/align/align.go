@@ -73,6 +73,21 @@ func SmithWaterman(stringA string, stringB string, scoring Scoring) (int, string
 	return res[0].Score, res[0].AlignA, res[0].AlignB, nil
 }
 
+// NeedlemanWunsch is align.go:100-166 (the traceback stops when either index reaches 0, as the reference's does).
+func NeedlemanWunsch(stringA string, stringB string, scoring Scoring) (int, string, string, error) {
+	A, offA := polyhip.Pack([]string{stringA})
+	B, _ := polyhip.Pack([]string{stringB})
+	B = B[:len(stringB) : len(stringB)+1]
+	raw, err := scoring.handle().NWAlignBatch(A, offA, B, nil, len(stringA))
+	if err != nil {
+		panic(err)
+	}
+	if raw[0].Err != 0 {
+		return 0, "", "", symbolError(raw[0].Err)
+	}
+	return int(raw[0].Score), raw[0].AlignA, raw[0].AlignB, nil
+}
+
 // Alignment is one result of SmithWatermanBatch.
 type Alignment struct {
 	Score          int
