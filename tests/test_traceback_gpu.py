@@ -299,3 +299,50 @@ def test_long_reads_wave_kernels(al, monkeypatch, maxA, LB, shared):
         sa = sa if isinstance(sa, bytes) else sa.encode()
         sb = sb if isinstance(sb, bytes) else sb.encode()
         assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s, ea, eb) and got[4][p] == sa and got[5][p] == sb, p
+
+
+def test_long_reads_chunked_workspace(al):
+    """the one-wave-per-pair traceback with a workspace that holds a third of the batch: the entry point loops over
+    chunks of pairs; same strings as with the full workspace, a sample equal to the oracle"""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(4)
+    LB, n = 1500, 700
+    ref = orc.synth_dna(0xC4, LB).tobytes()
+    reads = []
+    for _ in range(n):
+        L = int(rng.integers(300, 701))
+        at = int(rng.integers(0, LB - L))
+        reads.append(_mutate(rng, ref[at:at + L], sub=0.06, indel=0.02)[:700])
+    maxA = max(len(r) for r in reads)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    A_h, offA_h = _pack(reads)
+    A = torch.from_numpy(A_h).to(dev)
+    offA = torch.from_numpy(offA_h.view(np.int64)).to(dev)
+    B = torch.from_numpy(np.frombuffer(ref, np.uint8).copy()).to(dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, maxA, LB), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, A, offA, maxA, B, None, LB, score, ea, eb, er, work)
+    stride = align.sw_traceback_stride(sc, maxA, LB)
+    full = align.sw_traceback_workspace_bytes(sc, n, maxA, LB)
+    outs = []
+    for nbytes in (full, full // 3 + 4096):
+        tbw = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        a = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        b = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        ln = torch.zeros(n, dtype=torch.int32, device=dev)
+        align.sw_traceback_dev(sc, A, offA, maxA, B, None, LB, ea, eb, er, a, b, ln, tbw, score_t=score)
+        torch.cuda.synchronize()
+        assert align.sw_traceback_last_path() == 4
+        outs.append((a, b, ln))
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    a_h, b_h, l_h = (t.cpu().numpy() for t in outs[1])
+    for p in range(0, n, 101):
+        s, sa, sb, _, _ = orc.smith_waterman(reads[p], ref, om, -2)
+        sa = sa if isinstance(sa, bytes) else sa.encode()
+        sb = sb if isinstance(sb, bytes) else sb.encode()
+        assert int(score[p]) == s and a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, p
