@@ -24,6 +24,9 @@ CXXFLAGS = [
     # Tm parity with Go/amd64, which never fuses multiply-add
     "-ffp-contract=off",
     "-Wall", "-Wno-unused-function",
+    # the 256-row register-tiled kernels unroll 64 row groups; past the default 16K the pragma is silently dropped and
+    # the H arrays land in scratch (profiles/r01_kernel_resources.md)
+    "-mllvm", "-pragma-unroll-threshold=100000",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ]
 

@@ -44,9 +44,10 @@ constexpr int PADS = -1024; // score of a pad row / pad column: keeps d far belo
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // prof2 entry (q, cidx) = 4 dwords, one per column of block q: lo half = S(sym(code0), b_j), hi = S(sym(code1), b_j)
+// `lead` all-pad blocks in front and behind (nq counts them): the banded kernel's lanes run up to `lead` blocks apart
 __global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t nq,
-                                                      const int8_t *__restrict__ lutc, int ncodes, int ncp,
-                                                      uint32_t *__restrict__ prof2)
+                                                      uint32_t lead, const int8_t *__restrict__ lutc, int ncodes,
+                                                      int ncp, uint32_t *__restrict__ prof2)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // one (block, code pair) each
     const uint32_t ncc = (uint32_t)(ncp * ncp);
@@ -57,9 +58,9 @@ __global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict
     uint32_t w[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const uint32_t j = 4 * q + c;
+        const uint32_t j = 4 * (q - lead) + c; // wraps for the leading pad blocks: not < lenB
         int s0 = PADS, s1 = PADS;
-        if (j < lenB) {
+        if (q >= lead && j < lenB) {
             const uint8_t b = B[j];
             if (c0 < ncodes)
                 s0 = lutc[c0 * 256 + b];
@@ -243,6 +244,156 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
     if (p1 < npairs) {
         infoM[p1] = best >> 16;
         infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+    }
+}
+
+// ---- reads of 153 .. 256 rows: K lanes per pair ------------------------------------------------------
+// One lane cannot hold more than 152 packed rows at two workgroups per CU, and at one workgroup per CU the
+// dependent packed chain stands exposed (measured: 256 rows in one lane run no faster than the 32-bit kernel).
+// So a pair of reads is spread over K neighbouring lanes, RB rows each, as a short systolic array: the lane
+// of band b works on 4-column block t - b in step t, and its last row (four values + the diagonal one of the
+// block before) reaches the lane of band b + 1 by one DPP row shift per step, together with the running
+// block maximum of the bands above.  The last band's lane sees the pair's block maxima and keeps M / first
+// block / tie exactly as sw_pk_kernel does.  prof2 carries K - 1 all-pad blocks on either side (lanes ahead
+// of / behind the reference see pad columns, in which H only decays), an LDS chunk K - 1 extra blocks.
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+}
+
+template <int RB, int K>
+__global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                        uint64_t npairs, const uint32_t *__restrict__ prof2,
+                                                        uint32_t nq, uint32_t jcb, uint32_t tab_bytes, int ncp,
+                                                        const uint8_t *__restrict__ codeA, int ncodes, int gapabs,
+                                                        uint32_t *__restrict__ infoM, uint32_t *__restrict__ infoQ)
+{
+    static_assert(RB % 4 == 0 && RB <= 152 && K >= 2 && K <= 16 && (K & (K - 1)) == 0, "RB, K"); // a DPP row is 16 lanes
+    constexpr int G = THREADS / K; // lane groups per workgroup, two pairs each
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_pk[];
+    uint8_t *codeL = lds_pk + (size_t)(jcb + K - 1) * tab_bytes;
+    const int tid = threadIdx.x;
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    const int grp = tid / K, band = tid % K;
+    const uint64_t base = (uint64_t)blockIdx.x * (2 * G);
+    const uint64_t p0 = base + grp, p1 = base + G + grp;
+    const uint8_t *ap0 = A, *ap1 = A;
+    uint32_t len0 = 0, len1 = 0;
+    if (p0 < npairs) {
+        const uint64_t o = offA[p0], l = offA[p0 + 1] - o;
+        ap0 = A + o;
+        len0 = l > (uint64_t)(RB * K) ? 0u : (uint32_t)l; // too long: no score here, the locate kernel reports it
+    }
+    if (p1 < npairs) {
+        const uint64_t o = offA[p1], l = offA[p1 + 1] - o;
+        ap1 = A + o;
+        len1 = l > (uint64_t)(RB * K) ? 0u : (uint32_t)l;
+    }
+    uint32_t rpk[RB / 4]; // my band's rows
+#pragma unroll
+    for (int w = 0; w < RB / 4; ++w) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int i = band * RB + 4 * w + h;
+            const uint32_t c0 = row_code(ap0, len0, i, codeL, (uint32_t)ncodes);
+            const uint32_t c1 = row_code(ap1, len1, i, codeL, (uint32_t)ncodes);
+            pk |= (c0 * (uint32_t)ncp + c1) << (8 * h);
+        }
+        rpk[w] = pk;
+    }
+
+    uint32_t H[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        H[i] = 0;
+    const uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
+    const uint32_t inner = band ? 0xFFFFFFFFu : 0u; // band 0 has zeros above it
+    uint32_t best = 0, bestq = 0, ties = 0;
+    uint32_t out0 = 0, out1 = 0, out2 = 0, out3 = 0, outd = 0, outm = 0, last3 = 0; // what the band below reads next step
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk));
+    const uint32_t steps = nq + (K - 1); // nq real blocks, the last band K - 1 steps behind the first
+
+    for (uint32_t s0 = 0; s0 < steps; s0 += jcb) {
+        const uint32_t ns = min(jcb, steps - s0);
+        __syncthreads(); // previous chunk fully consumed
+        {
+            // extended blocks [s0, s0 + ns + K - 1): extended block e = real block e - (K - 1)
+            const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint8_t *>(prof2) + (size_t)s0 * tab_bytes);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds_pk);
+            const uint32_t nvec = (ns + K - 1) * tab_bytes / 16;
+            for (uint32_t v = tid; v < nvec; v += THREADS)
+                dst[v] = src[v];
+        }
+        __syncthreads();
+        for (uint32_t t = 0; t < ns; ++t) {
+            // my block: real t + s0 - band = extended slot t + (K - 1 - band) of this chunk
+            const uint32_t blk16 = (lds_base + (t + (uint32_t)(K - 1 - band)) * tab_bytes) >> 4;
+            uint32_t pr0 = from_lane_above(out0) & inner, pr1 = from_lane_above(out1) & inner;
+            uint32_t pr2 = from_lane_above(out2) & inner, pr3 = from_lane_above(out3) & inner;
+            uint32_t pdiag = from_lane_above(outd) & inner;
+            const uint32_t m_in = from_lane_above(outm) & inner;
+            uint32_t bm = 0;
+            u32x4 wa, wb;
+            PH_PK_ISSUE(wa, rpk[0], "BYTE_0");
+#pragma unroll
+            for (int g = 0; g < RB / 4; ++g) {
+                PH_PK_ISSUE(wb, rpk[g], "BYTE_1");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PK_ROW(4 * g, wa);
+                PH_PK_ISSUE(wa, rpk[g], "BYTE_2");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                PH_PK_ROW(4 * g + 1, wb);
+                PH_PK_ISSUE(wb, rpk[g], "BYTE_3");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PK_ROW(4 * g + 2, wa);
+                if (g + 1 < RB / 4) {
+                    PH_PK_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                }
+                PH_PK_ROW(4 * g + 3, wb);
+            }
+            // my last row and the block maximum so far, for the band below
+            out0 = pr0;
+            out1 = pr1;
+            out2 = pr2;
+            out3 = pr3;
+            outd = last3;
+            last3 = pr3;
+            bm = pk_max(bm, m_in);
+            outm = bm;
+            // last band: bm is the pair's maximum over block s0 + t - (K - 1) (all-pad blocks give 0: no effect)
+            const uint32_t q = s0 + t - (uint32_t)(K - 1);
+            const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
+            if (blo > mlo) {
+                best = (best & 0xFFFF0000u) | blo;
+                bestq = (bestq & 0xFFFF0000u) | (q & 0xFFFFu);
+                ties &= ~1u;
+            } else if (blo == mlo && blo != 0u) {
+                ties |= 1u;
+            }
+            if (bhi > mhi) {
+                best = (best & 0xFFFFu) | (bhi << 16);
+                bestq = (bestq & 0xFFFFu) | (q << 16);
+                ties &= ~0x10000u;
+            } else if (bhi == mhi && bhi != 0u) {
+                ties |= 0x10000u;
+            }
+        }
+    }
+    if (band == K - 1) {
+        if (p0 < npairs) {
+            infoM[p0] = best & 0xFFFFu;
+            infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+        }
+        if (p1 < npairs) {
+            infoM[p1] = best >> 16;
+            infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+        }
     }
 }
 #undef PH_PK_ROW
@@ -429,42 +580,53 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     if (!(sc->int8_ok && sc->gap <= -1 && -sc->gap < 16384 && sc->smax > 0 && sc->cp <= 8 &&
           lenB > 0 && lenB < (1ull << 18) && (uint64_t)sc->smax * minlen < 30000ull))
         return false;
-    if (max_lenA > 152 || npairs >= (1ull << 32))
+    if (max_lenA > 256 || npairs >= (1ull << 32))
         return false;
-    p.ra = max_lenA <= 64 ? 64 : 152;
+    p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
+    p.k = p.ra <= 152 ? 1 : 2; // lanes per pair (sw_pkb_kernel above 152 rows)
     p.ncp = sc->ncodes + 1;
     p.tab_bytes = (uint32_t)(p.ncp * p.ncp * 16);
     p.lenB_pad = (uint32_t)align_up(lenB, 4);
     p.nq = p.lenB_pad / 4;
     p.jcb = std::max<uint32_t>(1, std::min<uint32_t>(64, 36864u / p.tab_bytes));
-    p.pk_smem = (size_t)p.jcb * p.tab_bytes + 256;
+    p.pk_smem = (size_t)(p.jcb + p.k - 1) * p.tab_bytes + 256;
     p.locate_smem = (size_t)p.lenB_pad * 8 + 256;
     if (p.locate_smem > 160 * 1024)
         return false; // the byte profile of the reference has to sit whole in LDS for step 2
-    p.prof2_bytes = align_up((size_t)p.nq * p.tab_bytes, 256);
+    p.prof2_bytes = align_up((size_t)(p.nq + 2 * (p.k - 1)) * p.tab_bytes, 256);
     p.info_bytes = align_up((size_t)npairs * 4, 256);
     p.work_bytes = p.prof2_bytes + 3 * p.info_bytes + 256;
     *out = p;
     return true;
 }
 
-template <int RA>
+template <int RA, int K>
 static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
                          uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                          uint32_t *prof2, uint32_t *infoM, uint32_t *infoQ, uint32_t *list, uint32_t *count,
                          int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
 {
     {
-        const uint32_t n = p.nq * (uint32_t)(p.ncp * p.ncp);
-        hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, p.nq, sc->d_lutc,
-                           sc->ncodes, p.ncp, prof2);
+        const uint32_t nqe = p.nq + 2 * (K - 1); // K - 1 all-pad blocks on either side
+        const uint32_t n = nqe * (uint32_t)(p.ncp * p.ncp);
+        hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, nqe, (uint32_t)(K - 1),
+                           sc->d_lutc, sc->ncodes, p.ncp, prof2);
         PH_HIP(hipGetLastError());
     }
-    {
+    if constexpr (K == 1) {
         auto kern = sw_pk_kernel<RA>;
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.pk_smem));
         const uint64_t blocks = (npairs + 2 * THREADS - 1) / (2 * THREADS);
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.pk_smem, st, d_A, d_offA, npairs, prof2, p.nq,
+                           p.jcb, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
+        PH_HIP(hipGetLastError());
+    } else {
+        auto kern = sw_pkb_kernel<RA / K, K>;
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)p.pk_smem));
+        constexpr uint64_t per_block = 2 * THREADS / K;
+        const uint64_t blocks = (npairs + per_block - 1) / per_block;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.pk_smem, st, d_A, d_offA, npairs, prof2, p.nq,
                            p.jcb, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
         PH_HIP(hipGetLastError());
@@ -497,9 +659,12 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
     *list_out = list;
     *count_out = count;
     if (p.ra == 64)
-        return launch_packed<64>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
+        return launch_packed<64, 1>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
                                  d_score, d_endA, d_endB, d_err, st);
-    return launch_packed<152>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
+    if (p.ra == 152)
+        return launch_packed<152, 1>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
+                                  d_score, d_endA, d_endB, d_err, st);
+    return launch_packed<256, 2>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
                               d_score, d_endA, d_endB, d_err, st);
 }
 

@@ -60,7 +60,8 @@ namespace polyhip {
 namespace k3p {
 
 struct PackedPlan {
-    int ra, ncp;                    // rows per lane (template), codes incl. pad
+    int ra, ncp;                    // rows per pair (template), codes incl. pad
+    int k;                          // lanes per pair: 1, or 2 above 152 rows (sw_pkb_kernel)
     uint32_t tab_bytes;             // bytes of one block's table: ncp * ncp * 16
     uint32_t lenB_pad, nq, jcb;     // columns (multiple of 4), 4-column blocks, blocks per LDS chunk
     size_t pk_smem, locate_smem;

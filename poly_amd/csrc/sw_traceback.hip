@@ -1253,7 +1253,8 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
     const k3t::Plan p = k3t::plan(sc, max_lenA, lenB);
     PH_REQUIRE(aln_stride >= p.win.stride, "polyhip_sw_traceback: aln_stride %u < %u (polyhip_sw_traceback_stride)",
                aln_stride, p.win.stride);
-    const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr;
+    const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr &&
+                          !env_is("POLYHIP_TB_PROF", '0'); // testing aid: the table kernel for a shared reference
     const bool use_wave = !use_prof && p.ra == 0 && p.wave_r != 0 && d_score != nullptr && d_B != nullptr &&
                           !env_is("POLYHIP_TB_WAVE", '0'); // testing aid: generic kernel for long reads
     k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);

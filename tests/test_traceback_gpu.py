@@ -191,17 +191,18 @@ def test_device_resident_chunked_workspace(al):
         assert int(score[p]) == s
 
 
-@pytest.mark.parametrize("gap,LB", [(-2, 5000), (-7, 5000), (-2, 15000)])
-def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB):
+@pytest.mark.parametrize("gap,LB,L", [(-2, 5000, 150), (-7, 5000, 150), (-2, 15000, 150), (-2, 5000, 250), (-7, 5000, 250)])
+def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB, L):
     """(gap -2: even unrelated reads score > 300, the linear phase of local alignment; gap -7: scores fall
     to the noise floor, so the per-pair windows range from the tightest to the batch-wide bound.)  200k reads at 0..90 % substitutions + 0..12 % indels (scores from 750 down to the noise floor)
     against one 5 kb reference.  The byte-profile kernel (score given), the table kernel (no score: the
     batch-wide window) and the byte-profile kernel with the conservative per-pair window
-    (POLYHIP_TB_WIDE=1) must write identical alignments; a sample is checked against the oracle."""
+    (POLYHIP_TB_WIDE=1) must write identical alignments; a sample is checked against the oracle.
+    L = 250: the 256-row instantiations (one workgroup per CU, H rows partly in AGPRs)."""
     import torch
     align = al[0]
     dev = torch.device("cuda:0")
-    n, L = (200_000 if LB == 5000 else 60_000), 150  # 15 kb: the profile takes 120 KB of LDS
+    n = (200_000 if LB == 5000 else 60_000) * 150 // L  # 15 kb: the profile takes 120 KB of LDS
     ref = orc.synth_dna(0xC4, LB)
     B = torch.from_numpy(ref.copy()).to(dev)
     gen = torch.Generator(device=dev)
@@ -243,7 +244,7 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB):
     a2, b2, l2, path2 = run(None, False)
     a3, b3, l3, path3 = run(score, True)
     assert (path1, path2, path3) == (1, 2, 1)
-    assert int(score.min()) < (100 if gap == -7 else 400) and int(score.max()) == 750
+    assert int(score.min()) < (100 if gap == -7 else 400) * L // 150 and int(score.max()) == 5 * L
     for a, b, ln in ((a2, b2, l2), (a3, b3, l3)):
         assert torch.equal(l1, ln) and torch.equal(a1, a) and torch.equal(b1, b)
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
