@@ -265,8 +265,10 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
  * 1 = lane-per-pair register-tiled shared-B kernel, 2 = generic kernel, 3 = packed two-pairs-per-lane
  * pass + locate + one-wave-per-pair kernel for its ties, 4 = one-wave-per-pair kernel (small batches),
  * 5 = register-tiled kernel for per-pair B, 6 = one-wave-per-pair kernel for what those cannot take (reads of
- * 257..4096 symbols, gap >= 0, scores beyond int8; shared or per-pair B).  POLYHIP_SW_WAVE=0 /
- * POLYHIP_SW_PACKED=0 / POLYHIP_SW_PAIR=0 in the environment switch 4 and 6 / 3 / 5 off (testing aids). */
+ * 257..4096 symbols, gap >= 0, scores beyond int8; shared or per-pair B), 7 = reads of 257..2048 symbols
+ * against one reference, enough of them to fill the chip: packed pass with 2..16 lanes per pair + the
+ * one-wave-per-pair kernel over the columns that can reach the maximum.  POLYHIP_SW_WAVE=0 /
+ * POLYHIP_SW_PACKED=0 / POLYHIP_SW_PAIR=0 in the environment switch 4, 6 and 7 / 3 and 7 / 5 off (testing aids). */
 int polyhip_sw_last_path(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair

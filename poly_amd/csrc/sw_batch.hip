@@ -52,6 +52,7 @@ constexpr int THREADS = 256;
 constexpr int U = 4;          // columns per unrolled block
 constexpr int JC_MAX = 1024;  // columns per LDS chunk (10 key bits)
 constexpr int SCORE_LIMIT = 1 << 14;
+constexpr uint64_t LONG_PACKED_ROWS = 8ull << 20; // pairs x rows from which the packed banded pass pays for reads > 256 (a quarter of the chip's lanes busy)
 constexpr uint64_t WAVE_BATCH = 32768; // below this many pairs the one-wave-per-pair kernel (1.7e12 cell updates/s flat) beats the ~16 ms floor of one lane-per-pair wave
 
 static thread_local int g_last_path = 0;
@@ -440,7 +441,8 @@ __global__ __launch_bounds__(256) void sw_generic_kernel(
 
 struct Plan {
     int path;      // 1 fast, 2 generic, 3 packed (sw_packed.hip) + wave kernel for its ties, 4 wave kernel (small batch),
-                   // 5 per-pair B register-tiled, 6 wave kernel for what the others cannot take (long reads, ...)
+                   // 5 per-pair B register-tiled, 6 wave kernel for what the others cannot take (long reads, ...),
+                   // 7 long reads, shared B: packed banded pass (maximum + its block) + wave kernel in locate mode
     int ra, cp;    // fast: template parameters
     uint32_t lenB_pad, jc_max;
     size_t work_bytes, smem_bytes;
@@ -491,6 +493,15 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
         p.path = 5; // per-pair B, register-tiled (sw_pair_kernel)
         p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
         p.work_bytes = 256;
+    } else if (shared && max_lenA > 256 && lenB < (1ull << 31) - 64 &&
+               (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 && !wave_kernel_off() &&
+               k3p::packed_plan(sc, npairs, max_lenA, lenB, &p.pk) && npairs * (uint64_t)p.pk.ra >= LONG_PACKED_ROWS) {
+        // long reads against one reference, enough of them to fill the chip K lanes per pair: the packed banded
+        // pass finds each pair's maximum and the block it sits in, the wave kernel then sweeps only the columns
+        // that can reach it (a third of the reference for a read that aligns well)
+        p.path = 7;
+        p.fast_bytes = 256;
+        p.work_bytes = 256 + p.pk.work_bytes;
     } else if (max_lenA > 0 && max_lenA <= k3w::WAVE_MAX_LENA && lenB > 0 && lenB < (1ull << 31) - 64 &&
                (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 && !wave_kernel_off()) {
         // whatever the lane-per-pair kernels cannot take (reads longer than 256, gap >= 0, wide scores), shared or
@@ -714,6 +725,17 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
         PH_SW_FAST_LIST(PH_SW_CASE)
 #undef PH_SW_CASE
         return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_sw_batch: no kernel for RA=%d CP=%d", p.ra, p.cp);
+    }
+    if (p.path == 7) {
+        uint32_t *list = nullptr, *count = nullptr;
+        const uint32_t *infoM = nullptr, *infoQ = nullptr;
+        const int rc = k3p::packed_run(sc, p.pk, d_A, d_offA, npairs, d_B, (uint32_t)lenB, nullptr, nullptr,
+                                       static_cast<uint8_t *>(d_work) + p.fast_bytes, d_score, d_endA, d_endB, d_err, &list,
+                                       &count, st, &infoM, &infoQ);
+        if (rc != POLYHIP_OK)
+            return rc;
+        return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, nullptr, nullptr, nullptr,
+                             npairs, d_score, d_endA, d_endB, d_err, st, infoM, infoQ);
     }
     if (p.path == 6)
         return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, (uint32_t)lenB, nullptr, nullptr, nullptr,

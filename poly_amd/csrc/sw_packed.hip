@@ -580,10 +580,17 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     if (!(sc->int8_ok && sc->gap <= -1 && -sc->gap < 16384 && sc->smax > 0 && sc->cp <= 8 &&
           lenB > 0 && lenB < (1ull << 18) && (uint64_t)sc->smax * minlen < 30000ull))
         return false;
-    if (max_lenA > 256 || npairs >= (1ull << 32))
+    if (max_lenA > 2048 || npairs >= (1ull << 32))
         return false;
-    p.ra = max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 256;
-    p.k = p.ra <= 152 ? 1 : 2; // lanes per pair (sw_pkb_kernel above 152 rows)
+    // rows per lane x lanes per pair (sw_pkb_kernel above 152 rows): the smallest tile that holds the longest read
+    static const int tiles[][2] = {{64, 1}, {152, 1}, {128, 2}, {152, 2}, {128, 4}, {152, 4}, {128, 8}, {152, 8}, {128, 16}};
+    for (const auto &t : tiles)
+        if ((uint32_t)(t[0] * t[1]) >= max_lenA) {
+            p.rb = t[0];
+            p.k = t[1];
+            break;
+        }
+    p.ra = p.rb * p.k;
     p.ncp = sc->ncodes + 1;
     p.tab_bytes = (uint32_t)(p.ncp * p.ncp * 16);
     p.lenB_pad = (uint32_t)align_up(lenB, 4);
@@ -591,7 +598,7 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     p.jcb = std::max<uint32_t>(1, std::min<uint32_t>(64, 36864u / p.tab_bytes));
     p.pk_smem = (size_t)(p.jcb + p.k - 1) * p.tab_bytes + 256;
     p.locate_smem = (size_t)p.lenB_pad * 8 + 256;
-    if (p.locate_smem > 160 * 1024)
+    if (p.ra <= 256 && p.locate_smem > 160 * 1024)
         return false; // the byte profile of the reference has to sit whole in LDS for step 2
     p.prof2_bytes = align_up((size_t)(p.nq + 2 * (p.k - 1)) * p.tab_bytes, 256);
     p.info_bytes = align_up((size_t)npairs * 4, 256);
@@ -622,6 +629,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                            p.jcb, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
         PH_HIP(hipGetLastError());
     } else {
+        static_assert(RA % K == 0, "RA, K");
         auto kern = sw_pkb_kernel<RA / K, K>;
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.pk_smem));
@@ -631,7 +639,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                            p.jcb, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
         PH_HIP(hipGetLastError());
     }
-    {
+    if constexpr (RA <= 256) {
         auto kern = sw_locate_kernel<RA, 8>;
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.locate_smem));
@@ -647,7 +655,8 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
 int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
                uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
-               uint32_t **list_out, uint32_t **count_out, hipStream_t st)
+               uint32_t **list_out, uint32_t **count_out, hipStream_t st, const uint32_t **infoM_out,
+               const uint32_t **infoQ_out)
 {
     uint8_t *w = static_cast<uint8_t *>(d_work);
     uint32_t *count = reinterpret_cast<uint32_t *>(w);
@@ -658,6 +667,21 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
     PH_HIP(hipMemsetAsync(count, 0, 256, st));
     *list_out = list;
     *count_out = count;
+    if (infoM_out)
+        *infoM_out = infoM;
+    if (infoQ_out)
+        *infoQ_out = infoQ;
+#define PH_PKB_CASE(RB_, K_)                                                                                              \
+    if (p.rb == RB_ && p.k == K_)                                                                                         \
+        return launch_packed<RB_ * K_, K_>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, \
+                                           count, d_score, d_endA, d_endB, d_err, st);
+    PH_PKB_CASE(152, 2)
+    PH_PKB_CASE(128, 4)
+    PH_PKB_CASE(152, 4)
+    PH_PKB_CASE(128, 8)
+    PH_PKB_CASE(152, 8)
+    PH_PKB_CASE(128, 16)
+#undef PH_PKB_CASE
     if (p.ra == 64)
         return launch_packed<64, 1>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
                                  d_score, d_endA, d_endB, d_err, st);

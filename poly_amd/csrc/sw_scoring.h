@@ -60,8 +60,8 @@ namespace polyhip {
 namespace k3p {
 
 struct PackedPlan {
-    int ra, ncp;                    // rows per pair (template), codes incl. pad
-    int k;                          // lanes per pair: 1, or 2 above 152 rows (sw_pkb_kernel)
+    int ra, ncp;                    // rows per pair (template: rb * k), codes incl. pad
+    int rb, k;                      // rows per lane; lanes per pair: 1, or 2..16 above 152 rows (sw_pkb_kernel)
     uint32_t tab_bytes;             // bytes of one block's table: ncp * ncp * 16
     uint32_t lenB_pad, nq, jcb;     // columns (multiple of 4), 4-column blocks, blocks per LDS chunk
     size_t pk_smem, locate_smem;
@@ -74,10 +74,13 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
 
 // profile2 + packed pass + locate.  Pairs the exact kernel has to redo (ties) are left on *list_out
 // (count at *count_out, both inside d_work); every other pair has its four outputs written.
+// Above 256 rows (p.ra > 256) there is no locate step here: *infoM_out / *infoQ_out (maximum, its block, tie bit)
+// are handed to the one-wave-per-pair kernel's locate mode (wave_run) and no output is written yet.
 int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
                uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
-               uint32_t **list_out, uint32_t **count_out, hipStream_t st);
+               uint32_t **list_out, uint32_t **count_out, hipStream_t st, const uint32_t **infoM_out = nullptr,
+               const uint32_t **infoQ_out = nullptr);
 
 } // namespace k3p
 } // namespace polyhip
@@ -92,7 +95,8 @@ constexpr uint32_t WAVE_MAX_LENA = 4096; // 64 lanes x 64 rows
 int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
              const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
              const uint32_t *count,
-             uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st);
+             uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st,
+             const uint32_t *infoM = nullptr, const uint32_t *infoQ = nullptr); // locate mode: see sw_wave.hip
 
 } // namespace k3w
 } // namespace polyhip

@@ -31,7 +31,8 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     const uint64_t *__restrict__ offB, uint32_t lenB_shared, const uint8_t *__restrict__ codeA,
     const uint8_t *__restrict__ codeB,
     const int32_t *__restrict__ lutcc, int na, int nb, int gap, const uint32_t *__restrict__ binfo,
-    const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, int64_t *__restrict__ score,
+    const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, const uint32_t *__restrict__ infoM,
+    const uint32_t *__restrict__ infoQ, int smax, int64_t *__restrict__ score,
     uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb] (last row / column: pad, zeros), codeA, codeB
@@ -101,6 +102,25 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
             e = (1u << 8) | ap[mybad];
     }
 
+    // Locate mode (infoM / infoQ from the packed banded pass, sw_packed.hip): the maximum M and the only 4-column
+    // block that reaches it are known, so only the columns that can feed a cell worth M there are swept --
+    // lenA + (smax*lenA - M)/|gap| + 4 of them, as sw_locate_kernel.  A windowed H never exceeds the true H and
+    // equals it wherever the true value is M, so the first maximum of the window is the first maximum of the matrix.
+    // A pair whose maximum turned up in several blocks (tie bit) is swept in full.
+    uint32_t j0 = 0, ncols = lenB;
+    if (infoM) {
+        const uint32_t M = infoM[pair], iq = infoQ[pair];
+        if (M == 0u) {
+            ncols = 0; // no positive cell anywhere
+        } else if ((iq >> 31) == 0u) {
+            const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
+            const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
+            const uint32_t jend = min(4u * (iq & 0x7FFFFFFFu) + 4u, lenB);
+            j0 = jend > need ? jend - need : 0u;
+            ncols = jend - j0;
+        }
+    }
+
     int Hrow[R];
 #pragma unroll
     for (int k = 0; k < R; ++k)
@@ -109,12 +129,12 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     uint32_t last_b = (uint32_t)(nb - 1);
     int besth = 0;
     uint32_t besti = 0, bestj = 0;
-    const uint32_t steps = (e == 0u && lenA > 0 && lenB > 0) ? lenB + 63u : 0u;
+    const uint32_t steps = (e == 0u && lenA > 0 && ncols > 0) ? ncols + 63u : 0u;
     // B codes enter at lane 0, 64 columns per coalesced load, the next chunk in flight while this one is used
     auto load_chunk = [&](uint32_t s0) -> uint32_t {
         uint32_t c = (uint32_t)(nb - 1);
-        if (s0 + (uint32_t)lane < lenB) {
-            const uint32_t cc = cB[B[s0 + (uint32_t)lane]];
+        if (s0 + (uint32_t)lane < ncols) {
+            const uint32_t cc = cB[B[j0 + s0 + (uint32_t)lane]];
             c = cc == 0xFFu ? (uint32_t)(nb - 1) : cc;
         }
         return c;
@@ -133,8 +153,8 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
             top_in = 0;
             b_in = b_new;
         }
-        const uint32_t j = s - (uint32_t)lane; // wraps for lanes that have not started: not < lenB
-        const bool valid = j < lenB;
+        const uint32_t j = s - (uint32_t)lane; // column inside the window; wraps for lanes that have not started
+        const bool valid = j < ncols;
         int diag = topprev, up = top_in;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -147,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
             if (r < lenA && (h > besth || (h == besth && h > 0 && r < besti))) {
                 besth = h;
                 besti = r;
-                bestj = j;
+                bestj = j0 + j;
             }
             diag = left;
             up = h;
@@ -181,7 +201,8 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
 int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
              const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
              const uint32_t *count,
-             uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
+             uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st,
+             const uint32_t *infoM, const uint32_t *infoQ)
 {
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     const size_t smem = (size_t)na * nb * 4 + 512;
@@ -194,8 +215,8 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                    (int)smem));                                                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem, st, d_A, d_offA, npairs, d_B, d_offB, lenB, \
-                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, binfo, list, count, d_score,  \
-                           d_endA, d_endB, d_err);                                                                    \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, binfo, list, count, infoM,   \
+                           infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err);                                     \
     } while (0)
     if (max_lenA <= 64)
         PH_WAVE_LAUNCH(1);

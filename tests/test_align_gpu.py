@@ -340,3 +340,71 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
                 assert (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p])) == (s, ea_, eb_, 0), p
             except orc.AlphabetError:
                 assert int(got[3][p]) != 0 and int(got[0][p]) == 0
+
+
+@pytest.mark.parametrize("maxA,LB,n,repeats", [(300, 3000, 30_001, False), (500, 2000, 17_000, True), (600, 1500, 14_001, False),
+                                               (1000, 1500, 8_300, False), (1216, 1200, 7_001, True), (2048, 800, 4_200, False)])
+def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA, LB, n, repeats):
+    """Reads of 257..2048 rows against one reference, enough of them to fill the chip (path 7): the packed banded
+    pass (K = 2..16 lanes per pair, every (rows per lane, K) tile once) + the wave kernel in locate mode against the
+    wave kernel sweeping the whole reference (POLYHIP_SW_PACKED=0, path 6): score, endA, endB, err of every pair
+    equal; a sample against the oracle.  Ragged lengths, 0..90 % substitutions, indels; `repeats`: a tandem-repeat
+    reference, so maxima occur in several blocks (tie bit -> full sweep)."""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(maxA)
+    ref = orc.synth_dna(0xC4, LB).copy()
+    if repeats:
+        unit = ref[:LB // 8].copy()
+        ref = np.tile(unit, 8)[:LB]
+        ref[rng.integers(0, LB, 6)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 6)]
+    starts = rng.integers(0, LB, n)
+    starts[0] = 0  # read 0: an exact substring of full length
+    idx = (starts[:, None] + np.arange(maxA)[None, :]) % LB
+    reads = ref[idx]
+    rate = np.linspace(0.0, 0.9, n)[:, None]
+    hit = rng.random((n, maxA)) < rate
+    reads[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    # indels: drop one base at a random position in a third of the reads
+    cut = rng.integers(1, maxA, n)
+    drop = rng.random(n) < 0.33
+    drop[0] = False
+    col = np.arange(maxA)[None, :]
+    src = np.where(drop[:, None] & (col >= cut[:, None]), np.minimum(col + 1, maxA - 1), col)
+    reads = np.take_along_axis(reads, src, axis=1)
+    lens = rng.integers(maxA // 3, maxA + 1, n)
+    lens[0] = maxA
+    lens[rng.random(n) < 0.01] = 0
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)])
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    A = torch.from_numpy(flat.copy()).to(dev)
+    offA = torch.from_numpy(offs).to(dev)
+    B = torch.from_numpy(ref.copy()).to(dev)
+
+    def run(packed):
+        if packed:
+            monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        score = torch.full((n,), -7, dtype=torch.int64, device=dev)
+        ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+        work = torch.empty(align.sw_workspace_bytes(sc, n, maxA, LB), dtype=torch.uint8, device=dev)
+        align.sw_batch_dev(sc, A, offA, maxA, B, None, LB, score, ea, eb, er, work)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path()
+
+    got, path = run(True)
+    want, path0 = run(False)
+    assert (path, path0) == (7, 6)
+    for g, w in zip(got, want):
+        assert (g == w).all()
+    assert int(got[0].max()) == 5 * maxA if maxA <= LB else int(got[0].max()) >= 4 * LB  # a read longer than the reference wraps around it
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    refb = ref.tobytes()
+    for p in range(0, n, 1009):
+        a = flat[offs[p]:offs[p + 1]].tobytes()
+        s, _, _, ea_, eb_ = orc.smith_waterman(a, refb, om, -2)
+        assert (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p])) == (s, ea_, eb_, 0), p
