@@ -31,8 +31,11 @@ while time.time() < t_end:
     sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, mat), gap)
     om = orc.SubstitutionMatrix(syms, syms, mat)
     LB = int(rng.choice([7, 60, 333, 1000, 5000, 9000]))
-    L = int(rng.choice([5, 40, 64, 100, 150, 152]))
+    L = int(rng.choice([5, 40, 64, 100, 150, 152, 153, 200, 256, 257, 300, 500, 700, 1100, 1300, 2048]))
     n = 40_000
+    if L > 256:  # long reads: enough pairs for the packed banded pass (path 7), score pass only
+        rows = next(r for r in (304, 512, 608, 1024, 1216, 2048) if r >= L)
+        n = (8 << 20) // rows + 7
     symb = np.frombuffer(syms.encode(), np.uint8)
     ref = symb[rng.integers(0, nsym, LB)]
     if rng.random() < 0.3:  # repeats: many ties
@@ -68,6 +71,15 @@ while time.time() < t_end:
     got1, p1 = score_pass({"POLYHIP_SW_PACKED": "0"})
     for x, y in zip(got3, got1):
         assert torch.equal(x, y), ("packed vs exact", it, syms, mat, gap, LB, L, p3, p1)
+    if L > 256:
+        s_h, ea_h, eb_h = (t.cpu().numpy() for t in got3[:3])
+        refb = ref.tobytes()
+        for p in range(0, n, max(1, n // 6)):
+            rd = flat[offs[p]:offs[p + 1]].tobytes()
+            s, _, _, oa, ob = orc.smith_waterman(rd, refb, om, gap)
+            assert (int(s_h[p]), int(ea_h[p]), int(eb_h[p])) == (s, oa, ob), ("oracle score", it, p, syms, mat, gap, LB, L)
+        print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} n {n} paths {p3}/{p1} max score {int(got3[0].max())} ok", flush=True)
+        continue
     # wave kernel on the first 3000 pairs
     m = 3000
     sw = torch.full((m,), -7, dtype=torch.int64, device=dev)
