@@ -486,7 +486,8 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
             p.path = 3;
             p.work_bytes += p.pk.work_bytes;
         }
-    } else if (!shared && max_lenA <= 256 && max_lenA > 0 && lenB > 0 && lenB < (1ull << 31) &&
+    } else if (!shared && (max_lenA <= 152 || (max_lenA <= 256 && wave_kernel_off())) && max_lenA > 0 && lenB > 0 &&
+               lenB < (1ull << 31) && // 153..256 rows: the wave kernel (below) is faster than a lane at one wave per SIMD
                (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 &&
                (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) < 65536 &&
                (uint64_t)std::max(sc->smax, 0) * minlen < (uint64_t)SCORE_LIMIT && !pair_kernel_off()) {

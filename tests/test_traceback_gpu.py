@@ -243,7 +243,7 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB, L)
     a1, b1, l1, path1 = run(score, False)
     a2, b2, l2, path2 = run(None, False)
     a3, b3, l3, path3 = run(score, True)
-    assert (path1, path2, path3) == (1, 2, 1)
+    assert (path1, path2, path3) == ((1, 2, 1) if L <= 152 else (4, 2, 4))  # 153..256 rows: one wave per pair
     assert int(score.min()) < (100 if gap == -7 else 400) * L // 150 and int(score.max()) == 5 * L
     for a, b, ln in ((a2, b2, l2), (a3, b3, l3)):
         assert torch.equal(l1, ln) and torch.equal(a1, a) and torch.equal(b1, b)
