@@ -131,7 +131,9 @@ __device__ __forceinline__ uint32_t row_code(const uint8_t *__restrict__ ap, uin
     return c == 0xFFu ? pad : c;
 }
 
-template <int RA>
+// SKIP: the wave's longest read decides how many row groups of the unrolled sweep run (a uniform branch per group);
+// batches whose longest read nearly fills RA take the plain instantiation (the branches cost 3 % there)
+template <int RA, bool SKIP>
 __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
                                                        uint64_t npairs, const uint32_t *__restrict__ prof2,
                                                        uint32_t nq, uint32_t jcb, uint32_t tab_bytes, int ncp,
@@ -179,6 +181,16 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
 #pragma unroll
     for (int i = 0; i < RA; ++i)
         H[i] = 0;
+    // row groups this wave needs (its longest read): the rest of the unrolled sweep is skipped, so 100-bp reads
+    // cost their own rows, not RA
+    int ng = RA / 4;
+    if (SKIP) {
+        uint32_t wl = max(len0, len1);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+        ng = __builtin_amdgcn_readfirstlane((int)((wl + 3u) >> 2));
+    }
     const uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
     uint32_t best = 0, bestq = 0, ties = 0; // packed halves: maximum, its first block, bit 0 / bit 16 = tie
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk));
@@ -201,23 +213,27 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
             PH_PK_ISSUE(wa, rpk[0], "BYTE_0");
 #pragma unroll
             for (int g = 0; g < RA / 4; ++g) {
-                PH_PK_ISSUE(wb, rpk[g], "BYTE_1");
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-                PH_PK_ROW(4 * g, wa);
-                PH_PK_ISSUE(wa, rpk[g], "BYTE_2");
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
-                PH_PK_ROW(4 * g + 1, wb);
-                PH_PK_ISSUE(wb, rpk[g], "BYTE_3");
-                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-                PH_PK_ROW(4 * g + 2, wa);
-                if (g + 1 < RA / 4) {
-                    PH_PK_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                if (!SKIP || g < ng) { // wave-uniform
+                    PH_PK_ISSUE(wb, rpk[g], "BYTE_1");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                    PH_PK_ROW(4 * g, wa);
+                    PH_PK_ISSUE(wa, rpk[g], "BYTE_2");
                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                    PH_PK_ROW(4 * g + 1, wb);
+                    PH_PK_ISSUE(wb, rpk[g], "BYTE_3");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                    PH_PK_ROW(4 * g + 2, wa);
+                    if (g + 1 < RA / 4) {
+                        PH_PK_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                    }
+                    PH_PK_ROW(4 * g + 3, wb);
                 }
-                PH_PK_ROW(4 * g + 3, wb);
             }
+            if (SKIP)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa)); // the read issued ahead of a skipped group
             // block maximum against the running one, per half; a block reaching the maximum AGAIN is a tie
             const uint32_t q = q0 + t;
             const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
@@ -591,6 +607,7 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
             break;
         }
     p.ra = p.rb * p.k;
+    p.skip_rows = p.k == 1 && max_lenA + 16 <= (uint32_t)p.ra; // at least four row groups to save
     p.ncp = sc->ncodes + 1;
     p.tab_bytes = (uint32_t)(p.ncp * p.ncp * 16);
     p.lenB_pad = (uint32_t)align_up(lenB, 4);
@@ -621,7 +638,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         PH_HIP(hipGetLastError());
     }
     if constexpr (K == 1) {
-        auto kern = sw_pk_kernel<RA>;
+        auto kern = p.skip_rows ? sw_pk_kernel<RA, true> : sw_pk_kernel<RA, false>;
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.pk_smem));
         const uint64_t blocks = (npairs + 2 * THREADS - 1) / (2 * THREADS);
