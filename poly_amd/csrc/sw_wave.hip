@@ -106,13 +106,11 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     // block that reaches it are known, so only the columns that can feed a cell worth M there are swept --
     // lenA + (smax*lenA - M)/|gap| + 4 of them, as sw_locate_kernel.  A windowed H never exceeds the true H and
     // equals it wherever the true value is M, so the first maximum of the window is the first maximum of the matrix.
-    // A pair whose maximum turned up in several blocks (tie bit) is swept in full.
+    // A pair whose maximum turned up in several blocks (tie bit) or that has no maximum (M = 0) is swept in full.
     uint32_t j0 = 0, ncols = lenB;
     if (infoM) {
         const uint32_t M = infoM[pair], iq = infoQ[pair];
-        if (M == 0u) {
-            ncols = 0; // no positive cell anywhere
-        } else if ((iq >> 31) == 0u) {
+        if (M != 0u && (iq >> 31) == 0u) { // M == 0: nothing positive, or a read the packed pass did not take -- full sweep
             const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
             const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
             const uint32_t jend = min(4u * (iq & 0x7FFFFFFFu) + 4u, lenB);
