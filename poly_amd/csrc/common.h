@@ -58,4 +58,11 @@ inline bool env_is(const char *name, char value)
 
 inline hipStream_t as_stream(polyhip_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// value of the lane below (lane 0 gets 0): one DPP move (wave_shr:1, a GFX9 control gfx950 still has) instead of
+// the ds_bpermute a __shfl_up costs -- the systolic one-wave-per-pair kernels do this every step
+__device__ __forceinline__ int from_lane_below(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
+}
+
 } // namespace polyhip

@@ -53,7 +53,7 @@ constexpr int U = 4;          // columns per unrolled block
 constexpr int JC_MAX = 1024;  // columns per LDS chunk (10 key bits)
 constexpr int SCORE_LIMIT = 1 << 14;
 constexpr uint64_t LONG_PACKED_ROWS = 8ull << 20; // pairs x rows from which the packed banded pass pays for reads > 256 (a quarter of the chip's lanes busy)
-constexpr uint64_t WAVE_BATCH = 32768; // below this many pairs the one-wave-per-pair kernel (1.7e12 cell updates/s flat) beats the ~16 ms floor of one lane-per-pair wave
+constexpr uint64_t WAVE_BATCH = 49152; // below this many pairs the one-wave-per-pair kernel (2.5e12 cell updates/s flat) beats the ~15 ms floor of one lane-per-pair wave
 
 static thread_local int g_last_path = 0;
 
@@ -466,6 +466,8 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
 {
     Plan p{};
     const uint64_t minlen = std::min<uint64_t>(max_lenA, lenB);
+    const bool wave_possible = max_lenA > 0 && max_lenA <= k3w::WAVE_MAX_LENA && lenB > 0 && lenB < (1ull << 31) - 64 &&
+                               (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 && !wave_kernel_off();
     const bool fast = shared && sc->int8_ok && sc->gap <= -1 && max_lenA <= 256 && lenB < (1ull << 31) &&
                       sc->cp <= 32 && (uint64_t)std::max(sc->smax, 0) * minlen < (uint64_t)SCORE_LIMIT;
     if (fast) {
@@ -486,8 +488,8 @@ static Plan plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
             p.path = 3;
             p.work_bytes += p.pk.work_bytes;
         }
-    } else if (!shared && (max_lenA <= 152 || (max_lenA <= 256 && wave_kernel_off())) && max_lenA > 0 && lenB > 0 &&
-               lenB < (1ull << 31) && // 153..256 rows: the wave kernel (below) is faster than a lane at one wave per SIMD
+    } else if (!shared && (max_lenA <= 64 || (max_lenA <= 256 && !wave_possible)) && max_lenA > 0 && lenB > 0 &&
+               lenB < (1ull << 31) && // beyond 64 rows the wave kernel is faster (200k pairs of 150 x 150: 2.7 vs 3.9 ms)
                (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) * 4 + 512 <= 60 * 1024 &&
                (size_t)(sc->ncodes + 1) * (sc->ncodesB + 1) < 65536 &&
                (uint64_t)std::max(sc->smax, 0) * minlen < (uint64_t)SCORE_LIMIT && !pair_kernel_off()) {

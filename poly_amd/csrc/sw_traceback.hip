@@ -535,8 +535,8 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
                     chunk = next_chunk;
                 next_chunk = load_chunk(s + 64u);
             }
-            int top_in = __shfl_up(last_h, 1, 64);
-            uint32_t b_in = (uint32_t)__shfl_up((int)last_b, 1, 64);
+            int top_in = from_lane_below(last_h);
+            uint32_t b_in = (uint32_t)from_lane_below((int)last_b);
             const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
             if (lane == 0) {
                 top_in = 0;
@@ -1039,8 +1039,8 @@ __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
                 chunk = next_chunk;
             next_chunk = load_chunk(s + 64u);
         }
-        int top_in = __shfl_up(last_h, 1, 64);
-        uint32_t b_in = (uint32_t)__shfl_up((int)last_b, 1, 64);
+        int top_in = from_lane_below(last_h);
+        uint32_t b_in = (uint32_t)from_lane_below((int)last_b);
         const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
         const uint32_t jr = s - (uint32_t)lane; // 0-based column; wraps for lanes that have not started
         const bool valid = jr < n;

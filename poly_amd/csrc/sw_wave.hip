@@ -60,7 +60,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     const uint32_t lenA = too_long ? 0u : (uint32_t)l64;
     const uint8_t *ap = A + o0;
 
-    // my rows' table offsets (code * nb); the first byte outside FirstAlphabet, wave-wide
+    // my rows' table offsets (code * nb, in bytes); the first byte outside FirstAlphabet, wave-wide
     uint32_t ro[R];
     uint32_t mybad = 0xFFFFFFFFu;
 #pragma unroll
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
             else
                 code = c;
         }
-        ro[k] = code * (uint32_t)nb;
+        ro[k] = code * (uint32_t)nb * 4u; // byte offset of the row in T: the cell's address is one full-rate add
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
@@ -127,6 +127,16 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     uint32_t last_b = (uint32_t)(nb - 1);
     int besth = 0;
     uint32_t besti = 0, bestj = 0;
+    // up to 16 rows per lane: the best cell of every row (columns come in order, so strict > keeps the first), folded
+    // over rows and lanes at the end -- a compare and two selects per cell instead of the full (h, row) comparison
+    constexpr bool ROWBEST = R <= 16;
+    int bh[ROWBEST ? R : 1];
+    uint32_t bj[ROWBEST ? R : 1];
+#pragma unroll
+    for (int k = 0; k < (ROWBEST ? R : 1); ++k) {
+        bh[k] = 0;
+        bj[k] = 0;
+    }
     const uint32_t steps = (e == 0u && lenA > 0 && ncols > 0) ? ncols + 63u : 0u;
     // B codes enter at lane 0, 64 columns per coalesced load, the next chunk in flight while this one is used
     auto load_chunk = [&](uint32_t s0) -> uint32_t {
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
                 chunk = next_chunk;
             next_chunk = load_chunk(s + 64u);
         }
-        int top_in = __shfl_up(last_h, 1, 64);
-        uint32_t b_in = (uint32_t)__shfl_up((int)last_b, 1, 64);
+        int top_in = from_lane_below(last_h);
+        uint32_t b_in = (uint32_t)from_lane_below((int)last_b);
         const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
         if (lane == 0) {
             top_in = 0;
@@ -154,18 +164,24 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
         const uint32_t j = s - (uint32_t)lane; // column inside the window; wraps for lanes that have not started
         const bool valid = j < ncols;
         int diag = topprev, up = top_in;
+        const uint32_t b4 = b_in << 2;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const int left = Hrow[k];
-            const int sc = T[ro[k] + b_in];
+            const int sc = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(T) + (ro[k] + b4));
             int h = max(max(diag + sc, 0), max(up, left) + gap);
             h = valid ? h : 0;
-            const uint32_t r = (uint32_t)lane * R + k;
-            // first maximum in row-major order: higher h, else smaller row (columns come in order)
-            if (r < lenA && (h > besth || (h == besth && h > 0 && r < besti))) {
-                besth = h;
-                besti = r;
-                bestj = j0 + j;
+            if constexpr (ROWBEST) {
+                const bool better = h > bh[k];
+                bh[k] = better ? h : bh[k];
+                bj[k] = better ? j : bj[k];
+            } else {
+                const uint32_t r = (uint32_t)lane * R + k;
+                // first maximum in row-major order: higher h, else smaller row (columns come in order)
+                const bool better = (r < lenA) & ((h > besth) | ((h == besth) & (h > 0) & (r < besti)));
+                besth = better ? h : besth;
+                besti = better ? r : besti;
+                bestj = better ? j : bestj;
             }
             diag = left;
             up = h;
@@ -175,6 +191,18 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
         last_h = Hrow[R - 1];
         last_b = b_in;
     }
+    if constexpr (ROWBEST) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) { // my rows in order: strict > keeps the smaller row
+            const uint32_t r = (uint32_t)lane * R + k;
+            if (r < lenA && bh[k] > besth) {
+                besth = bh[k];
+                besti = r;
+                bestj = bj[k];
+            }
+        }
+    }
+    bestj += j0; // window-relative so far
     // fold the lanes: max h, then min row, then min column
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {

@@ -32,7 +32,7 @@ while time.time() < t_end:
     om = orc.SubstitutionMatrix(syms, syms, mat)
     LB = int(rng.choice([7, 60, 333, 1000, 5000, 9000]))
     L = int(rng.choice([5, 40, 64, 100, 150, 152, 153, 200, 256, 257, 300, 500, 700, 1100, 1300, 2048]))
-    n = 40_000
+    n = 50_000
     if L > 256:  # long reads: enough pairs for the packed banded pass (path 7), score pass only
         rows = next(r for r in (304, 512, 608, 1024, 1216, 2048) if r >= L)
         n = (8 << 20) // rows + 7

@@ -66,7 +66,8 @@ def _check(al, scoring, omat, gap, reads, ref=None, refs=None, expect_path=None)
         variants = [({}, (1, 3, 4)), ({"POLYHIP_SW_WAVE": "0"}, (1, 3)),
                     ({"POLYHIP_SW_WAVE": "0", "POLYHIP_SW_PACKED": "0"}, (1,))]
     elif expect_path == 2:  # "not a shared-reference fast path": per-pair register-tiled kernel (5) or generic (2)
-        variants = [({}, (2, 5, 6)), ({"POLYHIP_SW_PAIR": "0"}, (2, 6)), ({"POLYHIP_SW_PAIR": "0", "POLYHIP_SW_WAVE": "0"}, (2,))]
+        variants = [({}, (2, 5, 6)), ({"POLYHIP_SW_PAIR": "0"}, (2, 6)), ({"POLYHIP_SW_WAVE": "0"}, (2, 5)),
+                    ({"POLYHIP_SW_PAIR": "0", "POLYHIP_SW_WAVE": "0"}, (2,))]
     for env, paths in variants:
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
@@ -287,7 +288,7 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         unit = ref[:300].copy()
         ref = np.tile(unit, 16)
         ref[rng.integers(0, LB, 12)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 12)]
-    n, L = {"long_ref": 40_000, "short_ref": 120_001, "bad_symbols": 99_999}.get(kind, 120_000), 152  # odd counts: a lane's second pair may be missing
+    n, L = {"long_ref": 50_000, "short_ref": 120_001, "bad_symbols": 99_999}.get(kind, 120_000), 152  # odd counts: a lane's second pair may be missing
     if long_reads:
         n, L = n // 2 + 1, 256
     if short_reads:
