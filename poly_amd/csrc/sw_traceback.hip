@@ -461,6 +461,16 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
 // tb_prof_kernel, one word set per (step, lane) so a wave stores contiguously; the walk (all lanes in step,
 // lane 0 writes) carries the running score down from the score pass's maximum.
 
+// Direction bits of one (step, lane) with up to 16 rows per lane: G | L << BITS, a field of 2 * BITS bits; SP
+// consecutive steps of a lane share one dword (4 rows per lane: four steps), so a lane stores a word every SP-th
+// step instead of 8 useful bits in 32 every step.  Word (s / SP, lane), field s % SP.
+template <int R>
+struct WavePack {
+    static constexpr int BITS = R <= 4 ? 4 : R <= 8 ? 8 : 16;
+    static constexpr int FB = 2 * BITS;
+    static constexpr int SP = 32 / FB;
+};
+
 template <int R>
 __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
@@ -529,6 +539,8 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
         };
         uint32_t chunk = load_chunk(0), next_chunk = 0u;
         const uint32_t steps = ncol + 63u;
+        uint32_t acc = 0u; // the word being filled (R <= 16)
+        bool accany = false;
         for (uint32_t s = 0; s < steps; ++s) {
             if ((s & 63u) == 0u) {
                 if (s)
@@ -566,16 +578,25 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
             topprev = valid ? top_in : 0;
             last_h = Hrow[R - 1];
             last_b = b_in;
-            if (valid) {
+            if constexpr (R <= 16) {
+                constexpr int BITS = WavePack<R>::BITS, FB = WavePack<R>::FB, SP = WavePack<R>::SP;
+                const uint32_t sub = s % SP;
+                if (valid) {
+                    acc |= (gw[0] | (lw[0] << BITS)) << (sub * FB);
+                    accany = true;
+                }
+                if (sub == SP - 1 || s == steps - 1) {
+                    if (accany)
+                        dirw[(size_t)(s / SP) * 64 * NWL] = acc;
+                    acc = 0u;
+                    accany = false;
+                }
+            } else if (valid) {
                 uint32_t *o = dirw + (size_t)s * 64 * NWL;
-                if (R <= 16) {
-                    o[0] = gw[0] | (lw[0] << 16);
-                } else {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        o[g] = gw[g];
-                        o[NG + g] = lw[g];
-                    }
+                for (int g = 0; g < NG; ++g) {
+                    o[g] = gw[g];
+                    o[NG + g] = lw[g];
                 }
             }
         }
@@ -588,12 +609,13 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
         while (h > 0 && i > 0 && j >= c_s && len < stride) {
             const uint32_t r = i - 1u, l = r / R, k = r % R;
             const uint32_t s = (j - c_s) + l;
-            const uint32_t *wp = dbase + ((size_t)s * 64 + l) * NWL;
+            const uint32_t *wp = dbase + ((size_t)(R <= 16 ? s / WavePack<R>::SP : s) * 64 + l) * NWL;
             uint32_t gbit, lbit;
             if (R <= 16) {
-                const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >>
+                                   ((s % WavePack<R>::SP) * WavePack<R>::FB);
                 gbit = (w >> (R - 1 - k)) & 1u;
-                lbit = (w >> (16 + R - 1 - k)) & 1u;
+                lbit = (w >> (WavePack<R>::BITS + R - 1 - k)) & 1u;
             } else {
                 const uint32_t g = k >> 5, bit = 31u - (k & 31u);
                 gbit = (__hip_atomic_load(wp + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> bit) & 1u;
@@ -1033,6 +1055,8 @@ __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
     };
     uint32_t chunk = load_chunk(0), next_chunk = 0u;
     const uint32_t steps = n + 63u;
+    uint32_t acc = 0u; // the word being filled (R <= 16)
+    bool accany = false;
     for (uint32_t s = 0; s < steps; ++s) {
         if ((s & 63u) == 0u) {
             if (s)
@@ -1069,15 +1093,26 @@ __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
         if (valid) {
             topprev = top_in;
             last_h = Hrow[R - 1];
+        }
+        if constexpr (R <= 16) {
+            constexpr int BITS = WavePack<R>::BITS, FB = WavePack<R>::FB, SP = WavePack<R>::SP;
+            const uint32_t sub = s % SP;
+            if (valid) {
+                acc |= (gw[0] | (lw[0] << BITS)) << (sub * FB);
+                accany = true;
+            }
+            if (sub == SP - 1 || s == steps - 1) {
+                if (accany)
+                    dirw[(size_t)(s / SP) * 64 * NWL] = acc;
+                acc = 0u;
+                accany = false;
+            }
+        } else if (valid) {
             uint32_t *o = dirw + (size_t)s * 64 * NWL;
-            if (R <= 16) {
-                o[0] = gw[0] | (lw[0] << 16);
-            } else {
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    o[g] = gw[g];
-                    o[NG + g] = lw[g];
-                }
+            for (int g = 0; g < NG; ++g) {
+                o[g] = gw[g];
+                o[NG + g] = lw[g];
             }
         }
         last_b = b_in;
@@ -1094,12 +1129,14 @@ __global__ __launch_bounds__(THREADS) void nw_wave_kernel(
     uint32_t i = m, j = n, len = 0;
     while (i > 0 && j > 0 && len < stride) { // :141: stops as soon as EITHER index reaches 0
         const uint32_t r = i - 1u, l = r / R, k = r % R;
-        const uint32_t *wp = dbase + ((size_t)((j - 1u) + l) * 64 + l) * NWL;
+        const uint32_t s = (j - 1u) + l;
+        const uint32_t *wp = dbase + ((size_t)(R <= 16 ? s / WavePack<R>::SP : s) * 64 + l) * NWL;
         uint32_t gbit, lbit;
         if (R <= 16) {
-            const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t w = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >>
+                               ((s % WavePack<R>::SP) * WavePack<R>::FB);
             gbit = (w >> (R - 1 - k)) & 1u;
-            lbit = (w >> (16 + R - 1 - k)) & 1u;
+            lbit = (w >> (WavePack<R>::BITS + R - 1 - k)) & 1u;
         } else {
             const uint32_t g = k >> 5, bit = 31u - (k & 31u);
             gbit = (__hip_atomic_load(wp + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> bit) & 1u;
