@@ -1206,8 +1206,9 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
     p.wave_r = 0;
     // (153..256 rows: a lane-per-pair kernel holds them only at one wave per SIMD with part of H in AGPRs / scratch;
     // per-pair B at 250 x 250 the table kernel took 27.6 ms per 200k pairs, the wave kernel takes a third of that)
-    if (max_lenA > 152 && max_lenA <= 4096 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536) {
-        p.wave_r = max_lenA <= 256 ? 4 : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : 64;
+    if (max_lenA > 64 && max_lenA <= 4096 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536) {
+        p.wave_r = max_lenA <= 256 ? (int)((max_lenA + 63) / 64) // 2, 3, 4 rows per lane
+                                   : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : 64;
         const size_t nwl = p.wave_r <= 16 ? 1 : 2 * ((p.wave_r + 31) / 32);
         p.wave_per_pair = ((size_t)p.win.wcols + 63) * 64 * nwl * 4;
         p.per_pair = std::max(p.per_pair, p.wave_per_pair);
@@ -1229,10 +1230,10 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
 
 // NW workspace per pair: the larger of the generic layout (2-bit codes + the H column) and the
 // register-tiled one (G and L words per 32 rows of RA)
-static inline int nw_ra(uint32_t max_lenA) { return max_lenA <= 64 ? 64 : max_lenA <= 152 ? 152 : 0; } // beyond: one wave per pair
+static inline int nw_ra(uint32_t max_lenA) { return max_lenA <= 64 ? 64 : 0; } // beyond: one wave per pair
 static inline int nw_wave_r(uint32_t max_lenA)
 {
-    return max_lenA <= 152 ? 0 : max_lenA <= 256 ? 4 : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : max_lenA <= 4096 ? 64 : 0;
+    return max_lenA <= 64 ? 0 : max_lenA <= 256 ? (int)((max_lenA + 63) / 64) : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : max_lenA <= 4096 ? 64 : 0;
 }
 static uint64_t nw_per_pair(uint32_t max_lenA, uint64_t max_lenB)
 {
@@ -1298,7 +1299,7 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
                          !env_is("POLYHIP_TB_WAVE", '0'); // testing aid: no one-wave-per-pair traceback
     const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr && !(p.ra == 256 && wave_ok) &&
                           !env_is("POLYHIP_TB_PROF", '0'); // testing aid: the table kernel for a shared reference
-    const bool use_wave = !use_prof && (p.ra == 0 || p.ra == 256) && wave_ok;
+    const bool use_wave = !use_prof && (p.ra == 0 || p.ra >= 152) && wave_ok; // 65 rows up (the table kernel keeps <= 64)
     k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
     const int wide = env_is("POLYHIP_TB_WIDE", '1'); // testing aid: the conservative per-pair window
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
@@ -1330,7 +1331,11 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err, d_score, \
                            (int)sc->smax, p.win.wcols, wide, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);           \
     } while (0)
-            if (p.wave_r == 4)
+            if (p.wave_r == 2)
+                PH_TBW_LAUNCH(2);
+            else if (p.wave_r == 3)
+                PH_TBW_LAUNCH(3);
+            else if (p.wave_r == 4)
                 PH_TBW_LAUNCH(4);
             else if (p.wave_r == 8)
                 PH_TBW_LAUNCH(8);
@@ -1482,7 +1487,7 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
     PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_nw_align_batch: workspace too small (%zu B; %llu B per pair, >= %d pairs)",
                work_bytes, (unsigned long long)per_pair, k3t::THREADS);
     hipStream_t st = as_stream(stream);
-    // register-tiled kernel: lenA <= 152, the compact table fits LDS, columns below 2^31; else the generic one
+    // register-tiled kernel: lenA <= 64, the compact table fits LDS, columns below 2^31; else the generic one
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     const size_t reg_smem = (size_t)na * nb * 4 + 512;
     const bool nw_generic = env_is("POLYHIP_NW_GENERIC", '1'); // testing aid: force the generic kernel
@@ -1509,7 +1514,11 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, (uint32_t)lenB,               \
                            static_cast<uint32_t *>(d_work), d_score, d_err, d_alnA, d_alnB, d_alnLen, aln_stride);    \
     } while (0)
-            if (wave_r == 4)
+            if (wave_r == 2)
+                PH_NWW_LAUNCH(2);
+            else if (wave_r == 3)
+                PH_NWW_LAUNCH(3);
+            else if (wave_r == 4)
                 PH_NWW_LAUNCH(4);
             else if (wave_r == 8)
                 PH_NWW_LAUNCH(8);
@@ -1533,10 +1542,7 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, (uint32_t)lenB,               \
                            static_cast<uint32_t *>(d_work), d_score, d_err, d_alnA, d_alnB, d_alnLen, aln_stride);    \
     } while (0)
-            if (reg_ra == 64)
-                PH_NW_LAUNCH(64);
-            else
-                PH_NW_LAUNCH(152);
+            PH_NW_LAUNCH(64);
 #undef PH_NW_LAUNCH
             PH_HIP(hipGetLastError());
             continue;

@@ -81,7 +81,7 @@ def test_batch_matches_oracle(al, monkeypatch, maxlen, generic):
         pa, oa = _pack(A)
         pb, ob = _pack(B)
         score, err, sa, sb = al[0].nw_align_packed(sc, pa, oa, pb, ob)
-        assert al[0].nw_last_path() == (2 if generic or maxlen > 4096 else 1 if maxlen <= 152 else 3)
+        assert al[0].nw_last_path() == (2 if generic or maxlen > 4096 else 1 if maxlen <= 64 else 3)
         for p, (a, b) in enumerate(zip(A, B)):
             try:
                 w = orc.needleman_wunsch(a, b, om, gap)
