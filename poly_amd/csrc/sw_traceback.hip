@@ -1206,9 +1206,11 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
     p.wave_r = 0;
     // (153..256 rows: a lane-per-pair kernel holds them only at one wave per SIMD with part of H in AGPRs / scratch;
     // per-pair B at 250 x 250 the table kernel took 27.6 ms per 200k pairs, the wave kernel takes a third of that)
-    if (max_lenA > 64 && max_lenA <= 4096 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536) {
-        p.wave_r = max_lenA <= 256 ? (int)((max_lenA + 63) / 64) // 2, 3, 4 rows per lane
-                                   : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : 64;
+    // (not below 153 rows, although per-pair B at 150 x 150 it would be 5.2 against the table kernel's 6.6 ms: its
+    // 256 B per step and pair would shrink the chunks of every batch sized with polyhip_sw_traceback_workspace_bytes,
+    // config 4's byte-profile traceback included -- first the layout has to shrink to the packed word count)
+    if (max_lenA > 152 && max_lenA <= 4096 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536) {
+        p.wave_r = max_lenA <= 256 ? 4 : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : 64;
         const size_t nwl = p.wave_r <= 16 ? 1 : 2 * ((p.wave_r + 31) / 32);
         p.wave_per_pair = ((size_t)p.win.wcols + 63) * 64 * nwl * 4;
         p.per_pair = std::max(p.per_pair, p.wave_per_pair);
@@ -1299,7 +1301,7 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
                          !env_is("POLYHIP_TB_WAVE", '0'); // testing aid: no one-wave-per-pair traceback
     const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr && !(p.ra == 256 && wave_ok) &&
                           !env_is("POLYHIP_TB_PROF", '0'); // testing aid: the table kernel for a shared reference
-    const bool use_wave = !use_prof && (p.ra == 0 || p.ra >= 152) && wave_ok; // 65 rows up (the table kernel keeps <= 64)
+    const bool use_wave = !use_prof && (p.ra == 0 || p.ra == 256) && wave_ok;
     k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
     const int wide = env_is("POLYHIP_TB_WIDE", '1'); // testing aid: the conservative per-pair window
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
