@@ -6,26 +6,40 @@
 Metric (BASELINE.json): k-mers hashed / s through mash.Sketch on
 configs[1] -- 1,000,000 synthetic 10 kb reads, k=21, s=1000, per GPU.
 A "step" is one pass of K1 (polyhip_mash_sketch_batch_dev) over the whole
-read set, inputs already resident in HBM.  For N > 1 the driver launches one
-rank per GPU (torch.distributed.run); every rank sketches its own 1M reads
-(disjoint slice of one splitmix64 stream, no data-path collective) -> weak
-scaling; the timed region is bracketed by barrier + synchronize and the MAX
-over ranks is used.
+read set, inputs already resident in HBM.
 
-Also reported in the same JSON line:
-  roofline      HBM roofline of the K1 kernel: algorithmic bytes per launch
-                (n_reads * (read_len + 4*s)) / mean launch time
-                measured with HIP events on the launch stream; peak 8 TB/s.
+Ranks.  `--gpus N` ALWAYS means N ranks, one per GPU.  Started under
+torch.distributed.run (WORLD_SIZE set) the script is one of those ranks and
+refuses to run if WORLD_SIZE != N.  Started plain (`python bench.py --gpus 8`)
+it launches `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1 ...` on itself and returns that job's exit status.
+The JSON line carries what actually ran: n_gpus, the torch.distributed
+backend, the world size the process group reports, and every rank's device.
+
+Legs in the one JSON line:
+  value / roofline   WEAK scaling: every rank sketches its own 1M reads
+                (disjoint slice of one splitmix64 stream, no data-path
+                collective); timed region = barrier + synchronize on both
+                sides, MAX over ranks.
+  strong        (N > 1) the SAME 1M reads of configs[1] split over the ranks
+                (sharding.shard_range), timed the same way.
+  extra         N = 1: secondary rates of every other kernel (SW cell updates/s,
+                Tm windows/s, distance pairs/s ...), each with its own CPU baseline
+                and, for K1/SW/K4, the PCIe-inclusive host-pointer rate (`e2e`).
+                N > 1: configs[2] (per-rank sketches -> one RCCL all-gather ->
+                this rank's row block), configs[3] (reads sharded, shared
+                reference), configs[4] (window starts sharded with halo).
   cpu_baseline  the CPU oracle's faithful restatement of mash.go:68-104
-                (sort-on-accept) timed on this box, 1 thread, bounded sample.
-  extra         secondary rates (SW cell updates/s, Tm windows/s, distance
-                pairs/s) when those kernels are built.
+                (sort-on-accept) on this box: 1 core and all cores, plus the
+                tight (insertion) variant and configs[0] (phiX174) wall time.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -46,53 +60,112 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config: 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reads", type=int, default=400, help="reads in the CPU-baseline sample")
+    ap.add_argument("--cpu-reads", type=int, default=400, help="reads per core in the CPU-baseline sample")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
     return ap.parse_args()
 
 
-def cpu_baseline(n_reads: int):
-    """Oracle (port of mash.go:68-104, sort on every accepted hash) on host core(s)."""
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: become the launcher."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def host_cores() -> int:
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(reads_per_core: int):
+    """Oracle (port of mash.go:68-104) on host core(s): faithful = full sort on every accepted hash, as
+    mash.go:99; tight = one insertion per accepted hash (same result).  1 core and all cores (one thread
+    per shard of reads; the reference itself is single-goroutine)."""
+    import concurrent.futures as cf
+
     import numpy as np
     import oracle as orc
-    buf = orc.synth_dna(SEED, n_reads * READ_LEN)
-    offs = np.arange(0, (n_reads + 1) * READ_LEN, READ_LEN, dtype=np.uint64)
-    t = time.perf_counter()
-    orc.mash_sketch_batch(buf, offs, KMER, SKETCH, faithful=True)
-    dt = time.perf_counter() - t
-    t2 = time.perf_counter()
-    orc.mash_sketch_batch(buf, offs, KMER, SKETCH, faithful=False)
-    dt2 = time.perf_counter() - t2
-    kmers = n_reads * (READ_LEN - KMER)
-    return {
-        "value": kmers / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
-        "sample": f"first {n_reads} reads of the same stream ({kmers} k-mers, {dt:.1f} s), "
-                  "oracle/poly_oracle.c orc_mash_sketch faithful=1 (full sort on accept, as mash.go:99)",
-        "insertion_variant_value": kmers / dt2,
+
+    cores = host_cores()
+
+    def run(n_reads: int, faithful: bool, threads: int):
+        buf = orc.synth_dna(SEED, n_reads * READ_LEN)
+        per = n_reads // threads
+        parts = [(buf[t * per * READ_LEN:(t + 1) * per * READ_LEN],
+                  np.arange(0, (per + 1) * READ_LEN, READ_LEN, dtype=np.uint64)) for t in range(threads)]
+        t0 = time.perf_counter()
+        if threads == 1:
+            orc.mash_sketch_batch(parts[0][0], parts[0][1], KMER, SKETCH, faithful=faithful)
+        else:  # ctypes releases the GIL: these are real threads on the C restatement
+            with cf.ThreadPoolExecutor(threads) as ex:
+                list(ex.map(lambda p: orc.mash_sketch_batch(p[0], p[1], KMER, SKETCH, faithful=faithful), parts))
+        dt = time.perf_counter() - t0
+        return per * threads * (READ_LEN - KMER) / dt, dt, per * threads
+
+    v1, dt1, n1 = run(reads_per_core, True, 1)
+    out = {
+        "value": v1, "unit": "k-mers/s", "cores": 1, "kind": "port",
+        "sample": f"first {n1} reads of the same stream ({n1 * (READ_LEN - KMER)} k-mers, {dt1:.1f} s), "
+                  "oracle/poly_oracle.c orc_mash_sketch faithful=1 (full sort on accept, as mash.go:99); "
+                  "CPU restatement of the reference algorithm (no Go toolchain on this box)",
     }
+    vt, dtt, nt = run(reads_per_core * 4, False, 1)
+    out["tight_variant"] = {"value": vt, "unit": "k-mers/s", "cores": 1,
+                            "sample": f"{nt} reads, insertion instead of sort.Slice ({dtt:.1f} s)"}
+    if cores > 1:
+        va, dta, na = run(reads_per_core // 2 * cores, True, cores)
+        out["all_cores"] = {"value": va, "unit": "k-mers/s", "cores": cores,
+                            "sample": f"{na} reads, one thread per contiguous shard of reads, faithful ({dta:.1f} s)"}
+        vb, dtb, nb = run(reads_per_core * 2 * cores, False, cores)
+        out["all_cores_tight_variant"] = {"value": vb, "unit": "k-mers/s", "cores": cores,
+                                          "sample": f"{nb} reads, insertion variant ({dtb:.1f} s)"}
+    # configs[0]: mash.Sketch on phiX174, k=21 s=1000, CPU only (plumbing)
+    px = os.path.join(ROOT, "tests", "golden", "phix174.seq")
+    if os.path.exists(px):
+        seq = open(px, "rb").read().strip()
+        reps = 20
+        m = orc.Mash(KMER, SKETCH)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.Sketches[:] = 0
+            m.Sketch(seq, faithful=True)
+        dt = (time.perf_counter() - t0) / reps
+        out["config0_phix174"] = {"ms_per_sketch": dt * 1e3, "kmers_per_s": (len(seq) - KMER) / dt, "cores": 1,
+                                  "sketch0": int(m.Sketches[0]), "sample": f"{len(seq)} bp, faithful, mean of {reps}"}
+    return out
 
 
 def cpu_baseline_extra():
-    """The oracle timed on bounded samples of the secondary workloads (about 2 s each, one host core):
+    """The oracle timed on bounded samples of the secondary workloads (a few seconds each, one host core):
     what the reference's per-call API costs on the CPU for the same shapes as poly_amd/bench_extra.py."""
     import numpy as np
     import oracle as orc
+    from poly_amd import workloads
     out = {}
 
     def entry(units, unit, dt, sample):
         return {"value": units / dt, "unit": unit, "cores": 1, "kind": "port", "sample": f"{sample} ({dt:.1f} s)"}
 
-    # SmithWaterman, configs[3] shape: 150 bp reads vs one 5 kb reference, NUC_4, gap -2 (align.go:171-232)
-    ref = bytes(orc.synth_dna(0xC4, 5000))
+    # SmithWaterman, configs[3]: 150 bp mutated reads vs one 5 kb reference, NUC_4, gap -2 (align.go:171-232)
+    ref, reads = workloads.config4_reads(300)
+    ref = bytes(ref)
     rng = np.random.default_rng(0xC4)
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
-    starts = rng.integers(0, 5000 - 150, size=300)
     t = time.perf_counter()
-    for a in starts:
-        orc.smith_waterman(ref[a:a + 150], ref, om, -2)
-    out["smith_waterman"] = entry(len(starts) * 150 * 5000, "cell updates/s", time.perf_counter() - t,
-                                  f"{len(starts)} reads of 150 bp vs the 5000 bp reference, orc_smith_waterman "
-                                  "(full int64 matrix + traceback, as align.go:171-232)")
+    for r in reads:
+        orc.smith_waterman(bytes(r), ref, om, -2)
+    out["smith_waterman"] = entry(len(reads) * 150 * 5000, "cell updates/s", time.perf_counter() - t,
+                                  f"first {len(reads)} reads of the configs[3] generator vs the 5000 bp reference, "
+                                  "orc_smith_waterman (full int64 matrix + traceback, as align.go:171-232)")
+    starts = rng.integers(0, 5000 - 150, size=300)
     pairs = [(ref[a:a + 150], bytes(orc.synth_dna(int(a) + 7919 * r, 150))) for r in range(15) for a in starts]
     t = time.perf_counter()
     for x, y in pairs:
@@ -139,9 +212,33 @@ def cpu_baseline_extra():
     return out
 
 
+def timed_steps(step, steps: int, warmup: int, sync_all, world: int, dev):
+    """W untimed steps, then EXACTLY K steps between barrier + synchronize; (elapsed MAX over ranks, mean
+    per-launch ms from HIP events recorded on the launch stream)."""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    sync_all()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()  # same stream as the launch (torch's current stream)
+        step()
+        e1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, steps)
+    return elapsed, kern_ms
+
+
 def allgather_distance(dev, rank: int, world: int):
     """N = 100k sketches over `world` ranks: each rank sketches its own families, all ranks all-gather
-    (one ncclAllGather over xGMI), each computes its row block of the shared-count matrix."""
+    (one ncclAllGather over xGMI), each builds the index of the gathered set once and computes its row block."""
     import torch
     import torch.distributed as dist
     from poly_amd import bench_extra, mash, sharding
@@ -161,10 +258,11 @@ def allgather_distance(dev, rank: int, world: int):
             return state["counts"]
         return sharding.allvsall_row_block(local, compute)
 
-    step()
+    for _ in range(2):
+        step()
     dist.barrier()
     torch.cuda.synchronize()
-    reps = 3
+    reps = 5
     t0 = time.perf_counter()
     for _ in range(reps):
         counts, row0, gathered = step()
@@ -176,33 +274,102 @@ def allgather_distance(dev, rank: int, world: int):
     N = gathered.shape[0]
     ok = bool((counts[:, row0:row0 + counts.shape[0]].diagonal() == s).all())
     return {"workload": f"all-vs-all shared counts over {N} sketches (s={s}) sharded by rows over {world} GPUs, "
-                        "sketches all-gathered with one RCCL all-gather per step",
+                        "sketches all-gathered with one RCCL all-gather per step (BASELINE configs[2])",
             "pairs_per_s": N * N / float(dt.item()), "ms_per_step": float(dt.item()) * 1e3,
             "allgather_bytes_per_rank": local.numel() * 4, "self_pairs_share_all_hashes": ok}
 
 
+def sharded_tm_scan(dev, rank: int, world: int):
+    """configs[4]: the 5 Mb genome's window starts split over the ranks (sharding.scan_shard; the 29-byte
+    right halo is read from the same replicated genome buffer), no collective."""
+    import torch
+    import torch.distributed as dist
+    from poly_amd import mash, primers, sharding
+    n, Lmin, Lmax = 5_000_000, 18, 30
+    g = torch.empty(n, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC5, g)
+    start0, ns = sharding.scan_shard(n, Lmin, rank, world)
+    nl = Lmax - Lmin + 1
+    out = [torch.zeros(nl * ns, dtype=torch.float64, device=dev) for _ in range(3)]
+
+    def step():
+        primers.santalucia_scan_dev(g, n, start0, ns, Lmin, Lmax, 500e-9, 50e-3, 0.0, *out, ns)
+    for _ in range(5):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    win = sum(n - L + 1 for L in range(Lmin, Lmax + 1))
+    return {"workload": f"SantaLucia Tm/dH/dS of all {Lmin}..{Lmax}-mers of a {n} B genome, window starts sharded over "
+                        f"{world} GPUs (BASELINE configs[4])",
+            "windows_per_s": win / float(dt.item()), "ms_per_step": float(dt.item()) * 1e3,
+            "this_rank_starts": [int(start0), int(ns)]}
+
+
 def main() -> int:
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); refusing to report "
+                  "a number for a different GPU count", file=sys.stderr)
+        return 2
+    one_gpu_test = os.environ.get("BENCH_ONE_GPU_TEST") == "1"
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible (the HIP path has no CPU fallback)", file=sys.stderr)
+        return 3
+    if world > torch.cuda.device_count() and not one_gpu_test:
+        if rank == 0:
+            print(f"bench.py: {world} ranks but only {torch.cuda.device_count()} GPU(s) visible", file=sys.stderr)
+        return 2
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if os.environ.get("BENCH_ONE_GPU_TEST") == "1":
+        if one_gpu_test:
             # testing aid: all ranks share GPU 0 and talk over gloo (exercises the N > 1 code on a 1-GPU box)
             local_rank = 0
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        backend = dist.get_backend()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from poly_amd import mash
+    from poly_amd import mash, sharding
+
+    # who is actually here: every rank's (rank, device index, name, bus id) -- reported, not assumed
+    props = torch.cuda.get_device_properties(local_rank)
+    me = {"rank": rank, "device": local_rank, "name": torch.cuda.get_device_name(local_rank),
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "hbm_GiB": round(props.total_memory / 2**30, 1)}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+        # a collective that only succeeds if all `world` ranks are in the group: sum of 1 over ranks
+        one = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(one)
+        assert int(one.item()) == world == dist.get_world_size(), "process group does not span --gpus ranks"
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     n = args.reads
     seqs = torch.empty(n * READ_LEN, dtype=torch.uint8, device=dev)
@@ -210,34 +377,8 @@ def main() -> int:
     offs = torch.arange(0, (n + 1) * READ_LEN, READ_LEN, dtype=torch.int64, device=dev)
     out = torch.zeros((n, SKETCH), dtype=torch.int32, device=dev)
 
-    def step():
-        mash.sketch_batch_dev(seqs, offs, KMER, SKETCH, out)
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()  # same stream as the launch (torch's current stream)
-        step()
-        e1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, args.steps)
-
+    elapsed, kern_ms = timed_steps(lambda: mash.sketch_batch_dev(seqs, offs, KMER, SKETCH, out),
+                                   args.steps, args.warmup, sync_all, world, dev)
     kmers_per_step = n * (READ_LEN - KMER)
     value = world * kmers_per_step * args.steps / elapsed
     alg_bytes = n * (READ_LEN + 4 * SKETCH)  # per launch: reads in, sketches out
@@ -254,11 +395,28 @@ def main() -> int:
         got = out[:m].cpu().numpy().view(np.uint32)
         parity = bool((got == want).all())
 
-    traffic = None
+    # strong scaling: the SAME n reads of configs[1] (stream positions 0 .. n*READ_LEN) split over the ranks
+    strong = None
+    if world > 1:
+        lo, hi = sharding.shard_range(n, rank, world)
+        m_loc = hi - lo
+        mash.synth_dna_dev(SEED, seqs[:m_loc * READ_LEN], first=lo * READ_LEN)
+        s_offs, s_out = offs[:m_loc + 1], out[:m_loc]
+        s_elapsed, s_kern = timed_steps(lambda: mash.sketch_batch_dev(seqs[:m_loc * READ_LEN], s_offs, KMER, SKETCH, s_out),
+                                        args.steps, args.warmup, sync_all, world, dev)
+        strong = {"scaling": "strong", "value": kmers_per_step * args.steps / s_elapsed, "unit": "k-mers/s",
+                  "ms_per_step": s_elapsed / args.steps * 1e3, "this_rank_kernel_ms": s_kern,
+                  "workload": f"the same {n} reads (configs[1]) split over {world} ranks by sharding.shard_range, "
+                              "no data-path collective"}
+
+    traffic, traffic_source = None, None
     tp = os.path.join(ROOT, "profiles", "k1_traffic.json")
     if os.path.exists(tp):
         try:
-            traffic = json.load(open(tp)).get("hbm_bytes_per_launch_1M_reads")
+            tj = json.load(open(tp))
+            traffic = tj.get("hbm_bytes_per_launch_1M_reads")
+            traffic_source = (f"profiles/k1_traffic.json (round {tj.get('round')}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                              "passes of this command, corrected per MI355X_MICROARCH.md; NOT measured by this run)")
             if traffic is not None and n != 1_000_000:
                 traffic = traffic * n / 1_000_000
         except Exception:
@@ -273,12 +431,18 @@ def main() -> int:
                                f"(BASELINE configs[1]), splitmix64 seed 0x{SEED:X}",
                    "reads_per_gpu": n, "read_len": READ_LEN, "k": KMER, "s": SKETCH,
                    "parallelism": f"reads sharded over {world} GPU(s), no data-path collective"},
+        "launch": {"ranks": world, "backend": backend or "none (single process)",
+                   "group_world_size": dist.get_world_size() if world > 1 else 1,
+                   "self_launched": os.environ.get("BENCH_SELF_LAUNCHED") == "1",
+                   "one_gpu_test": one_gpu_test, "devices": ranks},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "polyhip::k1::sketch_fast_kernel<21>", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "parity_spot_check": parity,
     }
+    if strong is not None:
+        line["strong"] = strong
 
     # free the headline's buffers before the secondary kernels allocate theirs
     del seqs, out, offs
@@ -308,8 +472,13 @@ def main() -> int:
                         "cell_updates_per_s_with_traceback": cells / float(t[1].item()) * 1e3}
         else:
             sw_extra = {"error": sw_err or "another rank failed"}
+        try:
+            tm_extra = sharded_tm_scan(dev, rank, world)
+        except Exception as e:
+            tm_extra = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
-            line["extra"] = {"mash_distance_allgather": line_extra, "smith_waterman": sw_extra}
+            line["extra"] = {"mash_distance_allgather": line_extra, "smith_waterman": sw_extra,
+                             "santalucia_scan": tm_extra}
     if rank == 0 and world == 1:
         if not args.no_extra:
             try:

@@ -383,7 +383,8 @@ int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets,
  * without '\n' (:142-148), 5 empty identifier line and 6 identifier field without '='
  * (the reference PANICS there, :156 and :163), 7 more records than max_records),
  * [2] = the line the reference's message names, [3] = total sequence bytes.
- * Capacities: d_seqs nbytes, d_offsets / d_rec_start nbytes/8 + 2 entries (or max_records + 1).
+ * Capacities: d_seqs nbytes, d_offsets / d_rec_start nbytes/7 + 2 entries (or max_records + 1;
+ * the shortest record is the 7 bytes "@\nA\n\nI\n": the third line is read unseen, fastq.go:182).
  */
 size_t polyhip_fastq_workspace_bytes(uint64_t nbytes);
 int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes,

@@ -5,22 +5,40 @@ from __future__ import annotations
 
 import torch
 
-from . import align, alphabet, fasta, fastq, mash, matrix, primers, seqhash
+from . import align, alphabet, fasta, fastq, mash, matrix, primers, seqhash, workloads
 
 HBM_PEAK_GBS = 8000.0
 
 
-def _time(fn, reps: int, warm: int = 1) -> float:
+def _time(fn, reps: int = 10, warm: int = 5) -> float:
+    """median of `reps` (>= 10) separately event-timed launches after `warm` (>= 5) untimed ones
+    (>= 5 warm-ups, median of >= 10), in ms; events on the launch stream"""
+    reps, warm = max(reps, 10), max(warm, 5)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for e0, e1 in evs:
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    return 0.5 * (ts[(reps - 1) // 2] + ts[reps // 2])
+
+
+def _wall(fn, reps: int = 5, warm: int = 2) -> float:
+    """host-pointer (PCIe-inclusive) calls are synchronous: median wall time in ms"""
+    import time
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return ts[len(ts) // 2]
 
 
 def family_sketches(dev, nfam: int, copies: int, L: int, k: int, s: int, seed: int, sub: float = 0.01):
@@ -46,19 +64,13 @@ def family_sketches(dev, nfam: int, copies: int, L: int, k: int, s: int, seed: i
 
 
 def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
-    """config 4: n reads of LA bp (substrings of the reference, 5 % substitutions) vs one LB reference, NUC_4, gap -2;
+    """config 4: n reads of LA bp (windows of the reference, 5 % substitutions + 1 % indels) vs one LB reference, NUC_4, gap -2;
     `shard` picks this rank's reads when the pairs are split over GPUs (the reference is the same everywhere)"""
     a = alphabet.NewAlphabet(list("-ACGT"))
     sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
-    B = torch.empty(LB, dtype=torch.uint8, device=dev)
-    mash.synth_dna_dev(0xC4, B)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0xC4 + 1 + 7919 * shard)
-    starts = torch.randint(0, LB - LA, (n,), device=dev, generator=gen)
-    A = B[starts[:, None] + torch.arange(LA, device=dev)[None, :]]
-    hit = torch.rand(A.shape, device=dev, generator=gen) < 0.05
-    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-    A[hit] = lut[torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)]
+    # SURVEY 8d C4: windows of the reference with 5 % substitutions + 1 % indels (poly_amd/workloads.py); rank
+    # `shard` takes reads shard*n .. of the one definition
+    B, A = workloads.config4_reads(n, LA, LB, first=shard * n, device=dev)
     A = A.reshape(-1).contiguous()
     offA = torch.arange(0, (n + 1) * LA, LA, dtype=torch.int64, device=dev)
     score = torch.zeros(n, dtype=torch.int64, device=dev)
@@ -89,6 +101,13 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         # (88 cycles) per 512 cells (64 lanes x 2 pairs x 4 columns); 1024 SIMDs at ~2.4 GHz.
         "valu_issue_ceiling_cell_updates_per_s": 1024 * 2.4e9 * 512 / 88,
         "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / (1024 * 2.4e9 * 512 / 88),
+        "roofline": {"bound": "valu", "achieved": cells / ms_score * 1e3 / 1e12, "peak": 1024 * 2.4e9 * 512 / 88 / 1e12,
+                     "unit": "T cell updates/s", "frac": cells / ms_score * 1e3 / (1024 * 2.4e9 * 512 / 88),
+                     "kernel": "polyhip::k3pk::sw_pk_kernel<152,false> (+ locate + tie wave, all inside score_pass_ms)",
+                     "derivation": "packed int16 recurrence: 22 half-rate VALU instructions = 88 issue cycles per "
+                                   "512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x 2.4 GHz; HBM is not the "
+                                   "bound (166 B per 750,000 cells)",
+                     "hbm_achieved_GBs": alg / ms_score * 1e3 / 1e9},
         "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
     }
 
@@ -160,7 +179,7 @@ def fastq_feeder(dev, n: int = 200_000, L: int = 1000):
     img = torch.from_numpy(np.frombuffer(rec * n, np.uint8).copy()).to(dev)
     nb = img.numel()
     seqs = torch.empty(nb, dtype=torch.uint8, device=dev)
-    offs = torch.zeros(nb // 8 + 2, dtype=torch.int64, device=dev)
+    offs = torch.zeros(nb // 7 + 2, dtype=torch.int64, device=dev)
     res = torch.zeros(4, dtype=torch.int64, device=dev)
     work = torch.empty(fastq.workspace_bytes(nb), dtype=torch.uint8, device=dev)
     ms = _time(lambda: fastq.pack_dev(img, seqs, offs, None, res, work), 5)
@@ -233,7 +252,7 @@ def fasta_feeder(dev, n: int = 100_000, L: int = 4000, width: int = 80):
     img = torch.from_numpy(np.frombuffer(rec * n, np.uint8).copy()).to(dev)
     nb = img.numel()
     seqs = torch.empty(nb, dtype=torch.uint8, device=dev)
-    offs = torch.zeros(nb // 8 + 2, dtype=torch.int64, device=dev)
+    offs = torch.zeros(nb // 7 + 2, dtype=torch.int64, device=dev)
     res = torch.zeros(4, dtype=torch.int64, device=dev)
     work = torch.empty(fasta.workspace_bytes(nb), dtype=torch.uint8, device=dev)
     ms = _time(lambda: fasta.pack_dev(img, seqs, offs, None, res, work), 5)
@@ -242,12 +261,53 @@ def fasta_feeder(dev, n: int = 100_000, L: int = 4000, width: int = 80):
             "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
 
 
+def e2e(dev) -> dict:
+    """PCIe-inclusive rates of the host-pointer flavours (what a cgo caller with Go-heap buffers gets):
+    pageable numpy memory in, pageable numpy memory out, synchronous calls.  Never the headline value."""
+    import numpy as np
+    out = {}
+    # K1: 200k reads x 10 kb (2 GB in, 0.8 GB out)
+    n, L, k, s = 200_000, 10_000, 21, 1000
+    d = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC2, d)
+    host = d.cpu().numpy()
+    del d
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    sk = np.zeros((n, s), dtype=np.uint32)
+    ms = _wall(lambda: mash.sketch_batch_packed(host, offs, k, s, out=sk), 5, 1)
+    out["mash_sketch"] = {"workload": f"polyhip_mash_sketch_batch, {n} reads x {L} B from pageable host memory",
+                          "kmers_per_s": n * (L - k) / ms * 1e3, "ms": ms, "pcie_GBs": (n * L + 4 * n * s) / ms * 1e3 / 1e9}
+    del host, sk
+    # K3: configs[3], host reads in, (score, endA, endB, err) out; then with aligned strings
+    a = alphabet.NewAlphabet(list("-ACGT"))
+    sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
+    n, LA, LB = 1_000_000, 150, 5000
+    B, A = workloads.config4_reads(n, LA, LB, device=dev)
+    hA, hB = A.reshape(-1).cpu().numpy(), B.cpu().numpy()
+    del A, B
+    offA = np.arange(0, (n + 1) * LA, LA, dtype=np.uint64)
+    ms = _wall(lambda: align.sw_batch_packed(sc, hA, offA, hB, None), 5, 1)
+    out["smith_waterman"] = {"workload": f"polyhip_sw_batch, {n} x {LA} bp reads vs one {LB} bp reference, host pointers",
+                             "cell_updates_per_s": n * LA * LB / ms * 1e3, "ms": ms}
+    # K4: configs[4], 5 Mb genome in, three fp64 planes (1.56 GB) out
+    g = torch.empty(5_000_000, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC5, g)
+    hg = g.cpu().numpy()
+    del g
+    win = sum(len(hg) - L + 1 for L in range(18, 31))
+    ms = _wall(lambda: primers.SantaLuciaScan(hg, 18, 30), 3, 1)
+    out["santalucia_scan"] = {"workload": "polyhip_santalucia_scan, 5,000,000 B genome, 18..30-mers, host pointers "
+                                          "(includes allocating the 1.56 GB of numpy result planes)",
+                              "windows_per_s": win / ms * 1e3, "ms": ms, "pcie_GBs": win * 24 / ms * 1e3 / 1e9}
+    return out
+
+
 def run(dev) -> dict:
     out = {}
     for name, fn in (("smith_waterman", sw), ("smith_waterman_250bp", lambda d: sw(d, 400_000, 250)),
                      ("smith_waterman_1kb", lambda d: sw(d, 20_000, 1000)), ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder),
-                     ("fasta_feeder", fasta_feeder)):
+                     ("fasta_feeder", fasta_feeder), ("e2e_host_pointers", e2e)):
         try:
             out[name] = fn(dev)
         except Exception as e:  # a secondary number must never take the headline down

@@ -71,5 +71,20 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_abi_smoke() -> str:
+    """tests/abi/abi_smoke: the torch-free C consumer of the ABI (plain gcc, links -lpolyhip only)."""
+    src = os.path.join(ROOT, "tests", "abi", "abi_smoke.c")
+    exe = os.path.join(ROOT, "tests", "abi", "abi_smoke")
+    lib = build_lib()
+    if _newer(exe, [src, lib, os.path.join(ROOT, "include", "polyhip.h")]):
+        cmd = ["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", HERE, "-lpolyhip", "-lm",
+               "-Wl,-rpath,$ORIGIN/../../poly_amd"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode:
+            sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+            raise RuntimeError("build of tests/abi/abi_smoke failed")
+    return exe
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))

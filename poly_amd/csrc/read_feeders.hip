@@ -51,9 +51,10 @@ enum { R_NREC = 0, R_CODE = 1, R_LINE = 2, R_SEQBYTES = 3, R_NLINES = 4, R_FIRST
 
 // ---- single-workgroup exclusive scan of u32 counts into u64 offsets (out[n] = total) --------
 // n = n_host, or *n_dev / div when n_dev != NULL (a count that only exists on the device)
+// entries beyond out[cap] are not written (the caller's buffer may hold only cap + 1 of them)
 __global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *__restrict__ in, uint64_t n_host,
                                                        const uint64_t *__restrict__ n_dev, uint64_t div,
-                                                       uint64_t *__restrict__ out)
+                                                       uint64_t *__restrict__ out, uint64_t cap)
 {
     const uint64_t n = n_dev ? *n_dev / div : n_host;
     __shared__ uint64_t wsum[16];
@@ -78,14 +79,14 @@ __global__ __launch_bounds__(1024) void scan_u32_kernel(const uint32_t *__restri
         uint64_t pre = carry;
         for (int w = 0; w < (tid >> 6); ++w)
             pre += wsum[w];
-        if (i < n)
+        if (i < n && i <= cap)
             out[i] = pre + incl - v;
         __syncthreads();
         if (tid == 1023)
             carry = pre + incl;
         __syncthreads();
     }
-    if (tid == 0)
+    if (tid == 0 && n <= cap)
         out[n] = carry;
 }
 
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(const uint32_t *__restr
 
 __global__ __launch_bounds__(SCAN_SEGS) void scan_offsets_kernel(uint64_t *__restrict__ partial, uint64_t n_host,
                                                                 const uint64_t *__restrict__ n_dev, uint64_t div,
-                                                                uint64_t *__restrict__ out)
+                                                                uint64_t *__restrict__ out, uint64_t cap)
 {
     __shared__ uint64_t ws[SCAN_SEGS / 64];
     const int tid = threadIdx.x;
@@ -146,13 +147,15 @@ __global__ __launch_bounds__(SCAN_SEGS) void scan_offsets_kernel(uint64_t *__res
     for (int w = 0; w < (tid >> 6); ++w)
         pre += ws[w];
     partial[tid] = pre + incl - v; // exclusive: where segment tid starts
-    if (tid == SCAN_SEGS - 1)
-        out[n_dev ? *n_dev / div : n_host] = pre + incl;
+    const uint64_t n = n_dev ? *n_dev / div : n_host;
+    if (tid == SCAN_SEGS - 1 && n <= cap)
+        out[n] = pre + incl;
 }
 
 __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *__restrict__ in, uint64_t n_host,
                                                          const uint64_t *__restrict__ n_dev, uint64_t div,
-                                                         const uint64_t *__restrict__ partial, uint64_t *__restrict__ out)
+                                                         const uint64_t *__restrict__ partial, uint64_t *__restrict__ out,
+                                                         uint64_t cap)
 {
     const uint64_t n = n_dev ? *n_dev / div : n_host;
     uint64_t lo, hi;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *__rest
         uint64_t pre = carry;
         for (int w = 0; w < (tid >> 6); ++w)
             pre += wsum[w];
-        if (i < hi)
+        if (i < hi && i <= cap)
             out[i] = pre + incl - v;
         __syncthreads();
         if (tid == 1023)
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(THREADS) void records_kernel(const uint8_t *__restr
                                                          const uint64_t *__restrict__ line_end,
                                                          const uint64_t *__restrict__ nlines_dev,
                                                          uint32_t *__restrict__ seq_len, uint64_t *__restrict__ seq_start,
-                                                         uint64_t *__restrict__ rec_start,
+                                                         uint64_t *__restrict__ rec_start, uint64_t max_records,
                                                          unsigned long long *__restrict__ res)
 {
     const uint64_t nrec = *nlines_dev / 4; // complete 4-line records
@@ -287,7 +290,7 @@ __global__ __launch_bounds__(THREADS) void records_kernel(const uint8_t *__restr
         code = 1;
     seq_len[r] = (uint32_t)(e1 - e0 - 1);
     seq_start[r] = e0 + 1;
-    if (rec_start)
+    if (rec_start && r < max_records)
         rec_start[r] = l0;
     if (code) // the first bad record wins; (record << 8 | code) orders by record
         atomicMin(&res[R_FIRSTBAD], (unsigned long long)((r << 8) | code));
@@ -558,17 +561,17 @@ using namespace polyhip;
 // exclusive scan of `in` (n = n_host, or *n_dev / div) into out[0..n]; `upper` bounds n on the host: long
 // inputs go through SCAN_SEGS workgroups (its partial sums live in a stream-ordered scratch allocation)
 static int scan_u32(const uint32_t *in, uint64_t n_host, const uint64_t *n_dev, uint64_t div, uint64_t upper,
-                    uint64_t *out, hipStream_t st)
+                    uint64_t *out, hipStream_t st, uint64_t cap = ~0ull)
 {
     if (upper <= 262144) {
-        hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, n_host, n_dev, div, out);
+        hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, n_host, n_dev, div, out, cap);
         return POLYHIP_OK;
     }
     uint64_t *partial = nullptr;
     PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), fq::SCAN_SEGS * sizeof(uint64_t), st));
     hipLaunchKernelGGL(fq::scan_sums_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial);
-    hipLaunchKernelGGL(fq::scan_offsets_kernel, dim3(1), dim3(fq::SCAN_SEGS), 0, st, partial, n_host, n_dev, div, out);
-    hipLaunchKernelGGL(fq::scan_apply_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial, out);
+    hipLaunchKernelGGL(fq::scan_offsets_kernel, dim3(1), dim3(fq::SCAN_SEGS), 0, st, partial, n_host, n_dev, div, out, cap);
+    hipLaunchKernelGGL(fq::scan_apply_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial, out, cap);
     PH_HIP(hipFreeAsync(partial, st));
     return POLYHIP_OK;
 }
@@ -603,12 +606,13 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
                        blockoff, line_end);
     // The line count exists only on the device (blockoff[nblocks]); the record kernels are launched for
-    // the most records the file could hold ("@\nA\n+\nI\n" = 8 bytes each) and read the real count there.
+    // the most records the file could hold and read the real count there.  The shortest record is 7 bytes: the
+    // reference reads the third line without looking at it (fastq.go:182), so "@\nA\n\nI\n" parses.
     const uint64_t *nlines_dev = blockoff + L.nblocks;
-    const uint64_t most = nbytes / 8 + 1;
+    const uint64_t most = nbytes / 7 + 1;
     hipLaunchKernelGGL(fq::records_kernel, dim3((unsigned)((most + fq::THREADS - 1) / fq::THREADS)), dim3(fq::THREADS), 0, st,
-                       d_file, line_end, nlines_dev, seq_len, seq_start, d_rec_start, res);
-    if (int rc = scan_u32(seq_len, 0, nlines_dev, 4, nbytes / 8 + 1, d_offsets, st))
+                       d_file, line_end, nlines_dev, seq_len, seq_start, d_rec_start, max_records, res);
+    if (int rc = scan_u32(seq_len, 0, nlines_dev, 4, most, d_offsets, st, max_records))
         return rc;
     hipLaunchKernelGGL(fq::finish_kernel, dim3(1), dim3(1), 0, st, d_file, nbytes, line_end, nlines_dev, d_offsets,
                        max_records, res);
@@ -623,12 +627,13 @@ int polyhip_fastq_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs, uint
                        uint64_t max_records, uint64_t *result)
 {
     PH_REQUIRE(result && offsets && (file || nbytes == 0) && (seqs || nbytes == 0), "polyhip_fastq_pack: null pointer");
-    const uint64_t most = nbytes / 8 + 1;
+    const uint64_t most = nbytes / 7 + 1;
     DevBuf dfile, dseqs, doffs, drec, dres, dwork;
     PH_HIP(dfile.alloc(nbytes));
     PH_HIP(dseqs.alloc(nbytes));
-    PH_HIP(doffs.alloc((most + 1) * 8));
-    PH_HIP(drec.alloc(most * 8));
+    const uint64_t held = std::min(most, max_records); // the caller's offsets / rec_start hold this many records
+    PH_HIP(doffs.alloc((held + 1) * 8));
+    PH_HIP(drec.alloc((held + 1) * 8));
     PH_HIP(dres.alloc(4 * 8));
     const size_t wb = polyhip_fastq_workspace_bytes(nbytes);
     PH_HIP(dwork.alloc(wb));

@@ -31,7 +31,7 @@ def pack(data, max_records: int | None = None):
     Like ParseN, the records before the first bad one are returned together with the error."""
     buf = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
     nbytes = len(buf)
-    most = nbytes // 8 + 1
+    most = nbytes // 7 + 1  # shortest record: "@\nA\n\nI\n" (the third line is never looked at, fastq.go:182)
     cap = most if max_records is None else min(most, max_records)
     seqs = np.zeros(max(nbytes, 1), dtype=np.uint8)
     offsets = np.zeros(most + 2, dtype=np.uint64)
@@ -60,7 +60,7 @@ def workspace_bytes(nbytes: int) -> int:
 def pack_dev(file_t, seqs_t, offsets_t, rec_start_t, result_t, work_t, max_records: int | None = None, stream=None):
     """Device-resident feeder on torch CUDA tensors; result_t int64[4] = (n, code, line, sequence bytes)."""
     nbytes = file_t.numel()
-    cap = nbytes // 8 + 1 if max_records is None else max_records
+    cap = nbytes // 7 + 1 if max_records is None else max_records
     _lib.check(_lib.lib().polyhip_fastq_pack_dev(
         file_t.data_ptr(), nbytes, seqs_t.data_ptr(), offsets_t.data_ptr(),
         rec_start_t.data_ptr() if rec_start_t is not None else None, cap, result_t.data_ptr(), work_t.data_ptr(),

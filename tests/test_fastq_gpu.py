@@ -70,6 +70,43 @@ def test_synthetic_and_malformed():
     _check(b"@a k=v  \nAC\n+\nII\n")                   # empty field after a double space
 
 
+def test_shortest_records():
+    """the reference never looks at the third line (fastq.go:182 discards it), so a record can be 7 bytes:
+    more records than nbytes / 8, single- and multi-workgroup scan sizes"""
+    from poly_amd import fastq
+    rec = b"@\nA\n\nI\n"
+    for count in (1, 3, 5000, 300_000):
+        data = rec * count
+        seqs, offs, starts, err = fastq.pack(data)
+        assert err is None and len(offs) == count + 1 and bytes(seqs) == b"A" * count
+        assert (starts == np.arange(count, dtype=np.uint64) * 7).all()
+    _check(rec * 40 + b"@r\nAC\n+\nII\n" + rec * 3)
+    _check(rec * 9 + b"@\n\n\nI\n")
+
+
+def test_max_records_bounds_every_write():
+    """caller buffers sized for max_records + 1 entries: nothing is written past them (sentinels survive), code 7"""
+    import torch
+    from poly_amd import fastq
+    rng = np.random.default_rng(10)
+    data = b"".join(_record(rng, i, 50) for i in range(2000))
+    dev = torch.device("cuda:0")
+    img = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev)
+    cap = 100
+    seqs = torch.empty(img.numel(), dtype=torch.uint8, device=dev)
+    offs = torch.full((cap + 1 + 64,), -7, dtype=torch.int64, device=dev)
+    rec = torch.full((cap + 1 + 64,), -7, dtype=torch.int64, device=dev)
+    res = torch.zeros(4, dtype=torch.int64, device=dev)
+    work = torch.empty(fastq.workspace_bytes(img.numel()), dtype=torch.uint8, device=dev)
+    fastq.pack_dev(img, seqs, offs, rec, res, work, max_records=cap)
+    n, code, _, total = (int(x) for x in res.cpu())
+    assert (n, code, total) == (cap, 7, 50 * cap)
+    assert (offs[cap + 1:] == -7).all() and (rec[cap:] == -7).all()
+    assert offs[:cap + 1].tolist() == [50 * i for i in range(cap + 1)]
+    seqs_h, offs_h, _, err = fastq.pack(data, max_records=cap)
+    assert len(offs_h) == cap + 1 and "more records" in str(err)
+
+
 def test_packed_batch_feeds_the_sketch_kernel():
     """file image -> device packer -> K1, no host parse: equals sketching the oracle's records"""
     import torch
@@ -80,7 +117,7 @@ def test_packed_batch_feeds_the_sketch_kernel():
     img = torch.from_numpy(np.frombuffer(data, np.uint8).copy()).to(dev)
     nb = img.numel()
     seqs = torch.empty(nb, dtype=torch.uint8, device=dev)
-    offs = torch.zeros(nb // 8 + 2, dtype=torch.int64, device=dev)
+    offs = torch.zeros(nb // 7 + 2, dtype=torch.int64, device=dev)
     res = torch.zeros(4, dtype=torch.int64, device=dev)
     work = torch.empty(fastq.workspace_bytes(nb), dtype=torch.uint8, device=dev)
     fastq.pack_dev(img, seqs, offs, None, res, work)
