@@ -271,6 +271,65 @@ func SeqhashBatch(seqs []byte, offs []uint64, seqType int, circular, doubleStran
 	return res, codes[:n], err
 }
 
+// ---- read feeders: a FASTQ / FASTA file image -> the packed batch the kernels take (io/fastq, io/fasta) ----
+
+// Packed is a batch in the library's layout: sequence i = Seqs[Offsets[i]:Offsets[i+1]]; RecStart[i] is the byte
+// offset of record i's identifier / header line in the file image (identifiers are sliced lazily from there).
+type Packed struct {
+	Seqs     []byte
+	Offsets  []uint64
+	RecStart []uint64
+	Code     int    // 0, or the parse error's code (see polyhip_fastq_pack / polyhip_fasta_pack)
+	Line     uint64 // FASTQ: the line the reference's message names
+}
+
+// FastqPack parses a whole FASTQ image on the device (io/fastq (*Parser).ParseAll semantics: the records
+// before the first bad one are returned together with the error code).
+func FastqPack(file []byte) (Packed, error) {
+	most := len(file)/7 + 1 // shortest record: "@\nA\n\nI\n"
+	p := Packed{Seqs: make([]byte, len(file)+1), Offsets: make([]uint64, most+2), RecStart: make([]uint64, most+1)}
+	var result [4]uint64
+	var pf *C.uint8_t
+	if len(file) > 0 {
+		pf = (*C.uint8_t)(unsafe.Pointer(&file[0]))
+	}
+	err := call(func() C.int {
+		return C.polyhip_fastq_pack(pf, C.uint64_t(len(file)), (*C.uint8_t)(unsafe.Pointer(&p.Seqs[0])),
+			(*C.uint64_t)(unsafe.Pointer(&p.Offsets[0])), (*C.uint64_t)(unsafe.Pointer(&p.RecStart[0])), C.uint64_t(most),
+			(*C.uint64_t)(unsafe.Pointer(&result[0])))
+	})
+	if err != nil {
+		return Packed{}, err
+	}
+	n := int(result[0])
+	p.Code, p.Line = int(result[1]), result[2]
+	p.Seqs, p.Offsets, p.RecStart = p.Seqs[:result[3]], p.Offsets[:n+1], p.RecStart[:n]
+	return p, nil
+}
+
+// FastaPack parses a whole FASTA image on the device (io/fasta (*Parser).ParseAll semantics).
+func FastaPack(file []byte) (Packed, error) {
+	most := len(file)/2 + 2 // ">\n" is the shortest header line
+	p := Packed{Seqs: make([]byte, len(file)+1), Offsets: make([]uint64, most+2), RecStart: make([]uint64, most+2)}
+	var result [4]uint64
+	var pf *C.uint8_t
+	if len(file) > 0 {
+		pf = (*C.uint8_t)(unsafe.Pointer(&file[0]))
+	}
+	err := call(func() C.int {
+		return C.polyhip_fasta_pack(pf, C.uint64_t(len(file)), (*C.uint8_t)(unsafe.Pointer(&p.Seqs[0])),
+			(*C.uint64_t)(unsafe.Pointer(&p.Offsets[0])), (*C.uint64_t)(unsafe.Pointer(&p.RecStart[0])), C.uint64_t(most),
+			(*C.uint64_t)(unsafe.Pointer(&result[0])))
+	})
+	if err != nil {
+		return Packed{}, err
+	}
+	n := int(result[0])
+	p.Code = int(result[1])
+	p.Seqs, p.Offsets, p.RecStart = p.Seqs[:result[2]], p.Offsets[:n+1], p.RecStart[:n]
+	return p, nil
+}
+
 // ---- R1: all-gather of per-rank sketches (RCCL over xGMI; one process per GPU) ----
 
 // Comm wraps polyhip_comm.  Rank 0 calls CommUniqueID and ships the 128 bytes to the other ranks.

@@ -1,19 +1,48 @@
-// Package align: drop-in for github.com/bebop/poly/search/align (align.go:73-95,171-232) over libpolyhip.
-// NeedlemanWunsch (align.go:100-166) is not on the north-star path and keeps the reference's Go code.
-// UNCOMPILED here.
+// Package align: drop-in for github.com/bebop/poly/search/align over libpolyhip: Scoring / NewScoring / Score
+// (align.go:73-95), SmithWaterman (:171-232) and NeedlemanWunsch (:100-166) all run on the device.
+// UNCOMPILED here (no Go toolchain in the authoring image).
 package align
 
 import (
+	"sync"
+
 	"github.com/bebop/poly/alphabet"
 	"github.com/bebop/poly/internal/polyhip"
 	"github.com/bebop/poly/search/align/matrix"
 )
 
-// Scoring is align.go:73-76.
+// Scoring is align.go:73-76: exactly the reference's two exported fields, so that struct literals and
+// by-value copies (SmithWaterman takes a Scoring, not a *Scoring) keep working.
 type Scoring struct {
 	SubstitutionMatrix *matrix.SubstitutionMatrix
 	GapPenalty         int
-	dev                *polyhip.Scoring // flattened tables on the device, built on first use
+}
+
+// Device-side scoring tables are cached per (matrix pointer, gap penalty) at package level: a Scoring is
+// passed by value, so a handle stored inside it would land on a copy and every call would flatten the
+// matrix again (16k Score() lookups + 7 device allocations).  The reference's canned matrices are
+// package-level values that never change; a caller that mutates a matrix in place must call ForgetScoring.
+type scoringKey struct {
+	m   *matrix.SubstitutionMatrix
+	gap int
+}
+
+var (
+	scoringMu    sync.Mutex
+	scoringCache = map[scoringKey]*polyhip.Scoring{}
+)
+
+const scoringCacheLimit = 64 // handles are tiny (a few KB of HBM each); bound the map anyway
+
+// ForgetScoring drops the cached device tables of a matrix (all gap penalties).
+func ForgetScoring(m *matrix.SubstitutionMatrix) {
+	scoringMu.Lock()
+	defer scoringMu.Unlock()
+	for k := range scoringCache {
+		if k.m == m {
+			delete(scoringCache, k) // released by polyhip.Scoring's finalizer once no call uses it
+		}
+	}
 }
 
 // NewScoring is align.go:79-87 (nil matrix -> matrix.Default; never errors).
@@ -29,10 +58,13 @@ func (s Scoring) Score(a, b byte) (int, error) {
 	return s.SubstitutionMatrix.Score(string(a), string(b))
 }
 
-// flatten goes through the matrix's PUBLIC Score(): its score table is unexported (matrix.go:13-17).
-func (s *Scoring) handle() *polyhip.Scoring {
-	if s.dev != nil {
-		return s.dev
+// handle flattens through the matrix's PUBLIC Score(): its score table is unexported (matrix.go:13-17).
+func (s Scoring) handle() *polyhip.Scoring {
+	key := scoringKey{s.SubstitutionMatrix, s.GapPenalty}
+	scoringMu.Lock()
+	defer scoringMu.Unlock()
+	if h, ok := scoringCache[key]; ok {
+		return h
 	}
 	var lut [65536]int32
 	var va, vb [256]uint8
@@ -56,7 +88,13 @@ func (s *Scoring) handle() *polyhip.Scoring {
 	if err != nil {
 		panic(err)
 	}
-	s.dev = h
+	if len(scoringCache) >= scoringCacheLimit {
+		for k := range scoringCache { // drop an arbitrary entry; a call still using it keeps it alive, then
+			delete(scoringCache, k) // polyhip.Scoring's finalizer releases the device tables
+			break
+		}
+	}
+	scoringCache[key] = h
 	return h
 }
 
@@ -66,7 +104,7 @@ func symbolError(code uint32) error {
 
 // SmithWaterman is align.go:171-232.
 func SmithWaterman(stringA string, stringB string, scoring Scoring) (int, string, string, error) {
-	res := SmithWatermanBatch([]string{stringA}, stringB, &scoring)
+	res := SmithWatermanBatch([]string{stringA}, stringB, scoring)
 	if res[0].Err != nil {
 		return 0, "", "", res[0].Err
 	}
@@ -96,7 +134,7 @@ type Alignment struct {
 }
 
 // SmithWatermanBatch aligns every read against one shared reference in one device call.
-func SmithWatermanBatch(reads []string, reference string, scoring *Scoring) []Alignment {
+func SmithWatermanBatch(reads []string, reference string, scoring Scoring) []Alignment {
 	A, offA := polyhip.Pack(reads)
 	B, _ := polyhip.Pack([]string{reference})
 	B = B[:len(reference):len(reference)+1]

@@ -82,8 +82,11 @@ int polyhip_synth_dna_dev(uint64_t seed, uint64_t first, uint8_t *d_out,
  *                       survives, as in the reference);
  *   len_i - k <= 0 : nothing written.
  * So `out` is in/out: pass the current Sketches (zeros after mash.New).
- * Range: 0 <= k <= 4096; 2 <= s <= 8192.  s < 2 -> POLYHIP_ERR_PANIC
- * (mash.go:96,98 index Sketches[-1]).
+ * Range: 0 <= k <= 4096; 2 <= s <= 8192.  s < 2 -> POLYHIP_ERR_PANIC for the whole
+ * batch: a deliberate over-approximation of the reference, which indexes Sketches[-1]
+ * (mash.go:96,98) for s == 0 as soon as a sequence has one window and for s == 1 as
+ * soon as a later window hashes below the first one -- i.e. on practically any input,
+ * but not on sequences of at most k (s == 0) or k + 1 (s == 1) bytes.
  */
 int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets,
                               uint64_t n, uint32_t k, uint32_t s,
@@ -424,8 +427,11 @@ int polyhip_fasta_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs,
  * resolved at run time (dlopen librccl.so.1), so libpolyhip has no link-time dependency on it.
  * Rank 0 obtains the 128-byte id and passes it to the other ranks by its own channel; every
  * rank then creates its communicator on its current HIP device.  d_all receives
- * nranks * n_local sketches in rank order (every rank contributes the same n_local); the call
- * enqueues one ncclAllGather on `stream`.  Then each rank runs
+ * nranks * n_local sketches in rank order; the call enqueues one ncclAllGather on `stream`.
+ * EVERY rank must pass the SAME n_local (ncclAllGather's contract; the library cannot check it
+ * across processes): with ragged shards, pad each rank's block to the largest shard and trim
+ * after the gather, as poly_amd/sharding.py::gather_sketches does.  n_local == 0 still enters
+ * the collective (all ranks then contribute nothing).  Then each rank runs
  * polyhip_mash_shared_counts_dev(X = its block of d_all, Y = d_all).
  */
 typedef struct polyhip_comm polyhip_comm;

@@ -131,8 +131,8 @@ int polyhip_allgather_sketches_dev(polyhip_comm *c, const uint32_t *d_local, uin
 {
     PH_REQUIRE(c && c->comm, "polyhip_allgather_sketches: null communicator");
     PH_REQUIRE((d_local && d_all) || n_local == 0, "polyhip_allgather_sketches: null pointer");
-    if (n_local == 0)
-        return POLYHIP_OK;
+    // Always enter the collective, also with an empty contribution: a rank that returned early would leave the
+    // others waiting.  ncclAllGather needs the SAME count on every rank (see the header: pad ragged shards).
     r1::Api &a = r1::api();
     const int rc = a.AllGather(d_local, d_all, (size_t)n_local * s, r1::NCCL_UINT32, c->comm, as_stream(stream));
     if (rc != 0)

@@ -1,7 +1,8 @@
 """search/align/matrix of bebop/poly (host-side mirror of matrix.go; the canned
-tables of matrices.go are data and are supplied by the caller -- NUC_4 and
-NUC_4_4 are included because BASELINE config 4 and the reference's examples
-use them)."""
+tables of matrices.go are data and are supplied by the caller -- only NUC_4
+is included, because BASELINE config 4 and the reference's examples use it;
+any other table, NUC_4_4 or the protein matrices, goes through
+NewSubstitutionMatrix like a user's own)."""
 from __future__ import annotations
 
 from . import alphabet as _alphabet

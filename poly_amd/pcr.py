@@ -75,26 +75,37 @@ def DesignPrimers(sequence, targetTm: float):
 def _minimal_lengths(primer_list, targetTm: float):
     """pcr.go:95-101 for every primer: the LAST suffix length (from 7 up) whose MeltingTemp is still below
     the target, 0 if already the 7-mer reaches it, len(primer) if the whole primer stays below (the
-    primer is then rejected, :104).  One polyhip_santalucia_batch call over all suffixes."""
-    cands, first = [], []
+    primer is then rejected, :104).  Suffixes are scored in growing windows (7..70, then x4 while some primer
+    has not reached the target): one polyhip_santalucia_batch call per window, and a 100 kb amplicon used as a
+    primer in Simulate's second round (:181) costs the few dozen suffixes the reference would have scored."""
     for primer in primer_list:
         if len(primer) < minimalPrimerLength:
             raise _lib.GoPanic(_lib.ERR_PANIC, "slice bounds out of range (primer shorter than 7 nt, pcr.go:96)")
-        first.append(len(cands))
-        for index in range(minimalPrimerLength, len(primer) + 1):
-            cands.append(primer[len(primer) - index:])
-    if not cands:
-        return []
-    tm, _, _ = primers.santalucia_batch_packed(*_pack(cands), 500e-9, 50e-3, 0.0)
-    out = []
-    for primer, at in zip(primer_list, first):
-        minimal = 0
-        for index in range(minimalPrimerLength, len(primer) + 1):
-            if not (tm[at + index - minimalPrimerLength] < targetTm):
-                break
-            minimal = index
-        out.append(minimal)
-    return out
+    minimal = [0] * len(primer_list)
+    open_ = list(range(len(primer_list)))
+    lo, span = minimalPrimerLength, 64
+    while open_:
+        cands, owner = [], []
+        for i in open_:
+            primer = primer_list[i]
+            for index in range(lo, min(lo + span, len(primer) + 1)):
+                cands.append(primer[len(primer) - index:])
+                owner.append((i, index))
+        if not cands:
+            break
+        tm, _, _ = primers.santalucia_batch_packed(*_pack(cands), 500e-9, 50e-3, 0.0)
+        reached = set()
+        for (i, index), t in zip(owner, tm):
+            if i in reached:
+                continue
+            if not (t < targetTm):
+                reached.add(i)
+                continue
+            minimal[i] = index
+        open_ = [i for i in open_ if i not in reached and lo + span <= len(primer_list[i])]
+        lo += span
+        span *= 4
+    return minimal
 
 
 def _lookup(sequence: bytes, pattern: bytes):

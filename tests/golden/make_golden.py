@@ -12,6 +12,8 @@ committed so that nothing at test/bench time reads /root/reference.
   clone_goldengate_rotated.seq <- the `// Output:` line of clone/example_test.go:11-31 (ExampleGoldenGate prints
                    seqhash.RotateSequence(Clones[0])): a 4.4 kb circular construct already at its least rotation
 
+  clone_parts.json <- the clone.Part literals of clone/clone_test.go and clone/example_test.go
+
 Extraction follows io/genbank/genbank.go:125,627-633: every line between
 ORIGIN and // with all non-letters removed, case preserved.
 """
@@ -68,7 +70,32 @@ def clone_example_output():
     print("clone_goldengate_rotated.seq", len(out))
 
 
+def clone_parts():
+    """the clone.Part literals of the reference's own clone tests (clone/clone_test.go, clone/example_test.go):
+    the inputs of TestSignalKilledGoldenGate (:167-194: 1 clone + 4 looping constructs), TestPanicGoldenGate
+    (:196-214), TestCircularCutRegression (:216-228) and ExampleGoldenGate (example_test.go:11-31)"""
+    import json
+
+    def parts_of(path, start, end):
+        with open(os.path.join(REF, "clone", path)) as f:
+            lines = f.read().split("\n")[start - 1:end]
+        return [[m.group(1), m.group(2) == "true"] for ln in lines for m in re.finditer(r'Part\{"([A-Za-z]+)", (true|false)\}', ln)]
+
+    out = {
+        "popen": parts_of("clone_test.go", 8, 8)[0],
+        "signal_killed": parts_of("clone_test.go", 167, 179),
+        "panic": parts_of("clone_test.go", 196, 206),
+        "circular_cut_regression": parts_of("clone_test.go", 216, 222),
+        "example_golden_gate": parts_of("example_test.go", 11, 24),
+    }
+    assert len(out["signal_killed"]) == 9 and len(out["panic"]) == 5 and len(out["example_golden_gate"]) == 3
+    with open(os.path.join(HERE, "clone_parts.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("clone_parts.json", {k: len(v) for k, v in out.items()})
+
+
 if __name__ == "__main__":
     copy_fastq()
     clone_example_output()
+    clone_parts()
     sys.exit(main())

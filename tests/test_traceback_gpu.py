@@ -347,3 +347,84 @@ def test_long_reads_chunked_workspace(al):
         sa = sa if isinstance(sa, bytes) else sa.encode()
         sb = sb if isinstance(sb, bytes) else sb.encode()
         assert int(score[p]) == s and a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, p
+
+
+def test_config4_full_size_mutated_batch(al, monkeypatch):
+    """BASELINE configs[3] on the contract's input: all 1,000,000 reads of poly_amd.workloads.config4_reads (windows
+    of the 5 kb reference with 5 % substitutions AND 1 % indels, SURVEY 8d C4 -- the input bench.py times), device
+    resident.  (a) the generator is the same function on the GPU as on the CPU; (b) 2,500 sampled pairs equal the
+    oracle in score, endA, endB and both aligned strings; (c) the packed two-pairs-per-lane pass equals the exact
+    32-bit kernel (POLYHIP_SW_PACKED=0) on every pair; (d) size-independent properties on all pairs: an aligned
+    pair of strings has equal length, re-scores to the reported score, and stripping the gaps gives substrings of
+    the read and of the reference that end at (endA, endB)."""
+    import torch
+    from poly_amd import workloads
+    align = al[0]
+    dev = torch.device("cuda:0")
+    n, LA, LB = 1_000_000, 150, 5000
+    B, A2 = workloads.config4_reads(n, LA, LB, device=dev)
+    ref_h, reads_h = workloads.config4_reads(3000)
+    assert (A2[:3000].cpu().numpy() == reads_h).all() and (B.cpu().numpy() == ref_h).all()
+    assert (workloads.config4_reads(64, first=777_000)[1] == A2[777_000:777_064].cpu().numpy()).all()
+    A = A2.reshape(-1).contiguous()
+    offA = torch.arange(0, (n + 1) * LA, LA, dtype=torch.int64, device=dev)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    outs = {}
+    for packed in (True, False):
+        if packed:
+            monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        score = torch.zeros(n, dtype=torch.int64, device=dev)
+        ea, eb, er = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+        work = torch.empty(align.sw_workspace_bytes(sc, n, LA, LB, True), dtype=torch.uint8, device=dev)
+        align.sw_batch_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, work)
+        torch.cuda.synchronize()
+        assert align.last_path() == (3 if packed else 1)
+        outs[packed] = (score, ea, eb, er)
+    monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+    for x, y in zip(outs[True], outs[False]):
+        assert torch.equal(x, y)
+    score, ea, eb, er = outs[True]
+    assert int(er.abs().sum()) == 0
+    stride = align.sw_traceback_stride(sc, LA, LB)
+    tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, LA, LB), dtype=torch.uint8, device=dev)
+    alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+    ln = torch.zeros(n, dtype=torch.int32, device=dev)
+    align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score)
+    torch.cuda.synchronize()
+    # (b) the oracle on a sample spread over the whole batch
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(n, 2500, replace=False))
+    idx = torch.from_numpy(sample).to(dev)
+    h = {k: v[idx].cpu().numpy() for k, v in dict(score=score, ea=ea, eb=eb, ln=ln, A=A2, alnA=alnA, alnB=alnB).items()}
+    refb = ref_h.tobytes()
+    for j, p in enumerate(sample):
+        ws, wa, wb, wea, web = orc.smith_waterman(h["A"][j].tobytes(), refb, om, -2)
+        wa = wa if isinstance(wa, bytes) else wa.encode("latin-1")
+        wb = wb if isinstance(wb, bytes) else wb.encode("latin-1")
+        L = int(h["ln"][j])
+        got = (int(h["score"][j]), int(h["ea"][j]), int(h["eb"][j]), h["alnA"][j, stride - L:].tobytes(), h["alnB"][j, stride - L:].tobytes())
+        assert got == (ws, wea, web, wa, wb), f"pair {p}: got {got} want {(ws, wea, web, wa, wb)}"
+    # (d) on every pair, on the device: re-score the aligned strings
+    cols = torch.arange(stride, device=dev)[None, :]
+    live = cols >= (stride - ln.long())[:, None]
+    gapA, gapB = (alnA == ord("-")) & live, (alnB == ord("-")) & live
+    assert not bool((gapA & gapB).any())
+    match = (alnA == alnB) & live & ~gapA
+    mism = live & ~gapA & ~gapB & (alnA != alnB)
+    rescored = 5 * match.sum(1) - 4 * mism.sum(1) - 2 * (gapA.sum(1) + gapB.sum(1))
+    assert torch.equal(rescored, score)
+    # the ungapped strings are the read's and the reference's bytes ending at (endA, endB)
+    nA, nB = (live & ~gapA).sum(1), (live & ~gapB).sum(1)
+    assert bool((nA <= ea).all()) and bool((nB <= eb).all())
+    chk = idx  # byte-exact on the sample (a full gather of ragged substrings is not worth a kernel here)
+    for j, p in enumerate(sample[:200]):
+        L = int(h["ln"][j])
+        sa = h["alnA"][j, stride - L:].tobytes().replace(b"-", b"")
+        sb = h["alnB"][j, stride - L:].tobytes().replace(b"-", b"")
+        e_a, e_b = int(h["ea"][j]), int(h["eb"][j])
+        assert h["A"][j].tobytes()[e_a - len(sa):e_a] == sa and refb[e_b - len(sb):e_b] == sb
+    del chk
