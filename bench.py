@@ -79,10 +79,18 @@ def self_launch(args) -> int:
 
 
 def host_cores() -> int:
+    """cores this process may use: the affinity mask, cut down by a cgroup CPU quota if there is one"""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except AttributeError:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(reads_per_core: int):
@@ -121,10 +129,11 @@ def cpu_baseline(reads_per_core: int):
     out["tight_variant"] = {"value": vt, "unit": "k-mers/s", "cores": 1,
                             "sample": f"{nt} reads, insertion instead of sort.Slice ({dtt:.1f} s)"}
     if cores > 1:
-        va, dta, na = run(reads_per_core // 2 * cores, True, cores)
+        # bounded whatever the core count: 8 / 64 single-core samples' worth of reads, at least one read per thread
+        va, dta, na = run(max(cores, reads_per_core * 8 // cores * cores), True, cores)
         out["all_cores"] = {"value": va, "unit": "k-mers/s", "cores": cores,
                             "sample": f"{na} reads, one thread per contiguous shard of reads, faithful ({dta:.1f} s)"}
-        vb, dtb, nb = run(reads_per_core * 2 * cores, False, cores)
+        vb, dtb, nb = run(max(cores, reads_per_core * 64 // cores * cores), False, cores)
         out["all_cores_tight_variant"] = {"value": vb, "unit": "k-mers/s", "cores": cores,
                                           "sample": f"{nb} reads, insertion variant ({dtb:.1f} s)"}
     # configs[0]: mash.Sketch on phiX174, k=21 s=1000, CPU only (plumbing)

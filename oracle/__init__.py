@@ -48,6 +48,8 @@ def lib() -> C.CDLL:
         L.orc_murmur3_32.restype = C.c_uint32
         L.orc_mash_sketch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_mash_sketch.restype = C.c_int
+        L.orc_mash_sketch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_mash_sketch_batch.restype = C.c_int
         for f in (L.orc_mash_similarity, L.orc_mash_distance):
             f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
             f.restype = C.c_double
@@ -158,13 +160,12 @@ def mash_sketch_batch(seqs: np.ndarray, offsets: np.ndarray, k: int, s: int,
     n = len(offsets) - 1
     if out is None:
         out = np.zeros((n, s), dtype=np.uint32)
-    base = seqs.ctypes.data
-    L = lib()
-    for i in range(n):
-        o0, o1 = int(offsets[i]), int(offsets[i + 1])
-        rc = L.orc_mash_sketch(base + o0, o1 - o0, k, s, out[i].ctypes.data, int(faithful))
-        if rc != 0:
-            raise GoPanic("index out of range [-1]")
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    assert out.dtype == np.uint32 and out.flags.c_contiguous
+    # one C call for the whole batch (ctypes releases the GIL: threads over shards run in parallel)
+    if lib().orc_mash_sketch_batch(seqs.ctypes.data, offsets.ctypes.data, n, k, s, out.ctypes.data, int(faithful)) != 0:
+        raise GoPanic("index out of range [-1]")
     return out
 
 

@@ -146,6 +146,18 @@ int orc_mash_sketch(const uint8_t *seq, size_t n, int k, int s,
     return 0;
 }
 
+/* a loop of orc_mash_sketch over a packed batch: one C call per shard of reads, so that bench.py's
+ * all-cores CPU baseline runs one thread per shard without the interpreter between reads */
+int orc_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, size_t n, int k, int s,
+                          uint32_t *out, int faithful)
+{
+    for (size_t i = 0; i < n; i++)
+        if (orc_mash_sketch(seqs + offsets[i], (size_t)(offsets[i + 1] - offsets[i]), k, s, out + i * (size_t)s,
+                            faithful) != 0)
+            return -1;
+    return 0;
+}
+
 /* mash.go:107-135.  Receiver a is "larger" unless a.SketchSize <
  * b.SketchSize (mash.go:109-115). */
 static int mash_shared_core(const uint32_t *a, int sa, const uint32_t *b,

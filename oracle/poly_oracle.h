@@ -43,6 +43,9 @@ uint32_t orc_murmur3_32(const uint8_t *data, size_t len, uint32_t seed);
  * Returns 0, or -1 where the Go code would panic (index out of range). */
 int orc_mash_sketch(const uint8_t *seq, size_t n, int k, int s,
                     uint32_t *sketches, int faithful);
+/* the same for every sequence of a packed batch (out: n x s, in/out like Sketches) */
+int orc_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, size_t n, int k, int s,
+                          uint32_t *out, int faithful);
 
 /* (*Mash).Similarity / Distance, mash.go:107-140 (receiver = a). */
 double orc_mash_similarity(const uint32_t *a, int sa, const uint32_t *b, int sb);
