@@ -60,6 +60,7 @@ constexpr int WTW = PH_WTW;        // windows per WAVE tile (4 * GROUPS per lane
 constexpr int TW = WTW * WAVES;    // windows the workgroup covers per round
 constexpr int GROUPS = WTW / (4 * 64);
 constexpr int NB = 2048;  // counting-sort bins
+constexpr uint32_t REDO_POSITIONAL = 0x80000000u; // redo-list flag: a read with fewer windows than SketchSize
 constexpr uint32_t C1 = 0xcc9e2d51u, C2 = 0x1b873593u;
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -503,10 +504,16 @@ __device__ __forceinline__ void append4(uint32_t *__restrict__ counter, uint32_t
 
 // ---- fast pass's bottom-s: cand[0..C) all <= tau0, s <= C <= capf.  Counting sort on the top
 // bits + in-bin ranking, written straight to the output row.  All threads call it.
+// `src` / `first` / `step` / `cnt`: where this thread's candidates are -- the shared buffer (sm.cand, tid, THREADS, C)
+// or, for the slab pass, the thread's own wave's segment (segment, lane, 64, that wave's count).  FIN: the
+// candidates still lack fmix32's last `h ^= h >> 16` (the slab pass thresholds on the bits that step leaves alone).
+template <bool FIN>
 __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t C, uint32_t nbf_log2,
-                              uint32_t *__restrict__ outp)
+                              uint32_t *__restrict__ outp, const uint32_t *__restrict__ src, uint32_t first,
+                              uint32_t step, uint32_t cnt)
 {
     const int tid = threadIdx.x;
+    auto fin = [](uint32_t h) { return FIN ? h ^ (h >> 16) : h; };
     uint32_t *bins = sm.P;
     const uint32_t nbf = 1u << nbf_log2; // 1024 or 2048 bins, whatever fits in the P region
     const int sig = 32 - __builtin_clz(tau | 1u);
@@ -521,14 +528,14 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
     __syncthreads();
     // the loops over candidates are unrolled by four so that the LDS round trips of a thread's
     // elements overlap instead of queueing behind each other
-    for (uint32_t i0 = tid; i0 < C; i0 += 4 * THREADS) {
+    for (uint32_t i0 = first; i0 < cnt; i0 += 4 * step) {
         uint32_t h[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            h[u] = i0 + u * THREADS < C ? sm.cand[i0 + u * THREADS] : 0u;
+            h[u] = i0 + u * step < cnt ? fin(src[i0 + u * step]) : 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * THREADS < C)
+            if (i0 + u * step < cnt)
                 atomicAdd(&bins[h[u] >> shift], 1u);
     }
     __syncthreads();
@@ -569,18 +576,18 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
         }
     }
     __syncthreads();
-    for (uint32_t i0 = tid; i0 < C; i0 += 4 * THREADS) { // afterwards bins[b] = end of bin b
+    for (uint32_t i0 = first; i0 < cnt; i0 += 4 * step) { // afterwards bins[b] = end of bin b
         uint32_t h[4], at[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            h[u] = i0 + u * THREADS < C ? sm.cand[i0 + u * THREADS] : 0u;
+            h[u] = i0 + u * step < cnt ? fin(src[i0 + u * step]) : 0u;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * THREADS < C)
+            if (i0 + u * step < cnt)
                 at[u] = atomicAdd(&bins[h[u] >> shift], 1u);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (i0 + u * THREADS < C)
+            if (i0 + u * step < cnt)
                 sm.binned[at[u]] = h[u];
     }
     __syncthreads();
@@ -712,11 +719,272 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE,
                 for (uint32_t i = tid; i < s; i += THREADS)
                     outp[i] = sm.cand[i];
             } else {
-                bottom_s_fast(sm, s, tau0, C, nbf_log2, outp);
+                bottom_s_fast<false>(sm, s, tau0, C, nbf_log2, outp, sm.cand, (uint32_t)tid, THREADS, C);
             }
         } else if (tid == 0) {
             redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r;
         }
+    }
+}
+
+// ---- SLAB pass (the fast kernel for compile-time k): the same select-under-a-verified-threshold scheme with
+// the per-window overheads of the tile loop taken out.
+//   * A wave walks a CONTIGUOUS quarter of the read in slabs of 256 windows (4 per lane), and both its byte buffer
+//     and its premixed-block buffer are RINGS of two slabs with the first few entries duplicated behind the end,
+//     so a window that runs into the next slab reads on without a wrap.  Staging a slab is one dword per lane and
+//     premixing it one quad of byte positions per lane: no partial third pass for the k-1 bytes that tiles of
+//     independent windows have to overlap (that pass cost a quarter of the tile loop's staging + premix).
+//     Premix unit u covers quads [64u-1, 64u+63) -- shifted by one so that its last quad needs no byte of slab u+1;
+//     order per step: stage slab i+1, premix unit i+1, hash slab i.
+//   * Every wave appends to its OWN candidate segment; the running count is a scalar register, so the tile loop
+//     has no LDS atomic and no round trip, and a survivor's slot is mbcnt(ballot) seeded with that count.
+//   * The threshold is applied to the hash before fmix32's last `h ^= h >> 16` against tau | 0xFFFF (that step
+//     cannot change the top 16 bits), and only the ~12 % survivors take the last step, in the bottom-s.
+// Verified like the tile pass: a wave whose segment overflows, or fewer than s survivors in total, sends the read
+// to the general kernel.
+template <int KS> struct Slabs {
+    static constexpr int NBLK = KS >> 2, TAIL = KS & 3;
+    static constexpr int DUPD = NBLK + 2; // dwords [0, DUPD) of the ring live again at [128, 128 + DUPD)
+    const uint32_t *__restrict__ gdw;
+    uint32_t gsh;
+    int64_t gbytes;
+    uint32_t *__restrict__ seqb; // physical index = ring index + 1; [0] repeats ring dword 127
+    uint32_t *__restrict__ P;    // quads [0, 128) + quads [0, NBLK) again at [128, 128 + NBLK)
+    const uint32_t *__restrict__ lut;
+    int lane;
+
+    // dword 64u + lane of the read's aligned view (and its successor when the read does not start on a dword);
+    // u is wave-uniform, so the slab's base is a scalar pointer and the lane adds a constant offset
+    __device__ __forceinline__ void gload(int64_t u, uint32_t &lo, uint32_t &hi) const
+    {
+        const uint32_t *__restrict__ slab = gdw + u * 64;
+        hi = 0u;
+        if (__builtin_expect((u * 64 + 65) * 4 <= gbytes, 1)) { // the slab and one dword beyond lie inside the read
+            lo = slab[lane];
+            if (gsh)
+                hi = slab[lane + 1];
+        } else {
+            const int64_t left = gbytes - u * 256; // bytes of the view from this slab on (may be <= 0)
+            lo = (int64_t)lane * 4 < left ? slab[lane] : 0u;
+            if (gsh)
+                hi = (int64_t)(lane + 1) * 4 < left ? slab[lane + 1] : 0u;
+        }
+    }
+
+    template <int PAR> __device__ __forceinline__ void stage(uint32_t lo, uint32_t hi) const
+    {
+        const uint32_t v = gsh ? funnel_bytes(hi, lo, gsh) : lo;
+        seqb[1 + 64 * PAR + lane] = v;
+        if (PAR == 0) {
+            if (lane < DUPD)
+                seqb[129 + lane] = v;
+        } else if (lane == 63) {
+            seqb[0] = v;
+        }
+    }
+
+    template <int PAR> __device__ __forceinline__ void premix_unit() const
+    {
+        const uint32_t d0 = seqb[64 * PAR + lane], d1 = seqb[64 * PAR + lane + 1];
+        uint4 p;
+        p.x = premix(d0);
+        p.y = premix(funnel_bytes(d1, d0, 1));
+        p.z = premix(funnel_bytes(d1, d0, 2));
+        p.w = premix(funnel_bytes(d1, d0, 3));
+        uint4 *P4 = reinterpret_cast<uint4 *>(P);
+        if (PAR == 0) {
+            P4[(lane + 127) & 127] = p; // quads 127, 0, 1, ..., 62
+            if (lane >= 1 && lane <= NBLK)
+                P4[127 + lane] = p;
+        } else {
+            P4[63 + lane] = p;
+        }
+    }
+
+    // the lane's 4 windows of a slab: hashes WITHOUT fmix32's last xor-shift
+    template <int PAR> __device__ __forceinline__ void hash(uint32_t (&h)[4]) const
+    {
+        const uint4 *b = reinterpret_cast<const uint4 *>(P) + 64 * PAR + lane;
+        h[0] = h[1] = h[2] = h[3] = 0u;
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+            const uint4 p = b[j];
+            h[0] = chain(h[0] ^ p.x);
+            h[1] = chain(h[1] ^ p.y);
+            h[2] = chain(h[2] ^ p.z);
+            h[3] = chain(h[3] ^ p.w);
+        }
+        const uint32_t *t = seqb + 1 + 64 * PAR + lane + NBLK;
+        if (TAIL == 1) {
+            const uint32_t tb = t[0]; // the 4 windows' tail bytes are one aligned dword; lut[b] = premix(b) ^ k
+            h[0] ^= lut[tb & 0xFFu];
+            h[1] ^= lut[(tb >> 8) & 0xFFu];
+            h[2] ^= lut[(tb >> 16) & 0xFFu];
+            h[3] ^= lut[tb >> 24];
+        } else if (TAIL) {
+            constexpr uint32_t tailmask = 0xFFFFFFFFu >> (32 - 8 * (TAIL ? TAIL : 1));
+            const uint32_t d0 = t[0], d1 = t[1];
+            h[0] ^= premix(d0 & tailmask) ^ (uint32_t)KS;
+            h[1] ^= premix(funnel_bytes(d1, d0, 1) & tailmask) ^ (uint32_t)KS;
+            h[2] ^= premix(funnel_bytes(d1, d0, 2) & tailmask) ^ (uint32_t)KS;
+            h[3] ^= premix(funnel_bytes(d1, d0, 3) & tailmask) ^ (uint32_t)KS;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                h[c] ^= (uint32_t)KS;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { // fmix32 up to its last multiply
+            uint32_t x = h[c];
+            x ^= x >> 16;
+            x *= 0x85ebca6bu;
+            x ^= x >> 13;
+            x *= 0xc2b2ae35u;
+            h[c] = x;
+        }
+    }
+};
+
+// survivors of the lane's 4 hashes -> the wave's own segment; `cnt` is wave-uniform (kept in a scalar register)
+template <bool PARTIAL>
+__device__ __forceinline__ void append_own(uint32_t *__restrict__ seg, uint32_t capw, uint32_t &cnt, const uint32_t (&h)[4],
+                                           uint32_t nvalid, uint32_t tauq)
+{
+    bool a[4];
+    uint64_t m[4];
+    uint32_t n[4], total = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        a[c] = h[c] <= tauq && (!PARTIAL || (uint32_t)c < nvalid);
+        m[c] = __ballot(a[c]);
+        n[c] = (uint32_t)__popcll(m[c]);
+        total += n[c];
+    }
+    uint32_t base = __builtin_amdgcn_readfirstlane(cnt);
+    cnt = base + total;
+    if (cnt <= capw) { // wave-uniform; an overflowing wave stops storing and the read is redone
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t *__restrict__ at = seg + base; // scalar: the lane only adds its rank among the survivors
+            if (a[c])
+                at[__builtin_amdgcn_mbcnt_hi((uint32_t)(m[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[c], 0u))] = h[c];
+            base += n[c];
+        }
+    }
+}
+
+// all slabs of one read; returns this wave's survivor count (wave-uniform; > capw: the segment overflowed)
+template <int KS>
+__device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv, uint32_t n_seq_dw, uint32_t n_P_w,
+                                              uint32_t *__restrict__ seg, uint32_t capw, uint32_t tauq)
+{
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // scalar: slab indices and ring bases stay in SGPRs
+    Slabs<KS> S;
+    S.gdw = rv.gdw;
+    S.gsh = rv.gsh;
+    S.gbytes = rv.gbytes;
+    S.seqb = sm.seqb + wave * n_seq_dw;
+    S.P = sm.P + wave * n_P_w;
+    S.lut = sm.lut;
+    S.lane = threadIdx.x & 63;
+    const int64_t nslab = (rv.nwin + 255) >> 8;
+    const int64_t spw = (nslab + WAVES - 1) / WAVES;
+    const int64_t a = (int64_t)wave * spw, b = a + spw < nslab ? a + spw : nslab; // this wave hashes slabs [a, b)
+    uint32_t cnt = 0;
+    if (a >= b)
+        return cnt;
+    uint32_t l1, h1;
+    S.gload(a, l1, h1);
+    if (a & 1) {
+        S.template stage<1>(l1, h1);
+        wave_sync();
+        S.gload(a + 1, l1, h1);
+        S.template premix_unit<1>();
+    } else {
+        S.template stage<0>(l1, h1);
+        wave_sync();
+        S.gload(a + 1, l1, h1);
+        S.template premix_unit<0>();
+    }
+    for (int64_t i = a; i < b; ++i) {
+        uint32_t h[4];
+        // stage slab i+1 from the registers, then put slab i+2's loads in flight in the same registers: they land
+        // while this slab is premixed and hashed
+        if (i & 1) {
+            S.template stage<0>(l1, h1);
+            wave_sync();
+            S.gload(i + 2, l1, h1);
+            S.template premix_unit<0>();
+            wave_sync();
+            S.template hash<1>(h);
+        } else {
+            S.template stage<1>(l1, h1);
+            wave_sync();
+            S.gload(i + 2, l1, h1);
+            S.template premix_unit<1>();
+            wave_sync();
+            S.template hash<0>(h);
+        }
+        const int64_t left = rv.nwin - (i << 8); // windows of the read from this slab on
+        if (__builtin_expect(left >= 256, 1)) {
+            append_own<false>(seg, capw, cnt, h, 4u, tauq);
+        } else {
+            const int64_t mine = left - 4 * S.lane;
+            append_own<true>(seg, capw, cnt, h, mine <= 0 ? 0u : (mine < 4 ? (uint32_t)mine : 4u), tauq);
+        }
+        wave_sync(); // the rings are rewritten by the next step
+    }
+    return cnt;
+}
+
+template <int KS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE, 8))) void sketch_slab_kernel(
+    const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offs, uint64_t nseq, uint32_t s, uint32_t *__restrict__ out,
+    uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P, uint32_t capw, uint32_t capf, uint32_t nbf_log2,
+    uint32_t *__restrict__ redo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
+    Smem sm;
+    sm.seqb = smem_raw;                // WAVES rings of n_seq_dw
+    sm.P = sm.seqb + WAVES * n_seq_dw; // WAVES rings of n_P_w (whole region doubles as `bins`)
+    sm.cand = sm.P + n_P;              // WAVES segments of capw
+    sm.binned = sm.cand + WAVES * capw;
+    sm.misc = sm.binned + capf;
+    sm.lut = sm.misc + 16;
+    constexpr uint32_t k = (uint32_t)KS;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    sm.lut[tid] = premix((uint32_t)tid) ^ k; // THREADS == 256; visible after the first barrier
+    uint32_t *seg = sm.cand + wave * capw;
+
+    for (uint64_t r = blockIdx.x; r < nseq; r += gridDim.x) {
+        const ReadView rv = view(seqs, offs, r, k);
+        if (rv.nwin <= 0)
+            continue;
+        uint32_t *__restrict__ outp = out + r * (uint64_t)s;
+        if (rv.nwin < (int64_t)s) { // mash.go:81-84: positional, unsorted, tail untouched -- the general kernel's job
+            if (tid == 0)
+                redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r | REDO_POSITIONAL;
+            continue;
+        }
+        // threshold a uniform hash would need for s + 6 sqrt(s) + 16 survivors, rounded up to 16 bits
+        uint32_t tauq = 0xFFFFFFFFu;
+        {
+            const uint64_t target = (uint64_t)s + 6ull * (uint64_t)__builtin_sqrtf((float)s) + 16ull;
+            if ((int64_t)target < rv.nwin)
+                tauq = (uint32_t)((target << 32) / (uint64_t)rv.nwin) | 0xFFFFu;
+        }
+        __syncthreads(); // the previous read is done with LDS
+        const uint32_t cw = run_slabs<KS>(sm, rv, n_seq_dw, n_P_w, seg, capw, tauq);
+        if ((tid & 63) == 0)
+            sm.misc[10 + wave] = cw;
+        __syncthreads();
+        const uint32_t c0 = sm.misc[10], c1 = sm.misc[11], c2 = sm.misc[12], c3 = sm.misc[13];
+        const uint32_t C = c0 + c1 + c2 + c3;
+        const bool ok = max(max(c0, c1), max(c2, c3)) <= capw && C >= s && C <= capf; // enough survivors, none lost
+        if (ok)
+            bottom_s_fast<true>(sm, s, tauq, C, nbf_log2, outp, seg, (uint32_t)(tid & 63), 64u, cw);
+        else if (tid == 0)
+            redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r;
     }
 }
 
@@ -745,10 +1013,21 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
     const uint32_t nredo = redo[0];
 
     for (uint32_t q = blockIdx.x; q < nredo; q += gridDim.x) {
-        const uint64_t r = redo[1 + q];
+        const uint32_t entry = redo[1 + q];
+        const uint64_t r = entry & ~REDO_POSITIONAL;
         const ReadView rv = view(seqs, offs, r, k);
         uint32_t *__restrict__ outp = out + r * (uint64_t)s;
         __syncthreads(); // the previous sequence is done with LDS
+        if (entry & REDO_POSITIONAL) { // fewer windows than SketchSize (mash.go:81-84), sent here by the slab pass
+            auto put = [&](int64_t t0, uint32_t w0, const uint32_t(&h)[4], uint32_t nvalid) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if ((uint32_t)c < nvalid)
+                        outp[t0 + w0 + c] = h[c];
+            };
+            run_tiles<KS, false>(sm, rv.gdw, rv.gsh, rv.gbytes, rv.nwin, k, n_seq_dw, n_P_w, [](int64_t) {}, put, put);
+            continue;
+        }
         if (tid == 0) {
             sm.misc[0] = 0;
             sm.misc[1] = 0xFFFFFFFFu;
@@ -782,8 +1061,8 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
 }
 
 struct Launch {
-    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap;
-    size_t smem_fast, smem_general;
+    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap, capw;
+    size_t smem_fast, smem_general, smem_slab;
 };
 
 static Launch plan(uint32_t k, uint32_t s)
@@ -809,6 +1088,15 @@ static Launch plan(uint32_t k, uint32_t s)
     if (PH_ABL == 7)
         L.smem_fast = 70 * 1024; // occupancy probe
     L.smem_general = (common + 2 * (size_t)L.cap) * 4;
+    // slab pass: one segment per wave, a quarter of the expected survivors + 6 sigma of that quarter + slack
+    {
+        const uint32_t exp_w = (s + 6u * rt + 16u + WAVES - 1) / WAVES;
+        uint32_t rw = 1;
+        while ((uint64_t)rw * rw < exp_w)
+            ++rw;
+        L.capw = (exp_w + 6u * rw + 16u + 63u) & ~63u;
+    }
+    L.smem_slab = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + (size_t)WAVES * L.capw + (size_t)L.capf) * 4;
     return L;
 }
 
@@ -823,15 +1111,29 @@ template <int KS>
 static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uint32_t k, uint32_t s,
                   uint32_t *d_out, const Launch &L, uint32_t *d_redo, hipStream_t st)
 {
-    auto fast = sketch_fast_kernel<KS>;
     auto general = sketch_general_kernel<KS>;
-    PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)L.smem_fast));
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(general), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.smem_general));
     PH_HIP(hipMemsetAsync(d_redo, 0, 4, st));
-    hipLaunchKernelGGL(fast, dim3(persistent_grid(L.smem_fast, n)), dim3(THREADS), L.smem_fast, st, d_seqs, d_offs, n,
-                       k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capf, L.nbf_log2, d_redo);
+    bool slabs = false;
+    if constexpr (KS > 0) {
+        // POLYHIP_K1_SLABS=0 keeps the tile pass (testing aid: the two passes are cross-checked in tests/)
+        slabs = !env_is("POLYHIP_K1_SLABS", '0') && L.smem_slab <= 64 * 1024;
+        if (slabs) {
+            auto slab = sketch_slab_kernel<KS>;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(slab), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)L.smem_slab));
+            hipLaunchKernelGGL(slab, dim3(persistent_grid(L.smem_slab, n)), dim3(THREADS), L.smem_slab, st, d_seqs, d_offs, n, s,
+                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf, L.nbf_log2, d_redo);
+        }
+    }
+    if (!slabs) {
+        auto fast = sketch_fast_kernel<KS>;
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)L.smem_fast));
+        hipLaunchKernelGGL(fast, dim3(persistent_grid(L.smem_fast, n)), dim3(THREADS), L.smem_fast, st, d_seqs, d_offs, n,
+                           k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capf, L.nbf_log2, d_redo);
+    }
     PH_HIP(hipGetLastError());
     // normally the list is empty and these workgroups exit at once
     hipLaunchKernelGGL(general, dim3(persistent_grid(L.smem_general, n)), dim3(THREADS), L.smem_general, st, d_seqs,
