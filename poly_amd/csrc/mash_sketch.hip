@@ -47,6 +47,20 @@
 #ifndef PH_ABL
 #define PH_ABL 0
 #endif
+// slab pass (scripts/ubench/k1_ablate.hip sweeps these): sigmas of head-room of the survivor target over s, of a
+// wave's segment and of the sorted buffer over their expectations, and the waves per SIMD it is allocated for
+#ifndef PH_SLAB_SIG
+#define PH_SLAB_SIG 6u
+#endif
+#ifndef PH_SLAB_CW
+#define PH_SLAB_CW 6u
+#endif
+#ifndef PH_SLAB_CF
+#define PH_SLAB_CF 0u // 0: the tile pass's capf
+#endif
+#ifndef PH_SLAB_WPE
+#define PH_SLAB_WPE PH_WPE
+#endif
 
 namespace polyhip {
 namespace k1 {
@@ -754,17 +768,19 @@ template <int KS> struct Slabs {
     int lane;
 
     // dword 64u + lane of the read's aligned view (and its successor when the read does not start on a dword);
-    // u is wave-uniform, so the slab's base is a scalar pointer and the lane adds a constant offset
-    __device__ __forceinline__ void gload(int64_t u, uint32_t &lo, uint32_t &hi) const
+    // u is wave-uniform, so the slab's base is a scalar pointer and the lane adds a constant offset.  Slabs below
+    // `u_inside` lie, with one dword beyond them, inside the read: no per-lane guard.
+    uint32_t u_inside;
+    __device__ __forceinline__ void gload(uint32_t u, uint32_t &lo, uint32_t &hi) const
     {
-        const uint32_t *__restrict__ slab = gdw + u * 64;
+        const uint32_t *__restrict__ slab = gdw + (uint64_t)u * 64;
         hi = 0u;
-        if (__builtin_expect((u * 64 + 65) * 4 <= gbytes, 1)) { // the slab and one dword beyond lie inside the read
+        if (__builtin_expect(u < u_inside, 1)) {
             lo = slab[lane];
             if (gsh)
                 hi = slab[lane + 1];
         } else {
-            const int64_t left = gbytes - u * 256; // bytes of the view from this slab on (may be <= 0)
+            const int64_t left = gbytes - (int64_t)u * 256; // bytes of the view from this slab on (may be <= 0)
             lo = (int64_t)lane * 4 < left ? slab[lane] : 0u;
             if (gsh)
                 hi = (int64_t)(lane + 1) * 4 < left ? slab[lane + 1] : 0u;
@@ -816,11 +832,18 @@ template <int KS> struct Slabs {
         }
         const uint32_t *t = seqb + 1 + 64 * PAR + lane + NBLK;
         if (TAIL == 1) {
-            const uint32_t tb = t[0]; // the 4 windows' tail bytes are one aligned dword; lut[b] = premix(b) ^ k
-            h[0] ^= lut[tb & 0xFFu];
-            h[1] ^= lut[(tb >> 8) & 0xFFu];
-            h[2] ^= lut[(tb >> 16) & 0xFFu];
-            h[3] ^= lut[tb >> 24];
+            // the 4 windows' tail bytes are one aligned dword; lut[b] = premix(b) ^ k.  Byte select and the * 4 of the
+            // LDS address in ONE SDWA shift per byte (hipcc spends a v_bfe_u32 + a v_lshl_add_u32 on each)
+            const uint32_t tb = t[0];
+            uint32_t off[4];
+            const uint32_t two = 2u;
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(off[0]) : "v"(two), "v"(tb));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(off[1]) : "v"(two), "v"(tb));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(off[2]) : "v"(two), "v"(tb));
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(off[3]) : "v"(two), "v"(tb));
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                h[c] ^= *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(lut) + off[c]);
         } else if (TAIL) {
             constexpr uint32_t tailmask = 0xFFFFFFFFu >> (32 - 8 * (TAIL ? TAIL : 1));
             const uint32_t d0 = t[0], d1 = t[1];
@@ -887,9 +910,11 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
     S.P = sm.P + wave * n_P_w;
     S.lut = sm.lut;
     S.lane = threadIdx.x & 63;
-    const int64_t nslab = (rv.nwin + 255) >> 8;
-    const int64_t spw = (nslab + WAVES - 1) / WAVES;
-    const int64_t a = (int64_t)wave * spw, b = a + spw < nslab ? a + spw : nslab; // this wave hashes slabs [a, b)
+    // 32-bit slab indices: a read of 2^40 bytes does not fit the 288 GB of HBM
+    const uint32_t nslab = (uint32_t)((rv.nwin + 255) >> 8);
+    const uint32_t spw = (nslab + WAVES - 1) / WAVES;
+    const uint32_t a = (uint32_t)wave * spw, b = a + spw < nslab ? a + spw : nslab; // this wave hashes slabs [a, b)
+    S.u_inside = rv.gbytes >= 65 * 4 ? (uint32_t)(((rv.gbytes >> 2) - 65) >> 6) + 1u : 0u;
     uint32_t cnt = 0;
     if (a >= b)
         return cnt;
@@ -906,7 +931,7 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
         S.gload(a + 1, l1, h1);
         S.template premix_unit<0>();
     }
-    for (int64_t i = a; i < b; ++i) {
+    for (uint32_t i = a; i < b; ++i) {
         uint32_t h[4];
         // stage slab i+1 from the registers, then put slab i+2's loads in flight in the same registers: they land
         // while this slab is premixed and hashed
@@ -925,7 +950,7 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
             wave_sync();
             S.template hash<0>(h);
         }
-        const int64_t left = rv.nwin - (i << 8); // windows of the read from this slab on
+        const int64_t left = rv.nwin - ((int64_t)i << 8); // windows of the read from this slab on
         if (__builtin_expect(left >= 256, 1)) {
             append_own<false>(seg, capw, cnt, h, 4u, tauq);
         } else {
@@ -938,19 +963,19 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
 }
 
 template <int KS>
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE, 8))) void sketch_slab_kernel(
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB_WPE, 8))) void sketch_slab_kernel(
     const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offs, uint64_t nseq, uint32_t s, uint32_t *__restrict__ out,
     uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P, uint32_t capw, uint32_t capf, uint32_t nbf_log2,
     uint32_t *__restrict__ redo)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
     Smem sm;
-    sm.seqb = smem_raw;                // WAVES rings of n_seq_dw
+    sm.lut = smem_raw;                 // first, so that a tail byte's entry is at LDS address 4 * byte (no base to add)
+    sm.seqb = smem_raw + 256;          // WAVES rings of n_seq_dw
     sm.P = sm.seqb + WAVES * n_seq_dw; // WAVES rings of n_P_w (whole region doubles as `bins`)
     sm.cand = sm.P + n_P;              // WAVES segments of capw
     sm.binned = sm.cand + WAVES * capw;
     sm.misc = sm.binned + capf;
-    sm.lut = sm.misc + 16;
     constexpr uint32_t k = (uint32_t)KS;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     sm.lut[tid] = premix((uint32_t)tid) ^ k; // THREADS == 256; visible after the first barrier
@@ -969,7 +994,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE,
         // threshold a uniform hash would need for s + 6 sqrt(s) + 16 survivors, rounded up to 16 bits
         uint32_t tauq = 0xFFFFFFFFu;
         {
-            const uint64_t target = (uint64_t)s + 6ull * (uint64_t)__builtin_sqrtf((float)s) + 16ull;
+            const uint64_t target = (uint64_t)s + (uint64_t)PH_SLAB_SIG * (uint64_t)__builtin_sqrtf((float)s) + 16ull;
             if ((int64_t)target < rv.nwin)
                 tauq = (uint32_t)((target << 32) / (uint64_t)rv.nwin) | 0xFFFFu;
         }
@@ -1061,7 +1086,7 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
 }
 
 struct Launch {
-    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap, capw;
+    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap, capw, capf_slab;
     size_t smem_fast, smem_general, smem_slab;
 };
 
@@ -1088,15 +1113,18 @@ static Launch plan(uint32_t k, uint32_t s)
     if (PH_ABL == 7)
         L.smem_fast = 70 * 1024; // occupancy probe
     L.smem_general = (common + 2 * (size_t)L.cap) * 4;
-    // slab pass: one segment per wave, a quarter of the expected survivors + 6 sigma of that quarter + slack
+    // slab pass: one segment per wave (a quarter of the expected survivors + PH_SLAB_CW sigma of that quarter), and
+    // a sorted buffer for all of them
     {
-        const uint32_t exp_w = (s + 6u * rt + 16u + WAVES - 1) / WAVES;
+        const uint32_t target = s + PH_SLAB_SIG * rt + 16u;
+        const uint32_t exp_w = (target + WAVES - 1) / WAVES;
         uint32_t rw = 1;
         while ((uint64_t)rw * rw < exp_w)
             ++rw;
-        L.capw = (exp_w + 6u * rw + 16u + 63u) & ~63u;
+        L.capw = (exp_w + PH_SLAB_CW * rw + 8u + 63u) & ~63u;
+        L.capf_slab = PH_SLAB_CF ? ((target + PH_SLAB_CF * rt + 8u + 63u) & ~63u) : L.capf;
     }
-    L.smem_slab = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + (size_t)WAVES * L.capw + (size_t)L.capf) * 4;
+    L.smem_slab = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + (size_t)WAVES * L.capw + (size_t)L.capf_slab) * 4;
     return L;
 }
 
@@ -1124,7 +1152,7 @@ static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uin
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(slab), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)L.smem_slab));
             hipLaunchKernelGGL(slab, dim3(persistent_grid(L.smem_slab, n)), dim3(THREADS), L.smem_slab, st, d_seqs, d_offs, n, s,
-                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf, L.nbf_log2, d_redo);
+                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf_slab, L.nbf_log2, d_redo);
         }
     }
     if (!slabs) {

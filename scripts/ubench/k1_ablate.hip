@@ -22,6 +22,13 @@ int main()
     for (int r = 0; r < 5; ++r) polyhip_mash_sketch_batch_dev(seqs, offs, n, k, s, out, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    // checksum of all sketches: variants must agree with the baseline build word for word
+    std::vector<uint32_t> ho(n * s);
+    hipMemcpy(ho.data(), out, n * s * 4, hipMemcpyDeviceToHost);
+    uint64_t sum = 0, x = 0;
+    for (size_t i = 0; i < ho.size(); ++i) { sum += ho[i] * (uint64_t)(i % 1000003 + 1); x ^= ho[i]; }
+    const k1::Launch PL = k1::plan(k, s);
+    printf("checksum %016llx %08llx  smem_slab %zu capw %u capf_slab %u  ", (unsigned long long)sum, (unsigned long long)x, PL.smem_slab, PL.capw, PL.capf_slab);
     static const char *what[] = {"full kernel", "no premix", "1 chain block of 5", "no tail/fmix", "no select stores", "no bottom_s", "no global loads", "2 workgroups per CU"};
     printf("PH_ABL=%d %-20s %.3f ms per 100k reads\n", PH_ABL, what[PH_ABL], ms);
     return 0;
