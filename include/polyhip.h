@@ -119,6 +119,23 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx,
                                    uint16_t *d_counts, uint64_t ld,
                                    void *d_work, size_t work_bytes,
                                    polyhip_stream_t stream);
+/*
+ * The same in two steps, for callers that put several X against one Y (row blocks of one matrix, queries against a
+ * resident sketch database): polyhip_mash_index_build_dev builds Y's inverted index into d_work (a third of a
+ * 12,500 x 100,000 block's time), polyhip_mash_shared_counts_reuse_dev joins an X against the index that an earlier
+ * polyhip_mash_index_build_dev / polyhip_mash_shared_counts_dev call with the SAME d_Y, ny, sy left in the SAME
+ * d_work (the Y side sits at the front of the workspace, wherever nx puts the rest).  Workspace:
+ * polyhip_mash_shared_counts_workspace_bytes(largest nx, ...); index_build alone needs ..._workspace_bytes(0, ...).
+ */
+int polyhip_mash_index_build_dev(const uint32_t *d_Y, uint64_t ny, uint32_t sy,
+                                 void *d_work, size_t work_bytes,
+                                 polyhip_stream_t stream);
+int polyhip_mash_shared_counts_reuse_dev(const uint32_t *d_X, uint64_t nx,
+                                         uint32_t sx, const uint32_t *d_Y,
+                                         uint64_t ny, uint32_t sy,
+                                         uint16_t *d_counts, uint64_t ld,
+                                         void *d_work, size_t work_bytes,
+                                         polyhip_stream_t stream);
 /* What the last polyhip_mash_shared_counts_dev call on this workspace did
  * (synchronous read-back; tests and profiling): mode 0 = hash join, 1 = the
  * reference's merge for every pair; the number of non-ascending sketches on

@@ -38,6 +38,8 @@ SIGNATURES = {
     "polyhip_mash_sketch_batch_dev": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp, _vp]),
     "polyhip_mash_shared_counts_workspace_bytes": (C.c_size_t, [_u64, _u32, _u64, _u32]),
     "polyhip_mash_shared_counts_dev": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
+    "polyhip_mash_index_build_dev": (C.c_int, [_vp, _u64, _u32, _vp, C.c_size_t, _vp]),
+    "polyhip_mash_shared_counts_reuse_dev": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
     "polyhip_mash_shared_counts_mode_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "polyhip_mash_distance_from_counts_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _vp, _u64, _vp]),
     "polyhip_mash_distance_matrix": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _vp]),

@@ -87,12 +87,10 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     L.nc_log2 = L.nbk_log2 < 12u ? L.nbk_log2 : 12u; // NC_LOG2_MAX
     L.nc = 1u << L.nc_log2;
     L.fpc_log2 = L.nbk_log2 - L.nc_log2;
+    // the Y side (flags, irregular list, inverted index) comes first and does not depend on nx: a later call with
+    // another X (polyhip_mash_shared_counts_reuse_dev) finds it where the call that built it left it
     size_t o = al(H_WORDS * 4);
-    L.off_flagsX = o; o += al(nx);
     L.off_flagsY = o; o += al(ny);
-    L.off_irrX = o; o += al(nx * 4);
-    L.off_regX = o; o += al(nx * 4);
-    L.off_ovfX = o; o += al(nx * 4);
     L.off_irrY = o; o += al(ny * 4);
     L.off_start = o; o += al(((size_t)nbk + 1) * 4);
     L.off_gcount = o; o += al((size_t)L.nc * 4);
@@ -100,6 +98,10 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     L.off_gcur = o; o += al((size_t)L.nc * 4);
     L.off_citems = o; o += al(ny * (size_t)sy * 8);
     L.off_items = o; o += al(ny * (size_t)sy * 8);
+    L.off_flagsX = o; o += al(nx);
+    L.off_irrX = o; o += al(nx * 4);
+    L.off_regX = o; o += al(nx * 4);
+    L.off_ovfX = o; o += al(nx * 4);
     L.total = o;
     return L;
 }
@@ -478,31 +480,42 @@ __global__ __launch_bounds__(THREADS) void rowjoin_kernel(const uint32_t *__rest
 }
 
 constexpr int DENSE_THREADS = 1024; // one workgroup per CU (its LDS is the whole CU's): 16 waves keep the bucket loads coming
+constexpr int DENSE_U = 4;          // buckets a wave keeps in flight, 128 items of each
 
-// ---- rows whose LDS hash table overflowed (thousands of relatives) ----------------------------------
-// Same bucket walk as rowjoin_kernel, but the accumulator is a DENSE array of 16-bit counters in LDS, one
-// per column of a stripe of 2 * W columns (two counters per dword, bumped with one 32-bit LDS atomic: a count
-// never exceeds the sketch size, so the halves cannot carry into each other).  ceil(ny / 2W) stripes per
-// row; each stripe is flushed whole, zeros included.  Work follows the shared hashes, like the sparse join --
-// the reference's two-pointer merge for such a row would be ny * (sx + sy) steps.
-__global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint32_t *__restrict__ X, uint32_t sx,
+// ---- dense join: a counter per COLUMN in LDS ------------------------------------------------------------
+// Same bucket walk as rowjoin_kernel, but the accumulator is a dense array of BITS-bit counters in LDS, one per
+// column of a stripe (PER = 32 / BITS per dword, bumped with one 32-bit LDS atomic: a count never exceeds the smaller
+// SketchSize < 2^BITS, so the fields cannot carry into each other).  No hash probing, no zero-fill of the
+// output (a stripe is flushed whole, zeros included: the 2 B per pair the matrix costs anyway), and the work
+// follows the shared hashes.  With 10-bit counters (SketchSize <= 1023) the ~138 KB of LDS next to a 1000-hash
+// row hold 105k columns: config 3's 100k sketches are ONE stripe, every bucket is read once per row.
+// Rows: all regular ones (`rows` == NULL), or the rows the sparse join handed over (hdr[H_NOVF] of them).
+template <int BITS>
+__global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
+                                                               const uint8_t *__restrict__ flagsX,
                                                                const uint32_t *__restrict__ start,
                                                                const uint2 *__restrict__ items, uint32_t nbk,
                                                                const uint32_t *__restrict__ hdr,
-                                                               const uint32_t *__restrict__ ovfX, uint64_t ny,
-                                                               uint32_t w_log2, uint32_t id_bits,
-                                                               uint16_t *__restrict__ counts, uint64_t ld)
+                                                               const uint32_t *__restrict__ rows, uint64_t ny,
+                                                               uint32_t stripe_dwords, uint32_t id_bits,
+                                                               uint16_t *__restrict__ counts, uint64_t ld, int abl)
 {
     if (hdr[H_MODE] != MODE_SPARSE)
         return;
+    constexpr uint32_t PER = 32 / BITS, FMASK = (1u << BITS) - 1u;
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
     uint32_t *xv = dyn, *dval = dyn + sx, *dmul = dyn + 2 * (size_t)sx, *dbeg = dyn + 3 * (size_t)sx,
-             *dend = dyn + 4 * (size_t)sx, *dense = dyn + 5 * (size_t)sx;
+             *dend = dyn + 4 * (size_t)sx, *dense = dyn + ((5 * (size_t)sx + 3) & ~(size_t)3);
     __shared__ uint32_t ndist;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t shift = hdr[H_SHIFT], W = 1u << w_log2, novf = hdr[H_NOVF];
-    for (uint32_t r = blockIdx.x; r < novf; r += gridDim.x) {
-        const uint64_t i = ovfX[r];
+    const uint32_t shift = hdr[H_SHIFT], id_mask = (1u << id_bits) - 1u;
+    const uint64_t nrows = rows ? hdr[H_NOVF] : nx;
+    const uint32_t stripe_cols = stripe_dwords * PER;
+    const bool one_stripe = ny <= stripe_cols;
+    for (uint64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const uint64_t i = rows ? rows[r] : r;
+        if (!rows && flagsX[i])
+            continue; // irregular rows belong to the merge
         __syncthreads();
         if (tid == 0)
             ndist = 0;
@@ -531,25 +544,73 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
         }
         __syncthreads();
         const uint32_t nd = ndist;
-        for (uint64_t c0 = 0; c0 < ny; c0 += 2ull * W) {
-            for (uint32_t t = tid; t < W; t += DENSE_THREADS)
-                dense[t] = 0;
+        for (uint64_t c0 = 0; c0 < ny; c0 += stripe_cols) {
+            const uint32_t ncols = (uint32_t)min((uint64_t)stripe_cols, ny - c0);
+            const uint32_t ndw = (ncols + PER - 1) / PER;
+            for (uint32_t t = tid * 4; t < ndw; t += DENSE_THREADS * 4) // stripe_dwords is a multiple of 4
+                *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
             __syncthreads();
-            const uint32_t stripe = (uint32_t)(c0 >> (w_log2 + 1));
-            for (uint32_t d = wave; d < nd; d += DENSE_THREADS / 64) {
-                const uint32_t v = dval[d], a = dmul[d];
-                for (uint32_t t = dbeg[d] + lane; t < dend[d]; t += 64) {
-                    const uint2 it = items[t];
-                    const uint32_t id = it.y & ((1u << id_bits) - 1u);
-                    if (it.x == v && (it.y >> id_bits) < a && (id >> (w_log2 + 1)) == stripe)
-                        atomicAdd(&dense[(id & (2u * W - 1u)) >> 1], 1u << (16u * (id & 1u)));
+            auto consume = [&](const uint2 it, uint32_t v, uint32_t a) {
+                if (it.x != v || (it.y >> id_bits) >= a || (abl & 2)) // (0, 0xFFFFFFFF) = no item: occurrence number all ones
+                    return;
+                uint32_t col = it.y & id_mask;
+                if (!one_stripe) {
+                    if (col < c0 || col - c0 >= ncols)
+                        return;
+                    col -= (uint32_t)c0;
+                }
+                const uint32_t dw = PER == 3 ? (__umulhi(col, 0xAAAAAAABu) >> 1) : (col >> 1);
+                atomicAdd(&dense[dw], 1u << (BITS * (col - dw * PER)));
+            };
+            // a wave takes DENSE_U distinct values at a time: the first 128 items of each bucket are loaded back to
+            // back (a family's copies of one hash are one bucket), then consumed
+            for (uint32_t d0 = wave * DENSE_U; d0 < ((abl & 4) ? 0u : nd); d0 += (DENSE_THREADS / 64) * DENSE_U) {
+                uint2 it[DENSE_U][2];
+#pragma unroll
+                for (int u = 0; u < DENSE_U; ++u) {
+                    const uint32_t d = d0 + u;
+                    it[u][0] = it[u][1] = make_uint2(0u, 0xFFFFFFFFu);
+                    if (d < nd) {
+                        const uint32_t t = dbeg[d] + lane, e = dend[d];
+                        if (t < e)
+                            it[u][0] = items[t];
+                        if (t + 64 < e)
+                            it[u][1] = items[t + 64];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < DENSE_U; ++u) {
+                    const uint32_t d = d0 + u;
+                    if (d >= nd)
+                        break;
+                    const uint32_t v = dval[d], a = dmul[d];
+                    consume(it[u][0], v, a);
+                    consume(it[u][1], v, a);
+                    for (uint32_t t = dbeg[d] + 128 + lane; t < dend[d]; t += 64) // rest of a long bucket
+                        consume(items[t], v, a);
                 }
             }
             __syncthreads();
-            for (uint32_t t = tid; t < 2u * W; t += DENSE_THREADS) {
-                const uint64_t col = c0 + t;
-                if (col < ny)
-                    counts[i * ld + col] = (uint16_t)(dense[t >> 1] >> (16u * (t & 1u)));
+            uint16_t *crow = counts + i * ld + c0;
+            if (abl & 1) {
+            } else if ((((uintptr_t)crow) & 3) == 0) { // two columns per 4-byte store
+                for (uint32_t t = tid; 2 * t < ncols; t += DENSE_THREADS) {
+                    const uint32_t c = 2 * t, dw0 = PER == 3 ? (__umulhi(c, 0xAAAAAAABu) >> 1) : t;
+                    const uint32_t k0 = c - dw0 * PER;
+                    const uint32_t lo = (dense[dw0] >> (BITS * k0)) & FMASK;
+                    const uint32_t c1 = c + 1, dw1 = k0 + 1 == PER ? dw0 + 1 : dw0, k1 = k0 + 1 == PER ? 0 : k0 + 1;
+                    if (c1 < ncols) {
+                        const uint32_t hi = (dense[dw1] >> (BITS * k1)) & FMASK;
+                        *reinterpret_cast<uint32_t *>(crow + c) = lo | (hi << 16);
+                    } else {
+                        crow[c] = (uint16_t)lo;
+                    }
+                }
+            } else {
+                for (uint32_t c = tid; c < ncols; c += DENSE_THREADS) {
+                    const uint32_t dw = PER == 3 ? (__umulhi(c, 0xAAAAAAABu) >> 1) : (c >> 1);
+                    crow[c] = (uint16_t)((dense[dw] >> (BITS * (c - dw * PER))) & FMASK);
+                }
             }
             __syncthreads();
         }
@@ -654,23 +715,33 @@ size_t polyhip_mash_shared_counts_workspace_bytes(uint64_t nx, uint32_t sx, uint
     return k2::layout(nx, sx, ny, sy).total;
 }
 
-int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
-                                   uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
-                                   polyhip_stream_t stream)
+// resets what an earlier call left of its X side in a workspace whose index is being reused
+static __global__ void reset_x_kernel(uint32_t *__restrict__ hdr)
 {
-    if (sx == 0 || sy == 0)
+    hdr[k2::H_NIRRX] = hdr[k2::H_NREGX] = hdr[k2::H_NOVF] = 0;
+    hdr[k2::H_MODE] = k2::MODE_SPARSE;
+}
+
+// what: 1 = build the index of Y, 2 = join X against the index in the workspace, 3 = both
+static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
+                              uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
+                              polyhip_stream_t stream)
+{
+    const bool build = what & 1, join = what & 2;
+    if ((join && sx == 0) || sy == 0)
         return set_error(POLYHIP_ERR_PANIC,
                          "mash.Similarity with SketchSize 0 indexes Sketches[-1] (mash.go:117): the reference panics");
     PH_REQUIRE(sx <= 65535 && sy <= 65535, "polyhip_mash_shared_counts: SketchSize > 65535 does not fit the u16 counts");
-    if (nx == 0 || ny == 0)
+    if ((join && nx == 0) || ny == 0)
         return POLYHIP_OK;
-    PH_REQUIRE(d_X && d_Y && d_counts && d_work, "polyhip_mash_shared_counts: null pointer");
-    PH_REQUIRE(ld >= ny, "polyhip_mash_shared_counts: row stride %llu < ny %llu", (unsigned long long)ld,
+    PH_REQUIRE(d_Y && d_work && (!join || (d_X && d_counts)), "polyhip_mash_shared_counts: null pointer");
+    PH_REQUIRE(!join || ld >= ny, "polyhip_mash_shared_counts: row stride %llu < ny %llu", (unsigned long long)ld,
                (unsigned long long)ny);
     PH_REQUIRE(nx < (1ull << 31) && ny < (1ull << 31) && ny * (uint64_t)sy < (1ull << 32),
                "polyhip_mash_shared_counts: more than 2^31 sketches or 2^32 Y hashes in one call (split it)");
     const k2::Layout L = k2::layout(nx, sx, ny, sy);
-    PH_REQUIRE(work_bytes >= L.total, "polyhip_mash_shared_counts: workspace too small (%zu < %zu)", work_bytes, L.total);
+    PH_REQUIRE(work_bytes >= (join ? L.total : L.off_flagsX), "polyhip_mash_shared_counts: workspace too small (%zu < %zu)",
+               work_bytes, join ? L.total : L.off_flagsX);
     hipStream_t st = as_stream(stream);
     uint8_t *w = static_cast<uint8_t *>(d_work);
     uint32_t *hdr = reinterpret_cast<uint32_t *>(w);
@@ -683,29 +754,22 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
     uint2 *citems = reinterpret_cast<uint2 *>(w + L.off_citems);
     uint2 *items = reinterpret_cast<uint2 *>(w + L.off_items);
 
-    // header, flags and the histogram start at zero; so do the counts (rowjoin stores only non-zero cells)
-    PH_HIP(hipMemsetAsync(w, 0, L.off_irrX, st));
-    PH_HIP(hipMemsetAsync(gcount, 0, (size_t)L.nc * 4, st));
-    if (ld == ny) {
-        PH_HIP(hipMemsetAsync(d_counts, 0, nx * ny * 2, st));
-    } else {
-        PH_HIP(hipMemset2DAsync(d_counts, ld * 2, 0, ny * 2, nx, st));
-    }
-
     // the join packs the Y sketch id into 24 bits and stages an X row in LDS
     const int force = (ny > (1ull << k2::ID_BITS_MAX) || sx > k2::S_MAX) ? 1 : 0;
     uint32_t id_bits = 1; // bits of a Y sketch id; the rest of an item's second dword numbers the copies of a value
     while ((1ull << id_bits) < ny && id_bits < k2::ID_BITS_MAX)
         ++id_bits;
     const uint32_t max_occ = (1u << (32 - id_bits)) - 2u; // all-ones stays free (the join's "no item" marker)
-    const unsigned gx = (unsigned)nx, gy = (unsigned)ny; // one block per sketch
-    hipLaunchKernelGGL(k2::check_kernel, dim3(gx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0, 0xFFFFFFFEu);
-    hipLaunchKernelGGL(k2::check_kernel, dim3(gy), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1, max_occ);
-    const uint64_t nmax = std::max(nx, ny);
-    hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nmax + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
-                       flagsX, nx, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2);
-    // ---- inverted index of the Y side: two-level partition by value
-    {
+
+    if (build) {
+        // header, Y flags and the histogram start at zero
+        PH_HIP(hipMemsetAsync(w, 0, L.off_irrY, st));
+        PH_HIP(hipMemsetAsync(gcount, 0, (size_t)L.nc * 4, st));
+        hipLaunchKernelGGL(k2::check_kernel, dim3((unsigned)ny), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1,
+                           max_occ);
+        hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
+                           flagsX, (uint64_t)0, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2);
+        // ---- inverted index of the Y side: two-level partition by value
         const uint32_t per_batch = std::max<uint32_t>(1u, k2::BATCH_ITEMS / sy);
         const unsigned batches = (unsigned)((ny + per_batch - 1) / per_batch);
         hipLaunchKernelGGL(k2::coarse_count_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy, flagsY,
@@ -715,37 +779,80 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
                            flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, gcur, citems);
         hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(L.nc, 256u * 8u)), dim3(k2::THREADS), 0, st, citems, cstart,
                            L.nc, L.fpc_log2, hdr, start, items);
+        PH_HIP(hipGetLastError());
     }
+    if (!join)
+        return POLYHIP_OK;
+
+    // ---- X side
+    if (!build)
+        hipLaunchKernelGGL(reset_x_kernel, dim3(1), dim3(1), 0, st, hdr);
+    PH_HIP(hipMemsetAsync(flagsX, 0, nx, st));
+    hipLaunchKernelGGL(k2::check_kernel, dim3((unsigned)nx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0,
+                       0xFFFFFFFEu);
+    hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nx + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
+                       flagsX, nx, flagsY, (uint64_t)0, irrX, regX, irrY, hdr, L.nbk_log2);
     // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
     // value with its whole bucket: about (nx*sx/(ny*sy)) * sum_b cntY_b^2 compares when X is
     // distributed like Y (exact for the all-vs-all).  The join only loses on huge buckets.
     const double est_scale = ((double)nx * sx) / ((double)ny * sy);
     const double generic_cost = (double)nx * (double)ny * (double)(sx + sy) * 4.0;
     hipLaunchKernelGGL(k2::decide_kernel, dim3(1), dim3(1), 0, st, hdr, est_scale, generic_cost);
-    if (!force) {
-        const size_t smem = (size_t)sx * 20;
-        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_kernel),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull * 16ull);
-        hipLaunchKernelGGL(k2::rowjoin_kernel, dim3(blocks), dim3(k2::THREADS), smem, st, d_X, nx, sx, flagsX, start, items,
-                           L.nbk, id_bits, hdr, ovfX, d_counts, ld);
-    }
-    // rows that overflowed their hash table: dense 16-bit counters per column stripe, as many columns per
-    // stripe as LDS holds next to the row's own arrays (a power of two of dwords, two columns each)
-    int ovf_done = 0;
-    if (!force) {
-        const size_t row_bytes = (size_t)sx * 20, avail = 158 * 1024 > row_bytes ? 158 * 1024 - row_bytes : 0;
-        uint32_t w_log2 = 0;
-        while (w_log2 < 15 && ((size_t)4 << (w_log2 + 1)) <= avail)
-            ++w_log2;
-        if (((size_t)4 << w_log2) <= avail && w_log2 >= 12) { // at least 8192 columns per stripe
-            const size_t smem = row_bytes + ((size_t)4 << w_log2);
-            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel),
+
+    // dense join geometry: counter width from the largest possible count, stripe from what LDS holds next to the row
+    const int bits = std::min(sx, sy) <= 1023u ? 10 : 16;
+    const uint32_t per = 32u / (uint32_t)bits;
+    const size_t row_bytes = (((size_t)5 * sx + 3) & ~(size_t)3) * 4, lds_max = 160 * 1024 - 256;
+    const uint32_t stripe_dwords = row_bytes + 4096 <= lds_max ? (uint32_t)(((lds_max - row_bytes) / 4) & ~(size_t)3) : 0u;
+    const uint64_t stripe_cols = (uint64_t)stripe_dwords * per;
+    const uint64_t stripes = stripe_cols ? (ny + stripe_cols - 1) / stripe_cols : ~0ull;
+    const int abl = getenv("POLYHIP_K2_ABL") ? atoi(getenv("POLYHIP_K2_ABL")) : 0;
+    auto launch_dense = [&](const uint32_t *rows, unsigned blocks) -> int {
+        const uint32_t sdw = (uint32_t)std::min<uint64_t>(stripe_dwords, (((ny + per - 1) / per) + 3) & ~3ull);
+        const size_t smem = row_bytes + (size_t)sdw * 4;
+        if (bits == 10) {
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<10>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull);
-            hipLaunchKernelGGL(k2::rowjoin_dense_kernel, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, sx, start, items,
-                               L.nbk, hdr, ovfX, ny, w_log2, id_bits, d_counts, ld);
-            ovf_done = 1;
+            hipLaunchKernelGGL(k2::rowjoin_dense_kernel<10>, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX,
+                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld, abl);
+        } else {
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k2::rowjoin_dense_kernel<16>, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX,
+                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld, abl);
+        }
+        return POLYHIP_OK;
+    };
+    // Up to two stripes the dense join takes EVERY regular row: it reads each bucket at most twice, bumps one LDS counter
+    // per shared hash and writes the row's counts once, zeros included -- no zero-fill of the matrix, no hash probing.
+    // Beyond that (hundreds of thousands of columns) rows go through the sparse join first and only the ones whose
+    // table overflows come here.  POLYHIP_K2_DENSE=0 keeps the sparse join in front (testing aid).
+    const bool dense_all = !force && stripes <= 2 && !env_is("POLYHIP_K2_DENSE", '0');
+    int ovf_done = 0;
+    if (dense_all) {
+        if (int rc = launch_dense(nullptr, (unsigned)std::min<uint64_t>(nx, 256ull)))
+            return rc;
+        ovf_done = 1;
+    } else {
+        // rowjoin stores only non-zero cells
+        if (ld == ny) {
+            PH_HIP(hipMemsetAsync(d_counts, 0, nx * ny * 2, st));
+        } else {
+            PH_HIP(hipMemset2DAsync(d_counts, ld * 2, 0, ny * 2, nx, st));
+        }
+        if (!force) {
+            const size_t smem = (size_t)sx * 20;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            const unsigned blocks = (unsigned)std::min<uint64_t>(nx, 256ull * 16ull);
+            hipLaunchKernelGGL(k2::rowjoin_kernel, dim3(blocks), dim3(k2::THREADS), smem, st, d_X, nx, sx, flagsX, start, items,
+                               L.nbk, id_bits, hdr, ovfX, d_counts, ld);
+            // rows that overflowed their hash table: the dense join, as many columns per stripe as LDS holds
+            if (stripe_cols >= 8192) {
+                if (int rc = launch_dense(ovfX, (unsigned)std::min<uint64_t>(nx, 256ull)))
+                    return rc;
+                ovf_done = 1;
+            }
         }
     }
     {
@@ -756,6 +863,26 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
     }
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
+}
+
+int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
+                                   uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
+                                   polyhip_stream_t stream)
+{
+    return shared_counts_impl(3, d_X, nx, sx, d_Y, ny, sy, d_counts, ld, d_work, work_bytes, stream);
+}
+
+int polyhip_mash_index_build_dev(const uint32_t *d_Y, uint64_t ny, uint32_t sy, void *d_work, size_t work_bytes,
+                                 polyhip_stream_t stream)
+{
+    return shared_counts_impl(1, nullptr, 0, 1, d_Y, ny, sy, nullptr, 0, d_work, work_bytes, stream);
+}
+
+int polyhip_mash_shared_counts_reuse_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
+                                         uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
+                                         polyhip_stream_t stream)
+{
+    return shared_counts_impl(2, d_X, nx, sx, d_Y, ny, sy, d_counts, ld, d_work, work_bytes, stream);
 }
 
 int polyhip_mash_shared_counts_mode_dev(const void *d_work, uint32_t *mode, uint32_t *n_irregular_x,

@@ -150,6 +150,27 @@ def shared_counts_dev(X_t, Y_t, counts_t, work_t, stream=None) -> None:
         work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
 
 
+def index_build_dev(Y_t, work_t, stream=None) -> None:
+    """Builds Y's inverted index into `work_t` (sized by shared_counts_workspace_bytes for the largest X to come)."""
+    ny, sy = Y_t.shape
+    assert Y_t.is_cuda and Y_t.is_contiguous() and Y_t.element_size() == 4
+    _lib.check(_lib.lib().polyhip_mash_index_build_dev(Y_t.data_ptr(), ny, sy, work_t.data_ptr(),
+                                                       work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
+def shared_counts_reuse_dev(X_t, Y_t, counts_t, work_t, stream=None) -> None:
+    """shared_counts_dev against the index an earlier index_build_dev / shared_counts_dev call with the same Y left in
+    `work_t`: row blocks of one matrix, or queries against a resident sketch set, build the index once."""
+    nx, sx = X_t.shape
+    ny, sy = Y_t.shape
+    assert X_t.is_cuda and Y_t.is_cuda and counts_t.is_cuda and work_t.is_cuda
+    assert X_t.is_contiguous() and Y_t.is_contiguous() and X_t.element_size() == 4 and Y_t.element_size() == 4
+    assert counts_t.element_size() == 2 and counts_t.shape[0] == nx and counts_t.stride(1) == 1
+    _lib.check(_lib.lib().polyhip_mash_shared_counts_reuse_dev(
+        X_t.data_ptr(), nx, sx, Y_t.data_ptr(), ny, sy, counts_t.data_ptr(), counts_t.stride(0),
+        work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
 def shared_counts_mode(work_t):
     """(mode, irregular X, irregular Y, overflow rows, index self-join size) of the last
     shared_counts_dev on this workspace."""
