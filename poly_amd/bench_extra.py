@@ -134,16 +134,36 @@ def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
     counts = torch.empty((nrows, N), dtype=torch.int16, device=dev)
     work = torch.empty(mash.shared_counts_workspace_bytes(nrows, s, N, s), dtype=torch.uint8, device=dev)
     ms = _time(lambda: mash.shared_counts_dev(sk[:nrows], sk, counts, work), 3)
+    # the same row block against an index that is already there (the other row blocks of the matrix, a resident database)
+    ms_index = _time(lambda: mash.index_build_dev(sk, work), 3)
+    ms_join = _time(lambda: mash.shared_counts_reuse_dev(sk[:nrows], sk, counts, work), 3)
     dist = torch.empty((nrows, N), dtype=torch.float64, device=dev)
     ms_d = _time(lambda: mash.distance_from_counts_dev(counts, s, s, dist), 3)
     mode = mash.shared_counts_mode(work)
+    nonzero = int((counts != 0).sum())
     pairs = nrows * N
-    return {"workload": f"{nrows} x {N} sketch pairs (row block 1/{rows_div} of the all-vs-all over {N} sketches of s={s}; "
-                        f"{nfam} families x {copies} copies at 1 % substitution) (BASELINE configs[2], one rank)",
-            "pairs_per_s_counts": pairs / ms * 1e3, "counts_ms": ms,
-            "pairs_per_s_counts_plus_fp64_distance": pairs / (ms + ms_d) * 1e3, "distance_ms": ms_d,
-            "algorithmic_GBs_fp64_out": pairs * 8 / (ms + ms_d) * 1e3 / 1e9,
-            "join_mode": mode[0], "nonzero_pairs": int((counts != 0).sum())}
+    out = {"workload": f"{nrows} x {N} sketch pairs (row block 1/{rows_div} of the all-vs-all over {N} sketches of s={s}; "
+                       f"{nfam} families x {copies} copies at 1 % substitution) (BASELINE configs[2], one rank)",
+           "pairs_per_s_counts": pairs / ms * 1e3, "counts_ms": ms, "index_build_ms": ms_index, "join_only_ms": ms_join,
+           "pairs_per_s_join_only": pairs / ms_join * 1e3,
+           "pairs_per_s_counts_plus_fp64_distance": pairs / (ms + ms_d) * 1e3, "distance_ms": ms_d,
+           "algorithmic_GBs_fp64_out": pairs * 8 / (ms + ms_d) * 1e3 / 1e9,
+           # 2 B of u16 count per ordered pair is the algorithmic traffic of the counts call
+           "roofline": {"bound": "hbm", "achieved": pairs * 2 / ms * 1e3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": pairs * 2 / ms * 1e3 / 1e9 / HBM_PEAK_GBS,
+                        "frac_join_only": pairs * 2 / ms_join * 1e3 / 1e9 / HBM_PEAK_GBS,
+                        "kernel": "polyhip::k2::rowjoin_dense_kernel<10> (+ the index build in counts_ms)"},
+           "join_mode": mode[0], "nonzero_pairs": nonzero}
+    del dist, counts, work
+    torch.cuda.empty_cache()
+    # the whole matrix on one GPU: one index, every row
+    counts = torch.empty((N, N), dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(N, s, N, s), dtype=torch.uint8, device=dev)
+    ms_full = _time(lambda: mash.shared_counts_dev(sk, sk, counts, work), 3, 2)
+    out["full_matrix_one_gpu"] = {"pairs": N * N, "ms": ms_full, "pairs_per_s": N * N / ms_full * 1e3,
+                                  "u16_GBs": N * N * 2 / ms_full * 1e3 / 1e9,
+                                  "self_pairs_share_all_hashes": bool((counts.diagonal() == s).all())}
+    return out
 
 
 def rotation(dev, n: int = 100_000, L: int = 5000):

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                                                                const uint32_t *__restrict__ hdr,
                                                                const uint32_t *__restrict__ rows, uint64_t ny,
                                                                uint32_t stripe_dwords, uint32_t id_bits,
-                                                               uint16_t *__restrict__ counts, uint64_t ld, int abl)
+                                                               uint16_t *__restrict__ counts, uint64_t ld)
 {
     if (hdr[H_MODE] != MODE_SPARSE)
         return;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
             __syncthreads();
             auto consume = [&](const uint2 it, uint32_t v, uint32_t a) {
-                if (it.x != v || (it.y >> id_bits) >= a || (abl & 2)) // (0, 0xFFFFFFFF) = no item: occurrence number all ones
+                if (it.x != v || (it.y >> id_bits) >= a) // (0, 0xFFFFFFFF) = no item: occurrence number all ones
                     return;
                 uint32_t col = it.y & id_mask;
                 if (!one_stripe) {
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             };
             // a wave takes DENSE_U distinct values at a time: the first 128 items of each bucket are loaded back to
             // back (a family's copies of one hash are one bucket), then consumed
-            for (uint32_t d0 = wave * DENSE_U; d0 < ((abl & 4) ? 0u : nd); d0 += (DENSE_THREADS / 64) * DENSE_U) {
+            for (uint32_t d0 = wave * DENSE_U; d0 < nd; d0 += (DENSE_THREADS / 64) * DENSE_U) {
                 uint2 it[DENSE_U][2];
 #pragma unroll
                 for (int u = 0; u < DENSE_U; ++u) {
@@ -592,8 +592,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             }
             __syncthreads();
             uint16_t *crow = counts + i * ld + c0;
-            if (abl & 1) {
-            } else if ((((uintptr_t)crow) & 3) == 0) { // two columns per 4-byte store
+            if ((((uintptr_t)crow) & 3) == 0) { // two columns per 4-byte store
                 for (uint32_t t = tid; 2 * t < ncols; t += DENSE_THREADS) {
                     const uint32_t c = 2 * t, dw0 = PER == 3 ? (__umulhi(c, 0xAAAAAAABu) >> 1) : t;
                     const uint32_t k0 = c - dw0 * PER;
@@ -806,7 +805,6 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     const uint32_t stripe_dwords = row_bytes + 4096 <= lds_max ? (uint32_t)(((lds_max - row_bytes) / 4) & ~(size_t)3) : 0u;
     const uint64_t stripe_cols = (uint64_t)stripe_dwords * per;
     const uint64_t stripes = stripe_cols ? (ny + stripe_cols - 1) / stripe_cols : ~0ull;
-    const int abl = getenv("POLYHIP_K2_ABL") ? atoi(getenv("POLYHIP_K2_ABL")) : 0;
     auto launch_dense = [&](const uint32_t *rows, unsigned blocks) -> int {
         const uint32_t sdw = (uint32_t)std::min<uint64_t>(stripe_dwords, (((ny + per - 1) / per) + 3) & ~3ull);
         const size_t smem = row_bytes + (size_t)sdw * 4;
@@ -814,12 +812,12 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<10>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k2::rowjoin_dense_kernel<10>, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX,
-                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld, abl);
+                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);
         } else {
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k2::rowjoin_dense_kernel<16>, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX,
-                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld, abl);
+                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);
         }
         return POLYHIP_OK;
     };
