@@ -191,17 +191,44 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *__rest
     }
 }
 
-// newlines per PER_BLOCK bytes
-__global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
-                                                                uint32_t *__restrict__ counts)
+// ---- newline compaction, 16 bytes per lane ---------------------------------------------------------
+// A workgroup takes one 4096-byte window of the file's 16-byte-ALIGNED address space (the file itself may start
+// anywhere: `mis` = its offset inside the first window); every lane loads one uint4 and turns it into a 16-bit
+// mask of the bytes that are '\n' and lie inside the file.
+__device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) // bit 7 of every byte of x that is 0x00 (exact)
+{
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+__device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ abase, uint64_t chunk, uint32_t mis,
+                                                   uint64_t nbytes)
+{
+    // chunk = index of the aligned 16-byte chunk; file-relative position of its first byte = chunk * 16 - mis
+    const int64_t p0 = (int64_t)(chunk * 16) - (int64_t)mis;
+    if (p0 >= (int64_t)nbytes || p0 + 16 <= 0)
+        return 0u;
+    const uint4 v = *reinterpret_cast<const uint4 *>(abase + chunk * 16);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t f = zero_byte_flags(w[q] ^ 0x0A0A0A0Au); // 0x80 per newline byte
+        // gather the four flag bits into a nibble: bit 7 -> 0, 15 -> 1, 23 -> 2, 31 -> 3
+        m |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * q);
+    }
+    if (p0 < 0)
+        m &= 0xFFFFu << (uint32_t)(-p0);
+    if (p0 + 16 > (int64_t)nbytes)
+        m &= 0xFFFFu >> (uint32_t)(p0 + 16 - (int64_t)nbytes);
+    return m;
+}
+
+// newlines per 4096-byte window
+__global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ abase, uint32_t mis,
+                                                                uint64_t nbytes, uint32_t *__restrict__ counts)
 {
     __shared__ uint32_t ws[THREADS / 64];
-    const uint64_t base = (uint64_t)blockIdx.x * PER_BLOCK;
-    uint32_t c = 0;
-    for (uint32_t i = threadIdx.x; i < PER_BLOCK; i += THREADS) {
-        const uint64_t p = base + i;
-        c += (p < nbytes && file[p] == '\n') ? 1u : 0u;
-    }
+    uint32_t c = (uint32_t)__popc(newline_mask16(abase, (uint64_t)blockIdx.x * THREADS + threadIdx.x, mis, nbytes));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         c += (uint32_t)__shfl_xor((int)c, d, 64);
@@ -212,37 +239,61 @@ __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *
         counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// line_end[k] = position of the k-th '\n'
-__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
-                                                                const uint64_t *__restrict__ block_off,
+// line_end[k] = file-relative position of the k-th '\n'
+__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const uint8_t *__restrict__ abase, uint32_t mis,
+                                                                uint64_t nbytes, const uint64_t *__restrict__ block_off,
                                                                 uint64_t *__restrict__ line_end)
 {
-    __shared__ uint32_t wbase[THREADS / 64];
-    __shared__ uint32_t run;
-    const uint64_t base = (uint64_t)blockIdx.x * PER_BLOCK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0)
-        run = 0;
-    __syncthreads();
-    for (uint32_t i0 = 0; i0 < PER_BLOCK; i0 += THREADS) {
-        const uint64_t p = base + i0 + threadIdx.x;
-        const bool nl = p < nbytes && file[p] == '\n';
-        const uint64_t m = __ballot(nl);
-        if (lane == 0)
-            wbase[wave] = (uint32_t)__popcll(m);
-        __syncthreads();
-        uint32_t pre = run;
-        for (int w = 0; w < wave; ++w)
-            pre += wbase[w];
-        if (nl) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            line_end[block_off[blockIdx.x] + pre + rank] = p;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            run += wbase[0] + wbase[1] + wbase[2] + wbase[3];
-        __syncthreads();
+    __shared__ uint32_t ws[THREADS / 64];
+    const uint64_t chunk = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    uint32_t m = newline_mask16(abase, chunk, mis, nbytes);
+    const uint32_t c = (uint32_t)__popc(m);
+    uint32_t incl = c; // inclusive scan over the wave, then over the 4 waves
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+        if ((threadIdx.x & 63) >= d)
+            incl += t;
     }
+    if ((threadIdx.x & 63) == 63)
+        ws[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint64_t at = block_off[blockIdx.x] + incl - c;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w)
+        at += ws[w];
+    const int64_t p0 = (int64_t)(chunk * 16) - (int64_t)mis;
+    while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1u;
+        line_end[at++] = (uint64_t)(p0 + k);
+    }
+}
+
+// `G` consecutive lanes (this lane is number `gl` of its group) copy len bytes from src to dst, both in global memory
+// and of any alignment: whole destination dwords funnelled out of two source dwords, bytes only at the two ends
+template <int G>
+__device__ __forceinline__ void group_copy(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, uint64_t len, int gl)
+{
+    const uint32_t head = (uint32_t)min(len, (uint64_t)((4u - (uint32_t)((uintptr_t)dst & 3u)) & 3u));
+    if ((uint32_t)gl < head)
+        dst[gl] = src[gl];
+    dst += head;
+    src += head;
+    len -= head;
+    const uint64_t ndw = len >> 2;
+    const uint32_t sh = (uint32_t)((uintptr_t)src & 3u);
+    const uint32_t *__restrict__ s4 = reinterpret_cast<const uint32_t *>(src - sh);
+    uint32_t *__restrict__ d4 = reinterpret_cast<uint32_t *>(dst);
+    if (sh == 0) {
+        for (uint64_t w = gl; w < ndw; w += G)
+            d4[w] = s4[w];
+    } else {
+        for (uint64_t w = gl; w < ndw; w += G)
+            d4[w] = __builtin_amdgcn_alignbyte(s4[w + 1], s4[w], sh); // s4[w + 1] holds a byte of the source: in bounds
+    }
+    const uint32_t tail = (uint32_t)(len & 3u);
+    if ((uint32_t)gl < tail)
+        dst[4 * ndw + gl] = src[4 * ndw + gl];
 }
 
 // identifier-line checks of fastq.go:155-167: 0, or 5 (empty line), 6 (field without '=')
@@ -276,9 +327,7 @@ __global__ __launch_bounds__(THREADS) void records_kernel(const uint8_t *__restr
                                                          unsigned long long *__restrict__ res)
 {
     const uint64_t nrec = *nlines_dev / 4; // complete 4-line records
-    const uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (r >= nrec)
-        return;
+    for (uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x; r < nrec; r += (uint64_t)gridDim.x * THREADS) {
     const uint64_t l0 = r == 0 ? 0 : line_end[4 * r - 1] + 1;
     const uint64_t e0 = line_end[4 * r], e1 = line_end[4 * r + 1], e2 = line_end[4 * r + 2], e3 = line_end[4 * r + 3];
     uint32_t code = header_panics(file, l0, e0);
@@ -294,6 +343,7 @@ __global__ __launch_bounds__(THREADS) void records_kernel(const uint8_t *__restr
         rec_start[r] = l0;
     if (code) // the first bad record wins; (record << 8 | code) orders by record
         atomicMin(&res[R_FIRSTBAD], (unsigned long long)((r << 8) | code));
+    }
 }
 
 // n_records, error code / line, and the trailing partial record
@@ -341,7 +391,7 @@ __global__ void finish_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
     res[R_NLINES] = nlines;
 }
 
-// one workgroup per record (grid-stride): sequence bytes -> packed buffer
+// one wave per record (grid-stride): sequence bytes -> packed buffer, whole dwords
 __global__ __launch_bounds__(THREADS) void gather_kernel(const uint8_t *__restrict__ file,
                                                         const uint64_t *__restrict__ seq_start,
                                                         const uint64_t *__restrict__ offsets,
@@ -349,10 +399,11 @@ __global__ __launch_bounds__(THREADS) void gather_kernel(const uint8_t *__restri
                                                         uint8_t *__restrict__ seqs)
 {
     const uint64_t n = res[R_NREC];
-    for (uint64_t r = blockIdx.x; r < n; r += gridDim.x) {
-        const uint64_t src = seq_start[r], dst = offsets[r], len = offsets[r + 1] - dst;
-        for (uint64_t t = threadIdx.x; t < len; t += THREADS)
-            seqs[dst + t] = file[src + t];
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * THREADS + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (THREADS / 64);
+    for (uint64_t r = wave; r < n; r += nwaves) {
+        const uint64_t dst = offsets[r];
+        group_copy<64>(seqs + dst, file + seq_start[r], offsets[r + 1] - dst, lane);
     }
 }
 
@@ -367,9 +418,7 @@ __global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *
                                                                 uint32_t *__restrict__ seq_len)
 {
     const uint64_t nl = *nlines_dev;
-    const uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (k >= nl)
-        return;
+    for (uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x; k < nl; k += (uint64_t)gridDim.x * THREADS) {
     const uint64_t start = k == 0 ? 0 : line_end[k - 1] + 1;
     const uint64_t len = line_end[k] - start;
     const uint8_t b = len ? file[start] : 0;
@@ -390,6 +439,7 @@ __global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *
     const bool skippable = len == 0 || b == ';';
     is_header[k] = header ? 1u : 0u;
     seq_len[k] = (!header && !skippable) ? (uint32_t)len : 0u;
+    }
 }
 
 // lines before the first header carry no sequence
@@ -397,9 +447,10 @@ __global__ __launch_bounds__(THREADS) void fasta_prefix_kernel(const uint64_t *_
                                                               const uint64_t *__restrict__ hrank,
                                                               uint32_t *__restrict__ seq_len)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (k < *nlines_dev && hrank[k] == 0 && seq_len[k]) // hrank = headers strictly before line k
-        seq_len[k] = 0;
+    const uint64_t nl = *nlines_dev;
+    for (uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x; k < nl; k += (uint64_t)gridDim.x * THREADS)
+        if (hrank[k] == 0 && seq_len[k]) // hrank = headers strictly before line k
+            seq_len[k] = 0;
 }
 
 // offsets[r] = sequence bytes before record r's header; first record without sequence
@@ -412,16 +463,15 @@ __global__ __launch_bounds__(THREADS) void fasta_offsets_kernel(const uint64_t *
                                                                uint64_t *__restrict__ rec_start)
 {
     const uint64_t nl = *nlines_dev;
-    const uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (k >= nl)
-        return;
-    if (is_header[k]) {
-        offsets[hrank[k]] = dst[k];
-        if (rec_start)
-            rec_start[hrank[k]] = k == 0 ? 0 : line_end[k - 1] + 1;
+    for (uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x; k < nl; k += (uint64_t)gridDim.x * THREADS) {
+        if (is_header[k]) {
+            offsets[hrank[k]] = dst[k];
+            if (rec_start)
+                rec_start[hrank[k]] = k == 0 ? 0 : line_end[k - 1] + 1;
+        }
+        if (k == nl - 1)
+            offsets[hrank[nl]] = dst[nl]; // hrank[nl] = number of headers, dst[nl] = all sequence bytes
     }
-    if (k == nl - 1)
-        offsets[hrank[nl]] = dst[nl]; // hrank[nl] = number of headers, dst[nl] = all sequence bytes
 }
 
 __global__ __launch_bounds__(THREADS) void fasta_empty_kernel(const uint64_t *__restrict__ hrank,
@@ -430,9 +480,9 @@ __global__ __launch_bounds__(THREADS) void fasta_empty_kernel(const uint64_t *__
                                                              unsigned long long *__restrict__ res)
 {
     const uint64_t H = hrank[*nlines_dev];
-    const uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (r < H && offsets[r + 1] == offsets[r])
-        atomicMin(&res[F_FIRSTEMPTY], (unsigned long long)r);
+    for (uint64_t r = (uint64_t)blockIdx.x * THREADS + threadIdx.x; r < H; r += (uint64_t)gridDim.x * THREADS)
+        if (offsets[r + 1] == offsets[r])
+            atomicMin(&res[F_FIRSTEMPTY], (unsigned long long)r);
 }
 
 __global__ void fasta_finish_kernel(const uint8_t *__restrict__ file, uint64_t nbytes,
@@ -491,7 +541,7 @@ __global__ void fasta_finish_kernel(const uint8_t *__restrict__ file, uint64_t n
     res[F_NHEADERS] = H;
 }
 
-// one workgroup per line (grid-stride): sequence lines of the kept records -> packed buffer
+// 16 lanes per line (grid-stride): sequence lines of the kept records -> packed buffer, whole dwords
 __global__ __launch_bounds__(THREADS) void fasta_gather_kernel(const uint8_t *__restrict__ file,
                                                               const uint64_t *__restrict__ line_end,
                                                               const uint64_t *__restrict__ nlines_dev,
@@ -500,21 +550,22 @@ __global__ __launch_bounds__(THREADS) void fasta_gather_kernel(const uint8_t *__
                                                               const unsigned long long *__restrict__ res,
                                                               uint8_t *__restrict__ seqs)
 {
+    constexpr int G = 16;
     const uint64_t nl = *nlines_dev;
     const uint64_t total = res[F_SEQBYTES];
-    for (uint64_t k = blockIdx.x; k < nl; k += gridDim.x) {
+    const int gl = threadIdx.x & (G - 1);
+    const uint64_t group = ((uint64_t)blockIdx.x * THREADS + threadIdx.x) / G, ngroups = (uint64_t)gridDim.x * (THREADS / G);
+    for (uint64_t k = group; k < nl; k += ngroups) {
         const uint64_t len = seq_len[k], d = dst[k];
         if (len == 0 || d >= total)
             continue;
-        const uint64_t src = k == 0 ? 0 : line_end[k - 1] + 1;
-        for (uint64_t t = threadIdx.x; t < len; t += THREADS)
-            seqs[d + t] = file[src + t];
+        group_copy<G>(seqs + d, file + (k == 0 ? 0 : line_end[k - 1] + 1), len, gl);
     }
 }
 
 struct Layout {
     uint64_t nblocks, max_lines;
-    size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, total;
+    size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, off_scanpart, total;
     size_t off_ishdr, off_hrank, off_dst; // FASTA (per line)
 };
 
@@ -523,12 +574,11 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static Layout layout(uint64_t nbytes)
 {
     Layout L;
-    L.nblocks = (nbytes + PER_BLOCK - 1) / PER_BLOCK;
-    if (L.nblocks == 0)
-        L.nblocks = 1;
+    L.nblocks = (nbytes + PER_BLOCK - 1) / PER_BLOCK + 1; // + 1: the file may start anywhere inside its first window
     L.max_lines = nbytes; // every byte a newline
     size_t o = 0;
     L.off_res = o; o += al(R_WORDS * 8);
+    L.off_scanpart = o; o += al(SCAN_SEGS * 8);
     L.off_counts = o; o += al(L.nblocks * 4);
     L.off_blockoff = o; o += al((L.nblocks + 1) * 8);
     L.off_lineend = o; o += al((L.max_lines + 1) * 8);
@@ -559,20 +609,17 @@ static Layout layout_fasta(uint64_t nbytes)
 using namespace polyhip;
 
 // exclusive scan of `in` (n = n_host, or *n_dev / div) into out[0..n]; `upper` bounds n on the host: long
-// inputs go through SCAN_SEGS workgroups (its partial sums live in a stream-ordered scratch allocation)
+// inputs go through SCAN_SEGS workgroups, whose partial sums live in `partial` (SCAN_SEGS words of the workspace)
 static int scan_u32(const uint32_t *in, uint64_t n_host, const uint64_t *n_dev, uint64_t div, uint64_t upper,
-                    uint64_t *out, hipStream_t st, uint64_t cap = ~0ull)
+                    uint64_t *out, uint64_t *partial, hipStream_t st, uint64_t cap = ~0ull)
 {
-    if (upper <= 262144) {
+    if (upper <= 32768) {
         hipLaunchKernelGGL(fq::scan_u32_kernel, dim3(1), dim3(1024), 0, st, in, n_host, n_dev, div, out, cap);
         return POLYHIP_OK;
     }
-    uint64_t *partial = nullptr;
-    PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&partial), fq::SCAN_SEGS * sizeof(uint64_t), st));
     hipLaunchKernelGGL(fq::scan_sums_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial);
     hipLaunchKernelGGL(fq::scan_offsets_kernel, dim3(1), dim3(fq::SCAN_SEGS), 0, st, partial, n_host, n_dev, div, out, cap);
     hipLaunchKernelGGL(fq::scan_apply_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, in, n_host, n_dev, div, partial, out, cap);
-    PH_HIP(hipFreeAsync(partial, st));
     return POLYHIP_OK;
 }
 
@@ -592,6 +639,7 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     hipStream_t st = as_stream(stream);
     uint8_t *w = static_cast<uint8_t *>(d_work);
     unsigned long long *res = reinterpret_cast<unsigned long long *>(w + L.off_res);
+    uint64_t *scanpart = reinterpret_cast<uint64_t *>(w + L.off_scanpart);
     uint32_t *counts = reinterpret_cast<uint32_t *>(w + L.off_counts);
     uint64_t *blockoff = reinterpret_cast<uint64_t *>(w + L.off_blockoff);
     uint64_t *line_end = reinterpret_cast<uint64_t *>(w + L.off_lineend);
@@ -600,19 +648,21 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
 
     PH_HIP(hipMemsetAsync(res, 0, fq::R_WORDS * 8, st));
     PH_HIP(hipMemsetAsync(res + fq::R_FIRSTBAD, 0xFF, 8, st));
-    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes, counts);
-    if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, st))
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
+    const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
+    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts);
+    if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
-    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
+    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes,
                        blockoff, line_end);
     // The line count exists only on the device (blockoff[nblocks]); the record kernels are launched for
     // the most records the file could hold and read the real count there.  The shortest record is 7 bytes: the
     // reference reads the third line without looking at it (fastq.go:182), so "@\nA\n\nI\n" parses.
     const uint64_t *nlines_dev = blockoff + L.nblocks;
     const uint64_t most = nbytes / 7 + 1;
-    hipLaunchKernelGGL(fq::records_kernel, dim3((unsigned)((most + fq::THREADS - 1) / fq::THREADS)), dim3(fq::THREADS), 0, st,
+    hipLaunchKernelGGL(fq::records_kernel, dim3((unsigned)std::min<uint64_t>((most + fq::THREADS - 1) / fq::THREADS, 256ull * 16ull)), dim3(fq::THREADS), 0, st,
                        d_file, line_end, nlines_dev, seq_len, seq_start, d_rec_start, max_records, res);
-    if (int rc = scan_u32(seq_len, 0, nlines_dev, 4, most, d_offsets, st, max_records))
+    if (int rc = scan_u32(seq_len, 0, nlines_dev, 4, most, d_offsets, scanpart, st, max_records))
         return rc;
     hipLaunchKernelGGL(fq::finish_kernel, dim3(1), dim3(1), 0, st, d_file, nbytes, line_end, nlines_dev, d_offsets,
                        max_records, res);
@@ -668,6 +718,7 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     hipStream_t st = as_stream(stream);
     uint8_t *w = static_cast<uint8_t *>(d_work);
     unsigned long long *res = reinterpret_cast<unsigned long long *>(w + L.off_res);
+    uint64_t *scanpart = reinterpret_cast<uint64_t *>(w + L.off_scanpart);
     uint32_t *counts = reinterpret_cast<uint32_t *>(w + L.off_counts);
     uint64_t *blockoff = reinterpret_cast<uint64_t *>(w + L.off_blockoff);
     uint64_t *line_end = reinterpret_cast<uint64_t *>(w + L.off_lineend);
@@ -680,19 +731,22 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(res + fq::F_FIRSTEMPTY, 0xFF, 8, st));
     PH_HIP(hipMemsetAsync(hrank, 0, 16, st));
     PH_HIP(hipMemsetAsync(dst, 0, 16, st));
-    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes, counts);
-    if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, st))
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
+    const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
+    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts);
+    if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
-    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, d_file, nbytes,
+    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes,
                        blockoff, line_end);
     const uint64_t *nlines_dev = blockoff + L.nblocks; // the line count exists only on the device
-    const unsigned gl = (unsigned)((nbytes + fq::THREADS - 1) / fq::THREADS + 1); // >= lines
+    // per-line kernels: as many workgroups as keep the chip busy, each striding over the lines (their count exists only on the device)
+    const unsigned gl = (unsigned)std::min<uint64_t>((nbytes + fq::THREADS - 1) / fq::THREADS + 1, 256ull * 16ull);
     hipLaunchKernelGGL(fq::fasta_classify_kernel, dim3(gl), dim3(fq::THREADS), 0, st, d_file, line_end, nlines_dev, is_header,
                        seq_len);
-    if (int rc = scan_u32(is_header, 0, nlines_dev, 1, nbytes + 1, hrank, st))
+    if (int rc = scan_u32(is_header, 0, nlines_dev, 1, nbytes + 1, hrank, scanpart, st))
         return rc;
     hipLaunchKernelGGL(fq::fasta_prefix_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, hrank, seq_len);
-    if (int rc = scan_u32(seq_len, 0, nlines_dev, 1, nbytes + 1, dst, st))
+    if (int rc = scan_u32(seq_len, 0, nlines_dev, 1, nbytes + 1, dst, scanpart, st))
         return rc;
     hipLaunchKernelGGL(fq::fasta_offsets_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, is_header, hrank, dst, line_end,
                        d_offsets, d_rec_start);

@@ -85,3 +85,37 @@ def test_large_file_goes_through_the_multi_workgroup_scan():
     assert len(data) > 600_000
     _check(data)
     _check(data[:-1])      # EOF right behind the last sequence line
+
+
+def test_device_image_at_any_alignment():
+    """the packers read the file 16 bytes per lane and copy whole dwords: an image that starts at any byte offset of
+    a device buffer, with ragged line widths (every source / destination alignment in the gather), parses the same"""
+    import torch
+    from poly_amd import fasta
+    rng = np.random.default_rng(41)
+    parts = []
+    for i in range(3000):
+        L = int(rng.integers(1, 400))
+        body = bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+        w = int(rng.integers(1, 90))
+        parts.append(b">r%d\n" % i + b"\n".join(body[j:j + w] for j in range(0, L, w)) + b"\n")
+    data = b"".join(parts)
+    want, code = fr.parse_all(data)
+    assert code == 0
+    wbuf = b"".join(w[1] for w in want)
+    dev = torch.device("cuda:0")
+    for shift in (0, 1, 3, 4, 7, 8, 13, 15):
+        big = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+        img = big[shift:shift + len(data)]
+        img.copy_(torch.from_numpy(np.frombuffer(data, np.uint8).copy()))
+        nb = img.numel()
+        seqs = torch.zeros(nb + 3, dtype=torch.uint8, device=dev)[3 - (shift % 4):][:nb]   # the output misaligned too
+        offs = torch.zeros(nb // 2 + 4, dtype=torch.int64, device=dev)
+        res = torch.zeros(4, dtype=torch.int64, device=dev)
+        work = torch.empty(fasta.workspace_bytes(nb), dtype=torch.uint8, device=dev)
+        fasta.pack_dev(img, seqs, offs, None, res, work)
+        n, c, total, _ = (int(x) for x in res.cpu())
+        assert (n, c, total) == (len(want), 0, len(wbuf)), shift
+        assert seqs[:total].cpu().numpy().tobytes() == wbuf, shift
+        o = offs[:n + 1].cpu().numpy()
+        assert (np.diff(o) == [len(w[1]) for w in want]).all(), shift

@@ -142,3 +142,29 @@ def test_large_file_goes_through_the_multi_workgroup_scan():
     assert len(good) > 2_200_000
     _check(good)
     _check(good[:1_500_000] + b"@r\nACGT\n+\n\n" + good[1_500_000:])
+
+
+def test_device_image_at_any_alignment():
+    """the image may start at any byte of a device buffer (16-byte loads on the aligned address space, the bytes in
+    front masked out) and the packed sequences may land at any alignment (dword copies with byte ends)"""
+    import torch
+    from poly_amd import fastq
+    rng = np.random.default_rng(42)
+    data = b"".join(_record(rng, i, int(rng.integers(1, 300))) for i in range(4000))
+    want, code, _ = fr.parse_all(data)
+    assert code == 0
+    wbuf = b"".join(w[1] for w in want)
+    dev = torch.device("cuda:0")
+    for shift in (0, 1, 2, 5, 8, 11, 15):
+        big = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+        img = big[shift:shift + len(data)]
+        img.copy_(torch.from_numpy(np.frombuffer(data, np.uint8).copy()))
+        nb = img.numel()
+        seqs = torch.zeros(nb + 3, dtype=torch.uint8, device=dev)[(shift + 1) % 4:][:nb]
+        offs = torch.zeros(nb // 7 + 2, dtype=torch.int64, device=dev)
+        res = torch.zeros(4, dtype=torch.int64, device=dev)
+        work = torch.empty(fastq.workspace_bytes(nb), dtype=torch.uint8, device=dev)
+        fastq.pack_dev(img, seqs, offs, None, res, work)
+        n, c, _, total = (int(x) for x in res.cpu())
+        assert (n, c, total) == (len(want), 0, len(wbuf)), shift
+        assert seqs[:total].cpu().numpy().tobytes() == wbuf, shift
