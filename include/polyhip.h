@@ -328,6 +328,26 @@ int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin,
                             uint32_t Lmax, double primer_conc,
                             double salt_conc, double mg_conc, double *tm,
                             double *dH, double *dS);
+/*
+ * SCAN, reduced on the chip: for every start the FIRST length L in [Lmin, Lmax] whose SantaLucia Tm is not below
+ * target_tm -- the grow loop of primers/pcr (pcr.go:47-53: lengthen the primer while MeltingTemp < targetTm; the
+ * same comparison, so a NaN Tm stops it too) for every position of a sequence at once.  d_first_len[i - start0] = that L
+ * (0: no length up to Lmax reaches the target, or no window fits), d_first_tm (may be NULL) its Tm (a NaN where no
+ * length was found).  2 + 8 bytes per start leave the chip instead of 24 per window: the host flavour of the
+ * full scan is bound by PCIe (1.56 GB for a 5 Mb genome), this one is not.
+ */
+int polyhip_santalucia_scan_first_dev(const uint8_t *d_seq, uint64_t len,
+                                      uint64_t start0, uint64_t nstarts,
+                                      uint32_t Lmin, uint32_t Lmax,
+                                      double primer_conc, double salt_conc,
+                                      double mg_conc, double target_tm,
+                                      uint16_t *d_first_len, double *d_first_tm,
+                                      polyhip_stream_t stream);
+int polyhip_santalucia_scan_first(const uint8_t *seq, uint64_t len, uint32_t Lmin,
+                                  uint32_t Lmax, double primer_conc,
+                                  double salt_conc, double mg_conc,
+                                  double target_tm, uint16_t *first_len,
+                                  double *first_tm);
 /* BATCH: one SantaLucia call per packed sequence.  An empty sequence is
  * POLYHIP_ERR_PANIC in the host flavour (quiet NaN outputs in the _dev one). */
 int polyhip_santalucia_batch_dev(const uint8_t *d_seqs,

@@ -64,6 +64,8 @@ SIGNATURES = {
     "polyhip_santalucia_scan_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp,
                                               _u64, _vp]),
     "polyhip_santalucia_scan": (C.c_int, [_vp, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    "polyhip_santalucia_scan_first_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
+    "polyhip_santalucia_scan_first": (C.c_int, [_vp, _u64, _u32, _u32, _dbl, _dbl, _dbl, _dbl, _vp, _vp]),
     "polyhip_santalucia_batch_dev": (C.c_int, [_vp, _vp, _u64, _dbl, _dbl, _dbl, _vp, _vp, _vp, _vp]),
     "polyhip_santalucia_batch": (C.c_int, [_vp, _vp, _u64, _dbl, _dbl, _dbl, _vp, _vp, _vp]),
     "polyhip_marmurdoty_batch_dev": (C.c_int, [_vp, _vp, _u64, _vp, _vp]),

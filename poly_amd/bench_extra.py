@@ -309,16 +309,48 @@ def e2e(dev) -> dict:
     ms = _wall(lambda: align.sw_batch_packed(sc, hA, offA, hB, None), 5, 1)
     out["smith_waterman"] = {"workload": f"polyhip_sw_batch, {n} x {LA} bp reads vs one {LB} bp reference, host pointers",
                              "cell_updates_per_s": n * LA * LB / ms * 1e3, "ms": ms}
-    # K4: configs[4], 5 Mb genome in, three fp64 planes (1.56 GB) out
+    import ctypes as C
+    from . import _lib
+    L_ = _lib.lib()
+    stride = align.sw_traceback_stride(sc, LA, LB)
+    o_score, o_len = np.zeros(n, np.int64), np.zeros(n, np.uint32)
+    o_ea, o_eb, o_er = (np.zeros(n, np.uint32) for _ in range(3))
+    o_alnA, o_alnB = (np.zeros((n, stride), np.uint8) for _ in range(2))
+
+    def sw_strings():
+        _lib.check(L_.polyhip_sw_align_batch(sc.handle(), hA.ctypes.data, offA.ctypes.data, n, hB.ctypes.data, None, LB,
+                                             o_score.ctypes.data, o_ea.ctypes.data, o_eb.ctypes.data, o_er.ctypes.data,
+                                             o_alnA.ctypes.data, o_alnB.ctypes.data, o_len.ctypes.data, stride))
+    ms = _wall(sw_strings, 3, 1)
+    out["smith_waterman_with_strings"] = {
+        "workload": f"polyhip_sw_align_batch, {n} x {LA} bp reads vs one {LB} bp reference, host pointers, aligned strings in "
+                    f"{stride}-byte slots (2 x {n * stride / 1e6:.0f} MB cross PCIe into existing pageable buffers)",
+        "cell_updates_per_s": n * LA * LB / ms * 1e3, "ms": ms, "mean_alignment_len": float(o_len.mean())}
+    del o_alnA, o_alnB
+    # K4: configs[4], 5 Mb genome in, three fp64 planes (1.56 GB) out into buffers that already exist (a caller that
+    # scans more than one genome reuses them; fresh numpy / Go memory adds ~0.1 s of first-touch page faults)
     g = torch.empty(5_000_000, dtype=torch.uint8, device=dev)
     mash.synth_dna_dev(0xC5, g)
     hg = g.cpu().numpy()
     del g
-    win = sum(len(hg) - L + 1 for L in range(18, 31))
-    ms = _wall(lambda: primers.SantaLuciaScan(hg, 18, 30), 3, 1)
-    out["santalucia_scan"] = {"workload": "polyhip_santalucia_scan, 5,000,000 B genome, 18..30-mers, host pointers "
-                                          "(includes allocating the 1.56 GB of numpy result planes)",
+    n = len(hg)
+    ns = n - 18 + 1
+    win = sum(n - L + 1 for L in range(18, 31))
+    planes = [np.zeros((13, ns), dtype=np.float64) for _ in range(3)]
+
+    def scan():
+        _lib.check(L_.polyhip_santalucia_scan(hg.ctypes.data, n, 18, 30, 500e-9, 50e-3, 0.0, *(p.ctypes.data for p in planes)))
+    ms = _wall(scan, 5, 2)
+    out["santalucia_scan"] = {"workload": "polyhip_santalucia_scan, 5,000,000 B genome, 18..30-mers, host pointers, "
+                                          "three fp64 planes (1.56 GB) into existing pageable buffers",
                               "windows_per_s": win / ms * 1e3, "ms": ms, "pcie_GBs": win * 24 / ms * 1e3 / 1e9}
+    ms = _wall(lambda: primers.SantaLuciaScan(hg, 18, 30), 3, 1)
+    out["santalucia_scan"]["ms_with_fresh_result_arrays"] = ms
+    del planes
+    ms = _wall(lambda: primers.SantaLuciaScanFirst(hg, 18, 30, 60.0), 5, 2)
+    out["santalucia_scan_first"] = {"workload": "polyhip_santalucia_scan_first, same genome: first length with Tm >= 60 C per start "
+                                                "(the pcr grow loop, reduced on the chip: 10 B per start cross PCIe)",
+                                    "windows_per_s_equivalent": win / ms * 1e3, "starts_per_s": ns / ms * 1e3, "ms": ms}
     return out
 
 

@@ -141,7 +141,8 @@ template <int LMIN_CT, int LMAX_CT>
 __global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict__ seq, uint64_t len, uint64_t start0,
                                                       uint64_t nstarts, uint32_t Lmin_rt, uint32_t nl_rt, Consts cst,
                                                       double *__restrict__ tm, double *__restrict__ dHo,
-                                                      double *__restrict__ dSo, uint64_t ld)
+                                                      double *__restrict__ dSo, uint64_t ld, double target,
+                                                      uint16_t *__restrict__ firstL, double *__restrict__ firstTm)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t Lmin = LMIN_CT > 0 ? (uint32_t)LMIN_CT : Lmin_rt;
@@ -233,6 +234,30 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict
         }
     }
 
+    if (firstL) {
+        // the grow loop of primers/pcr (pcr.go:47-53: lengthen the primer while MeltingTemp < targetTm) as a reduction:
+        // only the first length that is no longer below the target leaves the chip, 2 + 8 bytes per start instead of
+        // 24 per window.  Lengths are scanned in ascending order, also across the launches of a long range.
+        if (firstL[col] != 0)
+            return;
+        bool found = false;
+#pragma unroll
+        for (int l = 0; l < NL_MAX; ++l) {
+            if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
+                break;
+            const uint32_t L = Lmin + l;
+            if (!found && (uint32_t)l < nl && g + L <= len) {
+                const double t = melting(aH[l], aS[l], sym[l] ? cst.rlog_sym : cst.rlog_non);
+                if (!(t < target)) {
+                    found = true;
+                    firstL[col] = (uint16_t)L;
+                    if (firstTm)
+                        firstTm[col] = t;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int l = 0; l < NL_MAX; ++l) {
         if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
@@ -338,9 +363,9 @@ using namespace polyhip;
 
 extern "C" {
 
-int polyhip_santalucia_scan_dev(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64_t nstarts, uint32_t Lmin,
-                                uint32_t Lmax, double primer_conc, double salt_conc, double mg_conc, double *d_tm,
-                                double *d_dH, double *d_dS, uint64_t ld, polyhip_stream_t stream)
+static int scan_impl(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64_t nstarts, uint32_t Lmin, uint32_t Lmax,
+                     double primer_conc, double salt_conc, double mg_conc, double *d_tm, double *d_dH, double *d_dS,
+                     uint64_t ld, double target, uint16_t *d_first_len, double *d_first_tm, polyhip_stream_t stream)
 {
     if (Lmin == 0)
         return set_error(POLYHIP_ERR_PANIC, "primers.SantaLucia(\"\") indexes sequence[-1] (primers.go:89): the reference panics");
@@ -349,29 +374,53 @@ int polyhip_santalucia_scan_dev(const uint8_t *d_seq, uint64_t len, uint64_t sta
                k4::LMAX_MAX);
     if (nstarts == 0)
         return POLYHIP_OK;
-    PH_REQUIRE(d_seq && d_tm && d_dH && d_dS, "polyhip_santalucia_scan: null pointer");
-    PH_REQUIRE(ld >= nstarts, "polyhip_santalucia_scan: plane stride %llu < nstarts %llu", (unsigned long long)ld,
+    PH_REQUIRE(d_seq && ((d_tm && d_dH && d_dS) || d_first_len), "polyhip_santalucia_scan: null pointer");
+    PH_REQUIRE(d_first_len || ld >= nstarts, "polyhip_santalucia_scan: plane stride %llu < nstarts %llu", (unsigned long long)ld,
                (unsigned long long)nstarts);
     PH_REQUIRE(start0 <= len && nstarts <= len - start0 + 0, "polyhip_santalucia_scan: starts [%llu, +%llu) outside the sequence",
                (unsigned long long)start0, (unsigned long long)nstarts);
     hipStream_t st = as_stream(stream);
     const uint64_t blocks = (nstarts + k4::THREADS - 1) / k4::THREADS;
     PH_REQUIRE(blocks < (1ull << 31), "polyhip_santalucia_scan: too many starts for one call");
+    if (d_first_len)
+        PH_HIP(hipMemsetAsync(d_first_len, 0, nstarts * sizeof(uint16_t), st)); // 0 = no length reaches the target
+    if (d_first_len && d_first_tm)
+        PH_HIP(hipMemsetAsync(d_first_tm, 0xFF, nstarts * sizeof(double), st)); // all ones: a NaN where nothing is found
     for (uint32_t L0 = Lmin; L0 <= Lmax; L0 += k4::NL_MAX) {
         const uint32_t nl = Lmax - L0 + 1 < (uint32_t)k4::NL_MAX ? Lmax - L0 + 1 : (uint32_t)k4::NL_MAX;
         const k4::Consts c = k4::make_consts(primer_conc, salt_conc, mg_conc, L0, nl);
-        const uint64_t plane0 = (uint64_t)(L0 - Lmin) * ld;
+        const uint64_t plane0 = d_first_len ? 0 : (uint64_t)(L0 - Lmin) * ld;
         const size_t smem = k4::scan_smem(L0 + nl - 1);
         if (L0 == 18 && nl == 13) {
             hipLaunchKernelGGL((k4::scan_kernel<18, 30>), dim3((unsigned)blocks), dim3(k4::THREADS), smem, st, d_seq,
-                               len, start0, nstarts, L0, nl, c, d_tm + plane0, d_dH + plane0, d_dS + plane0, ld);
+                               len, start0, nstarts, L0, nl, c, d_tm + plane0, d_dH + plane0, d_dS + plane0, ld, target,
+                               d_first_len, d_first_tm);
         } else {
             hipLaunchKernelGGL((k4::scan_kernel<0, 0>), dim3((unsigned)blocks), dim3(k4::THREADS), smem, st, d_seq,
-                               len, start0, nstarts, L0, nl, c, d_tm + plane0, d_dH + plane0, d_dS + plane0, ld);
+                               len, start0, nstarts, L0, nl, c, d_tm + plane0, d_dH + plane0, d_dS + plane0, ld, target,
+                               d_first_len, d_first_tm);
         }
         PH_HIP(hipGetLastError());
     }
     return POLYHIP_OK;
+}
+
+int polyhip_santalucia_scan_dev(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64_t nstarts, uint32_t Lmin,
+                                uint32_t Lmax, double primer_conc, double salt_conc, double mg_conc, double *d_tm,
+                                double *d_dH, double *d_dS, uint64_t ld, polyhip_stream_t stream)
+{
+    PH_REQUIRE(nstarts == 0 || Lmin == 0 || (d_tm && d_dH && d_dS), "polyhip_santalucia_scan: null pointer");
+    return scan_impl(d_seq, len, start0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc, d_tm, d_dH, d_dS, ld, 0.0, nullptr,
+                     nullptr, stream);
+}
+
+int polyhip_santalucia_scan_first_dev(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64_t nstarts, uint32_t Lmin,
+                                      uint32_t Lmax, double primer_conc, double salt_conc, double mg_conc, double target_tm,
+                                      uint16_t *d_first_len, double *d_first_tm, polyhip_stream_t stream)
+{
+    PH_REQUIRE(nstarts == 0 || Lmin == 0 || d_first_len, "polyhip_santalucia_scan_first: null pointer");
+    return scan_impl(d_seq, len, start0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc, nullptr, nullptr, nullptr, 0,
+                     target_tm, d_first_len, d_first_tm, stream);
 }
 
 static int validate_ascii(const uint8_t *p, uint64_t n, const char *who)
@@ -409,9 +458,55 @@ int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uin
     if (rc != POLYHIP_OK)
         return rc;
     PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(tm, dtm.p, nout * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(dH, ddh.p, nout * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(dS, dds.p, nout * 8, hipMemcpyDeviceToHost));
+    // three planes, three streams: one pageable download does not fill the link (a copy engine each does)
+    hipStream_t cs[3] = {nullptr, nullptr, nullptr};
+    void *dstp[3] = {tm, dH, dS};
+    void *srcp[3] = {dtm.p, ddh.p, dds.p};
+    hipError_t e = hipSuccess;
+    for (int q = 0; q < 3 && e == hipSuccess; ++q) {
+        e = hipStreamCreateWithFlags(&cs[q], hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(dstp[q], srcp[q], nout * 8, hipMemcpyDeviceToHost, cs[q]);
+    }
+    for (int q = 0; q < 3; ++q)
+        if (cs[q]) {
+            const hipError_t e2 = hipStreamSynchronize(cs[q]);
+            if (e == hipSuccess)
+                e = e2;
+            (void)hipStreamDestroy(cs[q]);
+        }
+    PH_HIP(e);
+    return POLYHIP_OK;
+}
+
+int polyhip_santalucia_scan_first(const uint8_t *seq, uint64_t len, uint32_t Lmin, uint32_t Lmax, double primer_conc,
+                                  double salt_conc, double mg_conc, double target_tm, uint16_t *first_len, double *first_tm)
+{
+    if (Lmin == 0)
+        return polyhip_santalucia_scan_dev(nullptr, 0, 0, 0, 0, Lmax, primer_conc, salt_conc, mg_conc, nullptr, nullptr,
+                                           nullptr, 0, nullptr);
+    PH_REQUIRE(Lmin <= Lmax, "polyhip_santalucia_scan_first: Lmin %u > Lmax %u", Lmin, Lmax);
+    if (len < Lmin)
+        return POLYHIP_OK; // no window fits
+    PH_REQUIRE(seq && first_len, "polyhip_santalucia_scan_first: null pointer");
+    int rc = validate_ascii(seq, len, "polyhip_santalucia_scan_first");
+    if (rc != POLYHIP_OK)
+        return rc;
+    const uint64_t nstarts = len - Lmin + 1;
+    DevBuf dseq, dlen, dtm;
+    PH_HIP(dseq.alloc(len));
+    PH_HIP(dlen.alloc(nstarts * 2));
+    if (first_tm)
+        PH_HIP(dtm.alloc(nstarts * 8));
+    PH_HIP(hipMemcpy(dseq.p, seq, len, hipMemcpyHostToDevice));
+    rc = polyhip_santalucia_scan_first_dev(dseq.as<uint8_t>(), len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
+                                           target_tm, dlen.as<uint16_t>(), first_tm ? dtm.as<double>() : nullptr, nullptr);
+    if (rc != POLYHIP_OK)
+        return rc;
+    PH_HIP(hipStreamSynchronize(nullptr));
+    PH_HIP(hipMemcpy(first_len, dlen.p, nstarts * 2, hipMemcpyDeviceToHost));
+    if (first_tm)
+        PH_HIP(hipMemcpy(first_tm, dtm.p, nstarts * 8, hipMemcpyDeviceToHost));
     return POLYHIP_OK;
 }
 

@@ -74,6 +74,31 @@ def SantaLuciaScan(genome, minLen: int, maxLen: int, primerConcentration=500e-9,
     return tm, dH, dS
 
 
+def SantaLuciaScanFirst(genome, minLen: int, maxLen: int, targetTm: float, primerConcentration=500e-9,
+                        saltConcentration=50e-3, magnesiumConcentration=0.0):
+    """Additive scan API: for every start of `genome` the first length in [minLen, maxLen] whose SantaLucia Tm is not
+    below targetTm (the grow loop of pcr.go:47-53 at every position) -> (first_len uint16[len - minLen + 1] with 0 =
+    none, first_tm float64, NaN where none).  Only 10 bytes per start cross PCIe."""
+    buf, _ = _pack([genome])
+    n = len(buf)
+    ns = max(0, n - minLen + 1)
+    first_len = np.zeros(ns, dtype=np.uint16)
+    first_tm = np.full(ns, np.nan, dtype=np.float64)
+    _lib.check(_lib.lib().polyhip_santalucia_scan_first(buf.ctypes.data, n, minLen, maxLen, primerConcentration,
+                                                        saltConcentration, magnesiumConcentration, targetTm,
+                                                        first_len.ctypes.data, first_tm.ctypes.data))
+    return first_len, first_tm
+
+
+def santalucia_scan_first_dev(seq_t, length: int, start0: int, nstarts: int, minLen: int, maxLen: int, primer_conc: float,
+                              salt_conc: float, mg_conc: float, target_tm: float, first_len_t, first_tm_t=None, stream=None) -> None:
+    """Device-resident reduced scan on torch CUDA tensors (uint8 genome, int16/uint16 first_len, float64 first_tm)."""
+    assert seq_t.is_cuda and first_len_t.is_cuda and first_len_t.element_size() == 2 and first_len_t.numel() >= nstarts
+    _lib.check(_lib.lib().polyhip_santalucia_scan_first_dev(
+        seq_t.data_ptr(), length, start0, nstarts, minLen, maxLen, primer_conc, salt_conc, mg_conc, target_tm,
+        first_len_t.data_ptr(), first_tm_t.data_ptr() if first_tm_t is not None else None, _lib.stream_ptr(stream)))
+
+
 def santalucia_scan_dev(seq_t, length: int, start0: int, nstarts: int, minLen: int, maxLen: int,
                         primer_conc: float, salt_conc: float, mg_conc: float, tm_t, dH_t, dS_t, ld: int,
                         stream=None) -> None:

@@ -168,3 +168,43 @@ def test_full_size_config5_properties(pr):
         got = (float(tm[o]), float(dh[o]), float(ds[o]))
         assert _bits(got[0]) == _bits(want[0]) and _bits(got[1]) == _bits(want[1]) and _bits(got[2]) == _bits(want[2])
         assert abs(got[0] - want[0]) <= 1e-6  # the north star's tolerance
+
+
+def test_scan_first_is_the_grow_loop_at_every_position(pr):
+    """polyhip_santalucia_scan_first: the first length whose Tm is not below the target, per start -- what the grow loop of
+    primers/pcr (pcr.go:47-53) finds -- equals walking the oracle's full table; the default 18..30 instantiation, a range
+    that needs several launches (15..50), palindromes / non-ACGT letters in the genome, and a shard of the starts"""
+    import torch
+    rng = np.random.default_rng(77)
+    g = bytearray(orc.synth_dna(0xF1, 3000).tobytes())
+    g[100:114] = b"ACGTAGATCTACGT"            # a self-complementary stretch
+    g[500:520] = b"acgtnnryACGTNNNNacgt"      # lower case and letters without nearest-neighbour entries
+    g[1000:1060] = b"AT" * 30                 # low Tm: long primers, some starts never reach the target
+    g = bytes(g)
+    for lo, hi, target in ((18, 30, 55.0), (15, 50, 62.0), (18, 30, 99.0), (7, 12, 20.0)):
+        first_len, first_tm = pr.SantaLuciaScanFirst(g, lo, hi, target)
+        tm_all, _, _ = orc.santalucia_scan(np.frombuffer(g, np.uint8), lo, hi, 500e-9, 50e-3, 0.0)
+        ns = len(g) - lo + 1
+        assert first_len.shape == (ns,)
+        want_len = np.zeros(ns, np.uint16)
+        want_tm = np.full(ns, np.nan)
+        for i in range(ns):
+            for L in range(lo, hi + 1):
+                if i + L > len(g):
+                    break
+                t = tm_all[L - lo, i]
+                if not (t < target):
+                    want_len[i], want_tm[i] = L, t
+                    break
+        assert (first_len == want_len).all(), (lo, hi, target, np.nonzero(first_len != want_len)[0][:5])
+        found = want_len > 0
+        assert (_bits(first_tm[found]) == _bits(want_tm[found])).all()
+        assert np.isnan(first_tm[~found]).all()
+    # device flavour on a shard of the starts
+    dev = torch.device("cuda:0")
+    gt = torch.from_numpy(np.frombuffer(g, np.uint8).copy()).to(dev)
+    fl = torch.zeros(700, dtype=torch.int16, device=dev)
+    pr.santalucia_scan_first_dev(gt, len(g), 1234, 700, 18, 30, 500e-9, 50e-3, 0.0, 55.0, fl)
+    torch.cuda.synchronize()
+    whole, _ = pr.SantaLuciaScanFirst(g, 18, 30, 55.0)
+    assert (fl.cpu().numpy().view(np.uint16) == whole[1234:1934]).all()
