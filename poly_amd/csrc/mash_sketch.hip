@@ -18,7 +18,7 @@
 //           aggregates the append per wave: one LDS atomic + lane ranks); tau is the value
 //           a uniform hash would need for s + 6 sqrt(s) + 16 survivors, and the pass is
 //           VERIFIED: fewer than s survivors, or more than the buffer holds, and the
-//           sequence goes on a redo list for the GENERAL kernel (tau = 2^32-1, buffer of
+//           sequence is marked in its output row for the GENERAL kernel (tau = 2^32-1, buffer of
 //           s + one round of tiles, shrunk whenever it could overflow), so the output is
 //           exact for any input.  Keeping the fast kernel's LDS at ~24 KB (6 workgroups per
 //           CU) matters more than its instruction count: the kernel is latency bound
@@ -74,7 +74,12 @@ constexpr int WTW = PH_WTW;        // windows per WAVE tile (4 * GROUPS per lane
 constexpr int TW = WTW * WAVES;    // windows the workgroup covers per round
 constexpr int GROUPS = WTW / (4 * 64);
 constexpr int NB = 2048;  // counting-sort bins
-constexpr uint32_t REDO_POSITIONAL = 0x80000000u; // redo-list flag: a read with fewer windows than SketchSize
+// A read the verified fast pass cannot finish (too few survivors, a full buffer) is MARKED in its own output row --
+// out[0] = 0xFFFFFFFF > out[1] = 0, which no sketch of a read with >= s windows can be (those are ascending) -- and the
+// general kernel, which scans the batch for marks, redoes it.  No side list: the _dev entry point needs no scratch.
+constexpr uint32_t MARK0 = 0xFFFFFFFFu, MARK1 = 0u;
+constexpr int GBATCH = 32; // reads a general-kernel workgroup scans at a time
+constexpr uint32_t WL_POSITIONAL = 0x80000000u; // work-list flag of the general kernel: fewer windows than SketchSize
 constexpr uint32_t C1 = 0xcc9e2d51u, C2 = 0x1b873593u;
 
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
@@ -664,14 +669,13 @@ __device__ __forceinline__ ReadView view(const uint8_t *__restrict__ seqs, const
 // ---- FAST kernel: every sequence, under a verified threshold -------------------------------
 // KS > 0: k known at compile time (full unroll of the block chain); KS == 0: runtime k.
 // Persistent workgroups: each one walks the batch with stride gridDim.x.  Sequences the fast
-// pass cannot finish exactly are appended to `redo` for the general kernel.
+// pass cannot finish exactly are marked (MARK0 / MARK1) for the general kernel.
 template <int KS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE, 8))) void sketch_fast_kernel(const uint8_t *__restrict__ seqs,
                                                              const uint64_t *__restrict__ offs, uint64_t nseq,
                                                              uint32_t k_rt, uint32_t s, uint32_t *__restrict__ out,
                                                              uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P,
-                                                             uint32_t capf, uint32_t nbf_log2,
-                                                             uint32_t *__restrict__ redo)
+                                                             uint32_t capf, uint32_t nbf_log2)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
     Smem sm;
@@ -736,7 +740,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE,
                 bottom_s_fast<false>(sm, s, tau0, C, nbf_log2, outp, sm.cand, (uint32_t)tid, THREADS, C);
             }
         } else if (tid == 0) {
-            redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r;
+            outp[0] = MARK0;
+            outp[1] = MARK1;
         }
     }
 }
@@ -965,8 +970,7 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
 template <int KS>
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB_WPE, 8))) void sketch_slab_kernel(
     const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offs, uint64_t nseq, uint32_t s, uint32_t *__restrict__ out,
-    uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P, uint32_t capw, uint32_t capf, uint32_t nbf_log2,
-    uint32_t *__restrict__ redo)
+    uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P, uint32_t capw, uint32_t capf, uint32_t nbf_log2)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
     Smem sm;
@@ -986,11 +990,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB
         if (rv.nwin <= 0)
             continue;
         uint32_t *__restrict__ outp = out + r * (uint64_t)s;
-        if (rv.nwin < (int64_t)s) { // mash.go:81-84: positional, unsorted, tail untouched -- the general kernel's job
-            if (tid == 0)
-                redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r | REDO_POSITIONAL;
-            continue;
-        }
+        if (rv.nwin < (int64_t)s)
+            continue; // mash.go:81-84: positional, unsorted, tail untouched -- the general kernel picks these up
         // threshold a uniform hash would need for s + 6 sqrt(s) + 16 survivors, rounded up to 16 bits
         uint32_t tauq = 0xFFFFFFFFu;
         {
@@ -1008,12 +1009,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB
         const bool ok = max(max(c0, c1), max(c2, c3)) <= capw && C >= s && C <= capf; // enough survivors, none lost
         if (ok)
             bottom_s_fast<true>(sm, s, tauq, C, nbf_log2, outp, seg, (uint32_t)(tid & 63), 64u, cw);
-        else if (tid == 0)
-            redo[1 + atomicAdd(&redo[0], 1u)] = (uint32_t)r;
+        else if (tid == 0) {
+            outp[0] = MARK0;
+            outp[1] = MARK1;
+        }
     }
 }
 
-// ---- GENERAL kernel: the sequences on the redo list, any input -------------------------------
+// ---- GENERAL kernel: the marked reads (and, behind the slab pass, the positional ones), any input ------------
 // Accepts every hash, shared candidate buffer of cap >= s + TW + 64, shrunk to the exact bottom-s
 // whenever a round of tiles might overflow it.
 template <int KS>
@@ -1021,7 +1024,7 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
                                                                 const uint64_t *__restrict__ offs, uint32_t k_rt,
                                                                 uint32_t s, uint32_t *__restrict__ out,
                                                                 uint32_t n_seq_dw, uint32_t n_P_w, uint32_t n_P,
-                                                                uint32_t cap, const uint32_t *__restrict__ redo)
+                                                                uint32_t cap, uint64_t nseq, int take_positional)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem_raw[];
     Smem sm;
@@ -1031,19 +1034,45 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
     sm.binned = sm.cand + cap;
     sm.misc = sm.binned + cap;
     sm.lut = sm.misc + 16;
+    // A workgroup scans GBATCH consecutive reads at a time and then works through the ones that need this kernel.
+    // Small batches: when every read is marked (low-complexity input) the work must still spread over the whole chip.
+    __shared__ uint32_t wl[GBATCH];
+    __shared__ uint32_t nwl;
 
     const uint32_t k = KS > 0 ? (uint32_t)KS : k_rt;
     const int tid = threadIdx.x;
     sm.lut[tid] = premix((uint32_t)tid) ^ k;
-    const uint32_t nredo = redo[0];
 
-    for (uint32_t q = blockIdx.x; q < nredo; q += gridDim.x) {
-        const uint32_t entry = redo[1 + q];
-        const uint64_t r = entry & ~REDO_POSITIONAL;
+    for (uint64_t base = (uint64_t)blockIdx.x * GBATCH; base < nseq; base += (uint64_t)gridDim.x * GBATCH) {
+        __syncthreads();
+        if (tid == 0)
+            nwl = 0;
+        __syncthreads();
+        {   // one read per thread: marked by the fast pass, or (slab pass in front) positional?
+            const uint64_t r = base + tid;
+            if (tid < GBATCH && r < nseq) {
+                const int64_t nwin = (int64_t)(offs[r + 1] - offs[r]) - (int64_t)k;
+                uint32_t need = 0;
+                if (nwin >= (int64_t)s) {
+                    const uint32_t *row = out + r * (uint64_t)s;
+                    if (row[0] == MARK0 && row[1] == MARK1)
+                        need = 1;
+                } else if (nwin > 0 && take_positional) {
+                    need = 2;
+                }
+                if (need)
+                    wl[atomicAdd(&nwl, 1u)] = (uint32_t)tid | (need == 2 ? WL_POSITIONAL : 0u);
+            }
+        }
+        __syncthreads();
+        const uint32_t nredo = nwl;
+    for (uint32_t q = 0; q < nredo; ++q) {
+        const uint32_t entry = wl[q];
+        const uint64_t r = base + (entry & ~WL_POSITIONAL);
         const ReadView rv = view(seqs, offs, r, k);
         uint32_t *__restrict__ outp = out + r * (uint64_t)s;
         __syncthreads(); // the previous sequence is done with LDS
-        if (entry & REDO_POSITIONAL) { // fewer windows than SketchSize (mash.go:81-84), sent here by the slab pass
+        if (entry & WL_POSITIONAL) { // fewer windows than SketchSize (mash.go:81-84), left to this kernel by the slab pass
             auto put = [&](int64_t t0, uint32_t w0, const uint32_t(&h)[4], uint32_t nvalid) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -1082,6 +1111,7 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
         shrink_shared();
         for (uint32_t i = tid; i < s; i += THREADS)
             outp[i] = sm.cand[i];
+    }
     }
 }
 
@@ -1137,12 +1167,11 @@ static unsigned persistent_grid(size_t smem, uint64_t n)
 
 template <int KS>
 static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uint32_t k, uint32_t s,
-                  uint32_t *d_out, const Launch &L, uint32_t *d_redo, hipStream_t st)
+                  uint32_t *d_out, const Launch &L, hipStream_t st)
 {
     auto general = sketch_general_kernel<KS>;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(general), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)L.smem_general));
-    PH_HIP(hipMemsetAsync(d_redo, 0, 4, st));
     bool slabs = false;
     if constexpr (KS > 0) {
         // POLYHIP_K1_SLABS=0 keeps the tile pass (testing aid: the two passes are cross-checked in tests/)
@@ -1152,7 +1181,7 @@ static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uin
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(slab), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)L.smem_slab));
             hipLaunchKernelGGL(slab, dim3(persistent_grid(L.smem_slab, n)), dim3(THREADS), L.smem_slab, st, d_seqs, d_offs, n, s,
-                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf_slab, L.nbf_log2, d_redo);
+                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf_slab, L.nbf_log2);
         }
     }
     if (!slabs) {
@@ -1160,12 +1189,14 @@ static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uin
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fast), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)L.smem_fast));
         hipLaunchKernelGGL(fast, dim3(persistent_grid(L.smem_fast, n)), dim3(THREADS), L.smem_fast, st, d_seqs, d_offs, n,
-                           k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capf, L.nbf_log2, d_redo);
+                           k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capf, L.nbf_log2);
     }
     PH_HIP(hipGetLastError());
-    // normally the list is empty and these workgroups exit at once
-    hipLaunchKernelGGL(general, dim3(persistent_grid(L.smem_general, n)), dim3(THREADS), L.smem_general, st, d_seqs,
-                       d_offs, k, s, d_out, L.n_seq_dw, L.n_P_w, L.n_P, L.cap, d_redo);
+    // scans the batch (one read per thread) for marked rows -- and, behind the slab pass, for reads with fewer windows
+    // than SketchSize; normally there are none and the workgroups are done after the scan
+    const unsigned ggrid = (unsigned)std::min<uint64_t>((n + GBATCH - 1) / GBATCH, persistent_grid(L.smem_general, n));
+    hipLaunchKernelGGL(general, dim3(ggrid), dim3(THREADS), L.smem_general, st, d_seqs, d_offs, k, s, d_out, L.n_seq_dw,
+                       L.n_P_w, L.n_P, L.cap, n, slabs ? 1 : 0);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
@@ -1195,26 +1226,20 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
                          L.smem_general);
     hipStream_t st = as_stream(stream);
     const uint64_t CHUNK = 1ull << 30;
-    // redo list of the fast kernel (count + sequence indices), stream-ordered scratch
-    uint32_t *d_redo = nullptr;
-    PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_redo), (std::min<uint64_t>(n, CHUNK) + 1) * 4, st));
     for (uint64_t i0 = 0; i0 < n; i0 += CHUNK) {
         const uint64_t m = n - i0 < CHUNK ? n - i0 : CHUNK;
         const uint64_t *offs = d_offsets + i0;
         uint32_t *outp = d_out + i0 * (uint64_t)s;
         int rc;
         switch (k) {
-        case 17: rc = k1::launch<17>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
-        case 21: rc = k1::launch<21>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
-        case 31: rc = k1::launch<31>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
-        default: rc = k1::launch<0>(d_seqs, offs, m, k, s, outp, L, d_redo, st); break;
+        case 17: rc = k1::launch<17>(d_seqs, offs, m, k, s, outp, L, st); break;
+        case 21: rc = k1::launch<21>(d_seqs, offs, m, k, s, outp, L, st); break;
+        case 31: rc = k1::launch<31>(d_seqs, offs, m, k, s, outp, L, st); break;
+        default: rc = k1::launch<0>(d_seqs, offs, m, k, s, outp, L, st); break;
         }
-        if (rc != POLYHIP_OK) {
-            (void)hipFreeAsync(d_redo, st);
+        if (rc != POLYHIP_OK)
             return rc;
-        }
     }
-    PH_HIP(hipFreeAsync(d_redo, st));
     return POLYHIP_OK;
 }
 
