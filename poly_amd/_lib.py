@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpolyhip.so")
+# POLYHIP_LIB: another build of the same library (kernel-variant A/B runs, scripts/build_variant.sh); tests use the default
+LIB_PATH = os.environ.get("POLYHIP_LIB") or os.path.join(HERE, "libpolyhip.so")
 
 OK, ERR_INVALID, ERR_HIP, ERR_UNSUPPORTED, ERR_PANIC, ERR_SYMBOL = 0, -1, -2, -3, -4, -5
 

@@ -58,6 +58,9 @@ constexpr uint32_t TAB = 2048;        // LDS hash accumulator slots per row
 constexpr uint32_t TAB_LIMIT = 1536;  // distinct columns a row may hit before it goes to the merge
 constexpr uint32_t S_MAX = 8192;      // X SketchSize rowjoin stages in LDS
 constexpr int JOIN_U = 8;             // buckets a wave keeps in flight
+#ifndef PH_K2_NCLOG
+#define PH_K2_NCLOG 10 // log2 of the most coarse buckets of the index build
+#endif
 
 enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_pad, H_EST_LO, H_EST_HI, H_WORDS = 16 };
 enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
@@ -84,7 +87,12 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     L.nbk_log2 = 0;
     while ((1u << L.nbk_log2) < nbk)
         ++L.nbk_log2;
-    L.nc_log2 = L.nbk_log2 < 12u ? L.nbk_log2 : 12u; // NC_LOG2_MAX
+    // coarse buckets: few enough that a level-1 workgroup's slice of one is several cache lines long (its 8-byte items
+    // are scattered straight to HBM), many enough that level 2 splits a coarse bucket with an LDS histogram (FPC_MAX)
+    uint32_t ncl = L.nbk_log2 < (uint32_t)PH_K2_NCLOG ? L.nbk_log2 : (uint32_t)PH_K2_NCLOG;
+    if (L.nbk_log2 - ncl > 13u)
+        ncl = L.nbk_log2 - 13u; // FPC_MAX = 2^13
+    L.nc_log2 = ncl;
     L.nc = 1u << L.nc_log2;
     L.fpc_log2 = L.nbk_log2 - L.nc_log2;
     // the Y side (flags, irregular list, inverted index) comes first and does not depend on nx: a later call with
@@ -166,7 +174,7 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
 // coarse bucket).  Level 2: one workgroup per coarse bucket splits it into its fine buckets with an
 // LDS histogram + scan, writes start[] and the final item order.
 
-constexpr uint32_t FPC_MAX = 2048;   // fine buckets per coarse bucket (nbk <= 2^23)
+constexpr uint32_t FPC_MAX = 8192;   // fine buckets per coarse bucket
 constexpr uint32_t BATCH_ITEMS = 65536; // items a level-1 workgroup takes at a time
 
 // coarse histogram: gcount[c] += items of my batch in coarse bucket c
@@ -302,10 +310,10 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
             atomicAdd(&cnt[(citems[t].x >> shift) & (fpc - 1u)], 1u);
         __syncthreads();
         // exclusive scan of cnt[0..fpc): PER consecutive entries per thread
-        const uint32_t per = (fpc + THREADS - 1) / THREADS; // <= 8
-        uint32_t v[8], sum = 0;
+        const uint32_t per = (fpc + THREADS - 1) / THREADS; // <= 32
+        uint32_t v[32], sum = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 32; ++i) {
             const uint32_t f = tid * per + i;
             v[i] = ((uint32_t)i < per && f < fpc) ? cnt[f] : 0u;
             sum += v[i];
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
         for (int w = 0; w < (tid >> 6); ++w)
             run += ws[w];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 32; ++i) {
             const uint32_t f = tid * per + i;
             if ((uint32_t)i < per && f < fpc) {
                 start[((size_t)c << fpc_log2) + f] = run;

@@ -285,7 +285,7 @@ __device__ uint32_t bottom_s(const Smem &sm, uint32_t s, uint32_t tau, uint32_t 
             sm.cand[pos] = h;
     }
     if (by_waves && nbig)
-        rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [&](uint32_t pos, uint32_t h) { sm.cand[pos] = h; });
+        rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [cand = sm.cand](uint32_t pos, uint32_t h) { cand[pos] = h; });
     __syncthreads();
     if (tid == 0) {
         sm.misc[0] = s;
@@ -643,7 +643,8 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
         }
     }
     if (by_waves && nbig) // rare: keep it out of line (and out of the common path's register budget)
-        rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [&](uint32_t pos, uint32_t hv) { outp[pos] = hv; });
+        rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [outp](uint32_t pos, uint32_t hv) { outp[pos] = hv; }); // by VALUE: a reference would
+                                                                                                            // park `outp` in scratch, per read
 }
 
 struct ReadView {

@@ -10,16 +10,9 @@ LA = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 LB = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
 a = alphabet.NewAlphabet(list("-ACGT"))
 sc = align.NewScoring(matrix.NewSubstitutionMatrix(a, a, matrix.NUC_4), -2)
-B = torch.empty(LB, dtype=torch.uint8, device=dev)
-mash.synth_dna_dev(0xC4, B)
-# reads = substrings of the reference with 5 % substitutions
-gen = torch.Generator(device=dev); gen.manual_seed(0xC4)
-starts = torch.randint(0, LB - LA, (n,), device=dev, generator=gen)
-idx = starts[:, None] + torch.arange(LA, device=dev)[None, :]
-A = B[idx]
-hit = torch.rand(A.shape, device=dev, generator=gen) < 0.05
-lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
-A[hit] = lut[torch.randint(0, 4, (int(hit.sum()),), device=dev, generator=gen)]
+# windows of the reference with 5 % substitutions + 1 % indels (the input bench.py times)
+from poly_amd import workloads
+B, A = workloads.config4_reads(n, LA, LB, device=dev)
 A = A.reshape(-1).contiguous()
 offA = torch.arange(0, (n + 1) * LA, LA, dtype=torch.int64, device=dev)
 score = torch.zeros(n, dtype=torch.int64, device=dev)
