@@ -245,6 +245,25 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A,
                              uint8_t *d_alnB, uint32_t *d_alnLen,
                              uint32_t aln_stride, void *d_work,
                              size_t work_bytes, polyhip_stream_t stream);
+/*
+ * The whole SmithWaterman on device pointers in one call: polyhip_sw_batch_dev + polyhip_sw_traceback_dev, same
+ * outputs (d_work / d_tb_work sized as for those two).  For batches that take the packed score pass and the
+ * byte-profile traceback (BASELINE config 4's shape: >= 48k reads of <= 152 symbols against one reference) the
+ * score pass skips its locate step -- a second DP over the columns around each pair's maximum -- and the traceback
+ * kernel, which sweeps those columns anyway, finds the row-major-first maximum in its last block: about 7 % less
+ * time than the two calls.  POLYHIP_SW_FUSE=0 in the environment keeps the two passes separate (testing aid).
+ */
+int polyhip_sw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A,
+                               const uint64_t *d_offA, uint64_t npairs,
+                               uint32_t max_lenA, const uint8_t *d_B,
+                               const uint64_t *d_offB, uint64_t lenB,
+                               int64_t *d_score, uint32_t *d_endA,
+                               uint32_t *d_endB, uint32_t *d_err,
+                               uint8_t *d_alnA, uint8_t *d_alnB,
+                               uint32_t *d_alnLen, uint32_t aln_stride,
+                               void *d_work, size_t work_bytes,
+                               void *d_tb_work, size_t tb_work_bytes,
+                               polyhip_stream_t stream);
 /* Host-pointer flavour of the whole SmithWaterman: score pass + traceback. */
 int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
                            const uint64_t *offA, uint64_t npairs,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "polyhip_sw_traceback_workspace_bytes": (C.c_size_t, [_vp, _u64, _u32, _u64]),
     "polyhip_sw_traceback_dev": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                            _u32, _vp, C.c_size_t, _vp]),
+    "polyhip_sw_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
+                                             _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "polyhip_sw_align_batch": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32]),
     "polyhip_santalucia_scan_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp,
                                               _u64, _vp]),

@@ -209,6 +209,19 @@ def sw_traceback_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, 
         work_t.data_ptr(), work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
 
 
+def sw_align_dev(scoring: Scoring, A_t, offA_t, max_lenA: int, B_t, offB_t, lenB: int, score_t, endA_t, endB_t, err_t,
+                 alnA_t, alnB_t, alnLen_t, work_t, tb_work_t, stream=None) -> None:
+    """Device-resident whole SmithWaterman (score pass + traceback in one call; the packed score pass leaves the end
+    cell to the traceback kernel where it can): same outputs as sw_batch_dev + sw_traceback_dev."""
+    n = offA_t.numel() - 1
+    _lib.check(_lib.lib().polyhip_sw_align_batch_dev(
+        scoring.handle(), A_t.data_ptr(), offA_t.data_ptr(), n, max_lenA, B_t.data_ptr(),
+        offB_t.data_ptr() if offB_t is not None else None, lenB, score_t.data_ptr(), endA_t.data_ptr(), endB_t.data_ptr(),
+        err_t.data_ptr(), alnA_t.data_ptr(), alnB_t.data_ptr(), alnLen_t.data_ptr(), alnA_t.shape[1],
+        work_t.data_ptr(), work_t.numel() * work_t.element_size(), tb_work_t.data_ptr(),
+        tb_work_t.numel() * tb_work_t.element_size(), _lib.stream_ptr(stream)))
+
+
 def sw_traceback_stride(scoring: Scoring, max_lenA: int, lenB: int) -> int:
     return int(_lib.lib().polyhip_sw_traceback_stride(scoring.handle(), max_lenA, lenB))
 

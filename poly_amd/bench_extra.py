@@ -82,6 +82,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
     alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
     alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
     ms_tb = _time(lambda: align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score), 2)
+    ms_fused = _time(lambda: align.sw_align_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, alnA, alnB, ln, work, tbw), 2)
     cells = n * LA * LB
     alg = n * (LA + 8 + 8)  # read + score + end position per pair
     if (n, LA, LB) != (1_000_000, 150, 5000):  # other read lengths: the plain figures (which kernels ran is the library's choice)
@@ -89,6 +90,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
             "workload": f"{n} x {LA} bp reads vs one {LB} bp reference, NUC_4, gap -2",
             "cell_updates_per_s": cells / ms_score * 1e3, "score_pass_ms": ms_score,
             "cell_updates_per_s_with_traceback": cells / (ms_score + ms_tb) * 1e3, "traceback_ms": ms_tb,
+            "align_one_call_ms": ms_fused, "cell_updates_per_s_align_one_call": cells / ms_fused * 1e3,
             "score_path": align.last_path(), "traceback_path": align.sw_traceback_last_path(),
             "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
         }
@@ -96,6 +98,8 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         "workload": f"{n} x {LA} bp reads vs one {LB} bp reference, NUC_4, gap -2 (BASELINE configs[3])",
         "cell_updates_per_s": cells / ms_score * 1e3, "score_pass_ms": ms_score,
         "cell_updates_per_s_with_traceback": cells / (ms_score + ms_tb) * 1e3, "traceback_ms": ms_tb,
+        # polyhip_sw_align_batch_dev: score + strings in one call, end cell found by the traceback kernel
+        "align_one_call_ms": ms_fused, "cell_updates_per_s_align_one_call": cells / ms_fused * 1e3,
         "algorithmic_GBs_score_pass": alg / ms_score * 1e3 / 1e9,
         # the bound that matters for K3: VALU issue.  The packed kernel spends 22 half-rate instructions
         # (88 cycles) per 512 cells (64 lanes x 2 pairs x 4 columns); 1024 SIMDs at ~2.4 GHz.

@@ -675,11 +675,17 @@ size_t polyhip_sw_workspace_bytes(const polyhip_scoring *sc, uint64_t npairs, ui
 
 int polyhip_sw_last_path(void) { return k3::g_last_path; }
 
-int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
-                         uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
-                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, void *d_work,
-                         size_t work_bytes, polyhip_stream_t stream)
+} // extern "C"
+
+// the score pass; `defer` != 0 asks the packed path (3, reads of at most 256 rows) to leave the end cell of a pair to
+// the traceback kernel (k3p::SW_END_DEFERRED): *deferred says whether it did
+int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                            uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB, int64_t *d_score,
+                            uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, void *d_work, size_t work_bytes,
+                            polyhip_stream_t stream, int defer, int *deferred)
 {
+    if (deferred)
+        *deferred = 0;
     PH_REQUIRE(sc, "polyhip_sw_batch: null scoring");
     if (npairs == 0)
         return POLYHIP_OK;
@@ -710,11 +716,14 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
         // exact one-wave-per-pair kernel (a lane-per-pair kernel would take a full DP's time for them)
         if (p.path == 3) {
             uint32_t *list = nullptr, *count = nullptr;
+            const int do_defer = defer && p.pk.ra <= 256 ? 1 : 0;
             const int rc = k3p::packed_run(sc, p.pk, d_A, d_offA, npairs, d_B, (uint32_t)lenB, prof, binfo,
                                            static_cast<uint8_t *>(d_work) + p.fast_bytes, d_score, d_endA, d_endB, d_err,
-                                           &list, &count, st);
+                                           &list, &count, st, nullptr, nullptr, do_defer);
             if (rc != POLYHIP_OK)
                 return rc;
+            if (deferred)
+                *deferred = do_defer;
             return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count,
                                  npairs, d_score, d_endA, d_endB, d_err, st);
         }
@@ -772,6 +781,17 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
                        d_score, d_endA, d_endB, d_err);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
+}
+
+extern "C" {
+
+int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                         uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, void *d_work,
+                         size_t work_bytes, polyhip_stream_t stream)
+{
+    return polyhip::k3::score_pass(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, lenB, d_score, d_endA, d_endB, d_err, d_work,
+                                   work_bytes, stream, 0, nullptr);
 }
 
 int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,

@@ -448,7 +448,8 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
     uint32_t lenB, uint32_t lenB_pad, const int8_t *__restrict__ prof, const uint8_t *__restrict__ codeA,
     const uint32_t *__restrict__ binfo, int ncodes, int gap, int smax, const uint32_t *__restrict__ infoM,
     const uint32_t *__restrict__ infoQ, uint32_t *__restrict__ list, uint32_t *__restrict__ count,
-    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err,
+    int defer)
 {
     static_assert(RA % 4 == 0 && RA <= 256, "RA");
     extern __shared__ __attribute__((aligned(16))) int8_t lds_lc[];
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
 
     // columns that can feed a cell worth M in block q: lenA + (smax*lenA - M)/|gap| before its last column
     uint32_t jb0 = 0, nblk = 0;
-    if (work) {
+    if (work && !defer) {
         const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
         const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u;
         const uint32_t jend = 4u * q + 4u; // one past the block's last column
@@ -573,14 +574,19 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
     if (!active)
         return;
     // a tie, or (never expected) no cell found: the exact kernel decides
-    if (e == 0u && M > 0 && (tie || key == 0xFFFFFFFFu)) {
+    if (e == 0u && M > 0 && (tie || (!defer && key == 0xFFFFFFFFu))) {
         list[atomicAdd(count, 1u)] = (uint32_t)pair;
         return;
     }
     const bool hit = e == 0u && M > 0;
     score[pair] = hit ? (int64_t)M : 0;
-    endA[pair] = hit ? (key >> 2) + 1u : 0u;
-    endB[pair] = hit ? 4u * q + (key & 3u) + 1u : 0u;
+    if (defer) { // the traceback kernel locates the cell inside block q
+        endA[pair] = hit ? SW_END_DEFERRED : 0u;
+        endB[pair] = hit ? 4u * q + 4u : 0u;
+    } else {
+        endA[pair] = hit ? (key >> 2) + 1u : 0u;
+        endB[pair] = hit ? 4u * q + (key & 3u) + 1u : 0u;
+    }
     err[pair] = e;
 }
 #undef PH_LC_ROW
@@ -628,7 +634,7 @@ template <int RA, int K>
 static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
                          uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                          uint32_t *prof2, uint32_t *infoM, uint32_t *infoQ, uint32_t *list, uint32_t *count,
-                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st)
+                         int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st, int defer)
 {
     {
         const uint32_t nqe = p.nq + 2 * (K - 1); // K - 1 all-pad blocks on either side
@@ -663,7 +669,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         const uint64_t blocks = (npairs + THREADS - 1) / THREADS;
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.locate_smem, st, d_A, d_offA, npairs, d_B, lenB,
                            p.lenB_pad, prof, sc->d_codeA, binfo, sc->ncodes, (int)sc->gap, (int)sc->smax, infoM, infoQ,
-                           list, count, d_score, d_endA, d_endB, d_err);
+                           list, count, d_score, d_endA, d_endB, d_err, defer);
         PH_HIP(hipGetLastError());
     }
     return POLYHIP_OK;
@@ -673,7 +679,7 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
                uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
                uint32_t **list_out, uint32_t **count_out, hipStream_t st, const uint32_t **infoM_out,
-               const uint32_t **infoQ_out)
+               const uint32_t **infoQ_out, int defer)
 {
     uint8_t *w = static_cast<uint8_t *>(d_work);
     uint32_t *count = reinterpret_cast<uint32_t *>(w);
@@ -691,7 +697,7 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
 #define PH_PKB_CASE(RB_, K_)                                                                                              \
     if (p.rb == RB_ && p.k == K_)                                                                                         \
         return launch_packed<RB_ * K_, K_>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, \
-                                           count, d_score, d_endA, d_endB, d_err, st);
+                                           count, d_score, d_endA, d_endB, d_err, st, defer);
     PH_PKB_CASE(152, 2)
     PH_PKB_CASE(128, 4)
     PH_PKB_CASE(152, 4)
@@ -701,12 +707,12 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
 #undef PH_PKB_CASE
     if (p.ra == 64)
         return launch_packed<64, 1>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
-                                 d_score, d_endA, d_endB, d_err, st);
+                                 d_score, d_endA, d_endB, d_err, st, defer);
     if (p.ra == 152)
         return launch_packed<152, 1>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
-                                  d_score, d_endA, d_endB, d_err, st);
+                                  d_score, d_endA, d_endB, d_err, st, defer);
     return launch_packed<256, 2>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, count,
-                              d_score, d_endA, d_endB, d_err, st);
+                              d_score, d_endA, d_endB, d_err, st, defer);
 }
 
 } // namespace k3p

@@ -81,9 +81,24 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
                uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
                uint32_t **list_out, uint32_t **count_out, hipStream_t st, const uint32_t **infoM_out = nullptr,
-               const uint32_t **infoQ_out = nullptr);
+               const uint32_t **infoQ_out = nullptr, int defer = 0);
+// defer != 0 (p.ra <= 256 only): the locate step does not run its DP.  A pair whose maximum sits in ONE block gets
+// score = M, endA = SW_END_DEFERRED, endB = the 1-based last column of that block; the traceback kernel, which sweeps
+// those columns anyway, finds the row-major-first cell worth M in its last block (sw_traceback.hip).  Ties still go
+// on the list for the exact kernel, errors are reported as usual.
+constexpr uint32_t SW_END_DEFERRED = 0xFFFFFFFFu;
 
 } // namespace k3p
+} // namespace polyhip
+
+namespace polyhip {
+namespace k3 {
+// polyhip_sw_batch_dev with the option of leaving end cells to the traceback kernel (sw_batch.hip)
+int score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
+               const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB, int64_t *d_score, uint32_t *d_endA,
+               uint32_t *d_endB, uint32_t *d_err, void *d_work, size_t work_bytes, polyhip_stream_t stream, int defer,
+               int *deferred);
+} // namespace k3
 } // namespace polyhip
 
 // ---- one-wave-per-pair exact score pass (sw_wave.hip): the packed pass's tie list and small batches ----

@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -268,7 +269,8 @@ __global__ __launch_bounds__(256) void tb_profile_kernel(const uint8_t *__restri
         col[c * 4] = c < live ? lutc[c * 256 + b] : (int8_t)-128;
 }
 
-// w = 2 * w + (x > y)
+// w = 2 * w + (x > y).  FIND (the wave's last block only): the first cell worth M in row-major order -- rows are
+// visited in ascending order and a row's four columns left to right, so the first hit is it
 #define PH_TB_CELL(S, DIAG, UP, LEFT, HOUT, C)         \
     do {                                               \
         const int up_ = (UP), left_ = (LEFT);          \
@@ -277,6 +279,8 @@ __global__ __launch_bounds__(256) void tb_profile_kernel(const uint8_t *__restri
         HOUT = max(d0_, t_);                           \
         PH_CARRY_BIT(wG[C], t_, d0_);                     \
         PH_CARRY_BIT(wL[C], left_, up_);                  \
+        if (FIND)                                      \
+            key = (key == 0xFFFFFFFFu && HOUT == Mi) ? (uint32_t)((i_ << 2) | (C)) : key; \
     } while (0)
 #define PH_TB_ROW(I, W)                                         \
     do {                                                        \
@@ -299,7 +303,7 @@ __global__ __launch_bounds__(256) void tb_profile_kernel(const uint8_t *__restri
         pr3 = h3;                                               \
         H[i_] = h3;                                             \
         if ((i_ & 31) == 31 || i_ == RA - 1) {                  \
-            uint32_t *o_ = dirw + ((size_t)t * TBU * NG + (i_ >> 5)) * 2 * 64; \
+            uint32_t *o_ = dirw + ((size_t)tt * TBU * NG + (i_ >> 5)) * 2 * 64; \
             _Pragma("unroll") for (int c_ = 0; c_ < TBU; ++c_)  \
             {                                                   \
                 o_[((size_t)c_ * NG * 2 + 0) * 64] = wG[c_];    \
@@ -312,8 +316,8 @@ template <int RA, int CP>
 __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
     const uint8_t *__restrict__ B, uint32_t lenB_pad, const int8_t *__restrict__ prof,
-    const uint8_t *__restrict__ codeA, int ncodes, int gap, const uint32_t *__restrict__ endA,
-    const uint32_t *__restrict__ endB, const uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
+    const uint8_t *__restrict__ codeA, int ncodes, int gap, uint32_t *__restrict__ endA,
+    uint32_t *__restrict__ endB, uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
     uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
     uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
 {
@@ -348,8 +352,13 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
             M = score[pair];
         }
     }
-    const bool work = active && eA > 0 && eB > 0 && M > 0 && lenA <= RA;
-    const uint32_t mycols = work ? pair_window(wcols, eA, M, smax, gap, wide) : 0u;
+    // The score pass may have left the end cell to this kernel (k3p::SW_END_DEFERRED): eB is then the last column of
+    // the ONE block of four columns that holds the maximum, and the first cell worth M in row-major order is found
+    // while that block -- the last of the window -- is swept.  The window is sized with lenA for the unknown end row.
+    const bool locate = active && eA == k3p::SW_END_DEFERRED;
+    const uint32_t rowsA = locate ? lenA : eA;
+    const bool work = active && rowsA > 0 && eB > 0 && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide) + (locate ? 4u : 0u)) : 0u;
     const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u; // first column (1-based) of my window
     const uint32_t jb0 = (c_s - 1u) & ~3u;                               // 0-based, on a block boundary
     const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u;        // <= nblk_alloc
@@ -381,45 +390,74 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
     uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
 
-    for (uint32_t t = 0; t < nblk_alloc; ++t) {
-        if (!__any(t < nblk))
-            break;
-        if (t < nblk) {
-            const uint32_t blk = lds_base + ((jb0 >> 2) + t) * (CP * 4);
-            int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
-            uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
-            uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
-            PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+    // Lanes sweep different numbers of blocks.  They are aligned at the END: a lane with fewer blocks idles first, so
+    // that the wave's last iteration is every lane's last block and the locate code is paid once per wave.
+    uint32_t nmax = nblk;
 #pragma unroll
-            for (int g = 0; g < RA / 4; ++g) {
-                if (g + 1 < RA / 4) {
-                    PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
-                }
-                PH_TB_ROW(4 * g + 0, wa0);
-                PH_TB_ROW(4 * g + 1, wa1);
-                PH_TB_ROW(4 * g + 2, wa2);
-                PH_TB_ROW(4 * g + 3, wa3);
-                wa0 = wb0;
-                wa1 = wb1;
-                wa2 = wb2;
-                wa3 = wb3;
+    for (int d = 32; d >= 1; d >>= 1)
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    const uint32_t lag = nmax - nblk;
+    const int Mi = (int)M;
+    uint32_t key = 0xFFFFFFFFu;
+    // tt = the wave's iteration (uniform: the direction words of one iteration are stored side by side, 256 B per
+    // store), bt = tt - lag = the lane's own block
+    auto sweep = [&](uint32_t tt, auto find_tag) {
+        constexpr bool FIND = decltype(find_tag)::value;
+        const uint32_t bt = tt - lag;
+        const uint32_t blk = lds_base + ((jb0 >> 2) + bt) * (CP * 4);
+        int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
+        uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
+        uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+        PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+#pragma unroll
+        for (int g = 0; g < RA / 4; ++g) {
+            if (g + 1 < RA / 4) {
+                PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
             }
+            PH_TB_ROW(4 * g + 0, wa0);
+            PH_TB_ROW(4 * g + 1, wa1);
+            PH_TB_ROW(4 * g + 2, wa2);
+            PH_TB_ROW(4 * g + 3, wa3);
+            wa0 = wb0;
+            wa1 = wb1;
+            wa2 = wb2;
+            wa3 = wb3;
         }
-    }
+    };
+    const bool any_locate = __any(locate) != 0; // wave-uniform
+    const uint32_t nplain = any_locate && nmax > 0 ? nmax - 1u : nmax;
+    for (uint32_t t = 0; t < nplain; ++t)
+        if (t >= lag) // (nblk == 0: lag == nmax, never)
+            sweep(t, std::false_type{});
+    if (nplain < nmax && nblk > 0) // the wave's last iteration, every sweeping lane's last block: with the search
+        sweep(nmax - 1u, std::true_type{});
 
     if (!active)
         return;
     uint32_t len = 0;
-    if (work) {
+    bool lost = false;
+    if (work && locate) {
+        lost = key == 0xFFFFFFFFu; // cannot happen: the packed pass saw M in this block
+        eA = lost ? 0u : (key >> 2) + 1u;
+        eB = lost ? 0u : eB - 3u + (key & 3u);
+        endA[pair] = eA;
+        endB[pair] = eB;
+        if (lost)
+            err[pair] = 0xFFFFFFFEu;
+    } else if (locate) { // deferred, but nothing to walk (cannot happen either: M > 0 and lenA > 0)
+        endA[pair] = 0u;
+        endB[pair] = 0u;
+    }
+    if (work && !lost) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
         uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
         uint32_t i = eA, j = eB;
         int h = (int)M;
         while (h > 0 && i > 0 && j > jb0 && len < stride) {
-            const uint32_t jj = j - 1u, rel = jj - jb0, r = i - 1u, g = r >> 5;
+            const uint32_t jj = j - 1u, rel = jj - jb0 + TBU * lag, r = i - 1u, g = r >> 5; // (stored by wave iteration)
             const uint32_t rows = min(32u, (uint32_t)RA - 32u * g);
             const uint32_t bit = rows - 1u - (r & 31u);
             const uint32_t *wp = dirw + ((size_t)rel * NG + g) * 2 * 64;
@@ -450,7 +488,7 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
             ++len;
         }
     }
-    alnLen[pair] = (active && eA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
+    alnLen[pair] = (active && rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
 }
 #undef PH_TB_ROW
 #undef PH_TB_CELL
@@ -1222,7 +1260,7 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
                 p.prof_smem <= 160 * 1024 && (uint64_t)sc->smax * max_lenA < (1ull << 30);
     if (p.prof_ok) {
         // a lane's window starts on a block boundary (up to 3 columns early) and ends inside a block
-        p.nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 1;
+        p.nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 2; // (+ one block for the deferred end cell's slack)
         p.prof_bytes = align_up((size_t)p.lenB_pad * p.cp, 256);
         const size_t per = (size_t)p.nblk_alloc * TBU * ((p.ra + 31) / 32) * 2 * 4;
         p.per_pair = std::max(p.per_pair, per);
@@ -1280,12 +1318,22 @@ size_t polyhip_sw_traceback_workspace_bytes(const polyhip_scoring *sc, uint64_t 
     return (size_t)want + 256 + p.prof_bytes;
 }
 
-int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
-                             uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
-                             const uint32_t *d_endA, const uint32_t *d_endB, const uint32_t *d_err,
-                             const int64_t *d_score, uint8_t *d_alnA,
-                             uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
-                             polyhip_stream_t stream)
+// would polyhip_sw_traceback_dev take the byte-profile kernel for this batch (score given, one shared reference)?
+// Only that kernel can find a deferred end cell.
+static bool traceback_uses_prof(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
+{
+    const k3t::Plan p = k3t::plan(sc, max_lenA, lenB);
+    const bool wave_ok = p.wave_r != 0 && !env_is("POLYHIP_TB_WAVE", '0');
+    return p.prof_ok && !(p.ra == 256 && wave_ok) && !env_is("POLYHIP_TB_PROF", '0');
+}
+
+// endA / endB / err are rewritten only for pairs whose end cell the score pass deferred (k3p::SW_END_DEFERRED)
+static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                          uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                          uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
+                          const int64_t *d_score, uint8_t *d_alnA,
+                          uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
+                          polyhip_stream_t stream)
 {
     PH_REQUIRE(sc, "polyhip_sw_traceback: null scoring");
     if (npairs == 0)
@@ -1407,6 +1455,44 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
     return POLYHIP_OK;
 }
 
+int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                             uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                             const uint32_t *d_endA, const uint32_t *d_endB, const uint32_t *d_err,
+                             const int64_t *d_score, uint8_t *d_alnA,
+                             uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
+                             polyhip_stream_t stream)
+{
+    // (nothing is deferred in ends that come from polyhip_sw_batch_dev: the arrays are only read)
+    return traceback_impl(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, lenB, const_cast<uint32_t *>(d_endA),
+                          const_cast<uint32_t *>(d_endB), const_cast<uint32_t *>(d_err), d_score, d_alnA, d_alnB, d_alnLen,
+                          aln_stride, d_work, work_bytes, stream);
+}
+
+// The whole SmithWaterman on device pointers: score pass + traceback in one call.  For batches that take the packed
+// score pass and the byte-profile traceback (config 4's shape) the score pass skips its locate step -- a second DP over
+// the columns around each pair's maximum -- and the traceback kernel, which sweeps those columns anyway, finds the
+// end cell in its last block.  Outputs as the two separate calls'.
+int polyhip_sw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
+                               uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB,
+                               int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, uint8_t *d_alnA,
+                               uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
+                               void *d_tb_work, size_t tb_work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(sc, "polyhip_sw_align_batch: null scoring");
+    if (npairs == 0)
+        return POLYHIP_OK;
+    const int want_defer = d_offB == nullptr && d_B != nullptr && traceback_uses_prof(sc, max_lenA, lenB) &&
+                           !env_is("POLYHIP_SW_FUSE", '0'); // testing aid: the two separate passes
+    int deferred = 0;
+    int rc = polyhip::k3::score_pass(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, lenB, d_score, d_endA, d_endB, d_err, d_work,
+                                     work_bytes, stream, want_defer, &deferred);
+    if (rc != POLYHIP_OK)
+        return rc;
+    (void)deferred;
+    return traceback_impl(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, lenB, d_endA, d_endB, d_err, d_score, d_alnA, d_alnB,
+                          d_alnLen, aln_stride, d_tb_work, tb_work_bytes, stream);
+}
+
 int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
                            const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
                            uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen,
@@ -1430,17 +1516,12 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     PH_HIP(dlen.alloc(npairs * 4));
     const size_t wb = polyhip_sw_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB, offB == nullptr);
     PH_HIP(dwork.alloc(wb));
-    int rc = polyhip_sw_batch_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
-                                  dscore.as<int64_t>(), dea.as<uint32_t>(), deb.as<uint32_t>(), derr.as<uint32_t>(), dwork.p,
-                                  wb, nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
     const size_t tb = polyhip_sw_traceback_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB);
     PH_HIP(dtb.alloc(tb));
-    rc = polyhip_sw_traceback_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
-                                  dea.as<uint32_t>(), deb.as<uint32_t>(),
-                                  derr.as<uint32_t>(), dscore.as<int64_t>(), dalA.as<uint8_t>(), dalB.as<uint8_t>(),
-                                  dlen.as<uint32_t>(), aln_stride, dtb.p, tb, nullptr);
+    int rc = polyhip_sw_align_batch_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
+                                        dscore.as<int64_t>(), dea.as<uint32_t>(), deb.as<uint32_t>(), derr.as<uint32_t>(),
+                                        dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(), aln_stride, dwork.p, wb,
+                                        dtb.p, tb, nullptr);
     if (rc != POLYHIP_OK)
         return rc;
     PH_HIP(hipStreamSynchronize(nullptr));

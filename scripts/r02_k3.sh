@@ -1,0 +1,11 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests/test_traceback_gpu.py tests/test_align_gpu.py tests/test_nw_gpu.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -8 | tee gpurun_out/r02_k3_tests.log
+python - <<'P' 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r02_k3_fused.log
+import sys, torch
+sys.path.insert(0,'.')
+from poly_amd import bench_extra
+r = bench_extra.sw(torch.device('cuda:0'))
+print({k:(round(v,3) if isinstance(v,float) else v) for k,v in r.items() if k not in ('workload','roofline')})
+P
+timeout 200 python scripts/fuzz_k3.py 60 2>&1 | tail -3

@@ -394,6 +394,19 @@ def test_config4_full_size_mutated_batch(al, monkeypatch):
     ln = torch.zeros(n, dtype=torch.int32, device=dev)
     align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score)
     torch.cuda.synchronize()
+    # (a') the one-call device path, where the score pass leaves the end cell to the traceback kernel: same seven outputs
+    f_score = torch.zeros(n, dtype=torch.int64, device=dev)
+    f_ea, f_eb, f_er, f_ln = (torch.full((n,), 7, dtype=torch.int32, device=dev) for _ in range(4))
+    f_alnA, f_alnB = torch.zeros_like(alnA), torch.zeros_like(alnB)
+    work = torch.empty(align.sw_workspace_bytes(sc, n, LA, LB, True), dtype=torch.uint8, device=dev)
+    align.sw_align_dev(sc, A, offA, LA, B, None, LB, f_score, f_ea, f_eb, f_er, f_alnA, f_alnB, f_ln, work, tbw)
+    torch.cuda.synchronize()
+    for x, y in ((f_score, score), (f_ea, ea), (f_eb, eb), (f_er, er), (f_ln, ln)):
+        assert torch.equal(x, y)
+    cols0 = torch.arange(stride, device=dev)[None, :]
+    live0 = cols0 >= (stride - ln.long())[:, None]
+    assert bool(((f_alnA == alnA) | ~live0).all()) and bool(((f_alnB == alnB) | ~live0).all())
+    del f_alnA, f_alnB, live0, work
     # (b) the oracle on a sample spread over the whole batch
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
     rng = np.random.default_rng(4)
@@ -428,3 +441,70 @@ def test_config4_full_size_mutated_batch(al, monkeypatch):
         e_a, e_b = int(h["ea"][j]), int(h["eb"][j])
         assert h["A"][j].tobytes()[e_a - len(sa):e_a] == sa and refb[e_b - len(sb):e_b] == sb
     del chk
+
+
+@pytest.mark.parametrize("kind", ["random", "repeats", "ragged_bad"])
+def test_fused_align_equals_two_passes(al, monkeypatch, kind):
+    """polyhip_sw_align_batch_dev (deferred end cell, found by the traceback kernel in its last block) against
+    POLYHIP_SW_FUSE=0 (locate in the score pass, then the traceback) on 100k reads at 0..60 % mutations: a tandem-repeat
+    reference (maxima in several blocks: the tie list), ragged lengths incl. empty reads, bad symbols; a sample vs the oracle"""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng({"random": 1, "repeats": 2, "ragged_bad": 3}[kind])
+    LB, n, L = 4000, 100_000, 150
+    ref = orc.synth_dna(0xC4, LB).copy()
+    if kind == "repeats":
+        ref = np.tile(ref[:250], 16)
+        ref[rng.integers(0, LB, 10)] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 10)]
+    lens = np.full(n, L) if kind != "ragged_bad" else rng.integers(0, L + 1, n)
+    starts = rng.integers(0, LB - L, n)
+    reads = ref[(starts[:, None] + np.arange(L)[None, :])]
+    hit = rng.random((n, L)) < np.linspace(0, 0.6, n)[:, None]
+    reads[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    if kind == "ragged_bad":
+        bad = rng.choice(n, 300, replace=False)
+        reads[bad, rng.integers(0, L, 300)] = ord("X")
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)]) if kind == "ragged_bad" else reads.reshape(-1)
+    A = torch.from_numpy(flat.copy()).to(dev)
+    offA = torch.from_numpy(offs).to(dev)
+    B = torch.from_numpy(ref.copy()).to(dev)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    stride = align.sw_traceback_stride(sc, L, LB)
+    outs = {}
+    for fuse in (True, False):
+        if fuse:
+            monkeypatch.delenv("POLYHIP_SW_FUSE", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_FUSE", "0")
+        score = torch.zeros(n, dtype=torch.int64, device=dev)
+        ea, eb, er, ln = (torch.full((n,), 9, dtype=torch.int32, device=dev) for _ in range(4))
+        alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        work = torch.empty(align.sw_workspace_bytes(sc, n, L, LB, True), dtype=torch.uint8, device=dev)
+        tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
+        align.sw_align_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, alnA, alnB, ln, work, tbw)
+        torch.cuda.synchronize()
+        assert align.last_path() == 3 and align.sw_traceback_last_path() == 1
+        outs[fuse] = (score, ea, eb, er, ln, alnA, alnB)
+    monkeypatch.delenv("POLYHIP_SW_FUSE", raising=False)
+    for x, y in zip(outs[True][:5], outs[False][:5]):
+        assert torch.equal(x, y)
+    ln = outs[True][4]
+    live = torch.arange(stride, device=dev)[None, :] >= (stride - ln.long())[:, None]
+    assert bool(((outs[True][5] == outs[False][5]) | ~live).all()) and bool(((outs[True][6] == outs[False][6]) | ~live).all())
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    refb = ref.tobytes()
+    score, ea, eb, er, ln, alnA, alnB = (t.cpu().numpy() for t in outs[True])
+    for p in rng.choice(n, 300, replace=False):
+        a = flat[offs[p]:offs[p + 1]].tobytes()
+        try:
+            ws, wa, wb, wea, web = orc.smith_waterman(a, refb, om, -2)
+        except orc.AlphabetError:
+            assert er[p] != 0 and ln[p] == 0
+            continue
+        Lp = int(ln[p])
+        got = (int(score[p]), int(ea[p]), int(eb[p]), alnA[p, stride - Lp:].tobytes().decode(), alnB[p, stride - Lp:].tobytes().decode())
+        assert got == (ws, wea, web, wa, wb), (p, got, (ws, wea, web, wa, wb))
