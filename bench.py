@@ -446,7 +446,7 @@ def main() -> int:
                    "one_gpu_test": one_gpu_test, "devices": ranks},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "polyhip::k1::sketch_fast_kernel<21>", "kernel_ms": kern_ms,
+                     "kernel": "polyhip::k1::sketch_slab_kernel<21>", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_launch": alg_bytes},
         "parity_spot_check": parity,
     }
