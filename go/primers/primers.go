@@ -46,3 +46,14 @@ func SantaLuciaScan(genome string, minLen, maxLen int, primerConcentration, salt
 	}
 	return TmTable{MinLen: minLen, MaxLen: maxLen, Stride: ld, Tm: tm, DH: h, DS: s}
 }
+
+// FirstPrimerLengths is the grow loop of primers/pcr (pcr.go:47-53) for EVERY start of genome in one device call:
+// Len[i] = the shortest primer genome[i:i+Len[i]] of minLen..maxLen nucleotides whose MeltingTemp is not below targetTm
+// (0 if none), Tm[i] its melting temperature.
+func FirstPrimerLengths(genome string, minLen, maxLen int, targetTm float64) (Len []uint16, Tm []float64) {
+	l, t, err := polyhip.SantaLuciaScanFirst([]byte(genome), minLen, maxLen, 500e-9, 50e-3, 0.0, targetTm)
+	if err != nil {
+		panic(err)
+	}
+	return l, t
+}

@@ -77,3 +77,39 @@ def test_error_classes_and_status_codes():
     assert e.status == -2 and "x" in str(e)
     # the binding table and the header agree (names + arity are checked against the library in test_abi_cpu)
     assert "polyhip_fasta_pack_dev" in _lib.SIGNATURES and len(_lib.SIGNATURES) >= 40
+
+
+def test_synthetic_workloads_are_pinned():
+    """poly_amd/workloads.py (SURVEY 8d inputs) is the one definition bench.py, the GPU tests and the CPU baselines draw
+    from: the DNA stream equals the oracle's, slices equal the whole, and the config-4 read generator (5 % substitutions +
+    1 % indels, integer torch ops only) is pinned on a digest so that a change of its bytes cannot go unnoticed"""
+    import hashlib
+    from poly_amd import workloads as w
+    assert (w.synth_dna(0xC2, 5000) == orc.synth_dna(0xC2, 5000)).all()
+    assert (w.synth_dna(0xC2, 777, first=4321) == orc.synth_dna(0xC2, 6000)[4321:4321 + 777]).all()
+    ref, reads = w.config4_reads(1000)
+    assert (ref == orc.synth_dna(0xC4, 5000)).all() and reads.shape == (1000, 150)
+    assert hashlib.sha256(reads.tobytes()).hexdigest() == "1f08f2aa6b80dbd7aa473bdef81dac58de9e666aa7981d0dbdaf3773e023f598"
+    assert (w.config4_reads(7, first=500)[1] == reads[500:507]).all()
+    # the channel does what it says: ~5 % of the aligned columns mismatch, ~1 % are gaps
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    mism = gaps = cols = 0
+    for r in reads[:60]:
+        _, a, b, _, _ = orc.smith_waterman(r.tobytes(), ref.tobytes(), om, -2)
+        cols += len(a)
+        gaps += a.count("-") + b.count("-")
+        mism += sum(1 for x, y in zip(a, b) if x != y and x != "-" and y != "-")
+    assert 0.025 < mism / cols < 0.08 and 0.003 < gaps / cols < 0.03
+
+
+def test_bench_refuses_a_rank_count_it_was_not_started_with():
+    """bench.py --gpus N under a launcher with a different WORLD_SIZE must not report a number (exit 2), whatever else
+    is available on the box"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 2 and "refusing" in res.stderr
