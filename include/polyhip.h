@@ -309,6 +309,11 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
  * one-wave-per-pair kernel over the columns that can reach the maximum.  POLYHIP_SW_WAVE=0 /
  * POLYHIP_SW_PACKED=0 / POLYHIP_SW_PAIR=0 in the environment switch 4, 6 and 7 / 3 and 7 / 5 off (testing aids). */
 int polyhip_sw_last_path(void);
+/* 1 when that call's packed pass (paths 3 and 7) ran the half-float cell of gfx950 (v_pk_maximum3_f16: three
+ * instructions per cell pair instead of four) -- taken when every H stays below 2048, i.e. smax * min(max_lenA, lenB)
+ * <= 2047 and |gap| <= 2047; same integers, bit for bit (halves scaled by 2^-11, every sum exact).
+ * POLYHIP_SW_F16=0 keeps the int16 cell (testing aid). */
+int polyhip_sw_last_packed_half(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
  * kernel for reads of 257..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off). */

@@ -129,6 +129,11 @@ def last_path() -> int:
     return int(_lib.lib().polyhip_sw_last_path())
 
 
+def last_packed_half() -> bool:
+    """the last packed pass ran gfx950's half-float cell (scores below 2048)"""
+    return bool(_lib.lib().polyhip_sw_last_packed_half())
+
+
 def sw_traceback_last_path() -> int:
     """1 = byte-profile traceback kernel, 2 = register-tiled table kernel, 3 = generic (tests)"""
     return int(_lib.lib().polyhip_sw_traceback_last_path())

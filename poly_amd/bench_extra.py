@@ -77,6 +77,9 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
     ea, eb, er, ln = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(4))
     work = torch.empty(align.sw_workspace_bytes(sc, n, LA, LB, True), dtype=torch.uint8, device=dev)
     ms_score = _time(lambda: align.sw_batch_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, work), 3)
+    half = align.last_packed_half()  # gfx950's half-float cell (scores < 2048): 17 instructions per row and block, else 22
+    per_blk = 17 if half else 22
+    ceiling = 1024 * 2.4e9 * 512 / (4 * per_blk)
     stride = align.sw_traceback_stride(sc, LA, LB)
     tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, LA, LB), dtype=torch.uint8, device=dev)
     alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
@@ -101,16 +104,17 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         # polyhip_sw_align_batch_dev: score + strings in one call, end cell found by the traceback kernel
         "align_one_call_ms": ms_fused, "cell_updates_per_s_align_one_call": cells / ms_fused * 1e3,
         "algorithmic_GBs_score_pass": alg / ms_score * 1e3 / 1e9,
-        # the bound that matters for K3: VALU issue.  The packed kernel spends 22 half-rate instructions
-        # (88 cycles) per 512 cells (64 lanes x 2 pairs x 4 columns); 1024 SIMDs at ~2.4 GHz.
-        "valu_issue_ceiling_cell_updates_per_s": 1024 * 2.4e9 * 512 / 88,
-        "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / (1024 * 2.4e9 * 512 / 88),
-        "roofline": {"bound": "valu", "achieved": cells / ms_score * 1e3 / 1e12, "peak": 1024 * 2.4e9 * 512 / 88 / 1e12,
-                     "unit": "T cell updates/s", "frac": cells / ms_score * 1e3 / (1024 * 2.4e9 * 512 / 88),
-                     "kernel": "polyhip::k3pk::sw_pk_kernel<152,false> (+ locate + tie wave, all inside score_pass_ms)",
-                     "derivation": "packed int16 recurrence: 22 half-rate VALU instructions = 88 issue cycles per "
-                                   "512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x 2.4 GHz; HBM is not the "
-                                   "bound (166 B per 750,000 cells)",
+        # the bound that matters for K3: VALU issue.  The packed kernel spends `per_blk` instructions of four
+        # issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns); 1024 SIMDs at ~2.4 GHz.
+        "packed_cell": "half-float (v_pk_maximum3_f16)" if half else "int16",
+        "valu_issue_ceiling_cell_updates_per_s": ceiling,
+        "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / ceiling,
+        "roofline": {"bound": "valu", "achieved": cells / ms_score * 1e3 / 1e12, "peak": ceiling / 1e12,
+                     "unit": "T cell updates/s", "frac": cells / ms_score * 1e3 / ceiling,
+                     "kernel": f"polyhip::k3p::sw_pk_kernel<152,false,{'true' if half else 'false'}> (+ locate + tie wave, all inside score_pass_ms)",
+                     "derivation": f"packed {'half-float' if half else 'int16'} recurrence: {per_blk} VALU instructions = "
+                                   f"{4 * per_blk} issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x 2.4 GHz; "
+                                   "HBM is not the bound (166 B per 750,000 cells)",
                      "hbm_achieved_GBs": alg / ms_score * 1e3 / 1e9},
         "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
     }

@@ -56,6 +56,7 @@ constexpr uint64_t LONG_PACKED_ROWS = 8ull << 20; // pairs x rows from which the
 constexpr uint64_t WAVE_BATCH = 49152; // below this many pairs the one-wave-per-pair kernel (2.5e12 cell updates/s flat) beats the ~15 ms floor of one lane-per-pair wave
 
 static thread_local int g_last_path = 0;
+static thread_local int g_last_half = 0;
 
 // prof[j][c] = S(symA[c], b_j) as int8; pad columns / pad code = -128.
 // Also finds the first byte of B that is not in SecondAlphabet.
@@ -674,6 +675,7 @@ size_t polyhip_sw_workspace_bytes(const polyhip_scoring *sc, uint64_t npairs, ui
 }
 
 int polyhip_sw_last_path(void) { return k3::g_last_path; }
+int polyhip_sw_last_packed_half(void) { return k3::g_last_half; }
 
 } // extern "C"
 
@@ -700,6 +702,7 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
                p.work_bytes);
     hipStream_t st = as_stream(stream);
     k3::g_last_path = p.path;
+    k3::g_last_half = (p.path == 3 || p.path == 7) && p.pk.f16 ? 1 : 0;
     if (p.path == 1 || p.path == 3 || p.path == 4) {
         uint32_t *binfo = static_cast<uint32_t *>(d_work);
         int8_t *prof = static_cast<int8_t *>(d_work) + 256;

@@ -43,11 +43,22 @@ constexpr int PADS = -1024; // score of a pad row / pad column: keeps d far belo
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// an integer score |v| <= 2048 as the half v * 2^-11 (exact), and back
+__device__ __forceinline__ uint32_t half_bits(int v)
+{
+    const _Float16 h = (_Float16)((float)v * (1.0f / 2048.0f));
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ uint32_t half_score(uint32_t bits)
+{
+    return (uint32_t)((float)__builtin_bit_cast(_Float16, (unsigned short)bits) * 2048.0f);
+}
+
 // prof2 entry (q, cidx) = 4 dwords, one per column of block q: lo half = S(sym(code0), b_j), hi = S(sym(code1), b_j)
 // `lead` all-pad blocks in front and behind (nq counts them): the banded kernel's lanes run up to `lead` blocks apart
 __global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t nq,
                                                       uint32_t lead, const int8_t *__restrict__ lutc, int ncodes,
-                                                      int ncp, uint32_t *__restrict__ prof2)
+                                                      int ncp, uint32_t *__restrict__ prof2, int f16)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // one (block, code pair) each
     const uint32_t ncc = (uint32_t)(ncp * ncp);
@@ -67,7 +78,10 @@ __global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict
             if (c1 < ncodes)
                 s1 = lutc[c1 * 256 + b];
         }
-        w[c] = ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 << 16);
+        if (f16) // sw_pk_kernel<.., F16>: scores as halves, scaled by 2^-11 (exact: |s| <= 2048)
+            w[c] = half_bits(s0) | (half_bits(s1) << 16);
+        else
+            w[c] = ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 << 16);
     }
     reinterpret_cast<uint4 *>(prof2)[e] = make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -90,6 +104,56 @@ __device__ __forceinline__ uint32_t pk_subsat(uint32_t a, uint32_t b)
     asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+
+// F16 flavour (scores < 2048): the same integers held as halves scaled by 2^-11, every sum exact.  gfx950's
+// three-operand packed maximum and the [0, 1] clamp of a packed float add make a cell three instructions:
+//     d = v_pk_add_f16(diag, s)
+//     h = v_pk_maximum3_f16(d, up - |gap|, left - |gap|)
+//     g = v_pk_add_f16(h, -|gap|) clamp          = max(0, h + gap): what the cell below and the cell right take
+// and the block maximum two v_pk_maximum3_f16 per row.  Non-negative halves order like their bit patterns, so the
+// block / tie bookkeeping is the integer one.
+__device__ __forceinline__ uint32_t pkf_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkf_addc(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pkf_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#define PH_PKF_ROW(I, W)                                   \
+    do {                                                   \
+        const int i_ = (I);                                \
+        const uint32_t left = H[i_];                       \
+        const uint32_t gl = pkf_addc(left, gap2);          \
+        const uint32_t h0 = pkf_max3(pkf_add(pdiag, (W).x), pg0, gl); \
+        const uint32_t g0 = pkf_addc(h0, gap2);            \
+        const uint32_t h1 = pkf_max3(pkf_add(pr0, (W).y), pg1, g0);   \
+        const uint32_t g1 = pkf_addc(h1, gap2);            \
+        const uint32_t h2 = pkf_max3(pkf_add(pr1, (W).z), pg2, g1);   \
+        const uint32_t g2 = pkf_addc(h2, gap2);            \
+        const uint32_t h3 = pkf_max3(pkf_add(pr2, (W).w), pg3, g2);   \
+        bm = pkf_max3(pkf_max3(bm, h0, h1), h2, h3);       \
+        pdiag = left;                                      \
+        pr0 = h0;                                          \
+        pr1 = h1;                                          \
+        pr2 = h2;                                          \
+        pr3 = h3;                                          \
+        pg0 = g0;                                          \
+        pg1 = g1;                                          \
+        pg2 = g2;                                          \
+        pg3 = pkf_addc(h3, gap2);                          \
+        H[i_] = h3;                                        \
+    } while (0)
 
 // address of a row's table entry = (block base / 16 + code-pair index) * 16: the index is a byte of the
 // packed row registers (SDWA add), the shift restores bytes
@@ -133,7 +197,7 @@ __device__ __forceinline__ uint32_t row_code(const uint8_t *__restrict__ ap, uin
 
 // SKIP: the wave's longest read decides how many row groups of the unrolled sweep run (a uniform branch per group);
 // batches whose longest read nearly fills RA take the plain instantiation (the branches cost 3 % there)
-template <int RA, bool SKIP>
+template <int RA, bool SKIP, bool F16>
 __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
                                                        uint64_t npairs, const uint32_t *__restrict__ prof2,
                                                        uint32_t nq, uint32_t jcb, uint32_t tab_bytes, int ncp,
@@ -191,7 +255,11 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
             wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
         ng = __builtin_amdgcn_readfirstlane((int)((wl + 3u) >> 2));
     }
-    const uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
+    uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
+    if (F16) { // -|gap| * 2^-11 in both halves
+        const uint32_t g = half_bits(-gapabs);
+        gap2 = g | (g << 16);
+    }
     uint32_t best = 0, bestq = 0, ties = 0; // packed halves: maximum, its first block, bit 0 / bit 16 = tie
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk));
 
@@ -209,27 +277,36 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
         for (uint32_t t = 0; t < nb; ++t) {
             const uint32_t blk16 = (lds_base + t * tab_bytes) >> 4; // lds_pk and tab_bytes are multiples of 16
             uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0, bm = 0;
+            uint32_t pg0 = 0, pg1 = 0, pg2 = 0, pg3 = 0; // F16: the row above, gap already taken
+            (void)pg0, (void)pg1, (void)pg2, (void)pg3;
             u32x4 wa, wb;
+#define PH_PK_STEP(I, W)       \
+    do {                       \
+        if constexpr (F16)     \
+            PH_PKF_ROW(I, W);  \
+        else                   \
+            PH_PK_ROW(I, W);   \
+    } while (0)
             PH_PK_ISSUE(wa, rpk[0], "BYTE_0");
 #pragma unroll
             for (int g = 0; g < RA / 4; ++g) {
                 if (!SKIP || g < ng) { // wave-uniform
                     PH_PK_ISSUE(wb, rpk[g], "BYTE_1");
                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-                    PH_PK_ROW(4 * g, wa);
+                    PH_PK_STEP(4 * g, wa);
                     PH_PK_ISSUE(wa, rpk[g], "BYTE_2");
                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
-                    PH_PK_ROW(4 * g + 1, wb);
+                    PH_PK_STEP(4 * g + 1, wb);
                     PH_PK_ISSUE(wb, rpk[g], "BYTE_3");
                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-                    PH_PK_ROW(4 * g + 2, wa);
+                    PH_PK_STEP(4 * g + 2, wa);
                     if (g + 1 < RA / 4) {
                         PH_PK_ISSUE(wa, rpk[g + 1], "BYTE_0");
                         asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
                     } else {
                         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
                     }
-                    PH_PK_ROW(4 * g + 3, wb);
+                    PH_PK_STEP(4 * g + 3, wb);
                 }
             }
             if (SKIP)
@@ -253,12 +330,18 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
             }
         }
     }
+#undef PH_PK_STEP
+    uint32_t m0 = best & 0xFFFFu, m1 = best >> 16;
+    if (F16) {
+        m0 = half_score(m0);
+        m1 = half_score(m1);
+    }
     if (p0 < npairs) {
-        infoM[p0] = best & 0xFFFFu;
+        infoM[p0] = m0;
         infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
     }
     if (p1 < npairs) {
-        infoM[p1] = best >> 16;
+        infoM[p1] = m1;
         infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
     }
 }
@@ -277,7 +360,7 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
 }
 
-template <int RB, int K>
+template <int RB, int K, bool F16>
 __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
                                                         uint64_t npairs, const uint32_t *__restrict__ prof2,
                                                         uint32_t nq, uint32_t jcb, uint32_t tab_bytes, int ncp,
@@ -325,7 +408,11 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__res
 #pragma unroll
     for (int i = 0; i < RB; ++i)
         H[i] = 0;
-    const uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
+    uint32_t gap2 = (uint32_t)gapabs | ((uint32_t)gapabs << 16);
+    if (F16) {
+        const uint32_t g = half_bits(-gapabs);
+        gap2 = g | (g << 16);
+    }
     const uint32_t inner = band ? 0xFFFFFFFFu : 0u; // band 0 has zeros above it
     uint32_t best = 0, bestq = 0, ties = 0;
     uint32_t out0 = 0, out1 = 0, out2 = 0, out3 = 0, outd = 0, outm = 0, last3 = 0; // what the band below reads next step
@@ -352,26 +439,40 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__res
             uint32_t pdiag = from_lane_above(outd) & inner;
             const uint32_t m_in = from_lane_above(outm) & inner;
             uint32_t bm = 0;
+            uint32_t pg0 = 0, pg1 = 0, pg2 = 0, pg3 = 0; // F16: the row above, gap already taken
+            if (F16) {
+                pg0 = pkf_addc(pr0, gap2);
+                pg1 = pkf_addc(pr1, gap2);
+                pg2 = pkf_addc(pr2, gap2);
+                pg3 = pkf_addc(pr3, gap2);
+            }
             u32x4 wa, wb;
+#define PH_PK_STEP(I, W)       \
+    do {                       \
+        if constexpr (F16)     \
+            PH_PKF_ROW(I, W);  \
+        else                   \
+            PH_PK_ROW(I, W);   \
+    } while (0)
             PH_PK_ISSUE(wa, rpk[0], "BYTE_0");
 #pragma unroll
             for (int g = 0; g < RB / 4; ++g) {
                 PH_PK_ISSUE(wb, rpk[g], "BYTE_1");
                 asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-                PH_PK_ROW(4 * g, wa);
+                PH_PK_STEP(4 * g, wa);
                 PH_PK_ISSUE(wa, rpk[g], "BYTE_2");
                 asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
-                PH_PK_ROW(4 * g + 1, wb);
+                PH_PK_STEP(4 * g + 1, wb);
                 PH_PK_ISSUE(wb, rpk[g], "BYTE_3");
                 asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-                PH_PK_ROW(4 * g + 2, wa);
+                PH_PK_STEP(4 * g + 2, wa);
                 if (g + 1 < RB / 4) {
                     PH_PK_ISSUE(wa, rpk[g + 1], "BYTE_0");
                     asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
                 } else {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
                 }
-                PH_PK_ROW(4 * g + 3, wb);
+                PH_PK_STEP(4 * g + 3, wb);
             }
             // my last row and the block maximum so far, for the band below
             out0 = pr0;
@@ -380,7 +481,7 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__res
             out3 = pr3;
             outd = last3;
             last3 = pr3;
-            bm = pk_max(bm, m_in);
+            bm = pk_max(bm, m_in); // non-negative halves order like their bit patterns
             outm = bm;
             // last band: bm is the pair's maximum over block s0 + t - (K - 1) (all-pad blocks give 0: no effect)
             const uint32_t q = s0 + t - (uint32_t)(K - 1);
@@ -401,17 +502,24 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__res
             }
         }
     }
+#undef PH_PK_STEP
     if (band == K - 1) {
+        uint32_t m0 = best & 0xFFFFu, m1 = best >> 16;
+        if (F16) {
+            m0 = half_score(m0);
+            m1 = half_score(m1);
+        }
         if (p0 < npairs) {
-            infoM[p0] = best & 0xFFFFu;
+            infoM[p0] = m0;
             infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
         }
         if (p1 < npairs) {
-            infoM[p1] = best >> 16;
+            infoM[p1] = m1;
             infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
         }
     }
 }
+#undef PH_PKF_ROW
 #undef PH_PK_ROW
 #undef PH_PK_ISSUE
 
@@ -614,6 +722,8 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
         }
     p.ra = p.rb * p.k;
     p.skip_rows = p.k == 1 && max_lenA + 16 <= (uint32_t)p.ra; // at least four row groups to save
+    // every H below 2048: the three-instruction half-float cell (POLYHIP_SW_F16=0: the int16 one, testing aid)
+    p.f16 = (uint64_t)sc->smax * minlen <= 2047ull && -sc->gap <= 2047 && !env_is("POLYHIP_SW_F16", '0');
     p.ncp = sc->ncodes + 1;
     p.tab_bytes = (uint32_t)(p.ncp * p.ncp * 16);
     p.lenB_pad = (uint32_t)align_up(lenB, 4);
@@ -640,11 +750,12 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         const uint32_t nqe = p.nq + 2 * (K - 1); // K - 1 all-pad blocks on either side
         const uint32_t n = nqe * (uint32_t)(p.ncp * p.ncp);
         hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, nqe, (uint32_t)(K - 1),
-                           sc->d_lutc, sc->ncodes, p.ncp, prof2);
+                           sc->d_lutc, sc->ncodes, p.ncp, prof2, (int)p.f16);
         PH_HIP(hipGetLastError());
     }
     if constexpr (K == 1) {
-        auto kern = p.skip_rows ? sw_pk_kernel<RA, true> : sw_pk_kernel<RA, false>;
+        auto kern = p.f16 ? (p.skip_rows ? sw_pk_kernel<RA, true, true> : sw_pk_kernel<RA, false, true>)
+                          : (p.skip_rows ? sw_pk_kernel<RA, true, false> : sw_pk_kernel<RA, false, false>);
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.pk_smem));
         const uint64_t blocks = (npairs + 2 * THREADS - 1) / (2 * THREADS);
@@ -653,7 +764,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         PH_HIP(hipGetLastError());
     } else {
         static_assert(RA % K == 0, "RA, K");
-        auto kern = sw_pkb_kernel<RA / K, K>;
+        auto kern = p.f16 ? sw_pkb_kernel<RA / K, K, true> : sw_pkb_kernel<RA / K, K, false>;
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)p.pk_smem));
         constexpr uint64_t per_block = 2 * THREADS / K;

@@ -1530,33 +1530,10 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     PH_HIP(hipMemcpy(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost));
     PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
     PH_HIP(hipMemcpy(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost));
-    // A pair's strings are the LAST alnLen bytes of its slot and nothing else of the slot is defined: only the columns
-    // the longest string of the batch reaches cross PCIe (config 4: ~160 of 525 bytes per slot), on two streams.
-    uint32_t w = 0;
-    for (uint64_t i = 0; i < npairs; ++i)
-        if (alnLen[i] != 0xFFFFFFFFu && alnLen[i] > w)
-            w = alnLen[i];
-    w = std::min<uint32_t>((w + 15u) & ~15u, aln_stride);
-    if (w) {
-        const size_t skip = aln_stride - w;
-        hipStream_t cs[2] = {nullptr, nullptr};
-        uint8_t *dst[2] = {alnA, alnB};
-        const uint8_t *src[2] = {dalA.as<uint8_t>(), dalB.as<uint8_t>()};
-        hipError_t e = hipSuccess;
-        for (int q = 0; q < 2 && e == hipSuccess; ++q) {
-            e = hipStreamCreateWithFlags(&cs[q], hipStreamNonBlocking);
-            if (e == hipSuccess)
-                e = hipMemcpy2DAsync(dst[q] + skip, aln_stride, src[q] + skip, aln_stride, w, npairs, hipMemcpyDeviceToHost, cs[q]);
-        }
-        for (int q = 0; q < 2; ++q)
-            if (cs[q]) {
-                const hipError_t e2 = hipStreamSynchronize(cs[q]);
-                if (e == hipSuccess)
-                    e = e2;
-                (void)hipStreamDestroy(cs[q]);
-            }
-        PH_HIP(e);
-    }
+    // whole slots in one contiguous copy each: a strided (2D) copy of only the columns the strings reach moves a third
+    // of the bytes but runs row by row on this runtime (measured 14 s for config 4 against 40 ms for the plain copy)
+    PH_HIP(hipMemcpy(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpy(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
     return POLYHIP_OK;
 }
 

@@ -311,18 +311,22 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
     A = torch.from_numpy(flat.copy()).to(dev)
     offA = torch.from_numpy(offs).to(dev)
 
-    def run(refarr, packed):
+    def run(refarr, packed, half=True):
         if packed:
             monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
         else:
             monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        if half:
+            monkeypatch.delenv("POLYHIP_SW_F16", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_F16", "0")
         B = torch.from_numpy(refarr.copy()).to(dev)
         score = torch.full((n,), -7, dtype=torch.int64, device=dev)
         ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
         work = torch.empty(align.sw_workspace_bytes(sc, n, L, len(refarr)), dtype=torch.uint8, device=dev)
         align.sw_batch_dev(sc, A, offA, L, B, None, len(refarr), score, ea, eb, er, work)
         torch.cuda.synchronize()
-        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path()
+        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path(), align.last_packed_half()
 
     refs = [ref]
     if kind == "bad_symbols":
@@ -331,11 +335,15 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         refs.append(r2)
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
     for refarr in refs:
-        got, path = run(refarr, True)
-        want, path0 = run(refarr, False)
-        assert (path, path0) == (3, 1)
-        for g, w in zip(got, want):
-            assert (g == w).all()
+        # up to 152 rows at NUC.4's 5 per match stay below 2048: the half-float cell of gfx950 is the default there,
+        # the int16 cell (POLYHIP_SW_F16=0) and the exact 32-bit kernel are both run beside it
+        got, path, half = run(refarr, True)
+        got16, path16, half16 = run(refarr, True, half=False)
+        want, path0, _ = run(refarr, False)
+        assert (path, path16, path0) == (3, 3, 1)
+        assert (half, half16) == (True, False)
+        for g, g16, w in zip(got, got16, want):
+            assert (g == w).all() and (g16 == w).all()
         refb = refarr.tobytes()
         for p in range(0, n, 1501):
             a = flat[offs[p]:offs[p + 1]].tobytes()
@@ -346,7 +354,66 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
                 assert int(got[3][p]) != 0 and int(got[0][p]) == 0
 
 
-@pytest.mark.parametrize("maxA,LB,n,repeats", [(300, 3000, 30_001, False), (500, 2000, 17_000, True), (600, 1500, 14_001, False),
+@pytest.mark.parametrize("smax,gap,expect_half", [(13, -1, True), (13, -2047, True), (14, -1, False), (13, -2048, False)])
+def test_half_float_cell_limits(al, monkeypatch, smax, gap, expect_half):
+    """The half-float packed cell holds integers below 2048 exactly: a matrix whose best score is 13 keeps 152 rows
+    inside (13 * 152 = 1976 -- reads equal to a stretch of the reference reach exactly that), 14 does not and takes
+    the int16 cell; |gap| up to 2047.  Every pair against the exact 32-bit kernel, a sample against the oracle."""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(smax * 7 + (-gap))
+    n, L, LB = 60_001, 152, 1500
+    scores = np.full((5, 5), -3, np.int64)
+    np.fill_diagonal(scores, [smax, smax, smax - 1, smax - 2, 1])
+    scores[1, 2] = scores[2, 1] = 2
+    scores = scores.tolist()
+    ref = orc.synth_dna(0x51, LB).copy()
+    starts = rng.integers(0, LB, n)
+    reads = ref[(starts[:, None] + np.arange(L)[None, :]) % LB]
+    reads[0] = ord("A")  # with a poly-A stretch in the reference: the largest score a read of 152 can reach
+    ref[700:700 + L] = ord("A")
+    rate = np.repeat(np.linspace(0.0, 0.6, n)[:, None], L, 1)
+    rate[:64] = 0.0
+    hit = rng.random((n, L)) < rate
+    reads[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    lens = np.where(rng.random(n) < 0.5, L, rng.integers(0, L + 1, n))
+    lens[:64] = L
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)])
+    sc = _scoring(al, "-ACGT", scores, gap)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", scores)
+    A = torch.from_numpy(flat.copy()).to(dev)
+    offA = torch.from_numpy(offs).to(dev)
+    B = torch.from_numpy(ref.copy()).to(dev)
+
+    def run(packed):
+        if packed:
+            monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        score = torch.full((n,), -7, dtype=torch.int64, device=dev)
+        ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+        work = torch.empty(align.sw_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
+        align.sw_batch_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, work)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path(), align.last_packed_half()
+
+    got, path, half = run(True)
+    want, path0, _ = run(False)
+    assert (path, path0, half) == (3, 1, expect_half)
+    for g, w in zip(got, want):
+        assert (g == w).all()
+    assert int(got[0][0]) == smax * L
+    refb = ref.tobytes()
+    for p in list(range(0, 64, 9)) + list(range(64, n, 2503)):
+        a = flat[offs[p]:offs[p + 1]].tobytes()
+        s, _, _, ea_, eb_ = orc.smith_waterman(a, refb, om, gap)
+        assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s, ea_, eb_), p
+
+
+@pytest.mark.parametrize("maxA,LB,n,repeats", [(300, 3000, 30_001, False), (400, 2000, 20_001, True), (500, 2000, 17_000, True), (600, 1500, 14_001, False),
                                                (1000, 1500, 8_300, False), (1216, 1200, 7_001, True), (2048, 800, 4_200, False)])
 def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA, LB, n, repeats):
     """Reads of 257..2048 rows against one reference, enough of them to fill the chip (path 7): the packed banded
@@ -388,23 +455,33 @@ def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA,
     offA = torch.from_numpy(offs).to(dev)
     B = torch.from_numpy(ref.copy()).to(dev)
 
-    def run(packed):
+    def run(packed, half=True):
         if packed:
             monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
         else:
             monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        if half:
+            monkeypatch.delenv("POLYHIP_SW_F16", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_F16", "0")
         score = torch.full((n,), -7, dtype=torch.int64, device=dev)
         ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
         work = torch.empty(align.sw_workspace_bytes(sc, n, maxA, LB), dtype=torch.uint8, device=dev)
         align.sw_batch_dev(sc, A, offA, maxA, B, None, LB, score, ea, eb, er, work)
         torch.cuda.synchronize()
-        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path()
+        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path(), align.last_packed_half()
 
-    got, path = run(True)
-    want, path0 = run(False)
+    got, path, half = run(True)
+    want, path0, _ = run(False)
     assert (path, path0) == (7, 6)
+    assert half == (5 * min(maxA, LB) <= 2047)  # 300 and 400 rows stay below 2048: the half-float cell
     for g, w in zip(got, want):
         assert (g == w).all()
+    if half:  # ... and the int16 cell on the same batch
+        got16, path16, half16 = run(True, half=False)
+        assert (path16, half16) == (7, False)
+        for g, w in zip(got16, want):
+            assert (g == w).all()
     assert int(got[0].max()) == 5 * maxA if maxA <= LB else int(got[0].max()) >= 4 * LB  # a read longer than the reference wraps around it
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
     refb = ref.tobytes()
