@@ -488,7 +488,13 @@ __global__ __launch_bounds__(THREADS) void rowjoin_kernel(const uint32_t *__rest
 }
 
 constexpr int DENSE_THREADS = 1024; // one workgroup per CU (its LDS is the whole CU's): 16 waves keep the bucket loads coming
-constexpr int DENSE_U = 4;          // buckets a wave keeps in flight, 128 items of each
+#ifndef PH_K2_DENSE_U
+#define PH_K2_DENSE_U 8
+#endif
+#ifndef PH_K2_PIPE
+#define PH_K2_PIPE 1
+#endif
+constexpr int DENSE_U = PH_K2_DENSE_U; // buckets a wave loads back to back, 128 items of each
 
 // ---- dense join: a counter per COLUMN in LDS ------------------------------------------------------------
 // Same bucket walk as rowjoin_kernel, but the accumulator is a dense array of BITS-bit counters in LDS, one per
@@ -498,6 +504,14 @@ constexpr int DENSE_U = 4;          // buckets a wave keeps in flight, 128 items
 // follows the shared hashes.  With 10-bit counters (SketchSize <= 1023) the ~138 KB of LDS next to a 1000-hash
 // row hold 105k columns: config 3's 100k sketches are ONE stripe, every bucket is read once per row.
 // Rows: all regular ones (`rows` == NULL), or the rows the sparse join handed over (hdr[H_NOVF] of them).
+// Barrier for LDS traffic only: the wave's LDS operations are complete, nothing is said about its global loads and
+// stores.  rowjoin_dense_kernel shares nothing through global memory inside a workgroup, and __syncthreads() would
+// also wait for the flush's stores (and any load issued ahead) to complete -- a memory round trip per row.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int BITS>
 __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
                                                                const uint8_t *__restrict__ flagsX,
@@ -520,46 +534,110 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
     const uint64_t nrows = rows ? hdr[H_NOVF] : nx;
     const uint32_t stripe_cols = stripe_dwords * PER;
     const bool one_stripe = ny <= stripe_cols;
-    for (uint64_t r = blockIdx.x; r < nrows; r += gridDim.x) {
-        const uint64_t i = rows ? rows[r] : r;
-        if (!rows && flagsX[i])
-            continue; // irregular rows belong to the merge
-        __syncthreads();
-        if (tid == 0)
-            ndist = 0;
-        const uint32_t *xp = X + i * sx;
-        for (uint32_t p = tid; p < sx; p += DENSE_THREADS)
-            xv[p] = xp[p];
-        __syncthreads();
-        for (uint32_t p = tid; p < sx; p += DENSE_THREADS) { // distinct values of the row and their buckets
-            const uint32_t v = xv[p];
-            if (p != 0 && xv[p - 1] == v)
-                continue;
-            const uint32_t b = v >> shift;
-            if (b >= nbk)
-                continue;
-            const uint32_t bs = start[b], be = start[b + 1];
-            if (be == bs)
-                continue;
-            uint32_t a = 1;
-            while (p + a < sx && xv[p + a] == v)
-                ++a;
-            const uint32_t slot = atomicAdd(&ndist, 1u);
-            dval[slot] = v;
-            dmul[slot] = a;
-            dbeg[slot] = bs;
-            dend[slot] = be;
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD with its own L2.  The rows in flight on one XCD
+    // are CONSECUTIVE ones (gridDim / 8 of them): neighbouring sketches share most of their hashes -- a family's
+    // copies -- so their buckets are fetched into that L2 once, not into all eight.
+    const uint32_t G = gridDim.x, per_xcd = G / 8u;
+    const bool by_xcd = per_xcd != 0 && G % 8u == 0;
+    const uint64_t off = by_xcd ? (uint64_t)(blockIdx.x % 8u) * per_xcd + blockIdx.x / 8u : blockIdx.x;
+    // Two rows ahead of the walk: row k + 2's hashes and row k + 1's bucket bounds are loaded while row k's buckets
+    // are walked (one hash per thread; sketches above 1024 hashes take the plain loads).  A row costs two dependent
+    // memory round trips before its first bucket can be touched -- off the critical path this way.
+    const bool ahead = sx <= (uint32_t)DENSE_THREADS;
+    struct Pre {
+        int64_t i;       // row of X, -1: past the end
+        uint32_t skip;   // irregular row (flagsX): the merge's
+        uint32_t v;      // my hash of it
+        uint32_t bs, be; // its bucket
+    };
+    auto load_row = [&](uint64_t k, Pre &q) {
+        const uint64_t r = k * G + off;
+        q.i = -1;
+        q.skip = 0;
+        q.v = 0;
+        if (r < nrows) {
+            q.i = (int64_t)(rows ? rows[r] : r);
+            q.skip = rows ? 0u : flagsX[q.i];
+            if (ahead && (uint32_t)tid < sx)
+                q.v = X[(uint64_t)q.i * sx + tid];
         }
-        __syncthreads();
+    };
+    auto load_bounds = [&](Pre &q) {
+        q.bs = q.be = 0;
+        if (ahead && q.i >= 0 && (uint32_t)tid < sx) {
+            const uint32_t b = q.v >> shift;
+            if (b < nbk) {
+                q.bs = start[b];
+                q.be = start[b + 1];
+            }
+        }
+    };
+    Pre cur, nxt;
+    load_row(0, cur);
+    load_bounds(cur);
+    load_row(1, nxt);
+    for (uint64_t k = 0; cur.i >= 0; ++k) {
+        const uint64_t i = (uint64_t)cur.i;
+        const bool work = !cur.skip; // wave-uniform (irregular rows belong to the merge)
+        if (work) {
+            lds_barrier();
+            if (tid == 0)
+                ndist = 0;
+            if (ahead) {
+                if ((uint32_t)tid < sx)
+                    xv[tid] = cur.v;
+            } else {
+                const uint32_t *xp = X + i * sx;
+                for (uint32_t p = tid; p < sx; p += DENSE_THREADS)
+                    xv[p] = xp[p];
+            }
+            lds_barrier();
+            for (uint32_t p = tid; p < sx; p += DENSE_THREADS) { // distinct values of the row and their buckets
+                const uint32_t v = xv[p];
+                if (p != 0 && xv[p - 1] == v)
+                    continue;
+                const uint32_t b = v >> shift;
+                if (b >= nbk)
+                    continue;
+                const uint32_t bs = ahead ? cur.bs : start[b], be = ahead ? cur.be : start[b + 1];
+                if (be == bs)
+                    continue;
+                uint32_t a = 1;
+                while (p + a < sx && xv[p + a] == v)
+                    ++a;
+                const uint32_t slot = atomicAdd(&ndist, 1u);
+                dval[slot] = v;
+                dmul[slot] = a;
+                dbeg[slot] = bs;
+                dend[slot] = be;
+            }
+            lds_barrier();
+        }
+        // issue the loads of the rows ahead now: they land while this row's buckets are walked
+        Pre nn;
+        load_bounds(nxt);
+        load_row(k + 2, nn);
+        cur = nxt;
+        nxt = nn;
+        if (!work)
+            continue;
         const uint32_t nd = ndist;
         for (uint64_t c0 = 0; c0 < ny; c0 += stripe_cols) {
             const uint32_t ncols = (uint32_t)min((uint64_t)stripe_cols, ny - c0);
-            const uint32_t ndw = (ncols + PER - 1) / PER;
-            for (uint32_t t = tid * 4; t < ndw; t += DENSE_THREADS * 4) // stripe_dwords is a multiple of 4
+            // column c of the stripe = field c / ndw of dword c % ndw: neighbouring columns (a bucket is a family's
+            // copies of one hash -- a run of them) sit in neighbouring dwords, so one LDS atomic's lanes hit distinct
+            // banks, and the flush reads whole dwords of one field
+            const uint32_t ndw = (((ncols + PER - 1) / PER) + 7u) & ~7u; // <= stripe_dwords (a multiple of 8)
+            for (uint32_t t = tid * 4; t < ndw; t += DENSE_THREADS * 4)
                 *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
-            __syncthreads();
-            auto consume = [&](const uint2 it, uint32_t v, uint32_t a) {
-                if (it.x != v || (it.y >> id_bits) >= a) // (0, 0xFFFFFFFF) = no item: occurrence number all ones
+            lds_barrier();
+            // k = col / ndw by one multiply-high: kmul = ceil(2^32 / ndw) is exact for col < PER * ndw while PER * ndw^2 < 2^32
+            // (the host caps the stripe accordingly)
+            const uint32_t kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
+            auto consume = [&](const uint2 it, uint32_t v, uint32_t alim) {
+                // alim = multiplicity << id_bits: "occurrence number < multiplicity" is one compare of the whole word
+                // ((0, 0xFFFFFFFF) = no item fails it)
+                if (it.x != v || it.y >= alim)
                     return;
                 uint32_t col = it.y & id_mask;
                 if (!one_stripe) {
@@ -567,59 +645,112 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                         return;
                     col -= (uint32_t)c0;
                 }
-                const uint32_t dw = PER == 3 ? (__umulhi(col, 0xAAAAAAABu) >> 1) : (col >> 1);
-                atomicAdd(&dense[dw], 1u << (BITS * (col - dw * PER)));
+                const uint32_t k = __umulhi(col, kmul);
+                atomicAdd(&dense[col - k * ndw], 1u << (BITS * k));
             };
-            // a wave takes DENSE_U distinct values at a time: the first 128 items of each bucket are loaded back to
-            // back (a family's copies of one hash are one bucket), then consumed
-            for (uint32_t d0 = wave * DENSE_U; d0 < nd; d0 += (DENSE_THREADS / 64) * DENSE_U) {
-                uint2 it[DENSE_U][2];
+            // Wave w owns the distinct values w, w + 16, w + 32, ...: lane l keeps the descriptor of the wave's l-th one
+            // in registers (one LDS pass per 64 buckets) and the walk takes them from there by v_readlane -- bucket
+            // bounds, value and multiplicity are scalars, no LDS round trip stands between two buckets.  DENSE_U
+            // buckets at a time: the first 128 items of each are loaded back to back (a family's copies of one hash are
+            // one bucket), then consumed.
+            constexpr uint32_t NW = DENSE_THREADS / 64;
+            for (uint32_t jb = 0; wave + NW * jb < nd; jb += 64) {
+                const uint32_t mine = wave + NW * (jb + lane);
+                uint32_t mval = 0, mlim = 0, mbeg = 0, mend = 0; // beyond nd: an empty bucket
+                if (mine < nd) {
+                    const uint32_t a = dmul[mine];
+                    mval = dval[mine];
+                    mlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
+                    mbeg = dbeg[mine];
+                    mend = dend[mine];
+                }
+                const uint32_t cnt = min(64u, (nd - wave - NW * jb + NW - 1) / NW); // my buckets in this chunk
+                for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
+                    uint2 it[DENSE_U][2];
+                    uint32_t beg[DENSE_U], end[DENSE_U];
 #pragma unroll
-                for (int u = 0; u < DENSE_U; ++u) {
-                    const uint32_t d = d0 + u;
-                    it[u][0] = it[u][1] = make_uint2(0u, 0xFFFFFFFFu);
-                    if (d < nd) {
-                        const uint32_t t = dbeg[d] + lane, e = dend[d];
-                        if (t < e)
+                    for (int u = 0; u < DENSE_U; ++u) {
+                        beg[u] = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
+                        end[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u));
+                        it[u][0] = it[u][1] = make_uint2(0u, 0xFFFFFFFFu);
+                        const uint32_t t = beg[u] + lane;
+                        if (t < end[u])
                             it[u][0] = items[t];
-                        if (t + 64 < e)
+                        if (t + 64 < end[u])
                             it[u][1] = items[t + 64];
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < DENSE_U; ++u) {
-                    const uint32_t d = d0 + u;
-                    if (d >= nd)
-                        break;
-                    const uint32_t v = dval[d], a = dmul[d];
-                    consume(it[u][0], v, a);
-                    consume(it[u][1], v, a);
-                    for (uint32_t t = dbeg[d] + 128 + lane; t < dend[d]; t += 64) // rest of a long bucket
-                        consume(items[t], v, a);
-                }
-            }
-            __syncthreads();
-            uint16_t *crow = counts + i * ld + c0;
-            if ((((uintptr_t)crow) & 3) == 0) { // two columns per 4-byte store
-                for (uint32_t t = tid; 2 * t < ncols; t += DENSE_THREADS) {
-                    const uint32_t c = 2 * t, dw0 = PER == 3 ? (__umulhi(c, 0xAAAAAAABu) >> 1) : t;
-                    const uint32_t k0 = c - dw0 * PER;
-                    const uint32_t lo = (dense[dw0] >> (BITS * k0)) & FMASK;
-                    const uint32_t c1 = c + 1, dw1 = k0 + 1 == PER ? dw0 + 1 : dw0, k1 = k0 + 1 == PER ? 0 : k0 + 1;
-                    if (c1 < ncols) {
-                        const uint32_t hi = (dense[dw1] >> (BITS * k1)) & FMASK;
-                        *reinterpret_cast<uint32_t *>(crow + c) = lo | (hi << 16);
-                    } else {
-                        crow[c] = (uint16_t)lo;
+                    for (int u = 0; u < DENSE_U; ++u) {
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
+                        const uint32_t alim = (uint32_t)__builtin_amdgcn_readlane((int)mlim, (int)(j0 + u));
+                        consume(it[u][0], v, alim);
+                        if (end[u] - beg[u] > 64u) { // wave-uniform
+                            consume(it[u][1], v, alim);
+                            for (uint32_t t = beg[u] + 128 + lane; t < end[u]; t += 64) // rest of a long bucket
+                                consume(items[t], v, alim);
+                        }
                     }
                 }
-            } else {
-                for (uint32_t c = tid; c < ncols; c += DENSE_THREADS) {
-                    const uint32_t dw = PER == 3 ? (__umulhi(c, 0xAAAAAAABu) >> 1) : (c >> 1);
-                    crow[c] = (uint16_t)((dense[dw] >> (BITS * (c - dw * PER))) & FMASK);
+            }
+            lds_barrier();
+            // flush the stripe whole, zeros included: field k of dwords [0, ndw) = columns [k * ndw, (k + 1) * ndw)
+            uint16_t *crow = counts + i * ld + c0;
+            const uint32_t al = (uint32_t)(((uintptr_t)crow) & 15u);
+#pragma unroll
+            for (uint32_t k = 0; k < PER; ++k) {
+                const uint32_t cb = k * ndw; // a multiple of 8: crow + cb keeps crow's alignment
+                if (cb >= ncols)
+                    break;
+                const uint32_t n = min(ndw, ncols - cb);
+                if (al == 0) { // eight columns per 16-byte store (the flush is bound by store issue, not bytes)
+                    for (uint32_t t = tid * 8; t < n; t += DENSE_THREADS * 8) {
+                        const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
+                        const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
+                        uint32_t f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            f[q] = (f[q] >> (BITS * k)) & FMASK;
+                        if (t + 8 <= n) {
+                            *reinterpret_cast<uint4 *>(crow + cb + t) =
+                                make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (t + q < n)
+                                    crow[cb + t + q] = (uint16_t)f[q];
+                        }
+                    }
+                } else if ((al & 7u) == 0) { // four columns per 8-byte store
+
+                    for (uint32_t t = tid * 4; t < n; t += DENSE_THREADS * 4) {
+                        const uint4 d = *reinterpret_cast<const uint4 *>(dense + t);
+                        const uint32_t f0 = (d.x >> (BITS * k)) & FMASK, f1 = (d.y >> (BITS * k)) & FMASK,
+                                       f2 = (d.z >> (BITS * k)) & FMASK, f3 = (d.w >> (BITS * k)) & FMASK;
+                        if (t + 4 <= n) {
+                            *reinterpret_cast<uint2 *>(crow + cb + t) = make_uint2(f0 | (f1 << 16), f2 | (f3 << 16));
+                        } else {
+                            crow[cb + t] = (uint16_t)f0; // t < n
+                            if (t + 1 < n)
+                                crow[cb + t + 1] = (uint16_t)f1;
+                            if (t + 2 < n)
+                                crow[cb + t + 2] = (uint16_t)f2;
+                        }
+                    }
+                } else if ((al & 3u) == 0) { // two per 4-byte store
+                    for (uint32_t t = tid * 2; t < n; t += DENSE_THREADS * 2) {
+                        const uint2 d = *reinterpret_cast<const uint2 *>(dense + t);
+                        const uint32_t f0 = (d.x >> (BITS * k)) & FMASK, f1 = (d.y >> (BITS * k)) & FMASK;
+                        if (t + 2 <= n)
+                            *reinterpret_cast<uint32_t *>(crow + cb + t) = f0 | (f1 << 16);
+                        else
+                            crow[cb + t] = (uint16_t)f0;
+                    }
+                } else {
+                    for (uint32_t t = tid; t < n; t += DENSE_THREADS)
+                        crow[cb + t] = (uint16_t)((dense[t] >> (BITS * k)) & FMASK);
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
 }
@@ -810,11 +941,14 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     const int bits = std::min(sx, sy) <= 1023u ? 10 : 16;
     const uint32_t per = 32u / (uint32_t)bits;
     const size_t row_bytes = (((size_t)5 * sx + 3) & ~(size_t)3) * 4, lds_max = 160 * 1024 - 256;
-    const uint32_t stripe_dwords = row_bytes + 4096 <= lds_max ? (uint32_t)(((lds_max - row_bytes) / 4) & ~(size_t)3) : 0u;
+    // <= 37832 dwords with three fields (the kernel's multiply-high `column / ndw` is exact for 3 * ndw^2 < 2^32)
+    const size_t sdw_cap = per == 3 ? 37832u : 46328u;
+    const uint32_t stripe_dwords =
+        row_bytes + 4096 <= lds_max ? (uint32_t)std::min<size_t>(((lds_max - row_bytes) / 4) & ~(size_t)7, sdw_cap) : 0u;
     const uint64_t stripe_cols = (uint64_t)stripe_dwords * per;
     const uint64_t stripes = stripe_cols ? (ny + stripe_cols - 1) / stripe_cols : ~0ull;
     auto launch_dense = [&](const uint32_t *rows, unsigned blocks) -> int {
-        const uint32_t sdw = (uint32_t)std::min<uint64_t>(stripe_dwords, (((ny + per - 1) / per) + 3) & ~3ull);
+        const uint32_t sdw = (uint32_t)std::min<uint64_t>(stripe_dwords, (((ny + per - 1) / per) + 7) & ~7ull);
         const size_t smem = row_bytes + (size_t)sdw * 4;
         if (bits == 10) {
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<10>),
