@@ -572,6 +572,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             }
         }
     };
+    // the counters start at zero and every flush leaves them so (a thread clears the dwords it has just written out)
+    for (uint32_t t = tid * 4; t < stripe_dwords; t += DENSE_THREADS * 4) // stripe_dwords is a multiple of 8
+        *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
     Pre cur, nxt;
     load_row(0, cur);
     load_bounds(cur);
@@ -628,9 +631,6 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             // copies of one hash -- a run of them) sit in neighbouring dwords, so one LDS atomic's lanes hit distinct
             // banks, and the flush reads whole dwords of one field
             const uint32_t ndw = (((ncols + PER - 1) / PER) + 7u) & ~7u; // <= stripe_dwords (a multiple of 8)
-            for (uint32_t t = tid * 4; t < ndw; t += DENSE_THREADS * 4)
-                *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
-            lds_barrier();
             // k = col / ndw by one multiply-high: kmul = ceil(2^32 / ndw) is exact for col < PER * ndw while PER * ndw^2 < 2^32
             // (the host caps the stripe accordingly)
             const uint32_t kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
@@ -702,10 +702,18 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 if (cb >= ncols)
                     break;
                 const uint32_t n = min(ndw, ncols - cb);
-                if (al == 0) { // eight columns per 16-byte store (the flush is bound by store issue, not bytes)
-                    for (uint32_t t = tid * 8; t < n; t += DENSE_THREADS * 8) {
+                // the last field's pass runs over all ndw dwords and clears them (the same thread has read a dword in
+                // every pass: no barrier needed in between)
+                const bool last = cb + ndw >= ncols;
+                const uint32_t lim = last ? ndw : n;
+                if (al == 0) { // eight columns per 16-byte store
+                    for (uint32_t t = tid * 8; t < lim; t += DENSE_THREADS * 8) {
                         const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
                         const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
+                        if (last) {
+                            *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
+                            *reinterpret_cast<uint4 *>(dense + t + 4) = make_uint4(0, 0, 0, 0);
+                        }
                         uint32_t f[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
                         for (int q = 0; q < 8; ++q)
@@ -721,15 +729,17 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                         }
                     }
                 } else if ((al & 7u) == 0) { // four columns per 8-byte store
-
-                    for (uint32_t t = tid * 4; t < n; t += DENSE_THREADS * 4) {
+                    for (uint32_t t = tid * 4; t < lim; t += DENSE_THREADS * 4) {
                         const uint4 d = *reinterpret_cast<const uint4 *>(dense + t);
+                        if (last)
+                            *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
                         const uint32_t f0 = (d.x >> (BITS * k)) & FMASK, f1 = (d.y >> (BITS * k)) & FMASK,
                                        f2 = (d.z >> (BITS * k)) & FMASK, f3 = (d.w >> (BITS * k)) & FMASK;
                         if (t + 4 <= n) {
                             *reinterpret_cast<uint2 *>(crow + cb + t) = make_uint2(f0 | (f1 << 16), f2 | (f3 << 16));
                         } else {
-                            crow[cb + t] = (uint16_t)f0; // t < n
+                            if (t < n)
+                                crow[cb + t] = (uint16_t)f0;
                             if (t + 1 < n)
                                 crow[cb + t + 1] = (uint16_t)f1;
                             if (t + 2 < n)
@@ -737,17 +747,24 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                         }
                     }
                 } else if ((al & 3u) == 0) { // two per 4-byte store
-                    for (uint32_t t = tid * 2; t < n; t += DENSE_THREADS * 2) {
+                    for (uint32_t t = tid * 2; t < lim; t += DENSE_THREADS * 2) {
                         const uint2 d = *reinterpret_cast<const uint2 *>(dense + t);
+                        if (last)
+                            *reinterpret_cast<uint2 *>(dense + t) = make_uint2(0, 0);
                         const uint32_t f0 = (d.x >> (BITS * k)) & FMASK, f1 = (d.y >> (BITS * k)) & FMASK;
                         if (t + 2 <= n)
                             *reinterpret_cast<uint32_t *>(crow + cb + t) = f0 | (f1 << 16);
-                        else
+                        else if (t < n)
                             crow[cb + t] = (uint16_t)f0;
                     }
                 } else {
-                    for (uint32_t t = tid; t < n; t += DENSE_THREADS)
-                        crow[cb + t] = (uint16_t)((dense[t] >> (BITS * k)) & FMASK);
+                    for (uint32_t t = tid; t < lim; t += DENSE_THREADS) {
+                        const uint32_t d = dense[t];
+                        if (last)
+                            dense[t] = 0;
+                        if (t < n)
+                            crow[cb + t] = (uint16_t)((d >> (BITS * k)) & FMASK);
+                    }
                 }
             }
             lds_barrier();

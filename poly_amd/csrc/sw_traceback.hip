@@ -1506,34 +1506,88 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     if (int rc0 = in.load("polyhip_sw_align_batch", A, offA, npairs, B, offB, lenB))
         return rc0;
     const uint64_t maxA = in.maxA, maxB = in.maxB;
-    DevBuf dscore, dea, deb, derr, dwork, dalA, dalB, dlen, dtb;
-    PH_HIP(dscore.alloc(npairs * 8));
-    PH_HIP(dea.alloc(npairs * 4));
-    PH_HIP(deb.alloc(npairs * 4));
-    PH_HIP(derr.alloc(npairs * 4));
-    PH_HIP(dalA.alloc(npairs * (size_t)aln_stride));
-    PH_HIP(dalB.alloc(npairs * (size_t)aln_stride));
-    PH_HIP(dlen.alloc(npairs * 4));
-    const size_t wb = polyhip_sw_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB, offB == nullptr);
-    PH_HIP(dwork.alloc(wb));
-    const size_t tb = polyhip_sw_traceback_workspace_bytes(sc, npairs, (uint32_t)maxA, maxB);
-    PH_HIP(dtb.alloc(tb));
-    int rc = polyhip_sw_align_batch_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
-                                        dscore.as<int64_t>(), dea.as<uint32_t>(), deb.as<uint32_t>(), derr.as<uint32_t>(),
-                                        dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(), aln_stride, dwork.p, wb,
-                                        dtb.p, tb, nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(endA, dea.p, npairs * 4, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost));
-    // whole slots in one contiguous copy each: a strided (2D) copy of only the columns the strings reach moves a third
-    // of the bytes but runs row by row on this runtime (measured 14 s for config 4 against 40 ms for the plain copy)
-    PH_HIP(hipMemcpy(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
+    // Chunks of pairs through two slots, each with its own stream, outputs and workspaces: the strings of chunk c cross
+    // PCIe (1 GB for config 4, as long as the kernels take) while chunk c + 1 is being aligned.  The reads and the
+    // reference are on the device already (PairStage); a chunk is a window of offA.  Shared reference only -- per-pair
+    // references keep the single shot.
+    // Chunk = a multiple of 262,144 pairs (one full round of the packed pass: 512 workgroups of 512 pairs), at most
+    // eight chunks, none when the strings are below ~200 MB.
+    const uint64_t out_bytes = npairs * (2ull * aln_stride + 24);
+    uint64_t per = npairs;
+    if (!offB) {
+        const uint64_t unit = 262144;
+        if (out_bytes >= (192ull << 20) && npairs > unit)
+            per = ((npairs + 7) / 8 + unit - 1) / unit * unit;
+        if (const char *e = getenv("POLYHIP_SW_HOST_CHUNKS")) // testing aid: 0 / 1 = single shot, 2..8 = that many chunks
+            if (e[0] >= '0' && e[0] <= '8') {
+                const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(e[0] - '0'), npairs));
+                per = (npairs + want - 1) / want;
+            }
+    }
+    const uint64_t nchunks = (npairs + per - 1) / per;
+    struct Slot {
+        DevBuf dscore, dea, deb, derr, dwork, dalA, dalB, dlen, dtb;
+        hipStream_t st = nullptr;
+        ~Slot()
+        {
+            if (st) {
+                (void)hipStreamSynchronize(st);
+                (void)hipStreamDestroy(st);
+            }
+        }
+    } slot[2];
+    const size_t wb = polyhip_sw_workspace_bytes(sc, per, (uint32_t)maxA, maxB, offB == nullptr);
+    const size_t tb = polyhip_sw_traceback_workspace_bytes(sc, per, (uint32_t)maxA, maxB);
+    for (uint64_t q = 0; q < std::min<uint64_t>(2, nchunks); ++q) {
+        Slot &S = slot[q];
+        PH_HIP(S.dscore.alloc(per * 8));
+        PH_HIP(S.dea.alloc(per * 4));
+        PH_HIP(S.deb.alloc(per * 4));
+        PH_HIP(S.derr.alloc(per * 4));
+        PH_HIP(S.dlen.alloc(per * 4));
+        PH_HIP(S.dalA.alloc(per * (size_t)aln_stride));
+        PH_HIP(S.dalB.alloc(per * (size_t)aln_stride));
+        PH_HIP(S.dwork.alloc(wb));
+        PH_HIP(S.dtb.alloc(tb));
+        if (nchunks > 1)
+            PH_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+    }
+    PH_HIP(hipStreamSynchronize(nullptr)); // PairStage's uploads
+    auto download = [&](uint64_t c) -> hipError_t {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = c * per, m = std::min(per, npairs - i0);
+        hipError_t e;
+        if ((e = hipMemcpyAsync(score + i0, S.dscore.p, m * 8, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(endA + i0, S.dea.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(endB + i0, S.deb.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(err + i0, S.derr.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(alnLen + i0, S.dlen.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            // whole slots in one contiguous copy each: a strided (2D) copy of only the columns the strings reach moves
+            // a third of the bytes but runs row by row on this runtime (measured 14 s for config 4 against 40 ms)
+            (e = hipMemcpyAsync(alnA + i0 * (size_t)aln_stride, S.dalA.p, m * (size_t)aln_stride, hipMemcpyDeviceToHost,
+                                S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(alnB + i0 * (size_t)aln_stride, S.dalB.p, m * (size_t)aln_stride, hipMemcpyDeviceToHost,
+                                S.st)) != hipSuccess)
+            return e;
+        return hipSuccess;
+    };
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = c * per, m = std::min(per, npairs - i0);
+        if (S.st)
+            PH_HIP(hipStreamSynchronize(S.st)); // chunk c - 2 has left this slot
+        const int rc = polyhip_sw_align_batch_dev(sc, in.A(), in.offA() + i0, m, (uint32_t)maxA, in.B(), in.offB() ? in.offB() + i0 : nullptr,
+                                                  maxB, S.dscore.as<int64_t>(), S.dea.as<uint32_t>(), S.deb.as<uint32_t>(),
+                                                  S.derr.as<uint32_t>(), S.dalA.as<uint8_t>(), S.dalB.as<uint8_t>(),
+                                                  S.dlen.as<uint32_t>(), aln_stride, S.dwork.p, wb, S.dtb.p, tb, S.st);
+        if (rc != POLYHIP_OK)
+            return rc;
+        if (c > 0)
+            PH_HIP(download(c - 1)); // the host waits here for chunk c - 1's copy while chunk c's kernels run
+    }
+    PH_HIP(download(nchunks - 1));
+    for (uint64_t q = 0; q < std::min<uint64_t>(2, nchunks); ++q)
+        PH_HIP(hipStreamSynchronize(slot[q].st));
     return POLYHIP_OK;
 }
 

@@ -101,6 +101,44 @@ def test_config4_shape(al):
     _check(al, sc, om, -2, reads, ref=ref)
 
 
+@pytest.mark.parametrize("chunks", ["3", "8"])
+def test_host_flavour_chunk_pipeline_equals_single_shot(al, monkeypatch, chunks):
+    """polyhip_sw_align_batch sends large batches through two slots in chunks of pairs (the strings of one chunk
+    cross PCIe while the next is aligned); POLYHIP_SW_HOST_CHUNKS forces the chunk count here.  Same scores, end
+    cells, errors and strings as the single shot (a ragged batch with bad symbols and empty reads whose size is no
+    multiple of the chunk count), a sample against the oracle."""
+    align = al[0]
+    rng = np.random.default_rng(int(chunks))
+    ref = orc.synth_dna(0xC4, 3000).tobytes()
+    reads = []
+    for i in range(20_003):
+        p = int(rng.integers(0, 3000 - 150))
+        r = _mutate(rng, ref[p:p + int(rng.integers(1, 151))])[:152]
+        if i % 997 == 0:
+            r = b"" if i % 2 else r[:5] + b"N" + r[6:]
+        reads.append(r)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    A, offA = _pack(reads)
+    B, _ = _pack([ref])
+    monkeypatch.setenv("POLYHIP_SW_HOST_CHUNKS", "1")
+    one = align.sw_align_packed(sc, A, offA, B, None)
+    monkeypatch.setenv("POLYHIP_SW_HOST_CHUNKS", chunks)
+    got = align.sw_align_packed(sc, A, offA, B, None)
+    for g, w in zip(got[:4], one[:4]):
+        assert (g == w).all()
+    assert got[4] == one[4] and got[5] == one[5]
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    for p in range(0, len(reads), 401):
+        try:
+            s_, sa, sb, _, _ = orc.smith_waterman(reads[p], ref, om, -2)
+        except orc.AlphabetError:
+            assert int(got[3][p]) != 0 and got[4][p] == b""
+            continue
+        sa = sa if isinstance(sa, bytes) else sa.encode("latin-1")
+        sb = sb if isinstance(sb, bytes) else sb.encode("latin-1")
+        assert (int(got[0][p]), got[4][p], got[5][p]) == (s_, sa, sb), p
+
+
 @pytest.mark.parametrize("maxlen,reflen", [(64, 300), (152, 1500), (256, 2100), (40, 3), (10, 1)])
 def test_ragged(al, maxlen, reflen):
     rng = np.random.default_rng(maxlen * 7 + reflen)
