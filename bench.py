@@ -328,6 +328,12 @@ def main() -> int:
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args)
 
+    # Anything a library prints on stdout (gloo / RCCL banners, runtime notices) goes to stderr: stdout carries the ONE
+    # JSON line, written by rank 0 to the original descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -502,7 +508,8 @@ def main() -> int:
                     if isinstance(line["extra"].get(name), dict):
                         line["extra"][name]["cpu_baseline"] = base
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
     return 0

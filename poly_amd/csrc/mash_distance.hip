@@ -719,8 +719,10 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                         for (int q = 0; q < 8; ++q)
                             f[q] = (f[q] >> (BITS * k)) & FMASK;
                         if (t + 8 <= n) {
-                            *reinterpret_cast<uint4 *>(crow + cb + t) =
-                                make_uint4(f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16));
+                            // written once, never read here: nontemporal, so the 2 B per pair do not push the index out of L2
+                            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                            const u32x4_t o = {f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16)};
+                            __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(crow + cb + t));
                         } else {
 #pragma unroll
                             for (int q = 0; q < 8; ++q)
