@@ -264,7 +264,10 @@ int polyhip_sw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A,
                                void *d_work, size_t work_bytes,
                                void *d_tb_work, size_t tb_work_bytes,
                                polyhip_stream_t stream);
-/* Host-pointer flavour of the whole SmithWaterman: score pass + traceback. */
+/* Host-pointer flavour of the whole SmithWaterman: score pass + traceback.  With one shared reference and more than
+ * ~200 MB of string slots the pairs go through two device slots in chunks of 262,144 (at most eight chunks): the strings
+ * of one chunk cross PCIe while the next chunk is aligned.  POLYHIP_SW_HOST_CHUNKS=1..8 sets the chunk count (testing
+ * aid; 1 = single shot). */
 int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
                            const uint64_t *offA, uint64_t npairs,
                            const uint8_t *B, const uint64_t *offB,

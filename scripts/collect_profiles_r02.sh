@@ -22,4 +22,5 @@ run ${R}_k3_pmc --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ
 run ${R}_k2_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_k2_stats -o x -- python scripts/quick_k2c.py
 run ${R}_k2_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_fetch -o x -- python scripts/quick_k2c.py
 run ${R}_k2_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_write -o x -- python scripts/quick_k2c.py
-for t in bench_stats bench_fetch bench_write k1_issue k3_stats k3_pmc k2_stats k2_fetch k2_write; do echo "== $t"; grep -E "polyhip" $ROOT/gpurun_out/${R}_$t.md | head -8 | cut -c1-180; done
+run ${R}_k2_pmc_sq --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_pmc_sq -o x -- python scripts/quick_k2d.py
+for t in bench_stats bench_fetch bench_write k1_issue k3_stats k3_pmc k2_stats k2_fetch k2_write k2_pmc_sq; do echo "== $t"; grep -E "polyhip" $ROOT/gpurun_out/${R}_$t.md | head -8 | cut -c1-180; done
