@@ -314,7 +314,7 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
 int polyhip_sw_last_path(void);
 /* 1 when that call's packed pass (paths 3 and 7) ran the half-float cell of gfx950 (v_pk_maximum3_f16: three
  * instructions per cell pair instead of four) -- taken when every H stays below 2048, i.e. smax * min(max_lenA, lenB)
- * <= 2047 and |gap| <= 2047; same integers, bit for bit (halves scaled by 2^-11, every sum exact).
+ * <= 2047 and smax + |gap| <= 2048; same integers, bit for bit (halves scaled by 2^-11, every sum exact).
  * POLYHIP_SW_F16=0 keeps the int16 cell (testing aid). */
 int polyhip_sw_last_packed_half(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,

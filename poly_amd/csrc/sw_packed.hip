@@ -58,7 +58,7 @@ __device__ __forceinline__ uint32_t half_score(uint32_t bits)
 // `lead` all-pad blocks in front and behind (nq counts them): the banded kernel's lanes run up to `lead` blocks apart
 __global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t nq,
                                                       uint32_t lead, const int8_t *__restrict__ lutc, int ncodes,
-                                                      int ncp, uint32_t *__restrict__ prof2, int f16)
+                                                      int ncp, uint32_t *__restrict__ prof2, int f16, int gapabs)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; // one (block, code pair) each
     const uint32_t ncc = (uint32_t)(ncp * ncp);
@@ -78,8 +78,11 @@ __global__ __launch_bounds__(256) void profile2_kernel(const uint8_t *__restrict
             if (c1 < ncodes)
                 s1 = lutc[c1 * 256 + b];
         }
-        if (f16) // sw_pk_kernel<.., F16>: scores as halves, scaled by 2^-11 (exact: |s| <= 2048)
-            w[c] = half_bits(s0) | (half_bits(s1) << 16);
+        if (f16) { // F16 cell: scores as halves, scaled by 2^-11 (exact: |s| <= 2048); column 0 of a block carries + |gap|:
+            // its diagonal value arrives with the gap already taken (PH_PKF_ROW)
+            const int bias = c == 0 ? gapabs : 0;
+            w[c] = half_bits(s0 + bias) | (half_bits(s1 + bias) << 16);
+        }
         else
             w[c] = ((uint32_t)s0 & 0xFFFFu) | ((uint32_t)s1 << 16);
     }
@@ -130,12 +133,15 @@ __device__ __forceinline__ uint32_t pkf_max3(uint32_t a, uint32_t b, uint32_t c)
     asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// The value left of column 0 (H[i], from the block before) serves twice: as "left - |gap|" of this row and as the
+// diagonal of the row below.  Both take it with the gap ALREADY subtracted (one unclamped add into a fresh register;
+// column 0 of the profile is biased by + |gap| to make up for it on the diagonal, and the maximum's other operand
+// pg0 >= 0 makes the missing clamp invisible), so H[i]'s register is free for this row's h3 and no copy is needed.
 #define PH_PKF_ROW(I, W)                                   \
     do {                                                   \
         const int i_ = (I);                                \
-        const uint32_t left = H[i_];                       \
-        const uint32_t gl = pkf_addc(left, gap2);          \
-        const uint32_t h0 = pkf_max3(pkf_add(pdiag, (W).x), pg0, gl); \
+        const uint32_t gu = pkf_add(H[i_], gap2);          \
+        const uint32_t h0 = pkf_max3(pkf_add(pdiag, (W).x), pg0, gu); \
         const uint32_t g0 = pkf_addc(h0, gap2);            \
         const uint32_t h1 = pkf_max3(pkf_add(pr0, (W).y), pg1, g0);   \
         const uint32_t g1 = pkf_addc(h1, gap2);            \
@@ -143,7 +149,7 @@ __device__ __forceinline__ uint32_t pkf_max3(uint32_t a, uint32_t b, uint32_t c)
         const uint32_t g2 = pkf_addc(h2, gap2);            \
         const uint32_t h3 = pkf_max3(pkf_add(pr2, (W).w), pg3, g2);   \
         bm = pkf_max3(pkf_max3(bm, h0, h1), h2, h3);       \
-        pdiag = left;                                      \
+        pdiag = gu;                                        \
         pr0 = h0;                                          \
         pr1 = h1;                                          \
         pr2 = h2;                                          \
@@ -276,9 +282,9 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
         __syncthreads();
         for (uint32_t t = 0; t < nb; ++t) {
             const uint32_t blk16 = (lds_base + t * tab_bytes) >> 4; // lds_pk and tab_bytes are multiples of 16
-            uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0, bm = 0;
+            uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = F16 ? gap2 : 0u, bm = 0; // F16: 0 - |gap| (PH_PKF_ROW)
             uint32_t pg0 = 0, pg1 = 0, pg2 = 0, pg3 = 0; // F16: the row above, gap already taken
-            (void)pg0, (void)pg1, (void)pg2, (void)pg3;
+            (void)pg0, (void)pg1, (void)pg2, (void)pg3, (void)pr3;
             u32x4 wa, wb;
 #define PH_PK_STEP(I, W)       \
     do {                       \
@@ -437,6 +443,8 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__res
             uint32_t pr0 = from_lane_above(out0) & inner, pr1 = from_lane_above(out1) & inner;
             uint32_t pr2 = from_lane_above(out2) & inner, pr3 = from_lane_above(out3) & inner;
             uint32_t pdiag = from_lane_above(outd) & inner;
+            if (F16)
+                pdiag = pkf_add(pdiag, gap2); // the diagonal travels with the gap taken (PH_PKF_ROW)
             const uint32_t m_in = from_lane_above(outm) & inner;
             uint32_t bm = 0;
             uint32_t pg0 = 0, pg1 = 0, pg2 = 0, pg3 = 0; // F16: the row above, gap already taken
@@ -723,7 +731,8 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     p.ra = p.rb * p.k;
     p.skip_rows = p.k == 1 && max_lenA + 16 <= (uint32_t)p.ra; // at least four row groups to save
     // every H below 2048: the three-instruction half-float cell (POLYHIP_SW_F16=0: the int16 one, testing aid)
-    p.f16 = (uint64_t)sc->smax * minlen <= 2047ull && -sc->gap <= 2047 && !env_is("POLYHIP_SW_F16", '0');
+    // (column 0 of the profile carries score + |gap|: that sum has to be a half-float integer too)
+    p.f16 = (uint64_t)sc->smax * minlen <= 2047ull && (int64_t)sc->smax - sc->gap <= 2048 && !env_is("POLYHIP_SW_F16", '0');
     p.ncp = sc->ncodes + 1;
     p.tab_bytes = (uint32_t)(p.ncp * p.ncp * 16);
     p.lenB_pad = (uint32_t)align_up(lenB, 4);
@@ -750,7 +759,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         const uint32_t nqe = p.nq + 2 * (K - 1); // K - 1 all-pad blocks on either side
         const uint32_t n = nqe * (uint32_t)(p.ncp * p.ncp);
         hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, nqe, (uint32_t)(K - 1),
-                           sc->d_lutc, sc->ncodes, p.ncp, prof2, (int)p.f16);
+                           sc->d_lutc, sc->ncodes, p.ncp, prof2, (int)p.f16, (int)(-sc->gap));
         PH_HIP(hipGetLastError());
     }
     if constexpr (K == 1) {

@@ -354,11 +354,11 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
                 assert int(got[3][p]) != 0 and int(got[0][p]) == 0
 
 
-@pytest.mark.parametrize("smax,gap,expect_half", [(13, -1, True), (13, -2047, True), (14, -1, False), (13, -2048, False)])
+@pytest.mark.parametrize("smax,gap,expect_half", [(13, -1, True), (13, -2035, True), (14, -1, False), (13, -2036, False)])
 def test_half_float_cell_limits(al, monkeypatch, smax, gap, expect_half):
     """The half-float packed cell holds integers below 2048 exactly: a matrix whose best score is 13 keeps 152 rows
     inside (13 * 152 = 1976 -- reads equal to a stretch of the reference reach exactly that), 14 does not and takes
-    the int16 cell; |gap| up to 2047.  Every pair against the exact 32-bit kernel, a sample against the oracle."""
+    the int16 cell; smax + |gap| up to 2048 (the profile's first column of a block carries score + |gap|).  Every pair against the exact 32-bit kernel, a sample against the oracle."""
     import torch
     align = al[0]
     dev = torch.device("cuda:0")
