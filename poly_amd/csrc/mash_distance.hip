@@ -288,6 +288,92 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
     }
 }
 
+// level 1 scatter through LDS: the batch's items are first ordered by coarse bucket in LDS (STAGE_ITEMS of them,
+// 64 KB: two workgroups per CU overlap each other's phases; 16384 measured 2.33 ms for the index, 8192 2.19), then leave as runs -- consecutive threads write consecutive items of one bucket's slice, so a wave's store
+// touches a handful of cache lines instead of 64 (the direct scatter writes 8 bytes per lane into 64 different lines).
+#ifndef PH_K2_STAGE_ITEMS
+#define PH_K2_STAGE_ITEMS 8192
+#endif
+#ifndef PH_K2_STAGE_THREADS
+#define PH_K2_STAGE_THREADS 1024
+#endif
+constexpr uint32_t STAGE_ITEMS = PH_K2_STAGE_ITEMS;
+constexpr int STAGE_THREADS = PH_K2_STAGE_THREADS;
+__global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
+    const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags,
+    const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t nc, uint32_t per_batch, uint32_t id_bits,
+    uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stage[];
+    uint2 *stage = reinterpret_cast<uint2 *>(lds_stage);      // STAGE_ITEMS
+    uint32_t *cnt = lds_stage + 2 * (size_t)STAGE_ITEMS;        // nc: count, then cursor
+    uint32_t *lstart = cnt + nc, *gbase = lstart + nc;          // nc each
+    __shared__ uint32_t wsum[STAGE_THREADS / 64];
+    const int tid = threadIdx.x;
+    const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
+    for (uint32_t c = tid; c < nc; c += STAGE_THREADS)
+        cnt[c] = 0;
+    __syncthreads();
+    const uint64_t q0 = (uint64_t)blockIdx.x * per_batch, q1 = min(n, q0 + per_batch);
+    for (uint64_t q = q0; q < q1; ++q) {
+        if (flags[q])
+            continue;
+        const uint32_t *p = sk + q * s;
+        for (uint32_t e = tid; e < s; e += STAGE_THREADS)
+            atomicAdd(&cnt[p[e] >> cshift], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of cnt[0..nc) -> lstart; my slice of every coarse bucket -> gbase; cnt becomes the cursor
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < nc; c0 += STAGE_THREADS) {
+        const uint32_t c = c0 + tid;
+        const uint32_t v = c < nc ? cnt[c] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            wsum[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t pre = carry, tot = 0;
+        for (int w = 0; w < STAGE_THREADS / 64; ++w) {
+            if (w < (tid >> 6))
+                pre += wsum[w];
+            tot += wsum[w];
+        }
+        if (c < nc) {
+            lstart[c] = pre + incl - v;
+            gbase[c] = v ? atomicAdd(&gcur[c], v) : 0u;
+            cnt[c] = 0;
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    const uint32_t nitems = carry;
+    for (uint64_t q = q0; q < q1; ++q) {
+        if (flags[q])
+            continue;
+        const uint32_t *p = sk + q * s;
+        for (uint32_t e = tid; e < s; e += STAGE_THREADS) {
+            const uint32_t v = p[e];
+            uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
+            while (occ < e && p[e - occ - 1] == v)
+                ++occ;
+            const uint32_t c = v >> cshift;
+            stage[lstart[c] + atomicAdd(&cnt[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
+        const uint2 it = stage[t];
+        const uint32_t c = it.x >> cshift;
+        citems[gbase[c] + (t - lstart[c])] = it;
+    }
+}
+
 // level 2: one workgroup per coarse bucket -> fine start[] + final item order (+ self-join size)
 __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__ citems,
                                                       const uint32_t *__restrict__ cstart, uint32_t nc,
@@ -932,8 +1018,18 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         hipLaunchKernelGGL(k2::coarse_count_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy, flagsY,
                            hdr, L.fpc_log2, L.nc, per_batch, gcount);
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, gcount, L.nc, cstart, gcur, start, L.nbk);
-        hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
-                           flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, gcur, citems);
+        // level-1 scatter: through LDS when a sketch fits the stage (POLYHIP_K2_STAGE=0: the direct scatter, testing aid)
+        if (sy <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0')) {
+            const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / sy);
+            const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k2::coarse_scatter_staged_kernel, dim3((unsigned)((ny + pb - 1) / pb)), dim3(k2::STAGE_THREADS),
+                               smem, st, d_Y, ny, sy, flagsY, hdr, L.fpc_log2, L.nc, pb, id_bits, gcur, citems);
+        } else {
+            hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
+                               flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, gcur, citems);
+        }
         hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(L.nc, 256u * 8u)), dim3(k2::THREADS), 0, st, citems, cstart,
                            L.nc, L.fpc_log2, hdr, start, items);
         PH_HIP(hipGetLastError());

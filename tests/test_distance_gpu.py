@@ -24,11 +24,14 @@ def mash():
 @pytest.fixture(autouse=True, params=["dense", "sparse"])
 def join_kind(request, monkeypatch):
     """every test runs twice: with the dense join in front (a counter per column in LDS; the default up to two
-    stripes of columns) and with POLYHIP_K2_DENSE=0 (sparse LDS hash join, dense join only for overflowing rows)"""
+    stripes of columns; index built with the LDS-staged level-1 scatter) and with POLYHIP_K2_DENSE=0 (sparse LDS hash
+    join, dense join only for overflowing rows) + POLYHIP_K2_STAGE=0 (the index's direct level-1 scatter)"""
     if request.param == "sparse":
         monkeypatch.setenv("POLYHIP_K2_DENSE", "0")
+        monkeypatch.setenv("POLYHIP_K2_STAGE", "0")
     else:
         monkeypatch.delenv("POLYHIP_K2_DENSE", raising=False)
+        monkeypatch.delenv("POLYHIP_K2_STAGE", raising=False)
     return request.param
 
 
