@@ -392,8 +392,18 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
         for (uint32_t f = tid; f < fpc; f += THREADS)
             cnt[f] = 0;
         __syncthreads();
-        for (uint32_t t = lo + tid; t < hi; t += THREADS)
-            atomicAdd(&cnt[(citems[t].x >> shift) & (fpc - 1u)], 1u);
+        // eight loads in flight per thread: the loop is a chain of memory round trips otherwise (96 % of the wave
+        // cycles were s_waitcnt, profiles/r02_k2_pmc_sq.md)
+        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * THREADS) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                x[u] = t0 + u * THREADS < hi ? citems[t0 + u * THREADS].x : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u * THREADS < hi)
+                    atomicAdd(&cnt[(x[u] >> shift) & (fpc - 1u)], 1u);
+        }
         __syncthreads();
         // exclusive scan of cnt[0..fpc): PER consecutive entries per thread
         const uint32_t per = (fpc + THREADS - 1) / THREADS; // <= 32
@@ -428,9 +438,19 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
             run += v[i];
         }
         __syncthreads();
-        for (uint32_t t = lo + tid; t < hi; t += THREADS) {
-            const uint2 it = citems[t];
-            items[atomicAdd(&cnt[(it.x >> shift) & (fpc - 1u)], 1u)] = it;
+        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * THREADS) {
+            uint2 it[8];
+            uint32_t at[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                it[u] = t0 + u * THREADS < hi ? citems[t0 + u * THREADS] : make_uint2(0u, 0u);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                at[u] = t0 + u * THREADS < hi ? atomicAdd(&cnt[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t0 + u * THREADS < hi)
+                    items[at[u]] = it[u];
         }
     }
 #pragma unroll
