@@ -321,6 +321,11 @@ int polyhip_sw_last_packed_half(void);
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
  * kernel for reads of 257..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off). */
 int polyhip_sw_traceback_last_path(void);
+/* 1 when that call's byte-profile kernel (path 1) ran in its half-float form (gfx950: packed halves, two bands of rows
+ * per lane, nine instructions per cell pair instead of eighteen) -- taken under the packed score pass's condition
+ * (every H < 2048) for reads of <= 152 symbols while the table of halves fits twice into a CU's LDS.
+ * POLYHIP_TB_F16=0 keeps the 32-bit form (testing aid). */
+int polyhip_sw_traceback_last_half(void);
 /* ... and the last polyhip_nw_align_batch_dev call: 1 = register-tiled kernel (lenA <= 256), 2 = generic kernel
  * (POLYHIP_NW_GENERIC=1 forces it), 3 = one-wave-per-pair kernel (lenA 257..4096); tests. */
 int polyhip_nw_last_path(void);

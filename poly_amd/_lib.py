@@ -53,6 +53,7 @@ SIGNATURES = {
     "polyhip_sw_last_path": (C.c_int, []),
     "polyhip_sw_last_packed_half": (C.c_int, []),
     "polyhip_sw_traceback_last_path": (C.c_int, []),
+    "polyhip_sw_traceback_last_half": (C.c_int, []),
     "polyhip_nw_last_path": (C.c_int, []),
     "polyhip_nw_workspace_bytes": (C.c_size_t, [_u64, _u32, _u64]),
     "polyhip_nw_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _u32, _vp,

@@ -139,6 +139,11 @@ def sw_traceback_last_path() -> int:
     return int(_lib.lib().polyhip_sw_traceback_last_path())
 
 
+def sw_traceback_last_half() -> bool:
+    """the last byte-profile traceback ran gfx950's half-float two-band form"""
+    return bool(_lib.lib().polyhip_sw_traceback_last_half())
+
+
 def nw_last_path() -> int:
     """1 = register-tiled NeedlemanWunsch kernel, 2 = generic (tests)"""
     return int(_lib.lib().polyhip_nw_last_path())

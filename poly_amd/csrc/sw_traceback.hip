@@ -43,6 +43,7 @@ namespace k3t {
 constexpr int THREADS = 256;
 
 static thread_local int g_tb_last_path = 0;
+static thread_local int g_tb_last_half = 0;
 static thread_local int g_nw_last_path = 0;
 
 struct Window {
@@ -492,6 +493,369 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
 }
 #undef PH_TB_ROW
 #undef PH_TB_CELL
+
+// ---- the same kernel on gfx950's packed half-floats: TWO BANDS of rows per lane ---------------------------
+// When every H stays below 2048 (the packed score pass's condition, sw_packed.hip) the recurrence runs on halves scaled
+// by 2^-11, three instructions per cell PAIR (add, v_pk_maximum3_f16, clamped add). One pair still owns a lane -- lanes
+// sit in different windows, so two pairs cannot share a register as they do in the score pass -- but its rows are split
+// into two bands of RB: rows [0, RB) in the low halves, rows [RB, 2 RB) in the high halves, the lower band one 4-column
+// block behind (its row RB needs row RB - 1 of the same columns: band 0's last row, four values + their gap-decayed
+// copies + one diagonal value, moves from the low to the high halves between two blocks). Direction bits: G = the gap
+// move won = h > diag + s (wherever h > 0, the only cells the walk reads), L = left > up, told from the gap-decayed
+// values (equal to comparing left and up wherever G holds); each is a clamped difference, an unsigned min with 1 and
+// one v_pk_mad_u16 (w = 2 w + bit) -- nine instructions per cell pair against eighteen. A G / L word carries 16 rows of
+// band 0 (low half) and 16 rows of band 1 (high half, one block earlier). The profile is a table of halves,
+// P16[block][code][4], read with two ds_read_b64 per row pair (one per band) and interleaved by four v_perm_b32.
+__device__ __forceinline__ uint32_t tbf_half_bits(int v)
+{
+    const _Float16 h = (_Float16)((float)v * (1.0f / 2048.0f));
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ int tbf_half_score(uint32_t bits)
+{
+    return (int)((float)__builtin_bit_cast(_Float16, (unsigned short)bits) * 2048.0f);
+}
+__device__ __forceinline__ uint32_t tbf_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t tbf_addc(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t tbf_subc(uint32_t a, uint32_t b) // max(0, a - b), per half
+{
+    uint32_t r;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1] clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t tbf_max3(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// w = 2 * w + (x != 0), per 16-bit half (x: non-negative halves)
+__device__ __forceinline__ uint32_t tbf_push(uint32_t w, uint32_t x, uint32_t one2, uint32_t two2)
+{
+    uint32_t f, r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(f) : "v"(x), "v"(one2));
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(w), "v"(two2), "v"(f));
+    return r;
+}
+
+// P16 entry (q, c) = the four halves S(sym c, b_{4q..4q+3}) * 2^-11; pad columns, the pad code (c = ncodes) and one
+// all-pad block behind the last one (q = lenB_pad / 4: what a band reads where it has no block) hold -128
+__global__ __launch_bounds__(256) void tb_profile16_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t lenB_pad,
+                                                          const int8_t *__restrict__ lutc, int ncodes, int ncp,
+                                                          uint2 *__restrict__ prof16)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nq = lenB_pad / 4 + 1;
+    if (e >= nq * (uint32_t)ncp)
+        return;
+    const uint32_t q = e / (uint32_t)ncp;
+    const int c = (int)(e % (uint32_t)ncp);
+    uint32_t h[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t j = 4 * q + u;
+        int sv = -128;
+        if (j < lenB && c < ncodes)
+            sv = lutc[c * 256 + B[j]];
+        h[u] = tbf_half_bits(sv);
+    }
+    prof16[e] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+}
+
+#define PH_TBF_CELL(W, DIAG, UPG, LEFTG, H, GOUT, C)                        \
+    do {                                                                    \
+        const uint32_t t_ = tbf_add((DIAG), (W));                           \
+        H = tbf_max3(t_, (UPG), (LEFTG));                                   \
+        wG[C] = tbf_push(wG[C], tbf_subc(H, t_), one2, two2);               \
+        wL[C] = tbf_push(wL[C], tbf_subc((LEFTG), (UPG)), one2, two2);      \
+        GOUT = tbf_addc(H, gap2);                                           \
+        if (FIND)                                                           \
+            key = (key == 0xFFFFFFFFu && ((H >> (FIND == 2 ? 16 : 0)) & 0xFFFFu) == Mh) \
+                      ? (uint32_t)(((r_ + (FIND == 2 ? RB : 0)) << 2) | (C)) \
+                      : key;                                                \
+    } while (0)
+// one row pair: row r_ of band 0 (low halves, block bt) and row RB + r_ of band 1 (high halves, block bt - 1);
+// (X0, X1) / (Y0, Y1) = the two dwords of band 0's / band 1's profile entry
+#define PH_TBF_ROW(R, X0, X1, Y0, Y1)                                       \
+    do {                                                                    \
+        const int r_ = (R);                                                 \
+        const uint32_t w0 = __builtin_amdgcn_perm((Y0), (X0), 0x05040100u); \
+        const uint32_t w1 = __builtin_amdgcn_perm((Y0), (X0), 0x07060302u); \
+        const uint32_t w2 = __builtin_amdgcn_perm((Y1), (X1), 0x05040100u); \
+        const uint32_t w3 = __builtin_amdgcn_perm((Y1), (X1), 0x07060302u); \
+        const uint32_t left = H[r_];                                        \
+        const uint32_t gl = tbf_addc(left, gap2);                           \
+        uint32_t h0, h1, h2, h3, g0, g1, g2, g3;                            \
+        PH_TBF_CELL(w0, pdiag, pg0, gl, h0, g0, 0);                         \
+        PH_TBF_CELL(w1, pr0, pg1, g0, h1, g1, 1);                           \
+        PH_TBF_CELL(w2, pr1, pg2, g1, h2, g2, 2);                           \
+        PH_TBF_CELL(w3, pr2, pg3, g2, h3, g3, 3);                           \
+        pdiag = left;                                                       \
+        pr0 = h0;                                                           \
+        pr1 = h1;                                                           \
+        pr2 = h2;                                                           \
+        pr3 = h3;                                                           \
+        pg0 = g0;                                                           \
+        pg1 = g1;                                                           \
+        pg2 = g2;                                                           \
+        pg3 = g3;                                                           \
+        H[r_] = h3;                                                         \
+        if ((r_ & 15) == 15 || r_ == RB - 1) {                              \
+            uint32_t *o_ = dirw + ((size_t)tt * TBU * NG + (r_ >> 4)) * 2 * 64; \
+            _Pragma("unroll") for (int c_ = 0; c_ < TBU; ++c_)              \
+            {                                                               \
+                o_[((size_t)c_ * NG * 2 + 0) * 64] = wG[c_];                \
+                o_[((size_t)c_ * NG * 2 + 1) * 64] = wL[c_];                \
+            }                                                               \
+        }                                                                   \
+    } while (0)
+// the profile entries of four row pairs (one packed register of code offsets per band): eight ds_read_b64
+#define PH_TBF_ISSUE(pk0, pk1, X, Y)                                                                       \
+    do {                                                                                                   \
+        uint32_t a_[8];                                                                                    \
+        PH_TBF_ADDR(a_[0], base0, pk0, "BYTE_0");                                                          \
+        PH_TBF_ADDR(a_[1], base1, pk1, "BYTE_0");                                                          \
+        PH_TBF_ADDR(a_[2], base0, pk0, "BYTE_1");                                                          \
+        PH_TBF_ADDR(a_[3], base1, pk1, "BYTE_1");                                                          \
+        PH_TBF_ADDR(a_[4], base0, pk0, "BYTE_2");                                                          \
+        PH_TBF_ADDR(a_[5], base1, pk1, "BYTE_2");                                                          \
+        PH_TBF_ADDR(a_[6], base0, pk0, "BYTE_3");                                                          \
+        PH_TBF_ADDR(a_[7], base1, pk1, "BYTE_3");                                                          \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[0]) : "v"(a_[0]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[0]) : "v"(a_[1]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[1]) : "v"(a_[2]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[1]) : "v"(a_[3]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[2]) : "v"(a_[4]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[2]) : "v"(a_[5]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[3]) : "v"(a_[6]));                                      \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[3]) : "v"(a_[7]));                                      \
+    } while (0)
+#define PH_TBF_ADDR(dst, base, pk, SEL)                                                                    \
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                 : "=v"(dst)                                                                               \
+                 : "v"(base), "v"(pk))
+
+typedef uint32_t tbf_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int RB>
+__global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ B, uint32_t lenB_pad, const uint2 *__restrict__ prof16,
+    const uint8_t *__restrict__ codeA, int ncodes, int gap, uint32_t *__restrict__ endA,
+    uint32_t *__restrict__ endB, uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
+    uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
+    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    static_assert(RB % 4 == 0 && RB <= 76, "RB");
+    constexpr int RA = 2 * RB;
+    constexpr int NG = (RB + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tbf[];
+    const int ncp = ncodes + 1;
+    const uint32_t nqB = lenB_pad / 4; // real blocks; block nqB is the all-pad one
+    const uint32_t pstride = (uint32_t)ncp * 8u;
+    uint2 *P = reinterpret_cast<uint2 *>(lds_tbf);
+    uint8_t *codeL = lds_tbf + (size_t)(nqB + 1) * pstride;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t v = tid; v < (nqB + 1) * (uint32_t)ncp; v += THREADS)
+        P[v] = prof16[v];
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    const uint64_t pair = pair0 + (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < pair1;
+    uint32_t lenA = 0, eA = 0, eB = 0;
+    int64_t M = 0;
+    const uint8_t *ap = A;
+    if (active) {
+        const uint64_t o0 = offA[pair];
+        lenA = (uint32_t)(offA[pair + 1] - o0);
+        ap = A + o0;
+        if (err[pair] == 0u) {
+            eA = endA[pair];
+            eB = endB[pair];
+            M = score[pair];
+        }
+    }
+    const bool locate = active && eA == k3p::SW_END_DEFERRED; // as tb_prof_kernel
+    const uint32_t rowsA = locate ? lenA : eA;
+    const bool work = active && rowsA > 0 && eB > 0 && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide) + (locate ? 4u : 0u)) : 0u;
+    const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u;
+    const uint32_t jb0 = (c_s - 1u) & ~3u;
+    const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u; // <= nblk_alloc - 1
+
+    // byte offsets (code * 8) of my rows inside a profile block, four rows per register and band
+    uint32_t apk0[RB / 4], apk1[RB / 4];
+#pragma unroll
+    for (int w = 0; w < RB / 4; ++w) {
+        uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i0 = 4 * w + b, i1 = RB + 4 * w + b;
+            uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+            if (work && (uint32_t)i0 < lenA) {
+                const uint32_t c = codeL[ap[i0]];
+                c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+            }
+            if (work && (uint32_t)i1 < lenA) {
+                const uint32_t c = codeL[ap[i1]];
+                c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+            }
+            k0 |= (c0 * 8u) << (8 * b);
+            k1 |= (c1 * 8u) << (8 * b);
+        }
+        apk0[w] = k0;
+        apk1[w] = k1;
+    }
+
+    uint32_t H[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        H[i] = 0;
+
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
+    const uint32_t pad_base = lds_base + nqB * pstride;
+
+    // end-aligned lanes as in tb_prof_kernel; a lane runs nblk + 1 iterations (band 1 finishes one block later)
+    uint32_t nmax = nblk;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    const uint32_t lag = nmax - nblk;
+    const uint32_t gh = tbf_half_bits(gap); // gap < 0
+    const uint32_t gap2 = gh | (gh << 16), one2 = 0x00010001u, two2 = 0x00020002u;
+    const uint32_t Mh = tbf_half_bits((int)M);
+    uint32_t key = 0xFFFFFFFFu;
+    // band 0's last row of the block before, already in the high halves: what band 1 finds above its first row
+    uint32_t hh0 = 0, hh1 = 0, hh2 = 0, hh3 = 0, hg0 = 0, hg1 = 0, hg2 = 0, hg3 = 0, hd = 0;
+    auto sweep = [&](uint32_t tt, auto find_tag) {
+        constexpr int FIND = decltype(find_tag)::value; // 0, 1 = search band 0's cells, 2 = band 1's
+        const uint32_t bt = tt - lag;                   // band 0's block; band 1 works on bt - 1
+        const uint32_t base0 = bt < nblk ? lds_base + ((jb0 >> 2) + bt) * pstride : pad_base;
+        const uint32_t base1 = bt >= 1u ? lds_base + ((jb0 >> 2) + bt - 1u) * pstride : pad_base;
+        uint32_t pr0 = hh0, pr1 = hh1, pr2 = hh2, pr3 = hh3, pg0 = hg0, pg1 = hg1, pg2 = hg2, pg3 = hg3, pdiag = hd;
+        uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
+        tbf_u32x2 xa[4], ya[4], xb[4], yb[4];
+        PH_TBF_ISSUE(apk0[0], apk1[0], xa, ya);
+#pragma unroll
+        for (int g = 0; g < RB / 4; ++g) {
+            if (g + 1 < RB / 4) {
+                PH_TBF_ISSUE(apk0[g + 1], apk1[g + 1], xb, yb);
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            }
+            PH_TBF_ROW(4 * g + 0, xa[0].x, xa[0].y, ya[0].x, ya[0].y);
+            PH_TBF_ROW(4 * g + 1, xa[1].x, xa[1].y, ya[1].x, ya[1].y);
+            PH_TBF_ROW(4 * g + 2, xa[2].x, xa[2].y, ya[2].x, ya[2].y);
+            PH_TBF_ROW(4 * g + 3, xa[3].x, xa[3].y, ya[3].x, ya[3].y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xa[q] = xb[q];
+                ya[q] = yb[q];
+            }
+        }
+        // band 0's last row (low halves) becomes band 1's row above (high halves) of the next iteration
+        hd = hh3;
+        hh0 = pr0 << 16;
+        hh1 = pr1 << 16;
+        hh2 = pr2 << 16;
+        hh3 = pr3 << 16;
+        hg0 = pg0 << 16;
+        hg1 = pg1 << 16;
+        hg2 = pg2 << 16;
+        hg3 = pg3 << 16;
+    };
+    const bool any_locate = __any(locate) != 0; // wave-uniform
+    // iterations 0 .. nmax; with a deferred end cell in the wave the last two carry the search (band 0's last block,
+    // then band 1's)
+    for (uint32_t t = 0; t <= nmax; ++t) {
+        if (nblk == 0u || t < lag)
+            continue;
+        if (any_locate && t + 1u == nmax)
+            sweep(t, std::integral_constant<int, 1>{});
+        else if (any_locate && t == nmax)
+            sweep(t, std::integral_constant<int, 2>{});
+        else
+            sweep(t, std::integral_constant<int, 0>{});
+    }
+
+    if (!active)
+        return;
+    uint32_t len = 0;
+    bool lost = false;
+    if (work && locate) {
+        lost = key == 0xFFFFFFFFu; // cannot happen: the packed pass saw M in this block
+        eA = lost ? 0u : (key >> 2) + 1u;
+        eB = lost ? 0u : eB - 3u + (key & 3u);
+        endA[pair] = eA;
+        endB[pair] = eB;
+        if (lost)
+            err[pair] = 0xFFFFFFFEu;
+    } else if (locate) {
+        endA[pair] = 0u;
+        endB[pair] = 0u;
+    }
+    if (work && !lost) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
+        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+        const uint16_t *P16 = reinterpret_cast<const uint16_t *>(P);
+        uint32_t i = eA, j = eB;
+        int h = (int)M;
+        while (h > 0 && i > 0 && j > jb0 && len < stride) {
+            const uint32_t jj = j - 1u, r = i - 1u, band = r >= (uint32_t)RB ? 1u : 0u, rr = r - band * RB, g = rr >> 4;
+            const uint32_t rows = min(16u, (uint32_t)RB - 16u * g);
+            const uint32_t bit = rows - 1u - (rr & 15u) + 16u * band;
+            const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
+            const uint32_t *wp = dirw + (((size_t)tt * TBU + (jj & 3u)) * NG + g) * 2 * 64;
+            const uint32_t wg = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wl = __hip_atomic_load(wp + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint8_t sa = ap[r], sb = B[jj];
+            uint8_t ca, cb;
+            if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
+                h -= tbf_half_score(P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
+                ca = sa;
+                cb = sb;
+                --i;
+                --j;
+            } else if (((wl >> bit) & 1u) == 0u) { // :220-223
+                h -= gap;
+                ca = sa;
+                cb = '-';
+                --i;
+            } else { // :224-227
+                h -= gap;
+                ca = '-';
+                cb = sb;
+                --j;
+            }
+            outA[stride - 1 - len] = ca;
+            outB[stride - 1 - len] = cb;
+            ++len;
+        }
+    }
+    alnLen[pair] = (active && rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
+}
+#undef PH_TBF_ISSUE
+#undef PH_TBF_ADDR
+#undef PH_TBF_ROW
+#undef PH_TBF_CELL
 
 // ---- reads longer than the 256 rows a lane can hold: ONE WAVE PER PAIR (like sw_wave.hip) ---------------
 // Lane l owns rows [l*R, l*R + R) and works on column s - l of the pair's window in step s; the row above
@@ -1218,6 +1582,9 @@ struct Plan {
     int cp;
     uint32_t lenB_pad, nblk_alloc;
     size_t prof_bytes, prof_smem;
+    // its half-float two-band form (tb_prof16_kernel): every H < 2048, the table of halves fits twice into a CU's LDS
+    bool half_ok;
+    size_t half_smem;
     // one wave per pair for 256 < lenA <= 4096 (score known): tb_wave_kernel
     int wave_r;            // 0 = not applicable
     size_t wave_per_pair;
@@ -1260,8 +1627,15 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
                 p.prof_smem <= 160 * 1024 && (uint64_t)sc->smax * max_lenA < (1ull << 30);
     if (p.prof_ok) {
         // a lane's window starts on a block boundary (up to 3 columns early) and ends inside a block
-        p.nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 2; // (+ one block for the deferred end cell's slack)
+        p.nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 3; // (+ one block for the deferred end cell's slack, + one
+                                                                // iteration for the half-float kernel's second band)
         p.prof_bytes = align_up((size_t)p.lenB_pad * p.cp, 256);
+        const size_t half_tab = ((size_t)p.lenB_pad / 4 + 1) * (size_t)(sc->ncodes + 1) * 8;
+        p.half_smem = half_tab + 256;
+        p.half_ok = (p.ra == 64 || p.ra == 152) && p.half_smem <= 79 * 1024 &&
+                    (uint64_t)sc->smax * std::min<uint64_t>(max_lenA, lenB) <= 2047ull && (int64_t)sc->smax - sc->gap <= 2048;
+        if (p.half_ok)
+            p.prof_bytes = std::max(p.prof_bytes, align_up(half_tab, 256));
         const size_t per = (size_t)p.nblk_alloc * TBU * ((p.ra + 31) / 32) * 2 * 4;
         p.per_pair = std::max(p.per_pair, per);
     }
@@ -1293,6 +1667,7 @@ using namespace polyhip;
 extern "C" {
 
 int polyhip_sw_traceback_last_path(void) { return k3t::g_tb_last_path; }
+int polyhip_sw_traceback_last_half(void) { return k3t::g_tb_last_half; }
 
 uint32_t polyhip_sw_traceback_stride(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
 {
@@ -1361,7 +1736,15 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     int8_t *prof = static_cast<int8_t *>(d_work);
     void *d_dir = static_cast<uint8_t *>(d_work) + p.prof_bytes;
-    if (use_prof) {
+    // half-float two-band form of the byte-profile kernel (POLYHIP_TB_F16=0: the 32-bit one, testing aid)
+    const bool use_half = use_prof && p.half_ok && !env_is("POLYHIP_TB_F16", '0');
+    k3t::g_tb_last_half = use_half ? 1 : 0;
+    if (use_half) {
+        const uint32_t n16 = (p.lenB_pad / 4 + 1) * (uint32_t)(sc->ncodes + 1);
+        hipLaunchKernelGGL(k3t::tb_profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, (uint32_t)lenB, p.lenB_pad,
+                           sc->d_lutc, sc->ncodes, sc->ncodes + 1, reinterpret_cast<uint2 *>(prof));
+        PH_HIP(hipGetLastError());
+    } else if (use_prof) {
         hipLaunchKernelGGL(k3t::tb_profile_kernel, dim3((p.lenB_pad + 255) / 256), dim3(256), 0, st, d_B, (uint32_t)lenB,
                            p.lenB_pad, sc->d_lutc, sc->ncodes, p.cp, prof);
         PH_HIP(hipGetLastError());
@@ -1396,6 +1779,25 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
             else
                 PH_TBW_LAUNCH(64);
 #undef PH_TBW_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
+        }
+        if (use_half) {
+#define PH_TBH_LAUNCH(RB_)                                                                                             \
+    do {                                                                                                               \
+        auto kern = k3t::tb_prof16_kernel<RB_>;                                                                        \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                   (int)p.half_smem));                                                                 \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.half_smem, st, d_A, d_offA, p0, p1, d_B,          \
+                           p.lenB_pad, reinterpret_cast<const uint2 *>(prof), sc->d_codeA, sc->ncodes, (int)sc->gap,   \
+                           d_endA, d_endB, d_err, d_score, (int)sc->smax, p.win.wcols, wide, p.nblk_alloc, dirbuf,     \
+                           d_alnA, d_alnB, d_alnLen, aln_stride);                                                      \
+    } while (0)
+            if (p.ra == 64)
+                PH_TBH_LAUNCH(32);
+            else
+                PH_TBH_LAUNCH(76);
+#undef PH_TBH_LAUNCH
             PH_HIP(hipGetLastError());
             continue;
         }

@@ -19,6 +19,17 @@ def al():
     return align, alphabet, matrix
 
 
+@pytest.fixture(autouse=True, params=["half", "int32"])
+def tb_cell(request, monkeypatch):
+    """every test runs twice: with the byte-profile traceback in its half-float two-band form where it applies (gfx950,
+    scores below 2048: the default) and with POLYHIP_TB_F16=0 (the 32-bit form everywhere)"""
+    if request.param == "int32":
+        monkeypatch.setenv("POLYHIP_TB_F16", "0")
+    else:
+        monkeypatch.delenv("POLYHIP_TB_F16", raising=False)
+    return request.param
+
+
 def _scoring(al, symbols, scores, gap):
     align, alphabet, matrix = al
     a = alphabet.NewAlphabet(list(symbols))
@@ -387,7 +398,7 @@ def test_long_reads_chunked_workspace(al):
         assert int(score[p]) == s and a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, p
 
 
-def test_config4_full_size_mutated_batch(al, monkeypatch):
+def test_config4_full_size_mutated_batch(al, monkeypatch, tb_cell):
     """BASELINE configs[3] on the contract's input: all 1,000,000 reads of poly_amd.workloads.config4_reads (windows
     of the 5 kb reference with 5 % substitutions AND 1 % indels, SURVEY 8d C4 -- the input bench.py times), device
     resident.  (a) the generator is the same function on the GPU as on the CPU; (b) 2,500 sampled pairs equal the
@@ -432,6 +443,7 @@ def test_config4_full_size_mutated_batch(al, monkeypatch):
     ln = torch.zeros(n, dtype=torch.int32, device=dev)
     align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score)
     torch.cuda.synchronize()
+    assert align.sw_traceback_last_path() == 1 and align.sw_traceback_last_half() == (tb_cell == "half")
     # (a') the one-call device path, where the score pass leaves the end cell to the traceback kernel: same seven outputs
     f_score = torch.zeros(n, dtype=torch.int64, device=dev)
     f_ea, f_eb, f_er, f_ln = (torch.full((n,), 7, dtype=torch.int32, device=dev) for _ in range(4))
