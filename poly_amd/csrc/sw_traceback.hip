@@ -1729,7 +1729,11 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     const int wide = env_is("POLYHIP_TB_WIDE", '1'); // testing aid: the conservative per-pair window
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
-    const uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
+    uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
+    // the lane-per-pair kernels run two 256-pair workgroups per CU: whole rounds of 256 CUs x 512 pairs per chunk
+    // (a chunk of 1.5 rounds spends its second round on half-empty CUs)
+    if (use_prof && chunk >= 131072)
+        chunk = chunk / 131072 * 131072;
     PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_sw_traceback: workspace too small (%zu B; %zu B per pair, >= %d pairs)",
                work_bytes, p.per_pair, k3t::THREADS);
     hipStream_t st = as_stream(stream);
