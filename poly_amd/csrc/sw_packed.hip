@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "common.h"
@@ -534,7 +535,8 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__res
 #define PH_LC_CELL(S, DIAG, UP, LEFT, HOUT, C)                                    \
     do {                                                                          \
         HOUT = max(max((DIAG) + (S), 0), max((UP), (LEFT)) + gap);                \
-        key = min(key, HOUT == M ? (uint32_t)((i_ << 2) | (C)) : 0xFFFFFFFFu);    \
+        if (FIND)                                                                 \
+            key = min(key, HOUT == M ? (uint32_t)((i_ << 2) | (C)) : 0xFFFFFFFFu); \
     } while (0)
 #define PH_LC_ROW(I, W)                                   \
     do {                                                  \
@@ -657,35 +659,44 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
         H[i] = 0;
     uint32_t key = 0xFFFFFFFFu;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
-    for (uint32_t t = 0;; ++t) {
-        if (!__any(t < nblk))
-            break;
-        if (t < nblk) {
-            const uint32_t blk = lds_base + ((jb0 >> 2) + t) * (CP * 4);
-            int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
-            uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
-            PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+    // Lanes sweep different numbers of blocks; they are aligned at the END (a lane with fewer blocks idles first), so the
+    // wave's last iteration is every lane's last block -- the only one that can hold M (earlier ones stayed below it) --
+    // and the search for the first cell worth M is a second instantiation of the block body, run once per wave: the other
+    // iterations pay 5 instructions per cell instead of 8.
+    uint32_t nmax = nblk;
 #pragma unroll
-            for (int g = 0; g < RA / 4; ++g) {
-                if (g + 1 < RA / 4) {
-                    PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
-                }
-                PH_LC_ROW(4 * g + 0, wa0);
-                PH_LC_ROW(4 * g + 1, wa1);
-                PH_LC_ROW(4 * g + 2, wa2);
-                PH_LC_ROW(4 * g + 3, wa3);
-                wa0 = wb0;
-                wa1 = wb1;
-                wa2 = wb2;
-                wa3 = wb3;
+    for (int d = 32; d >= 1; d >>= 1)
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    const uint32_t lag = nmax - nblk;
+    auto sweep = [&](uint32_t bt, auto find_tag) {
+        constexpr bool FIND = decltype(find_tag)::value;
+        const uint32_t blk = lds_base + ((jb0 >> 2) + bt) * (CP * 4);
+        int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
+        uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
+        PH_PROF_ISSUE(apk[0], wa0, wa1, wa2, wa3);
+#pragma unroll
+        for (int g = 0; g < RA / 4; ++g) {
+            if (g + 1 < RA / 4) {
+                PH_PROF_ISSUE(apk[g + 1], wb0, wb1, wb2, wb3);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa0), "+v"(wa1), "+v"(wa2), "+v"(wa3));
             }
-            if (t + 1 < nblk)
-                key = 0xFFFFFFFFu; // only the last block can hold M (earlier ones stayed below it)
+            PH_LC_ROW(4 * g + 0, wa0);
+            PH_LC_ROW(4 * g + 1, wa1);
+            PH_LC_ROW(4 * g + 2, wa2);
+            PH_LC_ROW(4 * g + 3, wa3);
+            wa0 = wb0;
+            wa1 = wb1;
+            wa2 = wb2;
+            wa3 = wb3;
         }
-    }
+    };
+    for (uint32_t t = 0; t + 1 < nmax; ++t)
+        if (t >= lag) // (nblk == 0: lag == nmax, never)
+            sweep(t - lag, std::false_type{});
+    if (nmax > 0 && nblk > 0)
+        sweep(nblk - 1u, std::true_type{});
 
     if (!active)
         return;
