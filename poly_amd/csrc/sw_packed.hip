@@ -719,6 +719,285 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
 #undef PH_LC_ROW
 #undef PH_LC_CELL
 
+// ---- the locate step on packed half-floats, two bands of rows per lane (gfx950) ----------------------------
+// Same job and outputs as sw_locate_kernel. Under the half-float condition of the packed pass (every H < 2048) the
+// windowed recurrence runs on halves: one pair per lane as before (lanes sit in different windows), but rows [0, RB) in
+// the low halves of the packed registers and rows [RB, 2 RB) in the high halves, the lower band one 4-column block
+// behind -- band 0's last row moves from the low to the high halves between two blocks. Three instructions per cell
+// PAIR (add, v_pk_maximum3_f16, clamped add) against five per cell; the profile is a table of halves P16[block][code][4]
+// (two ds_read_b64 per row pair, interleaved by four v_perm_b32). Lanes are aligned at the end of their windows; the
+// first cell worth M in row-major order is searched in the wave's last two iterations (band 0's last block, then band 1's).
+__global__ __launch_bounds__(256) void profile16_kernel(const uint8_t *__restrict__ B, uint32_t lenB, uint32_t lenB_pad,
+                                                       const int8_t *__restrict__ lutc, int ncodes, int ncp,
+                                                       uint2 *__restrict__ prof16)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nq = lenB_pad / 4 + 1; // the last block is all pad: what a band reads where it has no block
+    if (e >= nq * (uint32_t)ncp)
+        return;
+    const uint32_t q = e / (uint32_t)ncp;
+    const int c = (int)(e % (uint32_t)ncp);
+    uint32_t h[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t j = 4 * q + u;
+        int sv = -128; // pad columns / pad code: keeps every H at 0
+        if (j < lenB && c < ncodes)
+            sv = lutc[c * 256 + B[j]];
+        h[u] = half_bits(sv);
+    }
+    prof16[e] = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
+}
+
+#define PH_L16_CELL(W, DIAG, UPG, LEFTG, H, GOUT, C)                                          \
+    do {                                                                                      \
+        H = pkf_max3(pkf_add((DIAG), (W)), (UPG), (LEFTG));                                   \
+        GOUT = pkf_addc(H, gap2);                                                             \
+        if (FIND)                                                                             \
+            key = (key == 0xFFFFFFFFu && ((H >> (FIND == 2 ? 16 : 0)) & 0xFFFFu) == Mh)        \
+                      ? (uint32_t)(((r_ + (FIND == 2 ? RB : 0)) << 2) | (C))                  \
+                      : key;                                                                  \
+    } while (0)
+#define PH_L16_ROW(R, X0, X1, Y0, Y1)                                       \
+    do {                                                                    \
+        const int r_ = (R);                                                 \
+        const uint32_t w0 = __builtin_amdgcn_perm((Y0), (X0), 0x05040100u); \
+        const uint32_t w1 = __builtin_amdgcn_perm((Y0), (X0), 0x07060302u); \
+        const uint32_t w2 = __builtin_amdgcn_perm((Y1), (X1), 0x05040100u); \
+        const uint32_t w3 = __builtin_amdgcn_perm((Y1), (X1), 0x07060302u); \
+        const uint32_t left = H[r_];                                        \
+        const uint32_t gl = pkf_addc(left, gap2);                           \
+        uint32_t h0, h1, h2, h3, g0, g1, g2, g3;                            \
+        PH_L16_CELL(w0, pdiag, pg0, gl, h0, g0, 0);                         \
+        PH_L16_CELL(w1, pr0, pg1, g0, h1, g1, 1);                           \
+        PH_L16_CELL(w2, pr1, pg2, g1, h2, g2, 2);                           \
+        PH_L16_CELL(w3, pr2, pg3, g2, h3, g3, 3);                           \
+        pdiag = left;                                                       \
+        pr0 = h0;                                                           \
+        pr1 = h1;                                                           \
+        pr2 = h2;                                                           \
+        pr3 = h3;                                                           \
+        pg0 = g0;                                                           \
+        pg1 = g1;                                                           \
+        pg2 = g2;                                                           \
+        pg3 = g3;                                                           \
+        H[r_] = h3;                                                         \
+    } while (0)
+#define PH_L16_ADDR(dst, base, pk, SEL)                                                                    \
+    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                 : "=v"(dst)                                                                               \
+                 : "v"(base), "v"(pk))
+#define PH_L16_ISSUE(pk0, pk1, X, Y)                                          \
+    do {                                                                      \
+        uint32_t a_[8];                                                       \
+        PH_L16_ADDR(a_[0], base0, pk0, "BYTE_0");                             \
+        PH_L16_ADDR(a_[1], base1, pk1, "BYTE_0");                             \
+        PH_L16_ADDR(a_[2], base0, pk0, "BYTE_1");                             \
+        PH_L16_ADDR(a_[3], base1, pk1, "BYTE_1");                             \
+        PH_L16_ADDR(a_[4], base0, pk0, "BYTE_2");                             \
+        PH_L16_ADDR(a_[5], base1, pk1, "BYTE_2");                             \
+        PH_L16_ADDR(a_[6], base0, pk0, "BYTE_3");                             \
+        PH_L16_ADDR(a_[7], base1, pk1, "BYTE_3");                             \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[0]) : "v"(a_[0]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[0]) : "v"(a_[1]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[1]) : "v"(a_[2]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[1]) : "v"(a_[3]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[2]) : "v"(a_[4]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[2]) : "v"(a_[5]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(X[3]) : "v"(a_[6]));         \
+        asm volatile("ds_read_b64 %0, %1" : "=v"(Y[3]) : "v"(a_[7]));         \
+    } while (0)
+
+typedef uint32_t l16_u32x2 __attribute__((ext_vector_type(2)));
+
+template <int RB>
+__global__ __launch_bounds__(THREADS, 2) void sw_locate16_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    uint32_t lenB, uint32_t lenB_pad, const uint2 *__restrict__ prof16, const uint8_t *__restrict__ codeA,
+    const uint32_t *__restrict__ binfo, int ncodes, int gap, int smax, const uint32_t *__restrict__ infoM,
+    const uint32_t *__restrict__ infoQ, uint32_t *__restrict__ list, uint32_t *__restrict__ count,
+    int64_t *__restrict__ score, uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err,
+    int defer)
+{
+    static_assert(RB % 4 == 0 && RB <= 76, "RB");
+    constexpr int RA = 2 * RB;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_l16[];
+    const int ncp = ncodes + 1;
+    const uint32_t nqB = lenB_pad / 4, pstride = (uint32_t)ncp * 8u;
+    uint2 *P = reinterpret_cast<uint2 *>(lds_l16);
+    uint8_t *codeL = lds_l16 + (size_t)(nqB + 1) * pstride;
+    const int tid = threadIdx.x;
+    for (uint32_t v = tid; v < (nqB + 1) * (uint32_t)ncp; v += THREADS)
+        P[v] = prof16[v];
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    const uint64_t pair = (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < npairs;
+    uint64_t o0 = 0;
+    uint32_t lenA = 0;
+    if (active) {
+        o0 = offA[pair];
+        const uint64_t l = offA[pair + 1] - o0;
+        lenA = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+    }
+    const bool too_long = lenA > RA;
+    if (too_long)
+        lenA = 0;
+    const uint8_t *ap = A + o0;
+    // byte offsets (code * 8) of my rows inside a profile block, four rows per register and band; and the first byte of
+    // A outside FirstAlphabet (as sw_locate_kernel)
+    uint32_t apk0[RB / 4], apk1[RB / 4];
+    int firstbad = -1;
+    uint32_t badsym = 0, a0sym = 0;
+#pragma unroll
+    for (int band = 0; band < 2; ++band) {
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = band * RB + 4 * w + b;
+                uint32_t code = (uint32_t)ncodes;
+                if ((uint32_t)i < lenA) {
+                    const uint32_t sym = ap[i];
+                    if (i == 0)
+                        a0sym = sym;
+                    code = codeL[sym];
+                    if (code == 0xFFu) {
+                        if (firstbad < 0) {
+                            firstbad = i;
+                            badsym = sym;
+                        }
+                        code = (uint32_t)ncodes;
+                    }
+                }
+                pk |= (code * 8u) << (8 * b);
+            }
+            if (band == 0)
+                apk0[w] = pk;
+            else
+                apk1[w] = pk;
+        }
+    }
+    uint32_t e = 0;
+    if (too_long) {
+        e = 0xFFFFFFFFu;
+    } else if (lenA > 0 && lenB > 0) { // align.go:189-191 + matrix.go:29-36: row-major first failing cell
+        const uint32_t bbad = binfo[0];
+        if (firstbad == 0)
+            e = (1u << 8) | a0sym;
+        else if (bbad != 0xFFFFFFFFu)
+            e = (2u << 8) | B[bbad];
+        else if (firstbad > 0)
+            e = (1u << 8) | badsym;
+    }
+    const int M = active ? (int)infoM[pair] : 0;
+    const uint32_t iq = active ? infoQ[pair] : 0u;
+    const bool tie = (iq >> 31) != 0u;
+    const uint32_t q = iq & 0x7FFFFFFFu;
+    const bool work = active && e == 0u && M > 0 && !tie;
+
+    uint32_t jb0 = 0, nblk = 0;
+    if (work && !defer) {
+        const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
+        const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u;
+        const uint32_t jend = 4u * q + 4u; // one past the block's last column
+        jb0 = (jend > need ? jend - need : 0u) & ~3u;
+        nblk = (jend - jb0) >> 2;
+    }
+
+    uint32_t H[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        H[i] = 0;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
+    const uint32_t pad_base = lds_base + nqB * pstride;
+    uint32_t nmax = nblk;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    const uint32_t lag = nmax - nblk;
+    const uint32_t gh = half_bits(gap); // gap < 0
+    const uint32_t gap2 = gh | (gh << 16);
+    const uint32_t Mh = half_bits(M);
+    uint32_t key = 0xFFFFFFFFu;
+    // band 0's last row of the block before, already in the high halves: what band 1 finds above its first row
+    uint32_t hh0 = 0, hh1 = 0, hh2 = 0, hh3 = 0, hg0 = 0, hg1 = 0, hg2 = 0, hg3 = 0, hd = 0;
+    auto sweep = [&](uint32_t bt, auto find_tag) { // bt = band 0's block; band 1 works on bt - 1
+        constexpr int FIND = decltype(find_tag)::value; // 0, 1 = search band 0's cells, 2 = band 1's
+        const uint32_t base0 = bt < nblk ? lds_base + ((jb0 >> 2) + bt) * pstride : pad_base;
+        const uint32_t base1 = bt >= 1u ? lds_base + ((jb0 >> 2) + bt - 1u) * pstride : pad_base;
+        uint32_t pr0 = hh0, pr1 = hh1, pr2 = hh2, pr3 = hh3, pg0 = hg0, pg1 = hg1, pg2 = hg2, pg3 = hg3, pdiag = hd;
+        l16_u32x2 xa[4], ya[4], xb[4], yb[4];
+        PH_L16_ISSUE(apk0[0], apk1[0], xa, ya);
+#pragma unroll
+        for (int g = 0; g < RB / 4; ++g) {
+            if (g + 1 < RB / 4) {
+                PH_L16_ISSUE(apk0[g + 1], apk1[g + 1], xb, yb);
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            }
+            PH_L16_ROW(4 * g + 0, xa[0].x, xa[0].y, ya[0].x, ya[0].y);
+            PH_L16_ROW(4 * g + 1, xa[1].x, xa[1].y, ya[1].x, ya[1].y);
+            PH_L16_ROW(4 * g + 2, xa[2].x, xa[2].y, ya[2].x, ya[2].y);
+            PH_L16_ROW(4 * g + 3, xa[3].x, xa[3].y, ya[3].x, ya[3].y);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xa[u] = xb[u];
+                ya[u] = yb[u];
+            }
+        }
+        hd = hh3;
+        hh0 = pr0 << 16;
+        hh1 = pr1 << 16;
+        hh2 = pr2 << 16;
+        hh3 = pr3 << 16;
+        hg0 = pg0 << 16;
+        hg1 = pg1 << 16;
+        hg2 = pg2 << 16;
+        hg3 = pg3 << 16;
+    };
+    // iterations 0 .. nmax (a lane runs nblk + 1 of them); the last two carry the search
+    for (uint32_t t = 0; t <= nmax; ++t) {
+        if (nblk == 0u || t < lag)
+            continue;
+        if (t + 1u == nmax)
+            sweep(t - lag, std::integral_constant<int, 1>{});
+        else if (t == nmax)
+            sweep(t - lag, std::integral_constant<int, 2>{});
+        else
+            sweep(t - lag, std::integral_constant<int, 0>{});
+    }
+
+    if (!active)
+        return;
+    // a tie, or (never expected) no cell found: the exact kernel decides
+    if (e == 0u && M > 0 && (tie || (!defer && key == 0xFFFFFFFFu))) {
+        list[atomicAdd(count, 1u)] = (uint32_t)pair;
+        return;
+    }
+    const bool hit = e == 0u && M > 0;
+    score[pair] = hit ? (int64_t)M : 0;
+    if (defer) { // the traceback kernel locates the cell inside block q
+        endA[pair] = hit ? SW_END_DEFERRED : 0u;
+        endB[pair] = hit ? 4u * q + 4u : 0u;
+    } else {
+        endA[pair] = hit ? (key >> 2) + 1u : 0u;
+        endB[pair] = hit ? 4u * q + (key & 3u) + 1u : 0u;
+    }
+    err[pair] = e;
+}
+#undef PH_L16_ISSUE
+#undef PH_L16_ADDR
+#undef PH_L16_ROW
+#undef PH_L16_CELL
+
 // ---- host side ---------------------------------------------------------------------------------------
 bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, uint64_t lenB, PackedPlan *out)
 {
@@ -755,7 +1034,11 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
         return false; // the byte profile of the reference has to sit whole in LDS for step 2
     p.prof2_bytes = align_up((size_t)(p.nq + 2 * (p.k - 1)) * p.tab_bytes, 256);
     p.info_bytes = align_up((size_t)npairs * 4, 256);
-    p.work_bytes = p.prof2_bytes + 3 * p.info_bytes + 256;
+    const size_t tab16 = ((size_t)p.lenB_pad / 4 + 1) * (size_t)p.ncp * 8;
+    p.locate16_smem = tab16 + 256;
+    p.locate16 = p.f16 && p.k == 1 && p.locate16_smem <= 79 * 1024 && !env_is("POLYHIP_SW_LOCATE16", '0');
+    p.prof16_bytes = p.locate16 ? align_up(tab16, 256) : 0;
+    p.work_bytes = p.prof2_bytes + 3 * p.info_bytes + 256 + p.prof16_bytes;
     *out = p;
     return true;
 }
@@ -792,6 +1075,23 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), p.pk_smem, st, d_A, d_offA, npairs, prof2, p.nq,
                            p.jcb, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
         PH_HIP(hipGetLastError());
+    }
+    if constexpr (RA == 64 || RA == 152) {
+        if (p.locate16 && !defer) { // (a deferred end cell needs no sweep: the 32-bit kernel's bookkeeping does)
+            uint2 *prof16 = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(list) + p.info_bytes);
+            const uint32_t n16 = (p.lenB_pad / 4 + 1) * (uint32_t)p.ncp;
+            hipLaunchKernelGGL(profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, lenB, p.lenB_pad, sc->d_lutc,
+                               sc->ncodes, p.ncp, prof16);
+            auto kern16 = sw_locate16_kernel<RA / 2>;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)p.locate16_smem));
+            const uint64_t blocks = (npairs + THREADS - 1) / THREADS;
+            hipLaunchKernelGGL(kern16, dim3((unsigned)blocks), dim3(THREADS), p.locate16_smem, st, d_A, d_offA, npairs, d_B,
+                               lenB, p.lenB_pad, prof16, sc->d_codeA, binfo, sc->ncodes, (int)sc->gap, (int)sc->smax, infoM,
+                               infoQ, list, count, d_score, d_endA, d_endB, d_err, defer);
+            PH_HIP(hipGetLastError());
+            return POLYHIP_OK;
+        }
     }
     if constexpr (RA <= 256) {
         auto kern = sw_locate_kernel<RA, 8>;

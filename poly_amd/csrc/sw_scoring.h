@@ -68,6 +68,8 @@ struct PackedPlan {
     uint32_t lenB_pad, nq, jcb;     // columns (multiple of 4), 4-column blocks, blocks per LDS chunk
     size_t pk_smem, locate_smem;
     size_t prof2_bytes, info_bytes; // workspace pieces
+    bool locate16;                  // sw_locate16_kernel: half-float, two bands of rows per lane (f16, k == 1, table fits twice per CU)
+    size_t prof16_bytes, locate16_smem;
     size_t work_bytes;              // 256 (tie counter) + prof2 + infoM + infoQ + tie list
 };
 
