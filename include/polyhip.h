@@ -228,7 +228,11 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A,
  * aln_stride >= polyhip_sw_traceback_stride(sc, max_lenA, lenB).
  * d_work: any size >= 256 pairs' worth; polyhip_sw_traceback_workspace_bytes
  * returns enough for all pairs at once (capped at 8 GiB); smaller workspaces
- * make the call loop over chunks of pairs.
+ * make the call loop over chunks of pairs.  With several chunks the lane-per-pair
+ * kernels run them through the two halves of the workspace on two streams -- `stream`
+ * and one the library keeps per calling thread, joined to `stream` by events before
+ * and after -- so that the end of a chunk overlaps the start of the next; everything
+ * is ordered on `stream` as if it had run there (POLYHIP_TB_OVERLAP=0: it does).
  */
 uint32_t polyhip_sw_traceback_stride(const polyhip_scoring *sc,
                                      uint32_t max_lenA, uint64_t lenB);

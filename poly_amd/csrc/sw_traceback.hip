@@ -1730,10 +1730,17 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
-    // the lane-per-pair kernels run two 256-pair workgroups per CU: whole rounds of 256 CUs x 512 pairs per chunk
-    // (a chunk of 1.5 rounds spends its second round on half-empty CUs)
-    if (use_prof && chunk >= 131072)
-        chunk = chunk / 131072 * 131072;
+    // A batch that needs several chunks of the direction workspace: the byte-profile and the one-wave-per-pair kernels take them through the two
+    // HALVES of the workspace on two streams (the caller's and one of the library's), so that the end of one chunk --
+    // waves finish at different times, and the walk that closes a wave's work waits on memory, not on issue -- overlaps
+    // the sweeps of the next (one chunk after the other: the waves of a chunk were resident 67 % of its time,
+    // profiles/r02_tbh_pmc_a.md).  POLYHIP_TB_OVERLAP=0: one chunk after the other (testing aid).
+    const uint64_t half_chunk = (usable / 2) / p.per_pair / k3t::THREADS * k3t::THREADS;
+    const bool overlap = (use_prof || use_wave) && npairs > chunk && half_chunk >= 16384 && !env_is("POLYHIP_TB_OVERLAP", '0');
+    if (overlap)
+        chunk = half_chunk;
+    else if (use_prof && chunk >= 131072)
+        chunk = chunk / 131072 * 131072; // whole rounds of 256 CUs x 2 workgroups x 256 pairs
     PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_sw_traceback: workspace too small (%zu B; %zu B per pair, >= %d pairs)",
                work_bytes, p.per_pair, k3t::THREADS);
     hipStream_t st = as_stream(stream);
@@ -1753,10 +1760,28 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
                            p.lenB_pad, sc->d_lutc, sc->ncodes, p.cp, prof);
         PH_HIP(hipGetLastError());
     }
-    for (uint64_t p0 = 0; p0 < npairs; p0 += chunk) {
+    static thread_local hipStream_t aux_stream = nullptr;
+    static thread_local hipEvent_t aux_ev[2] = {nullptr, nullptr};
+    const hipStream_t caller_st = st;
+    if (overlap) {
+        if (!aux_stream) {
+            PH_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
+            PH_HIP(hipEventCreateWithFlags(&aux_ev[0], hipEventDisableTiming));
+            PH_HIP(hipEventCreateWithFlags(&aux_ev[1], hipEventDisableTiming));
+        }
+        PH_HIP(hipEventRecord(aux_ev[0], caller_st)); // the profile table (and everything before this call) is ready
+        PH_HIP(hipStreamWaitEvent(aux_stream, aux_ev[0], 0));
+    }
+    uint64_t chunk_no = 0;
+    for (uint64_t p0 = 0; p0 < npairs; p0 += chunk, ++chunk_no) {
         const uint64_t p1 = std::min(npairs, p0 + chunk);
         const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
         uint32_t *dirbuf = static_cast<uint32_t *>(d_dir);
+        if (overlap) { // odd chunks: the library's stream and the upper half of the workspace
+            st = (chunk_no & 1) ? aux_stream : caller_st;
+            if (chunk_no & 1)
+                dirbuf = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_dir) + ((usable / 2) & ~(size_t)255));
+        }
         if (use_wave) {
             const unsigned wblocks = (unsigned)((p1 - p0 + k3t::THREADS / 64 - 1) / (k3t::THREADS / 64));
 #define PH_TBW_LAUNCH(R_)                                                                                             \
@@ -1857,6 +1882,10 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
         }
 #undef PH_TB_LAUNCH
         PH_HIP(hipGetLastError());
+    }
+    if (overlap) { // the caller's stream continues after both
+        PH_HIP(hipEventRecord(aux_ev[1], aux_stream));
+        PH_HIP(hipStreamWaitEvent(caller_st, aux_ev[1], 0));
     }
     return POLYHIP_OK;
 }

@@ -173,6 +173,52 @@ def test_ties_and_repeats(al):
     _check(al, sc, om, -2, reads, refs=[ref] * len(reads))
 
 
+def test_chunks_overlapped_on_two_streams_equal_one_after_the_other(al, monkeypatch):
+    """A batch that needs several chunks of the direction workspace: the byte-profile kernels take them through the two
+    halves of the workspace on two streams; POLYHIP_TB_OVERLAP=0 runs one chunk after the other. 150k config-4-like reads
+    through a workspace that holds 60k pairs: seven outputs equal, a sample against the oracle; the call is followed by
+    work on the caller's stream that reads the results (ordering across the two streams)."""
+    import torch
+    from poly_amd import workloads
+    align = al[0]
+    dev = torch.device("cuda:0")
+    n, LA, LB = 150_000, 150, 5000
+    B, A2 = workloads.config4_reads(n, LA, LB, first=123_000, device=dev)
+    A = A2.reshape(-1).contiguous()
+    offA = torch.arange(0, (n + 1) * LA, LA, dtype=torch.int64, device=dev)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, LA, LB, True), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, work)
+    stride = align.sw_traceback_stride(sc, LA, LB)
+    tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, 60_000, LA, LB), dtype=torch.uint8, device=dev)
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("POLYHIP_TB_OVERLAP", mode)
+        alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        ln = torch.full((n,), -5, dtype=torch.int32, device=dev)
+        align.sw_traceback_dev(sc, A, offA, LA, B, None, LB, ea, eb, er, alnA, alnB, ln, tbw, score_t=score)
+        total = ln.long().sum()  # on the caller's stream, right behind the call
+        torch.cuda.synchronize()
+        outs.append((alnA, alnB, ln, int(total)))
+    monkeypatch.delenv("POLYHIP_TB_OVERLAP", raising=False)
+    assert outs[0][3] == outs[1][3] and torch.equal(outs[0][2], outs[1][2])
+    cols = torch.arange(stride, device=dev)[None, :]
+    live = cols >= (stride - outs[0][2].long())[:, None]
+    assert bool(((outs[0][0] == outs[1][0]) | ~live).all()) and bool(((outs[0][1] == outs[1][1]) | ~live).all())
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    refb = B.cpu().numpy().tobytes()
+    a_h, b_h, l_h, rd = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), outs[0][2].cpu().numpy(), A2.cpu().numpy()
+    for p_ in range(0, n, 1499):
+        ws, wa, wb, _, _ = orc.smith_waterman(rd[p_].tobytes(), refb, om, -2)
+        wa = wa if isinstance(wa, bytes) else wa.encode("latin-1")
+        wb = wb if isinstance(wb, bytes) else wb.encode("latin-1")
+        L = int(l_h[p_])
+        assert (int(score[p_]), a_h[p_, stride - L:].tobytes(), b_h[p_, stride - L:].tobytes()) == (ws, wa, wb), p_
+
+
 def test_generic_paths(al):
     """A longer than the register tile, per-pair B, and scoring without a window bound (gap >= 0)"""
     rng = np.random.default_rng(77)
