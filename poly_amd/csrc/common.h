@@ -58,6 +58,47 @@ inline bool env_is(const char *name, char value)
 
 inline hipStream_t as_stream(polyhip_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// A second stream the library keeps per calling thread, for entry points that run sub-batches of one call side by side
+// (the end of one sub-batch's kernels -- waves finish at different times -- overlaps the start of the next).  fork():
+// the aux stream waits for everything enqueued on the caller's stream so far; join(): the caller's stream waits for the
+// aux stream.  Everything stays ordered on the caller's stream as if it had run there.
+struct AuxStream {
+    hipStream_t s = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipError_t init()
+    {
+        if (s)
+            return hipSuccess;
+        hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+        return e;
+    }
+    hipError_t fork(hipStream_t caller)
+    {
+        hipError_t e = init();
+        if (e == hipSuccess)
+            e = hipEventRecord(ev[0], caller);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(s, ev[0], 0);
+        return e;
+    }
+    hipError_t join(hipStream_t caller)
+    {
+        hipError_t e = hipEventRecord(ev[1], s);
+        if (e == hipSuccess)
+            e = hipStreamWaitEvent(caller, ev[1], 0);
+        return e;
+    }
+};
+inline AuxStream &aux_stream()
+{
+    static thread_local AuxStream a;
+    return a;
+}
+
 // value of the lane below (lane 0 gets 0): one DPP move (wave_shr:1, a GFX9 control gfx950 still has) instead of
 // the ds_bpermute a __shfl_up costs -- the systolic one-wave-per-pair kernels do this every step
 __device__ __forceinline__ int from_lane_below(int v)

@@ -718,17 +718,50 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
         // packed pass first (two pairs per lane); the few pairs it leaves on its tie list go through the
         // exact one-wave-per-pair kernel (a lane-per-pair kernel would take a full DP's time for them)
         if (p.path == 3) {
-            uint32_t *list = nullptr, *count = nullptr;
             const int do_defer = defer && p.pk.ra <= 256 ? 1 : 0;
-            const int rc = k3p::packed_run(sc, p.pk, d_A, d_offA, npairs, d_B, (uint32_t)lenB, prof, binfo,
-                                           static_cast<uint8_t *>(d_work) + p.fast_bytes, d_score, d_endA, d_endB, d_err,
-                                           &list, &count, st, nullptr, nullptr, do_defer);
-            if (rc != POLYHIP_OK)
-                return rc;
             if (deferred)
                 *deferred = do_defer;
-            return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count,
-                                 npairs, d_score, d_endA, d_endB, d_err, st);
+            // Sub-batches of 262,144 pairs (one full round of the packed kernel), alternating between the caller's stream
+            // and the library's second one, each with its own slice of the packed pass's workspace: the packed kernel's
+            // last, partly filled round and the short locate / tie kernels of one sub-batch run beside the packed kernel of
+            // the next.  POLYHIP_SW_OVERLAP=0: the whole batch in one piece (testing aid).
+            const uint64_t SUB = 262144;
+            k3p::PackedPlan ps{};
+            const bool split = npairs >= 2 * SUB && !env_is("POLYHIP_SW_OVERLAP", '0') &&
+                               k3p::packed_plan(sc, SUB, max_lenA, lenB, &ps) && ps.ra == p.pk.ra && ps.k == p.pk.k &&
+                               2 * (ps.work_bytes + 256) <= p.pk.work_bytes;
+            if (!split) {
+                uint32_t *list = nullptr, *count = nullptr;
+                const int rc = k3p::packed_run(sc, p.pk, d_A, d_offA, npairs, d_B, (uint32_t)lenB, prof, binfo,
+                                               static_cast<uint8_t *>(d_work) + p.fast_bytes, d_score, d_endA, d_endB, d_err,
+                                               &list, &count, st, nullptr, nullptr, do_defer);
+                if (rc != POLYHIP_OK)
+                    return rc;
+                return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count,
+                                     npairs, d_score, d_endA, d_endB, d_err, st);
+            }
+            ps.skip_rows = p.pk.skip_rows; // (same kernels as the whole batch would take)
+            AuxStream &aux = aux_stream();
+            PH_HIP(aux.fork(st)); // the byte profile is ready
+            const size_t slice = (ps.work_bytes + 255) & ~(size_t)255;
+            uint64_t k = 0;
+            for (uint64_t i0 = 0; i0 < npairs; i0 += SUB, ++k) {
+                const uint64_t m = std::min(SUB, npairs - i0);
+                hipStream_t sk = (k & 1) ? aux.s : st;
+                uint8_t *wk = static_cast<uint8_t *>(d_work) + p.fast_bytes + (k & 1) * slice;
+                uint32_t *list = nullptr, *count = nullptr;
+                int rc = k3p::packed_run(sc, ps, d_A, d_offA + i0, m, d_B, (uint32_t)lenB, prof, binfo, wk, d_score + i0,
+                                         d_endA + i0, d_endB + i0, d_err + i0, &list, &count, sk, nullptr, nullptr, do_defer);
+                if (rc == POLYHIP_OK)
+                    rc = k3w::wave_run(sc, d_A, d_offA + i0, m, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count, m,
+                                       d_score + i0, d_endA + i0, d_endB + i0, d_err + i0, sk);
+                if (rc != POLYHIP_OK) {
+                    (void)aux.join(st);
+                    return rc;
+                }
+            }
+            PH_HIP(aux.join(st));
+            return POLYHIP_OK;
         }
 #define PH_SW_CASE(RA_, CP_)                                                                                       \
     if (p.ra == RA_ && p.cp == CP_)                                                                                \

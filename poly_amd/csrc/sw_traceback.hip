@@ -1760,25 +1760,17 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
                            p.lenB_pad, sc->d_lutc, sc->ncodes, p.cp, prof);
         PH_HIP(hipGetLastError());
     }
-    static thread_local hipStream_t aux_stream = nullptr;
-    static thread_local hipEvent_t aux_ev[2] = {nullptr, nullptr};
     const hipStream_t caller_st = st;
-    if (overlap) {
-        if (!aux_stream) {
-            PH_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
-            PH_HIP(hipEventCreateWithFlags(&aux_ev[0], hipEventDisableTiming));
-            PH_HIP(hipEventCreateWithFlags(&aux_ev[1], hipEventDisableTiming));
-        }
-        PH_HIP(hipEventRecord(aux_ev[0], caller_st)); // the profile table (and everything before this call) is ready
-        PH_HIP(hipStreamWaitEvent(aux_stream, aux_ev[0], 0));
-    }
+    AuxStream &aux = aux_stream();
+    if (overlap)
+        PH_HIP(aux.fork(caller_st)); // the profile table (and everything before this call) is ready
     uint64_t chunk_no = 0;
     for (uint64_t p0 = 0; p0 < npairs; p0 += chunk, ++chunk_no) {
         const uint64_t p1 = std::min(npairs, p0 + chunk);
         const unsigned blocks = (unsigned)((p1 - p0 + k3t::THREADS - 1) / k3t::THREADS);
         uint32_t *dirbuf = static_cast<uint32_t *>(d_dir);
         if (overlap) { // odd chunks: the library's stream and the upper half of the workspace
-            st = (chunk_no & 1) ? aux_stream : caller_st;
+            st = (chunk_no & 1) ? aux.s : caller_st;
             if (chunk_no & 1)
                 dirbuf = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_dir) + ((usable / 2) & ~(size_t)255));
         }
@@ -1883,10 +1875,8 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
 #undef PH_TB_LAUNCH
         PH_HIP(hipGetLastError());
     }
-    if (overlap) { // the caller's stream continues after both
-        PH_HIP(hipEventRecord(aux_ev[1], aux_stream));
-        PH_HIP(hipStreamWaitEvent(caller_st, aux_ev[1], 0));
-    }
+    if (overlap) // the caller's stream continues after both
+        PH_HIP(aux.join(caller_st));
     return POLYHIP_OK;
 }
 
