@@ -65,11 +65,17 @@ inline hipStream_t as_stream(polyhip_stream_t s) { return static_cast<hipStream_
 struct AuxStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
+    int dev = -1; // the device it was made on: a thread that moves to another device gets a new one
     hipError_t init()
     {
-        if (s)
+        int cur = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess)
+            return e;
+        if (s && dev == cur)
             return hipSuccess;
-        hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        dev = cur;
+        e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
         if (e == hipSuccess)
