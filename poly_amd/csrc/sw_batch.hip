@@ -742,8 +742,13 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
             }
             ps.skip_rows = p.pk.skip_rows; // (same kernels as the whole batch would take)
             AuxStream &aux = aux_stream();
-            PH_HIP(aux.fork(st)); // the byte profile is ready
             const size_t slice = (ps.work_bytes + 255) & ~(size_t)255;
+            // both slices' tables once, in front of the fork (a tiny kernel queued beside a full-chip one waits for it)
+            for (int q = 0; q < 2; ++q)
+                if (int rc = k3p::packed_profiles(sc, ps, d_B, (uint32_t)lenB, static_cast<uint8_t *>(d_work) + p.fast_bytes + q * slice, st))
+                    return rc;
+            ps.reuse_profiles = true;
+            PH_HIP(aux.fork(st)); // the byte profile and the tables are ready
             uint64_t k = 0;
             for (uint64_t i0 = 0; i0 < npairs; i0 += SUB, ++k) {
                 const uint64_t m = std::min(SUB, npairs - i0);

@@ -1049,7 +1049,7 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                          uint32_t *prof2, uint32_t *infoM, uint32_t *infoQ, uint32_t *list, uint32_t *count,
                          int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st, int defer)
 {
-    {
+    if (!p.reuse_profiles) {
         const uint32_t nqe = p.nq + 2 * (K - 1); // K - 1 all-pad blocks on either side
         const uint32_t n = nqe * (uint32_t)(p.ncp * p.ncp);
         hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, nqe, (uint32_t)(K - 1),
@@ -1080,8 +1080,9 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
         if (p.locate16 && !defer) { // (a deferred end cell needs no sweep: the 32-bit kernel's bookkeeping does)
             uint2 *prof16 = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(list) + p.info_bytes);
             const uint32_t n16 = (p.lenB_pad / 4 + 1) * (uint32_t)p.ncp;
-            hipLaunchKernelGGL(profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, lenB, p.lenB_pad, sc->d_lutc,
-                               sc->ncodes, p.ncp, prof16);
+            if (!p.reuse_profiles)
+                hipLaunchKernelGGL(profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, lenB, p.lenB_pad,
+                                   sc->d_lutc, sc->ncodes, p.ncp, prof16);
             auto kern16 = sw_locate16_kernel<RA / 2>;
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern16), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)p.locate16_smem));
@@ -1103,6 +1104,27 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                            list, count, d_score, d_endA, d_endB, d_err, defer);
         PH_HIP(hipGetLastError());
     }
+    return POLYHIP_OK;
+}
+
+// the tables packed_run builds at the front of its workspace (prof2, and the locate step's table of halves), on their own:
+// a caller that runs several sub-batches through one workspace slice builds them once and sets p.reuse_profiles
+int packed_profiles(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_B, uint32_t lenB, void *d_work,
+                    hipStream_t st)
+{
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    uint32_t *prof2 = reinterpret_cast<uint32_t *>(w + 256);
+    const uint32_t nqe = p.nq + 2 * (uint32_t)(p.k - 1);
+    const uint32_t n = nqe * (uint32_t)(p.ncp * p.ncp);
+    hipLaunchKernelGGL(profile2_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_B, lenB, nqe, (uint32_t)(p.k - 1), sc->d_lutc,
+                       sc->ncodes, p.ncp, prof2, (int)p.f16, (int)(-sc->gap));
+    if (p.locate16) {
+        uint2 *prof16 = reinterpret_cast<uint2 *>(w + 256 + p.prof2_bytes + 3 * p.info_bytes);
+        const uint32_t n16 = (p.lenB_pad / 4 + 1) * (uint32_t)p.ncp;
+        hipLaunchKernelGGL(profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, lenB, p.lenB_pad, sc->d_lutc,
+                           sc->ncodes, p.ncp, prof16);
+    }
+    PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
 

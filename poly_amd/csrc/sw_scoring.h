@@ -70,6 +70,7 @@ struct PackedPlan {
     size_t prof2_bytes, info_bytes; // workspace pieces
     bool locate16;                  // sw_locate16_kernel: half-float, two bands of rows per lane (f16, k == 1, table fits twice per CU)
     size_t prof16_bytes, locate16_smem;
+    bool reuse_profiles;            // the tables at the front of the workspace are there already (packed_profiles)
     size_t work_bytes;              // 256 (tie counter) + prof2 + infoM + infoQ + tie list
 };
 
@@ -80,6 +81,8 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
 // (count at *count_out, both inside d_work); every other pair has its four outputs written.
 // Above 256 rows (p.ra > 256) there is no locate step here: *infoM_out / *infoQ_out (maximum, its block, tie bit)
 // are handed to the one-wave-per-pair kernel's locate mode (wave_run) and no output is written yet.
+int packed_profiles(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_B, uint32_t lenB, void *d_work,
+                    hipStream_t st);
 int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_A, const uint64_t *d_offA,
                uint64_t npairs, const uint8_t *d_B, uint32_t lenB, const int8_t *prof, const uint32_t *binfo,
                void *d_work, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
