@@ -1735,7 +1735,8 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     // waves finish at different times, and the walk that closes a wave's work waits on memory, not on issue -- overlaps
     // the sweeps of the next (one chunk after the other: the waves of a chunk were resident 67 % of its time,
     // profiles/r02_tbh_pmc_a.md).  POLYHIP_TB_OVERLAP=0: one chunk after the other (testing aid).
-    const uint64_t half_chunk = (usable / 2) / p.per_pair / k3t::THREADS * k3t::THREADS;
+    const size_t half_bytes = (usable / 2) & ~(size_t)255; // where the upper half starts
+    const uint64_t half_chunk = half_bytes / p.per_pair / k3t::THREADS * k3t::THREADS;
     const bool overlap = (use_prof || use_wave) && npairs > chunk && half_chunk >= 16384 && !env_is("POLYHIP_TB_OVERLAP", '0');
     if (overlap)
         chunk = half_chunk;
@@ -1772,7 +1773,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
         if (overlap) { // odd chunks: the library's stream and the upper half of the workspace
             st = (chunk_no & 1) ? aux.s : caller_st;
             if (chunk_no & 1)
-                dirbuf = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_dir) + ((usable / 2) & ~(size_t)255));
+                dirbuf = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_dir) + half_bytes);
         }
         if (use_wave) {
             const unsigned wblocks = (unsigned)((p1 - p0 + k3t::THREADS / 64 - 1) / (k3t::THREADS / 64));
