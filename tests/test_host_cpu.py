@@ -113,3 +113,17 @@ def test_bench_refuses_a_rank_count_it_was_not_started_with():
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 2 and "refusing" in res.stderr
+
+
+def test_dense_join_column_division_bound():
+    """csrc/mash_distance.hip rowjoin_dense_kernel: field = column / ndw by one multiply-high with kmul = ceil(2^32 / ndw);
+    exact for column < PER * ndw as long as PER * ndw^2 < 2^32 -- the host caps a stripe at 37,832 dwords (three 10-bit
+    fields) / 46,328 dwords (two 16-bit fields) for that reason.  Checked at every multiple of 8 up to the caps, on the
+    columns where a floor can go wrong (just below and at every multiple of ndw), and that the caps are tight."""
+    def ok(ndw, per):
+        kmul = ((1 << 32) + ndw - 1) // ndw
+        cols = [m * ndw + d for m in range(1, per + 1) for d in (-1, 0) if m * ndw + d < per * ndw]
+        return all((c * kmul) >> 32 == c // ndw for c in cols)
+    assert all(ok(n, 3) for n in range(8, 37832 + 1, 8))
+    assert all(ok(n, 2) for n in range(8, 46328 + 1, 8))
+    assert not all(ok(n, 3) for n in range(37840, 40000, 8))  # beyond the cap the trick does fail somewhere
