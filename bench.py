@@ -453,7 +453,13 @@ def main() -> int:
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "polyhip::k1::sketch_slab_kernel<21>", "kernel_ms": kern_ms,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "algorithmic_bytes_per_launch": alg_bytes,
+                     # what actually bounds K1: VALU issue.  43.8 VALU instructions per k-mer
+                     # (profiles/r02_k1_issue.md: SQ_INSTS_VALU / k-mers), of which MurmurHash3 itself needs ~25; one
+                     # 64-lane instruction per 4 cycles per SIMD, 1024 SIMDs at the 2.4 GHz peak clock
+                     "valu_issue": {"instructions_per_kmer": 43.8, "source": "profiles/r02_k1_issue.md (counters, NOT measured by this run)",
+                                    "ceiling_kmers_per_s": 1024 * 2.4e9 / 4 * 64 / 43.8,
+                                    "frac": (kmers_per_step / (kern_ms * 1e-3)) / (1024 * 2.4e9 / 4 * 64 / 43.8)}},
         "parity_spot_check": parity,
     }
     if strong is not None:
