@@ -51,13 +51,14 @@ KMER = 21
 SKETCH = 1000
 SEED = 0xC2
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+WATCHDOG_S = 240      # the N > 1 all-gather leg may not hold the line hostage for longer
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU (config: 1,000,000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=400, help="reads per core in the CPU-baseline sample")
@@ -241,51 +242,148 @@ def timed_steps(step, steps: int, warmup: int, sync_all, world: int, dev):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / max(1, steps)
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    kern_ms = sum(ts) / max(1, steps)
+    timed_steps.last_median_ms = 0.5 * (ts[(steps - 1) // 2] + ts[steps // 2]) if steps else 0.0
     return elapsed, kern_ms
 
 
-def allgather_distance(dev, rank: int, world: int):
-    """N = 100k sketches over `world` ranks: each rank sketches its own families, all ranks all-gather
-    (one ncclAllGather over xGMI), each builds the index of the gathered set once and computes its row block."""
+def allgather_distance(dev, rank: int, world: int, one_gpu_test: bool = False):
+    """BASELINE configs[2]: N = 100k sketches over `world` ranks.  Each rank sketches its own families; the sketches are
+    all-gathered by THE PRODUCT'S collective -- polyhip_comm_unique_id (rank 0; the 128 bytes travel over the
+    torch.distributed rendezvous channel) -> polyhip_comm_init_rank -> polyhip_allgather_sketches_dev, RCCL over xGMI
+    behind the C ABI, what the Go host calls -- and every rank computes its row block.  Two ways to get the index:
+      replicated   every rank builds the whole index of the gathered set (polyhip_mash_shared_counts_dev)
+      sharded      rank r builds part r of the index (polyhip_mash_index_build_part_dev), the parts are exchanged with
+                   two ragged all-gathers (polyhip_mash_index_allgather_dev), then polyhip_mash_shared_counts_reuse_dev
+    both timed; `ms_per_step` is the faster.  BENCH_ONE_GPU_TEST (all ranks on GPU 0, gloo): RCCL refuses two ranks on
+    one device, so the gather falls back to torch.distributed and says so in `allgather.via`."""
     import torch
     import torch.distributed as dist
-    from poly_amd import bench_extra, mash, sharding
+    from poly_amd import bench_extra, comm as pcomm, mash, sharding
 
     s, total = SKETCH, 100_000
     lo, hi = sharding.shard_range(total // 100, rank, world)  # families of 100 copies, sharded by family
+    fam_max = max(sharding.shard_range(total // 100, r, world)[1] - sharding.shard_range(total // 100, r, world)[0]
+                  for r in range(world))
     local = bench_extra.family_sketches(dev, hi - lo, 100, READ_LEN, KMER, s, 0xC3 + 1000 * rank)
-    state = {}
+    n_local = local.shape[0]
+    n_pad = fam_max * 100                       # ncclAllGather's contract: the same count on every rank
+    ragged = any(sharding.shard_range(total // 100, r, world) != (r * fam_max, (r + 1) * fam_max) for r in range(world))
+    sizes = [100 * (sharding.shard_range(total // 100, r, world)[1] - sharding.shard_range(total // 100, r, world)[0])
+             for r in range(world)]
+    row0 = sum(sizes[:rank])
+    N = sum(sizes)
 
-    def step():
-        def compute(X, Y):
-            if "counts" not in state:
-                state["counts"] = torch.empty((X.shape[0], Y.shape[0]), dtype=torch.int16, device=dev)
-                state["work"] = torch.empty(mash.shared_counts_workspace_bytes(X.shape[0], s, Y.shape[0], s),
-                                            dtype=torch.uint8, device=dev)
-            mash.shared_counts_dev(X, Y, state["counts"], state["work"])
-            return state["counts"]
-        return sharding.allvsall_row_block(local, compute)
+    c, via = None, None
+    if not one_gpu_test:
+        uid = [pcomm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        torch.cuda.synchronize()
+        dist.barrier()                           # torch's communicator is idle while the product's one is in use
+        c = pcomm.Comm(uid[0], rank, world)
+        via = "polyhip_allgather_sketches_dev (libpolyhip's own RCCL communicator, C ABI)"
+    else:
+        via = "torch.distributed all_gather_into_tensor over gloo (one-GPU test: RCCL needs one device per rank)"
 
-    for _ in range(2):
-        step()
-    dist.barrier()
-    torch.cuda.synchronize()
-    reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        counts, row0, gathered = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    N = gathered.shape[0]
-    ok = bool((counts[:, row0:row0 + counts.shape[0]].diagonal() == s).all())
-    return {"workload": f"all-vs-all shared counts over {N} sketches (s={s}) sharded by rows over {world} GPUs, "
-                        "sketches all-gathered with one RCCL all-gather per step (BASELINE configs[2])",
-            "pairs_per_s": N * N / float(dt.item()), "ms_per_step": float(dt.item()) * 1e3,
-            "allgather_bytes_per_rank": local.numel() * 4, "self_pairs_share_all_hashes": ok}
+    send = local
+    if n_local != n_pad:
+        send = torch.zeros((n_pad, s), dtype=local.dtype, device=dev)
+        send[:n_local] = local
+    recv = torch.empty((world * n_pad, s), dtype=local.dtype, device=dev)
+    gathered = recv if not ragged else torch.empty((N, s), dtype=local.dtype, device=dev)
+    counts = torch.empty((n_local, N), dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(n_local, s, N, s), dtype=torch.uint8, device=dev)
+
+    def gather():
+        if c is not None:
+            c.allgather_sketches(send, recv)
+        else:
+            dist.all_gather_into_tensor(recv, send)
+        if ragged:                               # trim the padding (device copies on the same stream)
+            o = 0
+            for r in range(world):
+                gathered[o:o + sizes[r]] = recv[r * n_pad:r * n_pad + sizes[r]]
+                o += sizes[r]
+
+    def step_replicated():
+        gather()
+        mash.shared_counts_dev(gathered[row0:row0 + n_local], gathered, counts, work)
+
+    def step_sharded():
+        gather()
+        mash.index_build_part_dev(gathered, rank, world, work)
+        c.index_allgather(N, s, work)
+        mash.shared_counts_reuse_dev(gathered[row0:row0 + n_local], gathered, counts, work)
+
+    def sync():
+        torch.cuda.synchronize()
+        if c is None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def timed(fn, reps=5, warm=2):
+        """wall time per step, MAX over ranks; the ranks meet in the step's own collective, the clock starts after a
+        barrier on torch's (otherwise idle) communicator"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = torch.tensor([(time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        return float(dt.item())
+
+    out = {"workload": f"all-vs-all shared counts over {N} sketches (s={s}) sharded by rows over {world} GPUs, "
+                       "per-rank sketches all-gathered once per step (BASELINE configs[2])"}
+    t_gather = timed(gather, reps=10, warm=3)
+    recv_bytes = (world - 1) * n_pad * s * 4
+    out["allgather"] = {"via": via, "bytes_sent_per_rank": n_pad * s * 4, "bytes_received_per_rank": recv_bytes,
+                        "ms": t_gather * 1e3, "GBs_received_per_rank": recv_bytes / t_gather / 1e9,
+                        "bus_GBs": recv_bytes / t_gather / 1e9}
+    t_rep = timed(step_replicated)
+    ok_rep = bool((counts[:, row0:row0 + n_local].diagonal() == s).all())
+    keep = counts.clone()
+    out["replicated_index"] = {"ms_per_step": t_rep * 1e3, "pairs_per_s": N * N / t_rep,
+                               "self_pairs_share_all_hashes": ok_rep}
+    best = t_rep
+    if c is not None:
+        # every rank must reach the collectives of the sharded step or none: agree first
+        flag = torch.ones(1, dtype=torch.int64, device=dev)
+        try:
+            mash.index_build_part_dev(gathered, rank, world, work)
+            torch.cuda.synchronize()
+        except Exception as e:  # pragma: no cover - reported, not raised
+            flag.zero_()
+            out["sharded_index"] = {"error": f"{type(e).__name__}: {e}"}
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        if int(flag.item()) == 1:
+            t_sh = timed(step_sharded)
+            same = bool(torch.equal(counts, keep))
+            it, st = mash.index_part_spans(N, s, world, work)
+            out["sharded_index"] = {"ms_per_step": t_sh * 1e3, "pairs_per_s": N * N / t_sh,
+                                    "row_block_equals_replicated": same,
+                                    "index_bytes_received_per_rank": int((it[-1] - it[0]) - (it[rank + 1] - it[rank])
+                                                                         + (st[-1] - st[0]) - (st[rank + 1] - st[rank])),
+                                    "via": "polyhip_mash_index_build_part_dev + polyhip_mash_index_allgather_dev "
+                                           "(two grouped-ncclBroadcast ragged all-gathers)"}
+            if same:
+                best = min(best, t_sh)
+        elif "sharded_index" not in out:
+            out["sharded_index"] = {"error": "another rank failed to build its part"}
+        c.close()
+    else:
+        out["sharded_index"] = {"skipped": "needs the RCCL communicator (one device per rank)"}
+    out.update({"pairs_per_s": N * N / best, "ms_per_step": best * 1e3, "allgather_bytes_per_rank": n_pad * s * 4,
+                "self_pairs_share_all_hashes": ok_rep})
+    return out
 
 
 def sharded_tm_scan(dev, rank: int, world: int):
@@ -394,6 +492,7 @@ def main() -> int:
 
     elapsed, kern_ms = timed_steps(lambda: mash.sketch_batch_dev(seqs, offs, KMER, SKETCH, out),
                                    args.steps, args.warmup, sync_all, world, dev)
+    kern_ms_median = timed_steps.last_median_ms
     kmers_per_step = n * (READ_LEN - KMER)
     value = world * kmers_per_step * args.steps / elapsed
     alg_bytes = n * (READ_LEN + 4 * SKETCH)  # per launch: reads in, sketches out
@@ -453,6 +552,7 @@ def main() -> int:
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "polyhip::k1::sketch_slab_kernel<21>", "kernel_ms": kern_ms,
+                     "kernel_ms_median": kern_ms_median,
                      "algorithmic_bytes_per_launch": alg_bytes,
                      # what actually bounds K1: VALU issue.  43.8 VALU instructions per k-mer
                      # (profiles/r02_k1_issue.md: SQ_INSTS_VALU / k-mers), of which MurmurHash3 itself needs ~25; one
@@ -469,12 +569,6 @@ def main() -> int:
     del seqs, out, offs
     torch.cuda.empty_cache()
     if world > 1 and not args.no_extra:
-        # BASELINE configs[2]: per-rank sketches -> RCCL all-gather -> this rank's row block of the
-        # all-vs-all shared-count matrix (the one collective on the path)
-        try:
-            line_extra = allgather_distance(dev, rank, world)
-        except Exception as e:
-            line_extra = {"error": f"{type(e).__name__}: {e}"}
         # BASELINE configs[3] sharded: every rank aligns its own 1M reads against the shared reference
         # (pairs split N/G, no collective); the slowest rank sets the time
         r, sw_err = None, None
@@ -498,8 +592,30 @@ def main() -> int:
         except Exception as e:
             tm_extra = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
-            line["extra"] = {"mash_distance_allgather": line_extra, "smith_waterman": sw_extra,
-                             "santalucia_scan": tm_extra}
+            line["extra"] = {"smith_waterman": sw_extra, "santalucia_scan": tm_extra}
+        # BASELINE configs[2], LAST and under a watchdog: per-rank sketches -> the product's RCCL all-gather -> this
+        # rank's row block (the one collective on the path).  It drives a second communicator (libpolyhip's
+        # own); if a rank fails inside a step the others would wait in a collective for ever -- the watchdog then
+        # prints the line with what has been measured and ends every rank, instead of losing the whole run.
+        import threading
+
+        def bail():
+            if rank == 0:
+                line.setdefault("extra", {})["mash_distance_allgather"] = {
+                    "error": f"watchdog: the all-gather leg did not finish within {WATCHDOG_S} s (a rank failed or a "
+                             "collective hung); every other number in this line was measured before it"}
+                os.write(json_fd, (json.dumps(line) + "\n").encode())
+            os._exit(0)
+        dog = threading.Timer(WATCHDOG_S, bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            line_extra = allgather_distance(dev, rank, world, one_gpu_test)
+        except Exception as e:
+            line_extra = {"error": f"{type(e).__name__}: {e}"}
+        dog.cancel()
+        if rank == 0:
+            line["extra"]["mash_distance_allgather"] = line_extra
     if rank == 0 and world == 1:
         if not args.no_extra:
             try:

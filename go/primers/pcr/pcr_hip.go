@@ -1,8 +1,9 @@
 // Package pcr: the Tm-bound parts of github.com/bebop/poly/primers/pcr on the batched device Tm scorer.
 //
-// DesignPrimersWithOverhangs / DesignPrimers (pcr.go:44-66) keep their signatures; their grow-until-Tm loops
-// (:47-53) score a window of candidate lengths with ONE polyhip_santalucia_batch call and pick the first that
-// reaches the target.  DesignPrimersBatch does the same for many genes in one call ("design primers for every
+// DesignPrimersWithOverhangs / DesignPrimers (pcr.go:44-66) keep their signatures and, for one gene, the reference's
+// body (go/fork.sh renames the former to designPrimersWithOverhangsCPU; DesignPrimers stays the reference's and calls
+// the overlay).  DesignPrimersBatch scores the grow-until-Tm loops (:47-53) of many genes with ONE
+// polyhip_santalucia_batch call per growth window ("design primers for every
 // CDS of a genome", tutorials/002_primer_design_test.go:82-99).  MinimalBindingLengths replaces the per-primer
 // loop of SimulateSimple (pcr.go:95-101); the rest of SimulateSimple / Simulate (site lookup through
 // index/suffixarray, fragment assembly; :106-203) is host orchestration that stays the reference's code and
@@ -16,8 +17,7 @@ import (
 	"github.com/bebop/poly/transform"
 )
 
-const minimalPrimerLength int = 7          // pcr.go:35
-const designedMinimalPrimerLength int = 15 // pcr.go:38
+// minimalPrimerLength (7, pcr.go:35) and designedMinimalPrimerLength (15, pcr.go:38) are the reference's constants.
 
 // primers.MeltingTemp's conditions (primers.go:122-124)
 const (
@@ -96,15 +96,10 @@ func DesignPrimersBatch(sequences []string, targetTm float64) []PrimerPair {
 	return out
 }
 
-// DesignPrimersWithOverhangs is pcr.go:44-60.
+// DesignPrimersWithOverhangs is pcr.go:44-60 (renamed designPrimersWithOverhangsCPU in the fork's pcr.go; one gene is
+// two grow loops of a few MeltingTemp calls each -- the reference's body; DesignPrimersBatch is the device entry point).
 func DesignPrimersWithOverhangs(sequence, forwardOverhang, reverseOverhang string, targetTm float64) (string, string) {
-	p := DesignPrimersBatch([]string{sequence}, targetTm)[0]
-	return forwardOverhang + p.Forward, transform.ReverseComplement(reverseOverhang) + p.Reverse
-}
-
-// DesignPrimers is pcr.go:64-66.
-func DesignPrimers(sequence string, targetTm float64) (string, string) {
-	return DesignPrimersWithOverhangs(sequence, "", "", targetTm)
+	return designPrimersWithOverhangsCPU(sequence, forwardOverhang, reverseOverhang, targetTm)
 }
 
 // MinimalBindingLengths is the loop of pcr.go:95-101 for every primer of a reaction: minimalLength[i] = the

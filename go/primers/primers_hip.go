@@ -1,12 +1,18 @@
-// Package primers: drop-in for the Tm scorers of github.com/bebop/poly/primers (primers.go:70-128) over
-// libpolyhip; the barcode generator (primers.go:226-319) is not on the path and keeps the reference's code.
-// UNCOMPILED here.
+// Drop-in overlay of the Tm scorers of github.com/bebop/poly/primers (primers.go:70-128) over libpolyhip.
+//
+// The fork keeps the reference's primers.go with two declaration renames (go/fork.sh): SantaLucia -> santaLuciaCPU,
+// MarmurDoty -> marmurDotyCPU; MeltingTemp (:121-128), the thermodynamic tables and the barcode generator stay the
+// reference's code.  One sequence is 30 dinucleotide lookups: the exported single-call functions run the reference's
+// body (polyhip.MinTmCalls), the batch / scan entry points below are what uses the device.  UNCOMPILED here.
 package primers
 
 import "github.com/bebop/poly/internal/polyhip"
 
 // SantaLucia is primers.go:70-105.  Bit-identical results (same fp64 operation order, Go's math.Log algorithm).
 func SantaLucia(sequence string, primerConcentration, saltConcentration, magnesiumConcentration float64) (meltingTemp, dH, dS float64) {
+	if 1 < polyhip.MinTmCalls {
+		return santaLuciaCPU(sequence, primerConcentration, saltConcentration, magnesiumConcentration) // the reference's body
+	}
 	buf, offs := polyhip.Pack([]string{sequence})
 	tm, h, s, err := polyhip.SantaLuciaBatch(buf, offs, primerConcentration, saltConcentration, magnesiumConcentration)
 	if err != nil {
@@ -17,6 +23,9 @@ func SantaLucia(sequence string, primerConcentration, saltConcentration, magnesi
 
 // MarmurDoty is primers.go:108-118.
 func MarmurDoty(sequence string) float64 {
+	if 1 < polyhip.MinTmCalls {
+		return marmurDotyCPU(sequence) // the reference's body
+	}
 	buf, offs := polyhip.Pack([]string{sequence})
 	tm, err := polyhip.MarmurDotyBatch(buf, offs)
 	if err != nil {
@@ -25,10 +34,14 @@ func MarmurDoty(sequence string) float64 {
 	return tm[0]
 }
 
-// MeltingTemp is primers.go:121-128.
-func MeltingTemp(sequence string) float64 {
-	tm, _, _ := SantaLucia(sequence, 500e-9, 50e-3, 0.0)
-	return tm
+// SantaLuciaBatch scores many primers in one device call (bit-identical to SantaLucia of each).
+func SantaLuciaBatch(sequences []string, primerConcentration, saltConcentration, magnesiumConcentration float64) (meltingTemp, dH, dS []float64) {
+	buf, offs := polyhip.Pack(sequences)
+	tm, h, s, err := polyhip.SantaLuciaBatch(buf, offs, primerConcentration, saltConcentration, magnesiumConcentration)
+	if err != nil {
+		panic(err)
+	}
+	return tm, h, s
 }
 
 // TmTable is the result of SantaLuciaScan: Tm/DH/DS[(L-MinLen)*Stride + start]; NaN where the window runs off the end.

@@ -1,6 +1,9 @@
-// Package align: drop-in for github.com/bebop/poly/search/align over libpolyhip: Scoring / NewScoring / Score
-// (align.go:73-95), SmithWaterman (:171-232) and NeedlemanWunsch (:100-166) all run on the device.
-// UNCOMPILED here (no Go toolchain in the authoring image).
+// Drop-in overlay of github.com/bebop/poly/search/align over libpolyhip.
+//
+// The fork keeps the reference's align.go with two declaration renames (go/fork.sh): SmithWaterman -> smithWatermanCPU,
+// NeedlemanWunsch -> needlemanWunschCPU.  type Scoring, NewScoring and Scoring.Score (align.go:73-95) stay the
+// reference's code; this file supplies the two exported functions again -- small inputs run the reference's body, large
+// ones the device -- and SmithWatermanBatch.  UNCOMPILED here (no Go toolchain in the authoring image).
 package align
 
 import (
@@ -10,13 +13,6 @@ import (
 	"github.com/bebop/poly/internal/polyhip"
 	"github.com/bebop/poly/search/align/matrix"
 )
-
-// Scoring is align.go:73-76: exactly the reference's two exported fields, so that struct literals and
-// by-value copies (SmithWaterman takes a Scoring, not a *Scoring) keep working.
-type Scoring struct {
-	SubstitutionMatrix *matrix.SubstitutionMatrix
-	GapPenalty         int
-}
 
 // Device-side scoring tables are cached per (matrix pointer, gap penalty) at package level: a Scoring is
 // passed by value, so a handle stored inside it would land on a copy and every call would flatten the
@@ -45,21 +41,8 @@ func ForgetScoring(m *matrix.SubstitutionMatrix) {
 	}
 }
 
-// NewScoring is align.go:79-87 (nil matrix -> matrix.Default; never errors).
-func NewScoring(substitutionMatrix *matrix.SubstitutionMatrix, gapPenalty int) (Scoring, error) {
-	if substitutionMatrix == nil {
-		substitutionMatrix = matrix.Default
-	}
-	return Scoring{SubstitutionMatrix: substitutionMatrix, GapPenalty: gapPenalty}, nil
-}
-
-// Score is align.go:89-95.
-func (s Scoring) Score(a, b byte) (int, error) {
-	return s.SubstitutionMatrix.Score(string(a), string(b))
-}
-
 // handle flattens through the matrix's PUBLIC Score(): its score table is unexported (matrix.go:13-17).
-func (s Scoring) handle() *polyhip.Scoring {
+func handle(s Scoring) *polyhip.Scoring {
 	key := scoringKey{s.SubstitutionMatrix, s.GapPenalty}
 	scoringMu.Lock()
 	defer scoringMu.Unlock()
@@ -104,6 +87,9 @@ func symbolError(code uint32) error {
 
 // SmithWaterman is align.go:171-232.
 func SmithWaterman(stringA string, stringB string, scoring Scoring) (int, string, string, error) {
+	if len(stringA)*len(stringB) < polyhip.MinAlignCells {
+		return smithWatermanCPU(stringA, stringB, scoring) // the reference's body
+	}
 	res := SmithWatermanBatch([]string{stringA}, stringB, scoring)
 	if res[0].Err != nil {
 		return 0, "", "", res[0].Err
@@ -113,10 +99,13 @@ func SmithWaterman(stringA string, stringB string, scoring Scoring) (int, string
 
 // NeedlemanWunsch is align.go:100-166 (the traceback stops when either index reaches 0, as the reference's does).
 func NeedlemanWunsch(stringA string, stringB string, scoring Scoring) (int, string, string, error) {
+	if len(stringA)*len(stringB) < polyhip.MinAlignCells {
+		return needlemanWunschCPU(stringA, stringB, scoring) // the reference's body
+	}
 	A, offA := polyhip.Pack([]string{stringA})
 	B, _ := polyhip.Pack([]string{stringB})
 	B = B[:len(stringB) : len(stringB)+1]
-	raw, err := scoring.handle().NWAlignBatch(A, offA, B, nil, len(stringA))
+	raw, err := handle(scoring).NWAlignBatch(A, offA, B, nil, len(stringA))
 	if err != nil {
 		panic(err)
 	}
@@ -144,7 +133,7 @@ func SmithWatermanBatch(reads []string, reference string, scoring Scoring) []Ali
 			maxLen = len(r)
 		}
 	}
-	raw, err := scoring.handle().SWAlignBatch(A, offA, B, nil, maxLen)
+	raw, err := handle(scoring).SWAlignBatch(A, offA, B, nil, maxLen)
 	if err != nil {
 		panic(err)
 	}

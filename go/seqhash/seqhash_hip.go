@@ -1,5 +1,8 @@
-// Package seqhash: RotateSequence (seqhash.go:78-138) and Hash (seqhash.go:141-224) of
-// github.com/bebop/poly/seqhash over libpolyhip.  UNCOMPILED here.
+// Drop-in overlay of github.com/bebop/poly/seqhash over libpolyhip: RotateSequence (seqhash.go:78-138), Hash (:141-224).
+//
+// The fork keeps the reference's seqhash.go with two declaration renames (go/fork.sh): Hash -> hashCPU, RotateSequence ->
+// rotateSequenceCPU; SequenceType and its constants, boothLeastRotation and the v2 hashes stay the reference's code.
+// Small sequences run the reference's body, large ones and the batch entry points the device.  UNCOMPILED here.
 package seqhash
 
 import (
@@ -8,17 +11,11 @@ import (
 	"github.com/bebop/poly/internal/polyhip"
 )
 
-// SequenceType is seqhash.go:66-74.
-type SequenceType string
-
-const (
-	DNA     SequenceType = "DNA"
-	RNA     SequenceType = "RNA"
-	PROTEIN SequenceType = "PROTEIN"
-)
-
 // Hash is seqhash.go:141-224 (same seqhash strings, same error texts).
 func Hash(sequence string, sequenceType SequenceType, circular bool, doubleStranded bool) (string, error) {
+	if len(sequence) < polyhip.MinRotateBytes {
+		return hashCPU(sequence, sequenceType, circular, doubleStranded) // the reference's body
+	}
 	res, errs := HashBatch([]string{sequence}, sequenceType, circular, doubleStranded)
 	return res[0], errs[0]
 }
@@ -58,6 +55,9 @@ func HashBatch(sequences []string, sequenceType SequenceType, circular bool, dou
 
 // RotateSequence is seqhash.go:127-138.
 func RotateSequence(sequence string) string {
+	if len(sequence) < polyhip.MinRotateBytes {
+		return rotateSequenceCPU(sequence) // the reference's body
+	}
 	return RotateBatch([]string{sequence})[0]
 }
 

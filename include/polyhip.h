@@ -136,6 +136,33 @@ int polyhip_mash_shared_counts_reuse_dev(const uint32_t *d_X, uint64_t nx,
                                          uint16_t *d_counts, uint64_t ld,
                                          void *d_work, size_t work_bytes,
                                          polyhip_stream_t stream);
+/*
+ * The index built in PARTS (multi-rank all-vs-all: SURVEY 8e, BASELINE configs[2]).  Every rank holds the same
+ * gathered Y; rank r calls polyhip_mash_index_build_part_dev(part = r, nparts = nranks): it runs the cheap whole-set
+ * steps (ascending check, coarse histogram) and then sorts only ITS share of the value range -- coarse buckets chosen from
+ * the histogram so that every part holds about the same number of items -- writing its items and bucket starts at their
+ * FINAL offsets in d_work.  polyhip_mash_index_allgather_dev then exchanges the parts in place (two ragged RCCL
+ * all-gathers, polyhip_allgatherv_dev) and finishes the header; after it polyhip_mash_shared_counts_reuse_dev works as
+ * after polyhip_mash_index_build_dev.  Both calls synchronise `stream` once (the part bounds are read from the device's
+ * histogram).  Building parts 0 .. nparts-1 one after the other into ONE workspace, then polyhip_mash_index_finalize_dev,
+ * gives the same index as polyhip_mash_index_build_dev (same bucket starts; the same items in every bucket, in whatever
+ * order the atomics put them) -- how the parts are tested on one GPU.  polyhip_mash_index_part_spans reports where the
+ * parts sit: item_spans / start_spans get nparts + 1 byte offsets into d_work each (part p = [spans[p], spans[p+1])).
+ */
+struct polyhip_comm;
+int polyhip_mash_index_build_part_dev(const uint32_t *d_Y, uint64_t ny, uint32_t sy,
+                                      uint32_t part, uint32_t nparts,
+                                      void *d_work, size_t work_bytes,
+                                      polyhip_stream_t stream);
+int polyhip_mash_index_part_spans(uint64_t ny, uint32_t sy, uint32_t nparts,
+                                  const void *d_work, size_t work_bytes,
+                                  uint64_t *item_spans, uint64_t *start_spans,
+                                  polyhip_stream_t stream);
+int polyhip_mash_index_finalize_dev(uint64_t ny, uint32_t sy, void *d_work,
+                                    size_t work_bytes, polyhip_stream_t stream);
+int polyhip_mash_index_allgather_dev(struct polyhip_comm *c, uint64_t ny,
+                                     uint32_t sy, void *d_work,
+                                     size_t work_bytes, polyhip_stream_t stream);
 /* What the last polyhip_mash_shared_counts_dev call on this workspace did
  * (synchronous read-back; tests and profiling): mode 0 = hash join, 1 = the
  * reference's merge for every pair; the number of non-ascending sketches on
@@ -517,6 +544,11 @@ int polyhip_comm_size(const polyhip_comm *c);
 int polyhip_allgather_sketches_dev(polyhip_comm *c, const uint32_t *d_local,
                                    uint64_t n_local, uint32_t s,
                                    uint32_t *d_all, polyhip_stream_t stream);
+/* Ragged all-gather IN PLACE: rank r owns bytes [offsets[r], offsets[r+1]) of d_buf (nranks + 1 ascending offsets, the
+ * same on every rank) and every rank ends up with all segments -- one grouped call of nranks ncclBroadcasts, each rank
+ * the root of its own segment.  What polyhip_mash_index_allgather_dev moves the parts of the index with. */
+int polyhip_allgatherv_dev(polyhip_comm *c, void *d_buf, const uint64_t *offsets,
+                           polyhip_stream_t stream);
 
 #ifdef __cplusplus
 }

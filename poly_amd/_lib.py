@@ -40,6 +40,10 @@ SIGNATURES = {
     "polyhip_mash_shared_counts_workspace_bytes": (C.c_size_t, [_u64, _u32, _u64, _u32]),
     "polyhip_mash_shared_counts_dev": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
     "polyhip_mash_index_build_dev": (C.c_int, [_vp, _u64, _u32, _vp, C.c_size_t, _vp]),
+    "polyhip_mash_index_build_part_dev": (C.c_int, [_vp, _u64, _u32, _u32, _u32, _vp, C.c_size_t, _vp]),
+    "polyhip_mash_index_part_spans": (C.c_int, [_u64, _u32, _u32, _vp, C.c_size_t, _vp, _vp, _vp]),
+    "polyhip_mash_index_finalize_dev": (C.c_int, [_u64, _u32, _vp, C.c_size_t, _vp]),
+    "polyhip_mash_index_allgather_dev": (C.c_int, [_vp, _u64, _u32, _vp, C.c_size_t, _vp]),
     "polyhip_mash_shared_counts_reuse_dev": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
     "polyhip_mash_shared_counts_mode_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "polyhip_mash_distance_from_counts_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _vp, _u64, _vp]),
@@ -93,6 +97,7 @@ SIGNATURES = {
     "polyhip_comm_rank": (C.c_int, [_vp]),
     "polyhip_comm_size": (C.c_int, [_vp]),
     "polyhip_allgather_sketches_dev": (C.c_int, [_vp, _vp, _u64, _u32, _vp, _vp]),
+    "polyhip_allgatherv_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
 }
 
 

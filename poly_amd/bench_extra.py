@@ -162,6 +162,21 @@ def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
                         "frac_join_only": pairs * 2 / ms_join * 1e3 / 1e9 / HBM_PEAK_GBS,
                         "kernel": "polyhip::k2::rowjoin_dense_kernel<10> (+ the index build in counts_ms)"},
            "join_mode": mode[0], "nonzero_pairs": nonzero}
+    # the path's collective through the C ABI on a 1-rank communicator (libpolyhip's own RCCL calls; at N ranks
+    # bench.py --gpus N times the real exchange) and the index built as 8 parts, as 8 ranks would
+    try:
+        from . import comm as pcomm
+        c = pcomm.Comm(pcomm.unique_id(), 0, 1)
+        buf = torch.empty_like(sk[:nrows])
+        ms_ag = _time(lambda: c.allgather_sketches(sk[:nrows], buf), 3)
+        ms_part = _time(lambda: mash.index_build_part_dev(sk, 3, 8, work), 3)
+        c.close()
+        out["comm_one_rank"] = {"via": "polyhip_comm_unique_id / _init_rank / polyhip_allgather_sketches_dev (RCCL, C ABI)",
+                                "allgather_ms": ms_ag, "bytes": int(buf.numel() * 4), "copy_equal": bool(torch.equal(buf, sk[:nrows])),
+                                "index_part_1_of_8_ms": ms_part}
+        del buf
+    except Exception as e:  # reported, never fatal for the other numbers
+        out["comm_one_rank"] = {"error": f"{type(e).__name__}: {e}"}
     del dist, counts, work
     torch.cuda.empty_cache()
     # the whole matrix on one GPU: one index, every row

@@ -86,5 +86,21 @@ def build_abi_smoke() -> str:
     return exe
 
 
+def build_abi_allgather() -> str:
+    """tests/abi/abi_allgather: the torch-free multi-rank C host (libpolyhip + the HIP runtime for its device buffers)."""
+    src = os.path.join(ROOT, "tests", "abi", "abi_allgather.c")
+    exe = os.path.join(ROOT, "tests", "abi", "abi_allgather")
+    lib = build_lib()
+    if _newer(exe, [src, lib, os.path.join(ROOT, "include", "polyhip.h")]):
+        cmd = ["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", "/opt/rocm/include", src, "-o", exe,
+               "-L", HERE, "-lpolyhip", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm",
+               "-Wl,-rpath,$ORIGIN/../../poly_amd", "-Wl,-rpath,/opt/rocm/lib"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode:
+            sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+            raise RuntimeError("build of tests/abi/abi_allgather failed")
+    return exe
+
+
 if __name__ == "__main__":
     print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -21,7 +21,8 @@ namespace r1 {
 
 typedef struct { char internal[128]; } UniqueId; // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128)
 typedef void *Comm;                               // ncclComm_t
-constexpr int NCCL_UINT32 = 3;                    // ncclUint32 (ncclDataType_t)
+constexpr int NCCL_UINT8 = 1;                     // ncclUint8 (ncclDataType_t)
+constexpr int NCCL_UINT32 = 3;                    // ncclUint32
 
 struct Api {
     void *handle = nullptr;
@@ -29,6 +30,9 @@ struct Api {
     int (*CommInitRank)(Comm *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, Comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     char why[256] = "";
 };
@@ -51,9 +55,14 @@ static Api &api()
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
         a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
+        a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(dlsym(a.handle, "ncclBroadcast"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(a.handle, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(a.handle, "ncclGroupEnd"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
-        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather) {
-            snprintf(a.why, sizeof a.why, "librccl lacks ncclGetUniqueId/ncclCommInitRank/ncclCommDestroy/ncclAllGather");
+        if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllGather || !a.Broadcast || !a.GroupStart ||
+            !a.GroupEnd) {
+            snprintf(a.why, sizeof a.why,
+                     "librccl lacks one of ncclGetUniqueId/CommInitRank/CommDestroy/AllGather/Broadcast/GroupStart/GroupEnd");
             a.handle = nullptr;
         }
     });
@@ -137,6 +146,35 @@ int polyhip_allgather_sketches_dev(polyhip_comm *c, const uint32_t *d_local, uin
     const int rc = a.AllGather(d_local, d_all, (size_t)n_local * s, r1::NCCL_UINT32, c->comm, as_stream(stream));
     if (rc != 0)
         return r1::rccl_error("ncclAllGather", rc);
+    return POLYHIP_OK;
+}
+
+// Ragged all-gather in place: rank r's segment of d_buf is bytes [offsets[r], offsets[r+1]) and every rank ends up with
+// all of them.  One grouped call of nranks broadcasts (each rank is the root of its own segment) -- ncclAllGather needs
+// equal counts, and padding an inverted index's parts to the largest would move bytes nobody needs.
+int polyhip_allgatherv_dev(polyhip_comm *c, void *d_buf, const uint64_t *offsets, polyhip_stream_t stream)
+{
+    PH_REQUIRE(c && c->comm, "polyhip_allgatherv: null communicator");
+    PH_REQUIRE(offsets, "polyhip_allgatherv: null offsets");
+    for (int r = 0; r < c->nranks; ++r)
+        PH_REQUIRE(offsets[r] <= offsets[r + 1], "polyhip_allgatherv: offsets not ascending at rank %d", r);
+    PH_REQUIRE(d_buf || offsets[c->nranks] == offsets[0], "polyhip_allgatherv: null buffer");
+    r1::Api &a = r1::api();
+    int rc = a.GroupStart();
+    if (rc != 0)
+        return r1::rccl_error("ncclGroupStart", rc);
+    int first_bad = 0;
+    for (int r = 0; r < c->nranks; ++r) {
+        uint8_t *seg = static_cast<uint8_t *>(d_buf) + offsets[r];
+        const int e = a.Broadcast(seg, seg, (size_t)(offsets[r + 1] - offsets[r]), r1::NCCL_UINT8, r, c->comm, as_stream(stream));
+        if (e != 0 && first_bad == 0)
+            first_bad = e;
+    }
+    rc = a.GroupEnd(); // always close the group, also after a failed member
+    if (first_bad != 0)
+        return r1::rccl_error("ncclBroadcast", first_bad);
+    if (rc != 0)
+        return r1::rccl_error("ncclGroupEnd", rc);
     return POLYHIP_OK;
 }
 

@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
                                                                 const uint8_t *__restrict__ flags,
                                                                 const uint32_t *__restrict__ hdr, uint32_t cshift_extra,
                                                                 uint32_t nc, uint32_t per_batch, uint32_t id_bits,
+                                                                uint32_t c0, uint32_t c1,
                                                                 uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
 {
     extern __shared__ uint32_t lh[]; // count[nc] then base[nc]
@@ -263,8 +265,11 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
         if (flags[q])
             continue;
         const uint32_t *p = sk + q * s;
-        for (uint32_t e = threadIdx.x; e < s; e += THREADS)
-            atomicAdd(&lh[p[e] >> cshift], 1u);
+        for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
+            const uint32_t c = p[e] >> cshift;
+            if (c - c0 < c1 - c0) // a part of the index takes the coarse buckets [c0, c1) only
+                atomicAdd(&lh[c], 1u);
+        }
     }
     __syncthreads();
     for (uint32_t c = threadIdx.x; c < nc; c += THREADS) {
@@ -283,7 +288,8 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
             while (occ < e && p[e - occ - 1] == v)
                 ++occ;
             const uint32_t c = v >> cshift;
-            citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
+            if (c - c0 < c1 - c0)
+                citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
         }
     }
 }
@@ -302,7 +308,7 @@ constexpr int STAGE_THREADS = PH_K2_STAGE_THREADS;
 __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
     const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags,
     const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t nc, uint32_t per_batch, uint32_t id_bits,
-    uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
+    uint32_t c0, uint32_t c1, uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stage[];
     uint2 *stage = reinterpret_cast<uint2 *>(lds_stage);      // STAGE_ITEMS
@@ -319,8 +325,11 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
         if (flags[q])
             continue;
         const uint32_t *p = sk + q * s;
-        for (uint32_t e = tid; e < s; e += STAGE_THREADS)
-            atomicAdd(&cnt[p[e] >> cshift], 1u);
+        for (uint32_t e = tid; e < s; e += STAGE_THREADS) {
+            const uint32_t c = p[e] >> cshift;
+            if (c - c0 < c1 - c0) // a part of the index takes the coarse buckets [c0, c1) only
+                atomicAdd(&cnt[c], 1u);
+        }
     }
     __syncthreads();
     // exclusive scan of cnt[0..nc) -> lstart; my slice of every coarse bucket -> gbase; cnt becomes the cursor
@@ -363,7 +372,8 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
             while (occ < e && p[e - occ - 1] == v)
                 ++occ;
             const uint32_t c = v >> cshift;
-            stage[lstart[c] + atomicAdd(&cnt[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
+            if (c - c0 < c1 - c0)
+                stage[lstart[c] + atomicAdd(&cnt[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
         }
     }
     __syncthreads();
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
 
 // level 2: one workgroup per coarse bucket -> fine start[] + final item order (+ self-join size)
 __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__ citems,
-                                                      const uint32_t *__restrict__ cstart, uint32_t nc,
+                                                      const uint32_t *__restrict__ cstart, uint32_t cfirst, uint32_t nc,
                                                       uint32_t fpc_log2, uint32_t *__restrict__ hdr,
                                                       uint32_t *__restrict__ start, uint2 *__restrict__ items)
 {
@@ -386,7 +396,7 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
     const uint32_t shift = hdr[H_SHIFT];
     const int tid = threadIdx.x;
     unsigned long long sq = 0;
-    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+    for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) { // coarse buckets [cfirst, nc)
         const uint32_t lo = cstart[c], hi = cstart[c + 1];
         __syncthreads();
         for (uint32_t f = tid; f < fpc; f += THREADS)
@@ -966,6 +976,39 @@ __global__ __launch_bounds__(THREADS) void distance_kernel(const uint16_t *__res
     }
 }
 
+// the index's self-join size sum_b |Y_b|^2 from the finished start[] (an index assembled from parts built elsewhere:
+// fine_kernel only counted the buckets it built itself)
+__global__ __launch_bounds__(THREADS) void self_join_kernel(const uint32_t *__restrict__ start, uint32_t nbk,
+                                                           uint32_t *__restrict__ hdr)
+{
+    unsigned long long sq = 0;
+    for (uint32_t b = blockIdx.x * THREADS + threadIdx.x; b < nbk; b += gridDim.x * THREADS) {
+        const unsigned long long c = start[b + 1] - start[b];
+        sq += c * c;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        sq += __shfl_xor(sq, d, 64);
+    if ((threadIdx.x & 63) == 0 && sq)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), sq);
+}
+
+// Parts of one index: coarse bucket boundaries b[0] = 0 <= b[1] <= ... <= b[nparts] = nc such that every part holds about
+// the same number of ITEMS (bottom-s sketches crowd the low values: equal value ranges would be far from equal work).
+// A pure function of the coarse histogram's scan, which every rank computes from the same gathered sketches.
+static void part_bounds(const uint32_t *cstart, uint32_t nc, uint32_t nparts, uint32_t *b)
+{
+    const uint64_t total = cstart[nc];
+    uint32_t c = 0;
+    for (uint32_t p = 0; p <= nparts; ++p) {
+        const uint64_t want = (total * p + nparts - 1) / nparts;
+        while (c < nc && cstart[c] < want)
+            ++c;
+        b[p] = p == nparts ? nc : c;
+    }
+    b[0] = 0;
+}
+
 } // namespace k2
 } // namespace polyhip
 
@@ -988,7 +1031,7 @@ static __global__ void reset_x_kernel(uint32_t *__restrict__ hdr)
 // what: 1 = build the index of Y, 2 = join X against the index in the workspace, 3 = both
 static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
                               uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
-                              polyhip_stream_t stream)
+                              polyhip_stream_t stream, uint32_t part = 0, uint32_t nparts = 1)
 {
     const bool build = what & 1, join = what & 2;
     if ((join && sx == 0) || sy == 0)
@@ -1038,6 +1081,17 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         hipLaunchKernelGGL(k2::coarse_count_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy, flagsY,
                            hdr, L.fpc_log2, L.nc, per_batch, gcount);
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, gcount, L.nc, cstart, gcur, start, L.nbk);
+        // one part of the index (multi-rank build): the coarse buckets [c0, c1) only, every item at its final place.  The
+        // bounds come from the coarse histogram -- the one point where the host has to look at device data.
+        uint32_t c0 = 0, c1 = L.nc;
+        if (nparts > 1) {
+            std::vector<uint32_t> hc(L.nc + 1), b(nparts + 1);
+            PH_HIP(hipMemcpyAsync(hc.data(), cstart, (size_t)(L.nc + 1) * 4, hipMemcpyDeviceToHost, st));
+            PH_HIP(hipStreamSynchronize(st));
+            k2::part_bounds(hc.data(), L.nc, nparts, b.data());
+            c0 = b[part];
+            c1 = b[part + 1];
+        }
         // level-1 scatter: through LDS when a sketch fits the stage (POLYHIP_K2_STAGE=0: the direct scatter, testing aid)
         if (sy <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0')) {
             const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / sy);
@@ -1045,13 +1099,14 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k2::coarse_scatter_staged_kernel, dim3((unsigned)((ny + pb - 1) / pb)), dim3(k2::STAGE_THREADS),
-                               smem, st, d_Y, ny, sy, flagsY, hdr, L.fpc_log2, L.nc, pb, id_bits, gcur, citems);
+                               smem, st, d_Y, ny, sy, flagsY, hdr, L.fpc_log2, L.nc, pb, id_bits, c0, c1, gcur, citems);
         } else {
             hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
-                               flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, gcur, citems);
+                               flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems);
         }
-        hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(L.nc, 256u * 8u)), dim3(k2::THREADS), 0, st, citems, cstart,
-                           L.nc, L.fpc_log2, hdr, start, items);
+        if (c1 > c0)
+            hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::THREADS), 0, st, citems,
+                               cstart, c0, c1, L.fpc_log2, hdr, start, items);
         PH_HIP(hipGetLastError());
     }
     if (!join)
@@ -1151,6 +1206,62 @@ int polyhip_mash_index_build_dev(const uint32_t *d_Y, uint64_t ny, uint32_t sy, 
                                  polyhip_stream_t stream)
 {
     return shared_counts_impl(1, nullptr, 0, 1, d_Y, ny, sy, nullptr, 0, d_work, work_bytes, stream);
+}
+
+int polyhip_mash_index_build_part_dev(const uint32_t *d_Y, uint64_t ny, uint32_t sy, uint32_t part, uint32_t nparts,
+                                      void *d_work, size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(nparts >= 1 && part < nparts, "polyhip_mash_index_build_part: part %u of %u", part, nparts);
+    return shared_counts_impl(1, nullptr, 0, 1, d_Y, ny, sy, nullptr, 0, d_work, work_bytes, stream, part, nparts);
+}
+
+int polyhip_mash_index_part_spans(uint64_t ny, uint32_t sy, uint32_t nparts, const void *d_work, size_t work_bytes,
+                                  uint64_t *item_spans, uint64_t *start_spans, polyhip_stream_t stream)
+{
+    PH_REQUIRE(nparts >= 1 && d_work && item_spans && start_spans, "polyhip_mash_index_part_spans: bad argument");
+    PH_REQUIRE(ny >= 1 && sy >= 1, "polyhip_mash_index_part_spans: empty index");
+    const k2::Layout L = k2::layout(0, 1, ny, sy);
+    PH_REQUIRE(work_bytes >= L.off_flagsX, "polyhip_mash_index_part_spans: workspace too small");
+    const uint8_t *w = static_cast<const uint8_t *>(d_work);
+    std::vector<uint32_t> hc(L.nc + 1), b(nparts + 1);
+    PH_HIP(hipMemcpyAsync(hc.data(), w + L.off_cstart, (size_t)(L.nc + 1) * 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    PH_HIP(hipStreamSynchronize(as_stream(stream)));
+    k2::part_bounds(hc.data(), L.nc, nparts, b.data());
+    for (uint32_t p = 0; p <= nparts; ++p) {
+        item_spans[p] = L.off_items + (uint64_t)hc[b[p]] * 8;
+        start_spans[p] = L.off_start + ((uint64_t)b[p] << L.fpc_log2) * 4;
+    }
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_index_finalize_dev(uint64_t ny, uint32_t sy, void *d_work, size_t work_bytes, polyhip_stream_t stream)
+{
+    PH_REQUIRE(d_work && ny >= 1 && sy >= 1, "polyhip_mash_index_finalize: bad argument");
+    const k2::Layout L = k2::layout(0, 1, ny, sy);
+    PH_REQUIRE(work_bytes >= L.off_flagsX, "polyhip_mash_index_finalize: workspace too small");
+    uint8_t *w = static_cast<uint8_t *>(d_work);
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(w);
+    PH_HIP(hipMemsetAsync(hdr + k2::H_EST_LO, 0, 8, as_stream(stream)));
+    hipLaunchKernelGGL(k2::self_join_kernel, dim3(std::min<uint32_t>((L.nbk + k2::THREADS - 1) / k2::THREADS, 2048u)),
+                       dim3(k2::THREADS), 0, as_stream(stream), reinterpret_cast<const uint32_t *>(w + L.off_start), L.nbk, hdr);
+    PH_HIP(hipGetLastError());
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_index_allgather_dev(polyhip_comm *c, uint64_t ny, uint32_t sy, void *d_work, size_t work_bytes,
+                                     polyhip_stream_t stream)
+{
+    const int nranks = polyhip_comm_size(c);
+    PH_REQUIRE(nranks >= 1, "polyhip_mash_index_allgather: null communicator");
+    std::vector<uint64_t> items(nranks + 1), starts(nranks + 1);
+    if (int rc = polyhip_mash_index_part_spans(ny, sy, (uint32_t)nranks, d_work, work_bytes, items.data(), starts.data(), stream))
+        return rc;
+    // two ragged all-gathers in place: every rank's items sit at their final offsets already
+    if (int rc = polyhip_allgatherv_dev(c, d_work, items.data(), stream))
+        return rc;
+    if (int rc = polyhip_allgatherv_dev(c, d_work, starts.data(), stream))
+        return rc;
+    return polyhip_mash_index_finalize_dev(ny, sy, d_work, work_bytes, stream);
 }
 
 int polyhip_mash_shared_counts_reuse_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,

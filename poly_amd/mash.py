@@ -158,6 +158,29 @@ def index_build_dev(Y_t, work_t, stream=None) -> None:
                                                        work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
 
 
+def index_build_part_dev(Y_t, part: int, nparts: int, work_t, stream=None) -> None:
+    """One part of Y's index (polyhip_mash_index_build_part_dev): the multi-rank build, rank r builds part r of nranks."""
+    ny, sy = Y_t.shape
+    assert Y_t.is_cuda and Y_t.is_contiguous() and Y_t.element_size() == 4
+    _lib.check(_lib.lib().polyhip_mash_index_build_part_dev(Y_t.data_ptr(), ny, sy, part, nparts, work_t.data_ptr(),
+                                                            work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
+def index_part_spans(ny: int, sy: int, nparts: int, work_t, stream=None):
+    """(item_spans, start_spans): nparts + 1 byte offsets into the workspace each; part p = [spans[p], spans[p+1])."""
+    it = np.zeros(nparts + 1, dtype=np.uint64)
+    st = np.zeros(nparts + 1, dtype=np.uint64)
+    _lib.check(_lib.lib().polyhip_mash_index_part_spans(ny, sy, nparts, work_t.data_ptr(),
+                                                        work_t.numel() * work_t.element_size(), it.ctypes.data,
+                                                        st.ctypes.data, _lib.stream_ptr(stream)))
+    return it, st
+
+
+def index_finalize_dev(ny: int, sy: int, work_t, stream=None) -> None:
+    _lib.check(_lib.lib().polyhip_mash_index_finalize_dev(ny, sy, work_t.data_ptr(),
+                                                          work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))
+
+
 def shared_counts_reuse_dev(X_t, Y_t, counts_t, work_t, stream=None) -> None:
     """shared_counts_dev against the index an earlier index_build_dev / shared_counts_dev call with the same Y left in
     `work_t`: row blocks of one matrix, or queries against a resident sketch set, build the index once."""
