@@ -368,6 +368,44 @@ func CommInitRank(id [128]byte, rank, nranks int) (*Comm, error) {
 
 func (cm *Comm) Close() { C.polyhip_comm_destroy(cm.c); cm.c = nil }
 
+// AllGatherV: ragged all-gather in place, rank r owns bytes [offsets[r], offsets[r+1]) of dBuf (device pointer).
+func (cm *Comm) AllGatherV(dBuf unsafe.Pointer, offsets []uint64, stream unsafe.Pointer) error {
+	return call(func() C.int {
+		return C.polyhip_allgatherv_dev(cm.c, dBuf, (*C.uint64_t)(unsafe.Pointer(&offsets[0])), C.polyhip_stream_t(stream))
+	})
+}
+
+// MashIndexBuildPart: rank r of n builds its part of the index of the gathered sketches dY (device) into dWork.
+func MashIndexBuildPart(dY unsafe.Pointer, ny uint64, sy uint32, part, nparts uint32, dWork unsafe.Pointer, workBytes uint64, stream unsafe.Pointer) error {
+	return call(func() C.int {
+		return C.polyhip_mash_index_build_part_dev((*C.uint32_t)(dY), C.uint64_t(ny), C.uint32_t(sy), C.uint32_t(part),
+			C.uint32_t(nparts), dWork, C.size_t(workBytes), C.polyhip_stream_t(stream))
+	})
+}
+
+// MashIndexAllGather exchanges the parts (two ragged all-gathers) and finishes the index; then MashSharedCountsReuse.
+func (cm *Comm) MashIndexAllGather(ny uint64, sy uint32, dWork unsafe.Pointer, workBytes uint64, stream unsafe.Pointer) error {
+	return call(func() C.int {
+		return C.polyhip_mash_index_allgather_dev(cm.c, C.uint64_t(ny), C.uint32_t(sy), dWork, C.size_t(workBytes),
+			C.polyhip_stream_t(stream))
+	})
+}
+
+// MashSharedCountsWorkspaceBytes sizes dWork for the calls above and below.
+func MashSharedCountsWorkspaceBytes(nx uint64, sx uint32, ny uint64, sy uint32) uint64 {
+	return uint64(C.polyhip_mash_shared_counts_workspace_bytes(C.uint64_t(nx), C.uint32_t(sx), C.uint64_t(ny), C.uint32_t(sy)))
+}
+
+// MashSharedCountsReuse: this rank's row block dX (device) against the index in dWork -> dCounts (u16, row stride ld).
+func MashSharedCountsReuse(dX unsafe.Pointer, nx uint64, sx uint32, dY unsafe.Pointer, ny uint64, sy uint32, dCounts unsafe.Pointer,
+	ld uint64, dWork unsafe.Pointer, workBytes uint64, stream unsafe.Pointer) error {
+	return call(func() C.int {
+		return C.polyhip_mash_shared_counts_reuse_dev((*C.uint32_t)(dX), C.uint64_t(nx), C.uint32_t(sx), (*C.uint32_t)(dY),
+			C.uint64_t(ny), C.uint32_t(sy), (*C.uint16_t)(dCounts), C.uint64_t(ld), dWork, C.size_t(workBytes),
+			C.polyhip_stream_t(stream))
+	})
+}
+
 // AllGatherSketches takes DEVICE pointers (the sketches never leave HBM between K1 and K2).
 func (cm *Comm) AllGatherSketches(dLocal unsafe.Pointer, nLocal uint64, s uint32, dAll unsafe.Pointer, stream unsafe.Pointer) error {
 	return call(func() C.int {

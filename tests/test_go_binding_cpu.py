@@ -1,0 +1,238 @@
+"""What stands in for the Go compiler (this image has none): mechanical checks of go/ against include/polyhip.h, the
+package's own Go signatures and the reference's declaration lines.
+
+1. every `C.polyhip_*(...)` call in go/polyhip/*.go has the header's arity and, argument by argument, the header's C
+   type (inferred from the cgo conversion that wraps each argument);
+2. every `polyhip.X(...)` use in the overlay packages names a function / variable that package polyhip declares, with the
+   declared number of arguments;
+3. go/fork.sh renames exactly the declarations the overlays re-supply, and every *CPU function an overlay calls is
+   produced by one of those renames."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GO = os.path.join(ROOT, "go")
+
+
+# ---------------------------------------------------------------- the header
+def _header_prototypes():
+    src = open(os.path.join(ROOT, "include", "polyhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][\w\s\*]*?)\b(polyhip_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith("typedef"):
+            continue
+        plist = [] if params in ("", "void") else [_norm_c_param(p) for p in _split_top(params)]
+        protos[name] = (_norm_c_type(ret), plist)
+    return protos
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur)
+    return [x.strip() for x in out]
+
+
+def _norm_c_type(t):
+    t = re.sub(r"\b(const|struct)\b", "", t)
+    t = re.sub(r"\s+", "", t)
+    return {"polyhip_stream_t": "void*"}.get(t, t)
+
+
+def _norm_c_param(p):
+    p = p.strip()
+    arr = re.search(r"\[\d*\]\s*$", p)
+    if arr:
+        p = p[: arr.start()]
+    m = re.match(r"(.*?)([A-Za-z_]\w*)$", p.strip(), flags=re.S)   # drop the parameter name
+    t = m.group(1) if m and m.group(1).strip() else p
+    t = _norm_c_type(t)
+    return t + "*" if arr else t
+
+
+# ---------------------------------------------------------------- the cgo calls
+def _matching_paren(s, i):
+    depth = 0
+    for j in range(i, len(s)):
+        if s[j] == "(":
+            depth += 1
+        elif s[j] == ")":
+            depth -= 1
+            if depth == 0:
+                return j
+    raise ValueError("unbalanced")
+
+
+def _go_symbols(src):
+    """Go-side knowledge the argument expressions lean on: variables / fields of C type, helper funcs returning C types"""
+    sym = {}
+    for m in re.finditer(r"\bvar\s+(\w+)\s+(\*?)C\.(\w+)", src):
+        sym[m.group(1)] = m.group(3) + ("*" if m.group(2) else "")
+    for m in re.finditer(r"\b(\w+)\s*:=\s*C\.(\w+)\(", src):
+        sym[m.group(1)] = m.group(2)
+    for m in re.finditer(r"\b(\w+)\s*:=\s*func\([^)]*\)\s*C\.(\w+)\s*{", src):
+        sym[m.group(1) + "()"] = m.group(2)
+    for m in re.finditer(r"type\s+(\w+)\s+struct\s*{\s*(\w+)\s+\*C\.(\w+)\s*}", src):
+        sym["." + m.group(2)] = m.group(3) + "*"          # any x.<field>
+    return sym
+
+
+def _arg_c_type(arg, sym):
+    a = arg.strip()
+    m = re.match(r"^\(\*C\.(\w+)\)\((.*)\)$", a, flags=re.S)
+    if m:                                                  # (*C.T)(unsafe.Pointer(&x[0])) or (*C.T)(ptr)
+        return m.group(1) + "*"
+    m = re.match(r"^C\.(\w+)\((.*)\)$", a, flags=re.S)
+    if m:
+        return m.group(1)
+    m = re.match(r"^&(\w+)\.(\w+)$", a)
+    if m and "." + m.group(2) in sym:
+        return sym["." + m.group(2)] + "*"
+    m = re.match(r"^(\w+)\.(\w+)$", a)
+    if m and "." + m.group(2) in sym:
+        return sym["." + m.group(2)]
+    m = re.match(r"^(\w+)\((.*)\)$", a, flags=re.S)
+    if m and m.group(1) + "()" in sym:
+        return sym[m.group(1) + "()"]
+    if a in sym:
+        return sym[a]
+    if re.match(r"^d[A-Z]\w*$", a):                        # unsafe.Pointer parameters named dBuf / dWork ...: void*
+        return "void*"
+    return None
+
+
+def _go_to_header_type(t):
+    t = {"polyhip_stream_t": "void*", "char*": "char*"}.get(t, t)
+    return t
+
+
+def test_every_cgo_call_matches_the_header():
+    protos = _header_prototypes()
+    assert len(protos) >= 50
+    seen = set()
+    for fn in sorted(os.listdir(os.path.join(GO, "polyhip"))):
+        if not fn.endswith(".go"):
+            continue
+        src = open(os.path.join(GO, "polyhip", fn)).read()
+        sym = _go_symbols(src)
+        for m in re.finditer(r"\bC\.(polyhip_[a-z0-9_]+)\(", src):
+            name = m.group(1)
+            if name.endswith("_t"):      # a type conversion (C.polyhip_stream_t(x)), not a call
+                continue
+            assert name in protos, f"{fn}: C.{name} is not declared in include/polyhip.h"
+            end = _matching_paren(src, m.end() - 1)
+            args = _split_top(src[m.end():end])
+            want = protos[name][1]
+            assert len(args) == len(want), f"{fn}: C.{name} called with {len(args)} arguments, the header has {len(want)}"
+            for k, (a, w) in enumerate(zip(args, want)):
+                got = _arg_c_type(a, sym)
+                assert got is not None, f"{fn}: C.{name} argument {k} `{a}`: cannot tell its C type (wrap it in a cgo conversion)"
+                got = _norm_c_type(_go_to_header_type(got))
+                ok = got == w or (w == "void*" and got.endswith("*")) or (got == "void*" and w.endswith("*") and False)
+                assert ok, f"{fn}: C.{name} argument {k} `{a}` is {got}, the header wants {w}"
+            seen.add(name)
+    # the binding covers the host-pointer entry point of every operation the four packages need, and the multi-rank calls
+    for need in ("polyhip_mash_sketch_batch", "polyhip_mash_distance_matrix", "polyhip_sw_align_batch", "polyhip_nw_align_batch",
+                 "polyhip_santalucia_batch", "polyhip_santalucia_scan", "polyhip_santalucia_scan_first", "polyhip_marmurdoty_batch",
+                 "polyhip_least_rotation_batch", "polyhip_seqhash_batch", "polyhip_fastq_pack", "polyhip_fasta_pack",
+                 "polyhip_comm_unique_id", "polyhip_comm_init_rank", "polyhip_allgather_sketches_dev", "polyhip_allgatherv_dev",
+                 "polyhip_mash_index_build_part_dev", "polyhip_mash_index_allgather_dev", "polyhip_mash_shared_counts_reuse_dev"):
+        assert need in seen, f"go/polyhip does not bind {need}"
+
+
+# ---------------------------------------------------------------- polyhip.X uses in the overlays
+def _polyhip_go_api():
+    funcs, values = {}, set()
+    for fn in os.listdir(os.path.join(GO, "polyhip")):
+        if not fn.endswith(".go"):
+            continue
+        src = open(os.path.join(GO, "polyhip", fn)).read()
+        for m in re.finditer(r"^func\s+(?:\((\w+)\s+\*?(\w+)\)\s+)?([A-Z]\w*)\(", src, flags=re.M):
+            end = _matching_paren(src, m.end() - 1)
+            params = src[m.end():end]
+            n = 0
+            for grp in _split_top(params):
+                if grp:
+                    n += 1
+            funcs[(m.group(2), m.group(3))] = n
+        for m in re.finditer(r"^\s+(Min[A-Z]\w*)\s*=", src, flags=re.M):
+            values.add(m.group(1))
+        for m in re.finditer(r"^type\s+([A-Z]\w*)\s", src, flags=re.M):
+            values.add(m.group(1))
+    return funcs, values
+
+
+def _overlay_files():
+    for dirpath, _, files in os.walk(GO):
+        if os.path.basename(dirpath) == "polyhip":
+            continue
+        for f in files:
+            if f.endswith(".go"):
+                yield os.path.join(dirpath, f)
+
+
+def test_overlays_use_package_polyhip_consistently():
+    funcs, values = _polyhip_go_api()
+    free = {name: n for (recv, name), n in funcs.items() if recv is None}
+    methods = {name: n for (recv, name), n in funcs.items() if recv is not None}
+    n_uses = 0
+    for path in _overlay_files():
+        src = open(path).read()
+        assert "UNCOMPILED" in src.split("package ")[0], f"{path}: header comment must say the file is uncompiled"
+        for m in re.finditer(r"\bpolyhip\.([A-Z]\w*)(\()?", src):
+            name = m.group(1)
+            if m.group(2):
+                assert name in free, f"{path}: polyhip.{name}() is not a function of package polyhip"
+                end = _matching_paren(src, m.end() - 1)
+                nargs = len([a for a in _split_top(src[m.end():end]) if a])
+                assert nargs == free[name], f"{path}: polyhip.{name} called with {nargs} arguments, declared with {free[name]}"
+            else:
+                assert name in values or name in free, f"{path}: polyhip.{name} is not declared in package polyhip"
+            n_uses += 1
+        for m in re.finditer(r"handle\(scoring\)\.([A-Z]\w*)\(", src):
+            assert m.group(1) in methods
+    assert n_uses >= 20
+
+
+# ---------------------------------------------------------------- fork.sh vs the overlays (and the reference, if here)
+def _renames():
+    out = []
+    for m in re.finditer(r"^ren\s+(\S+)\s+'([^']*)'\s+'([^']*)'", open(os.path.join(GO, "fork.sh")).read(), flags=re.M):
+        out.append((m.group(1), m.group(2).replace("\\*", "*"), m.group(3)))
+    return out
+
+
+def test_fork_renames_match_overlays_and_reference():
+    ren = _renames()
+    assert len(ren) == 10
+    produced = {}
+    for path, old, new in ren:
+        oldname = re.search(r"(\w+)\($", old).group(1)
+        newname = re.search(r"(\w+)\($", new).group(1)
+        assert newname.lower() == (oldname + "CPU").lower() and newname[0].islower()
+        produced.setdefault(os.path.dirname(path), {})[newname] = oldname
+        # the overlay of that package declares the exported name again
+        pkg = os.path.join(GO, os.path.dirname(path))
+        text = "".join(open(os.path.join(pkg, f)).read() for f in os.listdir(pkg) if f.endswith("_hip.go"))
+        assert re.search(r"^func\s+(\([^)]*\)\s+)?" + oldname + r"\(", text, flags=re.M), f"{pkg}: no overlay declares {oldname}"
+        assert re.search(r"\b" + newname + r"\(", text), f"{pkg}: the overlay never calls {newname} (no small-input path)"
+        ref = os.path.join("/root/reference", path)
+        if os.path.exists(ref):   # in the authoring container only: the declaration line really exists in the reference
+            assert any(line.startswith(old) for line in open(ref)), f"{path}: `{old}` is not a declaration of the reference"
+    # every *CPU identifier an overlay calls comes from a rename of ITS package
+    for path in _overlay_files():
+        pkg = os.path.relpath(os.path.dirname(path), GO)
+        for m in re.finditer(r"\b([a-z]\w*CPU)\(", open(path).read()):
+            assert m.group(1) in produced.get(pkg, {}), f"{path}: {m.group(1)} is not produced by go/fork.sh for {pkg}"
