@@ -82,11 +82,15 @@ int polyhip_synth_dna_dev(uint64_t seed, uint64_t first, uint8_t *d_out,
  *                       survives, as in the reference);
  *   len_i - k <= 0 : nothing written.
  * So `out` is in/out: pass the current Sketches (zeros after mash.New).
- * Range: 0 <= k <= 4096; 2 <= s <= 8192.  s < 2 -> POLYHIP_ERR_PANIC for the whole
- * batch: a deliberate over-approximation of the reference, which indexes Sketches[-1]
- * (mash.go:96,98) for s == 0 as soon as a sequence has one window and for s == 1 as
- * soon as a later window hashes below the first one -- i.e. on practically any input,
- * but not on sequences of at most k (s == 0) or k + 1 (s == 1) bytes.
+ * Range: any k; s <= 2^24.  SketchSize up to 8192 with KmerSize up to 4096 run the LDS-resident kernels (k = 17 / 21 / 31
+ * specialised); beyond that (mash.New(21, 10000) is ordinary usage) a kernel that hashes every window straight from
+ * global memory and keeps its candidates in a stream-ordered scratch allocation (hipMallocAsync / hipFreeAsync on
+ * `stream`) -- same results, about an order of magnitude slower per k-mer.
+ * s < 2 is the reference's behaviour READ BY READ (mash.go:96,98 index Sketches[-1]): with s == 0 a sequence panics iff it
+ * has a window (len > k); with s == 1 window 0 fills Sketches[0] and the sequence panics iff a LATER window hashes below
+ * it.  If any sequence of the batch would panic the call returns POLYHIP_ERR_PANIC naming the first one (rows of the
+ * sequences that do not panic are written as the reference leaves them, the others are left alone); otherwise
+ * POLYHIP_OK.  This one case synchronises `stream` (the verdict comes from the device).
  */
 int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets,
                               uint64_t n, uint32_t k, uint32_t s,
@@ -108,7 +112,9 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs,
  * rank's row block of Y, d_counts = its row block of the matrix.
  * Similarity = counts / min(sx, sy); Distance = 1 - that (next call).
  * SketchSize 0 -> POLYHIP_ERR_PANIC (mash.go:117 indexes Sketches[-1]).
- * Range: sx, sy <= 65535; nx, ny < 2^31; ny*sy < 2^32 per call.
+ * Range: sx, sy <= 65535; nx, ny < 2^31.  A Y set of 2^32 hashes or more is joined in column stripes of fewer than
+ * that, one index after the other in the same workspace (polyhip_mash_shared_counts_dev only; the index_build / reuse
+ * pair keeps ONE index and so ny*sy < 2^32).  POLYHIP_K2_MAX_ITEMS=<n> lowers the stripe bound (testing aid).
  * d_work: polyhip_mash_shared_counts_workspace_bytes(...) bytes of scratch.
  */
 size_t polyhip_mash_shared_counts_workspace_bytes(uint64_t nx, uint32_t sx,

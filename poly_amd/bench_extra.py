@@ -374,6 +374,41 @@ def e2e(dev) -> dict:
     out["santalucia_scan_first"] = {"workload": "polyhip_santalucia_scan_first, same genome: first length with Tm >= 60 C per start "
                                                 "(the pcr grow loop, reduced on the chip: 10 B per start cross PCIe)",
                                     "windows_per_s_equivalent": win / ms * 1e3, "starts_per_s": ns / ms * 1e3, "ms": ms}
+    del hg
+    # ---- the flavours pipelined in round 3 (chunks through two slots on the calling thread's two streams)
+    # K2: 4,000 x 20,000 sketches of s = 1000: the matrix is what crosses PCIe (160 MB of u16 + 640 MB of fp64)
+    skd = family_sketches(dev, 200, 100, 10_000, 21, 1000, 0xC3)
+    hs_ = skd.cpu().numpy().view(np.uint32)
+    del skd
+    X = np.ascontiguousarray(hs_[:4000])
+    ms_c = _wall(lambda: mash.distance_matrix_packed(X, hs_, True, False), 3, 1)
+    ms_cd = _wall(lambda: mash.distance_matrix_packed(X, hs_, True, True), 3, 1)
+    out["mash_distance_matrix"] = {"workload": "polyhip_mash_distance_matrix, 4000 x 20000 sketches of s = 1000, host pointers "
+                                               "(row blocks of ~64 MB: block b joined while block b-1 crosses PCIe)",
+                                   "pairs_per_s_counts": 4000 * 20000 / ms_c * 1e3, "ms_counts": ms_c,
+                                   "pairs_per_s_counts_and_fp64": 4000 * 20000 / ms_cd * 1e3, "ms_counts_and_fp64": ms_cd,
+                                   "pcie_GBs_counts_and_fp64": (4000 * 20000 * 10 + hs_.nbytes) / ms_cd * 1e3 / 1e9}
+    del hs_, X
+    # K5 / S2: 100k circular sequences of 5 kb (500 MB in; rotated: 500 MB out; seqhash: 7.2 MB out)
+    nq, Lq = 100_000, 5000
+    dq = torch.empty(nq * Lq, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0x5EED, dq)
+    hq = dq.cpu().numpy()
+    del dq
+    oq = np.arange(0, (nq + 1) * Lq, Lq, dtype=np.uint64)
+    ms = _wall(lambda: seqhash.least_rotation_batch_packed(hq, oq, True), 3, 1)
+    out["least_rotation"] = {"workload": f"polyhip_least_rotation_batch, {nq} x {Lq} bp, host pointers, rotated sequences back",
+                             "bases_per_s": nq * Lq / ms * 1e3, "ms": ms, "pcie_GBs": 2 * nq * Lq / ms * 1e3 / 1e9}
+    ms = _wall(lambda: seqhash.seqhash_batch_packed(hq, oq, 0, True, True), 3, 1)
+    out["seqhash"] = {"workload": f"polyhip_seqhash_batch, {nq} x {Lq} bp (DNA, circular, double-stranded), host pointers",
+                      "sequences_per_s": nq / ms * 1e3, "ms": ms, "pcie_GBs": nq * Lq / ms * 1e3 / 1e9}
+    # K4 batch: 4M primers of 24 nt (96 MB in, 96 MB out)
+    npz = 4_000_000
+    hp = hq[: npz * 24]
+    op = np.arange(0, (npz + 1) * 24, 24, dtype=np.uint64)
+    ms = _wall(lambda: primers.santalucia_batch_packed(hp, op, 500e-9, 50e-3, 0.0), 3, 1)
+    out["santalucia_batch"] = {"workload": f"polyhip_santalucia_batch, {npz} primers of 24 nt, host pointers",
+                               "primers_per_s": npz / ms * 1e3, "ms": ms}
     return out
 
 

@@ -86,6 +86,21 @@ def build_abi_smoke() -> str:
     return exe
 
 
+def build_abi_threads() -> str:
+    """tests/abi/abi_threads: 8 pthreads in mixed entry points of the C ABI (plain gcc, links -lpolyhip -lpthread)."""
+    src = os.path.join(ROOT, "tests", "abi", "abi_threads.c")
+    exe = os.path.join(ROOT, "tests", "abi", "abi_threads")
+    lib = build_lib()
+    if _newer(exe, [src, lib, os.path.join(ROOT, "include", "polyhip.h")]):
+        cmd = ["gcc", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", exe, "-L", HERE, "-lpolyhip", "-lpthread",
+               "-lm", "-Wl,-rpath,$ORIGIN/../../poly_amd"]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode:
+            sys.stderr.write(" ".join(cmd) + "\n" + res.stdout + res.stderr)
+            raise RuntimeError("build of tests/abi/abi_threads failed")
+    return exe
+
+
 def build_abi_allgather() -> str:
     """tests/abi/abi_allgather: the torch-free multi-rank C host (libpolyhip + the HIP runtime for its device buffers)."""
     src = os.path.join(ROOT, "tests", "abi", "abi_allgather.c")

@@ -72,14 +72,27 @@ struct AuxStream {
         hipError_t e = hipGetDevice(&cur);
         if (e != hipSuccess)
             return e;
-        if (s && dev == cur)
+        if (s && ev[0] && ev[1] && dev == cur)
             return hipSuccess;
-        dev = cur;
+        // another device, or an earlier creation that failed half way: drop what is there and start over; `dev` marks
+        // the set as usable only once the stream AND both events exist
+        if (s) {
+            (void)hipStreamDestroy(s);
+            s = nullptr;
+        }
+        for (int q = 0; q < 2; ++q)
+            if (ev[q]) {
+                (void)hipEventDestroy(ev[q]);
+                ev[q] = nullptr;
+            }
+        dev = -1;
         e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&ev[0], hipEventDisableTiming);
         if (e == hipSuccess)
             e = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+        if (e == hipSuccess)
+            dev = cur;
         return e;
     }
     hipError_t fork(hipStream_t caller)

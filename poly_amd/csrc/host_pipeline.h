@@ -1,0 +1,113 @@
+// host_pipeline.h -- what the host-pointer (cgo) entry points share: two streams per calling thread and a packed batch
+// cut into chunks that alternate between two device slots, so that the upload and the kernels of chunk c overlap the
+// download of chunk c-1.  Nothing here touches the null stream: concurrent goroutines (cgo calls arrive on arbitrary OS
+// threads) do not serialise on it.
+#pragma once
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace polyhip {
+
+// two non-blocking streams + one event per calling thread and device, made on first use and kept (a stream costs tens
+// of microseconds to create: too much for a single-sequence call)
+struct HostStreams {
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t ev = nullptr;
+    int dev = -1;
+    hipError_t init()
+    {
+        int cur = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess)
+            return e;
+        if (s[0] && s[1] && ev && dev == cur)
+            return hipSuccess;
+        for (int q = 0; q < 2; ++q)
+            if (s[q]) {
+                (void)hipStreamDestroy(s[q]);
+                s[q] = nullptr;
+            }
+        if (ev) {
+            (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
+        dev = -1;
+        for (int q = 0; q < 2 && e == hipSuccess; ++q)
+            e = hipStreamCreateWithFlags(&s[q], hipStreamNonBlocking);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e == hipSuccess)
+            dev = cur;
+        return e;
+    }
+    hipError_t sync_both()
+    {
+        hipError_t e = hipStreamSynchronize(s[0]);
+        const hipError_t e1 = hipStreamSynchronize(s[1]);
+        return e != hipSuccess ? e : e1;
+    }
+};
+inline HostStreams &host_streams()
+{
+    static thread_local HostStreams h;
+    return h;
+}
+
+// A packed batch cut into chunks of about `target` bytes (sequence bytes + out_per_item per sequence); items cut[c] ..
+// cut[c + 1] form chunk c.
+struct Chunks {
+    std::vector<uint64_t> cut{0};
+    uint64_t max_bytes = 0, max_items = 0;
+    size_t count() const { return cut.size() - 1; }
+};
+inline Chunks cut_packed(const uint64_t *offsets, uint64_t n, uint64_t out_per_item, uint64_t target)
+{
+    Chunks c;
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i, sz = 0;
+        do {
+            sz += offsets[j + 1] - offsets[j] + out_per_item;
+            ++j;
+        } while (j < n && sz < target);
+        c.cut.push_back(j);
+        c.max_bytes = std::max(c.max_bytes, offsets[j] - offsets[i]);
+        c.max_items = std::max(c.max_items, j - i);
+        i = j;
+    }
+    return c;
+}
+
+// the input side of one slot: sequence bytes + rebased offsets of the chunk it currently holds
+struct PackedSlot {
+    DevBuf dseq, doff;
+    std::vector<uint64_t> hoff;
+    hipStream_t st = nullptr;
+    hipError_t alloc(const Chunks &c, hipStream_t stream)
+    {
+        st = stream;
+        hoff.resize(c.max_items + 1);
+        hipError_t e = dseq.alloc(c.max_bytes + 16);
+        if (e == hipSuccess)
+            e = doff.alloc((c.max_items + 1) * sizeof(uint64_t));
+        return e;
+    }
+    // chunk [i0, i0 + m): offsets rebased so that the device copy starts at byte 0.  The caller has synchronised `st`
+    // since this slot's previous chunk (hoff is reused).
+    hipError_t upload(const uint8_t *seqs, const uint64_t *offsets, uint64_t i0, uint64_t m)
+    {
+        const uint64_t b0 = offsets[i0];
+        for (uint64_t i = 0; i <= m; ++i)
+            hoff[i] = offsets[i0 + i] - b0;
+        hipError_t e = hipMemcpyAsync(doff.p, hoff.data(), (m + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess && offsets[i0 + m] > b0)
+            e = hipMemcpyAsync(dseq.p, seqs + b0, offsets[i0 + m] - b0, hipMemcpyHostToDevice, st);
+        return e;
+    }
+};
+
+constexpr uint64_t HOST_CHUNK_BYTES = 64ull << 20;
+
+} // namespace polyhip

@@ -28,6 +28,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_pipeline.h"
 
 namespace polyhip {
 namespace k5 {
@@ -356,27 +357,39 @@ int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets, u
         if (offsets[i + 1] - offsets[i] > max_len)
             max_len = offsets[i + 1] - offsets[i];
     }
-    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
-    DevBuf dseq, doff, drot, dout;
-    PH_HIP(dseq.alloc(nbytes));
-    PH_HIP(doff.alloc((n + 1) * 8));
-    PH_HIP(drot.alloc(n * 8));
-    std::vector<uint64_t> tmp(n + 1);
-    for (uint64_t i = 0; i <= n; ++i)
-        tmp[i] = offsets[i] - b0;
-    PH_HIP(hipMemcpy(doff.p, tmp.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    if (nbytes)
-        PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
-    if (rotated)
-        PH_HIP(dout.alloc(nbytes));
-    int rc = polyhip_least_rotation_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, max_len, drot.as<uint64_t>(),
-                                              rotated ? dout.as<uint8_t>() : nullptr, nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(rot_index, drot.p, n * 8, hipMemcpyDeviceToHost));
-    if (rotated && nbytes)
-        PH_HIP(hipMemcpy(rotated + b0, dout.p, nbytes, hipMemcpyDeviceToHost));
+    (void)max_len;
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    const Chunks ch = cut_packed(offsets, n, 8, HOST_CHUNK_BYTES);
+    struct Slot {
+        PackedSlot in;
+        DevBuf drot, dout;
+    } slot[2];
+    for (size_t q = 0; q < std::min<size_t>(2, ch.count()); ++q) {
+        PH_HIP(slot[q].in.alloc(ch, hs.s[q]));
+        PH_HIP(slot[q].drot.alloc(ch.max_items * 8));
+        if (rotated)
+            PH_HIP(slot[q].dout.alloc(ch.max_bytes + 16));
+    }
+    for (size_t c = 0; c < ch.count(); ++c) {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0, cb = offsets[i0 + m] - offsets[i0];
+        PH_HIP(hipStreamSynchronize(S.in.st)); // chunk c-2 has left this slot
+        PH_HIP(S.in.upload(seqs, offsets, i0, m));
+        uint64_t ml = 0;
+        for (uint64_t i = 0; i < m; ++i)
+            ml = std::max(ml, offsets[i0 + i + 1] - offsets[i0 + i]);
+        const int rc = polyhip_least_rotation_batch_dev(S.in.dseq.as<uint8_t>(), S.in.doff.as<uint64_t>(), m, ml, S.drot.as<uint64_t>(),
+                                                        rotated ? S.dout.as<uint8_t>() : nullptr, S.in.st);
+        if (rc != POLYHIP_OK) {
+            (void)hs.sync_both();
+            return rc;
+        }
+        PH_HIP(hipMemcpyAsync(rot_index + i0, S.drot.p, m * 8, hipMemcpyDeviceToHost, S.in.st));
+        if (rotated && cb)
+            PH_HIP(hipMemcpyAsync(rotated + offsets[i0], S.dout.p, cb, hipMemcpyDeviceToHost, S.in.st));
+    }
+    PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }
 

@@ -41,9 +41,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
+#include "host_pipeline.h"
 
 namespace polyhip {
 namespace k2 {
@@ -1016,9 +1018,23 @@ using namespace polyhip;
 
 extern "C" {
 
+// Y sets of 2^32 hashes and more are joined in column stripes of fewer than that (an index item's position is 32 bits);
+// POLYHIP_K2_MAX_ITEMS lowers the bound (testing aid: the striping then runs on small inputs)
+static uint64_t stripe_sketches(uint64_t ny, uint32_t sy)
+{
+    uint64_t max_items = (1ull << 32) - 1;
+    if (const char *e = getenv("POLYHIP_K2_MAX_ITEMS")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 1 && v < max_items)
+            max_items = v;
+    }
+    const uint64_t per = std::max<uint64_t>(1, max_items / std::max<uint32_t>(sy, 1u));
+    return std::min<uint64_t>(std::min<uint64_t>(ny, per), (1ull << 31) - 1);
+}
+
 size_t polyhip_mash_shared_counts_workspace_bytes(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
 {
-    return k2::layout(nx, sx, ny, sy).total;
+    return k2::layout(nx, sx, stripe_sketches(ny, sy), sy).total;
 }
 
 // resets what an earlier call left of its X side in a workspace whose index is being reused
@@ -1044,7 +1060,8 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     PH_REQUIRE(!join || ld >= ny, "polyhip_mash_shared_counts: row stride %llu < ny %llu", (unsigned long long)ld,
                (unsigned long long)ny);
     PH_REQUIRE(nx < (1ull << 31) && ny < (1ull << 31) && ny * (uint64_t)sy < (1ull << 32),
-               "polyhip_mash_shared_counts: more than 2^31 sketches or 2^32 Y hashes in one call (split it)");
+               "polyhip_mash_shared_counts: 2^31 sketches / 2^32 Y hashes or more behind ONE index (polyhip_mash_shared_counts_dev "
+               "stripes such sets itself; the index_build / reuse pair does not)");
     const k2::Layout L = k2::layout(nx, sx, ny, sy);
     PH_REQUIRE(work_bytes >= (join ? L.total : L.off_flagsX), "polyhip_mash_shared_counts: workspace too small (%zu < %zu)",
                work_bytes, join ? L.total : L.off_flagsX);
@@ -1199,7 +1216,19 @@ int polyhip_mash_shared_counts_dev(const uint32_t *d_X, uint64_t nx, uint32_t sx
                                    uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
                                    polyhip_stream_t stream)
 {
-    return shared_counts_impl(3, d_X, nx, sx, d_Y, ny, sy, d_counts, ld, d_work, work_bytes, stream);
+    const uint64_t per = sy ? stripe_sketches(ny, sy) : ny;
+    if (ny <= per || sx == 0 || sy == 0)
+        return shared_counts_impl(3, d_X, nx, sx, d_Y, ny, sy, d_counts, ld, d_work, work_bytes, stream);
+    // column stripes: each with its own index, one after the other in the same workspace; the pairs of a stripe depend
+    // on nothing outside it, so the matrix is the stripes side by side
+    PH_REQUIRE(ld >= ny, "polyhip_mash_shared_counts: row stride %llu < ny %llu", (unsigned long long)ld, (unsigned long long)ny);
+    for (uint64_t c0 = 0; c0 < ny; c0 += per) {
+        const uint64_t m = std::min<uint64_t>(per, ny - c0);
+        if (int rc = shared_counts_impl(3, d_X, nx, sx, d_Y + c0 * (uint64_t)sy, m, sy, d_counts ? d_counts + c0 : nullptr, ld, d_work,
+                                        work_bytes, stream))
+            return rc;
+    }
+    return POLYHIP_OK;
 }
 
 int polyhip_mash_index_build_dev(const uint32_t *d_Y, uint64_t ny, uint32_t sy, void *d_work, size_t work_bytes,
@@ -1316,29 +1345,68 @@ int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, co
     if (nx == 0 || ny == 0)
         return POLYHIP_OK;
     PH_REQUIRE(X && Y && (counts || dist), "polyhip_mash_distance_matrix: null pointer");
-    DevBuf dX, dY, dC, dD, dW;
+    // The matrix is what crosses PCIe (2 and/or 8 bytes per pair): row blocks of ~64 MB alternate between two device
+    // slots; block b is joined on the calling thread's first stream while block b-1 travels back on the second (the
+    // joins themselves share the workspace's X side and stay in order on one stream).  One index for all blocks.
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    hipStream_t sc = hs.s[0], sd = hs.s[1];
+    const uint64_t per_pair = (counts ? 2 : 0) + (dist ? 8 : 0);
+    const uint64_t rows = std::max<uint64_t>(1, std::min<uint64_t>(nx, HOST_CHUNK_BYTES / std::max<uint64_t>(1, ny * per_pair)));
+    const uint64_t nblocks = (nx + rows - 1) / rows;
+    const bool one_index = stripe_sketches(ny, sy) >= ny; // else every block builds its stripes' indexes itself
+    DevBuf dX, dY, dW;
+    struct Slot {
+        DevBuf dC, dD;
+        hipEvent_t computed = nullptr, downloaded = nullptr;
+        ~Slot()
+        {
+            if (computed)
+                (void)hipEventDestroy(computed);
+            if (downloaded)
+                (void)hipEventDestroy(downloaded);
+        }
+    } slot[2];
     PH_HIP(dX.alloc(nx * (size_t)sx * 4));
     PH_HIP(dY.alloc(ny * (size_t)sy * 4));
-    PH_HIP(dC.alloc(nx * ny * 2 + 16));
-    const size_t wb = polyhip_mash_shared_counts_workspace_bytes(nx, sx, ny, sy);
+    const size_t wb = polyhip_mash_shared_counts_workspace_bytes(rows, sx, ny, sy);
     PH_HIP(dW.alloc(wb));
-    PH_HIP(hipMemcpy(dX.p, X, nx * (size_t)sx * 4, hipMemcpyHostToDevice));
-    PH_HIP(hipMemcpy(dY.p, Y, ny * (size_t)sy * 4, hipMemcpyHostToDevice));
-    int rc = polyhip_mash_shared_counts_dev(dX.as<uint32_t>(), nx, sx, dY.as<uint32_t>(), ny, sy, dC.as<uint16_t>(), ny, dW.p,
-                                            wb, nullptr);
+    for (uint64_t q = 0; q < std::min<uint64_t>(2, nblocks); ++q) {
+        PH_HIP(slot[q].dC.alloc(rows * ny * 2 + 16));
+        if (dist)
+            PH_HIP(slot[q].dD.alloc(rows * ny * 8));
+        PH_HIP(hipEventCreateWithFlags(&slot[q].computed, hipEventDisableTiming));
+        PH_HIP(hipEventCreateWithFlags(&slot[q].downloaded, hipEventDisableTiming));
+    }
+    PH_HIP(hipMemcpyAsync(dY.p, Y, ny * (size_t)sy * 4, hipMemcpyHostToDevice, sc));
+    PH_HIP(hipMemcpyAsync(dX.p, X, nx * (size_t)sx * 4, hipMemcpyHostToDevice, sc));
+    int rc = POLYHIP_OK;
+    if (one_index)
+        rc = polyhip_mash_index_build_dev(dY.as<uint32_t>(), ny, sy, dW.p, wb, sc);
+    for (uint64_t b = 0; b < nblocks && rc == POLYHIP_OK; ++b) {
+        Slot &S = slot[b & 1];
+        const uint64_t r0 = b * rows, m = std::min<uint64_t>(rows, nx - r0);
+        if (b >= 2)
+            PH_HIP(hipStreamWaitEvent(sc, S.downloaded, 0)); // block b-2 has left this slot
+        const uint32_t *dx = dX.as<uint32_t>() + r0 * (uint64_t)sx;
+        rc = one_index ? polyhip_mash_shared_counts_reuse_dev(dx, m, sx, dY.as<uint32_t>(), ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc)
+                       : polyhip_mash_shared_counts_dev(dx, m, sx, dY.as<uint32_t>(), ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc);
+        if (rc == POLYHIP_OK && dist)
+            rc = polyhip_mash_distance_from_counts_dev(S.dC.as<uint16_t>(), m, ny, ny, sx, sy, S.dD.as<double>(), ny, sc);
+        if (rc != POLYHIP_OK)
+            break;
+        PH_HIP(hipEventRecord(S.computed, sc));
+        PH_HIP(hipStreamWaitEvent(sd, S.computed, 0));
+        if (counts)
+            PH_HIP(hipMemcpyAsync(counts + r0 * ny, S.dC.p, m * ny * 2, hipMemcpyDeviceToHost, sd));
+        if (dist)
+            PH_HIP(hipMemcpyAsync(dist + r0 * ny, S.dD.p, m * ny * 8, hipMemcpyDeviceToHost, sd));
+        PH_HIP(hipEventRecord(S.downloaded, sd));
+    }
+    const hipError_t e = hs.sync_both();
     if (rc != POLYHIP_OK)
         return rc;
-    if (dist) {
-        PH_HIP(dD.alloc(nx * ny * 8));
-        rc = polyhip_mash_distance_from_counts_dev(dC.as<uint16_t>(), nx, ny, ny, sx, sy, dD.as<double>(), ny, nullptr);
-        if (rc != POLYHIP_OK)
-            return rc;
-    }
-    PH_HIP(hipStreamSynchronize(nullptr));
-    if (counts)
-        PH_HIP(hipMemcpy(counts, dC.p, nx * ny * 2, hipMemcpyDeviceToHost));
-    if (dist)
-        PH_HIP(hipMemcpy(dist, dD.p, nx * ny * 8, hipMemcpyDeviceToHost));
+    PH_HIP(e);
     return POLYHIP_OK;
 }
 

@@ -1116,6 +1116,136 @@ __global__ __launch_bounds__(THREADS) void sketch_general_kernel(const uint8_t *
     }
 }
 
+
+// ---- WIDE kernel: SketchSize or KmerSize beyond what the LDS layouts above hold --------------------------------
+// (mash.New(21, 10000) is ordinary usage; a KmerSize of thousands is not, but the reference takes any.)  One workgroup per
+// read, every window hashed straight from global memory -- no premixed blocks shared between windows, k/4 block mixes
+// per window --, candidates and the sort buffer in a GLOBAL scratch slice per workgroup (2 * cap words, allocated
+// stream-ordered by the entry point), the same exact bottom-s as the general kernel (counting sort with its bins in LDS).
+// Rounds of WIDE_ROUND windows; the buffer is shrunk to the s smallest whenever a round might overflow it, and after a
+// shrink only hashes at most tau = the s-th smallest so far are appended.
+constexpr uint32_t WIDE_ROUND = 4 * THREADS;
+
+__device__ __forceinline__ uint32_t murmur3_window(const uint8_t *__restrict__ p, uint32_t k)
+{
+    uint32_t h = 0;
+    const uint32_t nblk = k >> 2;
+    for (uint32_t j = 0; j < nblk; ++j) {
+        uint32_t w;
+        __builtin_memcpy(&w, p + 4 * (size_t)j, 4); // any alignment: the compiler picks the loads
+        h = chain(h ^ premix(w));
+    }
+    const uint8_t *t = p + 4 * (size_t)nblk;
+    uint32_t w = 0;
+    switch (k & 3u) {
+    case 3: w ^= (uint32_t)t[2] << 16; [[fallthrough]];
+    case 2: w ^= (uint32_t)t[1] << 8; [[fallthrough]];
+    case 1: w ^= (uint32_t)t[0]; h ^= premix(w); break;
+    default: break;
+    }
+    return fmix32(h ^ k);
+}
+
+__global__ __launch_bounds__(THREADS) void sketch_wide_kernel(const uint8_t *__restrict__ seqs,
+                                                             const uint64_t *__restrict__ offs, uint64_t nseq, uint32_t k,
+                                                             uint32_t s, uint32_t *__restrict__ out,
+                                                             uint32_t *__restrict__ scratch, uint32_t cap)
+{
+    __shared__ uint32_t bins[NB];
+    __shared__ uint32_t biglist[BIG_LIST_CAP];
+    __shared__ uint32_t misc[16];
+    Smem sm;
+    sm.seqb = biglist;
+    sm.P = bins;
+    sm.cand = scratch + (size_t)blockIdx.x * 2 * cap;
+    sm.binned = sm.cand + cap;
+    sm.misc = misc;
+    sm.lut = nullptr;
+    const int tid = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < nseq; r += gridDim.x) {
+        const uint64_t o0 = offs[r];
+        const int64_t nwin = (int64_t)(offs[r + 1] - o0) - (int64_t)k; // mash.go:73
+        if (nwin <= 0)
+            continue;
+        const uint8_t *__restrict__ sp = seqs + o0;
+        uint32_t *__restrict__ outp = out + r * (uint64_t)s;
+        if (nwin < (int64_t)s) { // mash.go:81-84: positional, unsorted, tail untouched
+            for (int64_t w = tid; w < nwin; w += THREADS)
+                outp[w] = murmur3_window(sp + w, k);
+            continue;
+        }
+        __syncthreads(); // the previous read is done with LDS and the scratch
+        if (tid == 0) {
+            misc[0] = 0;
+            misc[1] = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        auto shrink = [&]() {
+            const uint32_t C = misc[0];
+            bottom_s(sm, s, misc[1], cap, true, [&](auto f) {
+                for (uint32_t i = tid; i < C; i += THREADS)
+                    f(sm.cand[i]);
+            });
+        };
+        for (int64_t base = 0; base < nwin; base += WIDE_ROUND) {
+            __syncthreads(); // the previous round's appends are counted
+            const bool room = misc[0] + WIDE_ROUND <= cap;
+            __syncthreads();
+            if (!room)
+                shrink();
+            const uint32_t tau = misc[1];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t w = base + c * THREADS + tid;
+                if (w < nwin) {
+                    const uint32_t h = murmur3_window(sp + w, k);
+                    if (h <= tau)
+                        sm.cand[atomicAdd(&misc[0], 1u)] = h;
+                }
+            }
+        }
+        __syncthreads();
+        shrink();
+        for (uint32_t i = tid; i < s; i += THREADS)
+            outp[i] = sm.cand[i];
+    }
+}
+
+// ---- SketchSize 0 and 1: what the reference does read by read (mash.go:68-104 with maxShiftedSketchSize = -1 / 0) ----
+// s == 0: the first window already evaluates Sketches[-1] (:96) -> the read PANICS iff it has a window.
+// s == 1: window 0 fills Sketches[0] (:88-92); any later window whose hash is below it is stored and then Sketches[-1] is
+//         read (:98) -> PANICS iff some later hash undercuts the first one; otherwise Sketches[0] = hash of window 0.
+// first_panic: the smallest read index on which the reference panics (atomicMin; ~0 = none).
+__global__ __launch_bounds__(THREADS) void sketch_tiny_kernel(const uint8_t *__restrict__ seqs,
+                                                             const uint64_t *__restrict__ offs, uint64_t nseq, uint32_t k,
+                                                             uint32_t s, uint32_t *__restrict__ out,
+                                                             unsigned long long *__restrict__ first_panic)
+{
+    const int tid = threadIdx.x;
+    for (uint64_t r = blockIdx.x; r < nseq; r += gridDim.x) {
+        const uint64_t o0 = offs[r];
+        const int64_t nwin = (int64_t)(offs[r + 1] - o0) - (int64_t)k;
+        if (nwin <= 0)
+            continue;
+        if (s == 0) {
+            if (tid == 0)
+                atomicMin(first_panic, (unsigned long long)r);
+            continue;
+        }
+        const uint8_t *__restrict__ sp = seqs + o0;
+        const uint32_t h0 = murmur3_window(sp, k);
+        bool under = false;
+        for (int64_t w = 1 + tid; w < nwin && !under; w += THREADS)
+            under = murmur3_window(sp + w, k) < h0;
+        if (__syncthreads_or(under ? 1 : 0)) {
+            if (tid == 0)
+                atomicMin(first_panic, (unsigned long long)r);
+        } else if (tid == 0) {
+            out[r] = h0;
+        }
+    }
+}
+
 struct Launch {
     uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap, capw, capf_slab;
     size_t smem_fast, smem_general, smem_slab;
@@ -1212,20 +1342,43 @@ extern "C" {
 int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint32_t k,
                                   uint32_t s, uint32_t *d_out, polyhip_stream_t stream)
 {
-    if (s < 2)
-        return set_error(POLYHIP_ERR_PANIC,
-                         "mash.Sketch with SketchSize %u indexes Sketches[-1] (mash.go:96,98): the reference panics",
-                         s);
-    PH_REQUIRE(s <= 8192, "polyhip_mash_sketch_batch: SketchSize %u > 8192 is not implemented", s);
-    PH_REQUIRE(k <= 4096, "polyhip_mash_sketch_batch: KmerSize %u > 4096 is not implemented", k);
     if (n == 0)
         return POLYHIP_OK;
-    PH_REQUIRE(d_seqs && d_offsets && d_out, "polyhip_mash_sketch_batch: null pointer");
-    const k1::Launch L = k1::plan(k, s);
-    if (L.smem_general > 160 * 1024)
-        return set_error(POLYHIP_ERR_UNSUPPORTED, "polyhip_mash_sketch_batch: k=%u s=%u needs %zu B of LDS", k, s,
-                         L.smem_general);
+    PH_REQUIRE(d_seqs && d_offsets && (d_out || s == 0), "polyhip_mash_sketch_batch: null pointer");
+    PH_REQUIRE(s <= (1u << 24), "polyhip_mash_sketch_batch: SketchSize %u > 2^24 is not implemented", s);
     hipStream_t st = as_stream(stream);
+    if (s < 2) {
+        // the reference's behaviour read by read (see sketch_tiny_kernel); the verdict needs the device's answer, so this
+        // rare path synchronises the stream
+        unsigned long long *d_first = nullptr, h_first = ~0ull;
+        PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_first), sizeof h_first, st));
+        PH_HIP(hipMemsetAsync(d_first, 0xFF, sizeof h_first, st));
+        hipLaunchKernelGGL(k1::sketch_tiny_kernel, dim3((unsigned)std::min<uint64_t>(n, 4096)), dim3(k1::THREADS), 0, st, d_seqs,
+                           d_offsets, n, k, s, d_out, d_first);
+        PH_HIP(hipGetLastError());
+        PH_HIP(hipMemcpyAsync(&h_first, d_first, sizeof h_first, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipFreeAsync(d_first, st));
+        PH_HIP(hipStreamSynchronize(st));
+        if (h_first != ~0ull)
+            return set_error(POLYHIP_ERR_PANIC,
+                             "mash.Sketch with SketchSize %u indexes Sketches[-1] on sequence %llu (mash.go:%s): the reference panics",
+                             s, h_first, s == 0 ? "96" : "98");
+        return POLYHIP_OK;
+    }
+    const k1::Launch L = k1::plan(k <= 4096 ? k : 4096, s <= 8192 ? s : 8192);
+    if (s > 8192 || k > 4096 || L.smem_general > 160 * 1024) {
+        // beyond the LDS layouts: the wide kernel, candidates in a stream-ordered global scratch
+        const uint32_t s4 = (s + 3u) & ~3u;
+        const uint32_t cap = 2 * s4 + 2 * k1::WIDE_ROUND;
+        const unsigned grid = (unsigned)std::min<uint64_t>(n, s > 16384 ? 256 : 1024);
+        uint32_t *scratch = nullptr;
+        PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), (size_t)grid * 2 * cap * sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k1::sketch_wide_kernel, dim3(grid), dim3(k1::THREADS), 0, st, d_seqs, d_offsets, n, k, s, d_out, scratch,
+                           cap);
+        PH_HIP(hipGetLastError());
+        PH_HIP(hipFreeAsync(scratch, st));
+        return POLYHIP_OK;
+    }
     const uint64_t CHUNK = 1ull << 30;
     for (uint64_t i0 = 0; i0 < n; i0 += CHUNK) {
         const uint64_t m = n - i0 < CHUNK ? n - i0 : CHUNK;
@@ -1247,11 +1400,10 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
 int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t s,
                               uint32_t *out)
 {
-    if (s < 2)
-        return polyhip_mash_sketch_batch_dev(nullptr, nullptr, n, k, s, nullptr, nullptr);
     if (n == 0)
         return POLYHIP_OK;
-    PH_REQUIRE(seqs && offsets && out, "polyhip_mash_sketch_batch: null pointer");
+    PH_REQUIRE(seqs && offsets && (out || s == 0), "polyhip_mash_sketch_batch: null pointer");
+    PH_REQUIRE(s <= (1u << 24), "polyhip_mash_sketch_batch: SketchSize %u > 2^24 is not implemented", s);
     // `out` is in/out: rows of sequences with fewer than s windows keep (part of) the caller's prior
     // Sketches (mash.go:81-84), so those rows have to travel to the device first; a batch without such
     // sequences -- the normal case -- skips that upload.

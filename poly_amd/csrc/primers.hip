@@ -31,6 +31,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_pipeline.h"
 
 namespace polyhip {
 namespace k4 {
@@ -361,6 +362,65 @@ static size_t scan_smem(uint32_t Lmax)
 
 using namespace polyhip;
 
+static int validate_ascii(const uint8_t *p, uint64_t n, const char *who)
+{
+    for (uint64_t i = 0; i < n; ++i)
+        if (p[i] >= 0x80)
+            return set_error(POLYHIP_ERR_INVALID, "%s: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
+                             who, p[i], (unsigned long long)i);
+    return POLYHIP_OK;
+}
+
+// validation shared by the two packed-batch host entry points
+static int check_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, const char *who, bool empty_panics)
+{
+    PH_REQUIRE(seqs && offsets, "%s: null pointer", who);
+    for (uint64_t i = 0; i < n; ++i) {
+        PH_REQUIRE(offsets[i] <= offsets[i + 1], "%s: offsets not ascending at %llu", who, (unsigned long long)i);
+        if (empty_panics && offsets[i] == offsets[i + 1])
+            return set_error(POLYHIP_ERR_PANIC, "%s: sequence %llu is empty; primers.SantaLucia(\"\") panics (primers.go:89)",
+                             who, (unsigned long long)i);
+    }
+    return validate_ascii(seqs + offsets[0], offsets[n] - offsets[0], who);
+}
+
+// Both host flavours: chunks of ~64 MB through two slots on the calling thread's two streams (host_pipeline.h); NOUT
+// planes of one double per sequence come back per chunk.
+template <int NOUT, class Launch>
+static int run_batch_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double *const (&outs)[NOUT], Launch launch)
+{
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    const Chunks ch = cut_packed(offsets, n, 8 * NOUT, HOST_CHUNK_BYTES);
+    struct Slot {
+        PackedSlot in;
+        DevBuf d[NOUT];
+    } slot[2];
+    for (size_t q = 0; q < std::min<size_t>(2, ch.count()); ++q) {
+        PH_HIP(slot[q].in.alloc(ch, hs.s[q]));
+        for (int o = 0; o < NOUT; ++o)
+            PH_HIP(slot[q].d[o].alloc(ch.max_items * 8));
+    }
+    for (size_t c = 0; c < ch.count(); ++c) {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0;
+        PH_HIP(hipStreamSynchronize(S.in.st)); // chunk c-2 has left this slot
+        PH_HIP(S.in.upload(seqs, offsets, i0, m));
+        double *dd[NOUT];
+        for (int o = 0; o < NOUT; ++o)
+            dd[o] = S.d[o].template as<double>();
+        const int rc = launch(S.in.dseq.template as<uint8_t>(), S.in.doff.template as<uint64_t>(), m, dd, S.in.st);
+        if (rc != POLYHIP_OK) {
+            (void)hs.sync_both();
+            return rc;
+        }
+        for (int o = 0; o < NOUT; ++o)
+            PH_HIP(hipMemcpyAsync(outs[o] + i0, dd[o], m * 8, hipMemcpyDeviceToHost, S.in.st));
+    }
+    PH_HIP(hs.sync_both());
+    return POLYHIP_OK;
+}
+
 extern "C" {
 
 static int scan_impl(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64_t nstarts, uint32_t Lmin, uint32_t Lmax,
@@ -423,15 +483,6 @@ int polyhip_santalucia_scan_first_dev(const uint8_t *d_seq, uint64_t len, uint64
                      target_tm, d_first_len, d_first_tm, stream);
 }
 
-static int validate_ascii(const uint8_t *p, uint64_t n, const char *who)
-{
-    for (uint64_t i = 0; i < n; ++i)
-        if (p[i] >= 0x80)
-            return set_error(POLYHIP_ERR_INVALID, "%s: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
-                             who, p[i], (unsigned long long)i);
-    return POLYHIP_OK;
-}
-
 int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uint32_t Lmax, double primer_conc,
                             double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
 {
@@ -452,12 +503,16 @@ int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uin
     PH_HIP(dtm.alloc(nout * 8));
     PH_HIP(ddh.alloc(nout * 8));
     PH_HIP(dds.alloc(nout * 8));
-    PH_HIP(hipMemcpy(dseq.p, seq, len, hipMemcpyHostToDevice));
+    HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
+    PH_HIP(hs.init());
+    PH_HIP(hipMemcpyAsync(dseq.p, seq, len, hipMemcpyHostToDevice, hs.s[0]));
     rc = polyhip_santalucia_scan_dev(dseq.as<uint8_t>(), len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
-                                     dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nstarts, nullptr);
-    if (rc != POLYHIP_OK)
+                                     dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nstarts, hs.s[0]);
+    if (rc != POLYHIP_OK) {
+        (void)hipStreamSynchronize(hs.s[0]);
         return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
+    }
+    PH_HIP(hipStreamSynchronize(hs.s[0]));
     // three planes, three streams: one pageable download does not fill the link (a copy engine each does)
     hipStream_t cs[3] = {nullptr, nullptr, nullptr};
     void *dstp[3] = {tm, dH, dS};
@@ -498,15 +553,20 @@ int polyhip_santalucia_scan_first(const uint8_t *seq, uint64_t len, uint32_t Lmi
     PH_HIP(dlen.alloc(nstarts * 2));
     if (first_tm)
         PH_HIP(dtm.alloc(nstarts * 8));
-    PH_HIP(hipMemcpy(dseq.p, seq, len, hipMemcpyHostToDevice));
+    HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
+    PH_HIP(hs.init());
+    hipStream_t st = hs.s[0];
+    PH_HIP(hipMemcpyAsync(dseq.p, seq, len, hipMemcpyHostToDevice, st));
     rc = polyhip_santalucia_scan_first_dev(dseq.as<uint8_t>(), len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
-                                           target_tm, dlen.as<uint16_t>(), first_tm ? dtm.as<double>() : nullptr, nullptr);
-    if (rc != POLYHIP_OK)
+                                           target_tm, dlen.as<uint16_t>(), first_tm ? dtm.as<double>() : nullptr, st);
+    if (rc != POLYHIP_OK) {
+        (void)hipStreamSynchronize(st);
         return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(first_len, dlen.p, nstarts * 2, hipMemcpyDeviceToHost));
+    }
+    PH_HIP(hipMemcpyAsync(first_len, dlen.p, nstarts * 2, hipMemcpyDeviceToHost, st));
     if (first_tm)
-        PH_HIP(hipMemcpy(first_tm, dtm.p, nstarts * 8, hipMemcpyDeviceToHost));
+        PH_HIP(hipMemcpyAsync(first_tm, dtm.p, nstarts * 8, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
     return POLYHIP_OK;
 }
 
@@ -526,54 +586,19 @@ int polyhip_santalucia_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offset
     return POLYHIP_OK;
 }
 
-// shared staging for the two packed-batch host entry points
-static int stage_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, const char *who, bool empty_panics,
-                       DevBuf &dseq, DevBuf &doff)
-{
-    PH_REQUIRE(seqs && offsets, "%s: null pointer", who);
-    for (uint64_t i = 0; i < n; ++i) {
-        PH_REQUIRE(offsets[i] <= offsets[i + 1], "%s: offsets not ascending at %llu", who, (unsigned long long)i);
-        if (empty_panics && offsets[i] == offsets[i + 1])
-            return set_error(POLYHIP_ERR_PANIC, "%s: sequence %llu is empty; primers.SantaLucia(\"\") panics (primers.go:89)",
-                             who, (unsigned long long)i);
-    }
-    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
-    int rc = validate_ascii(seqs + b0, nbytes, who);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(dseq.alloc(nbytes));
-    PH_HIP(doff.alloc((n + 1) * 8));
-    std::vector<uint64_t> tmp(n + 1);
-    for (uint64_t i = 0; i <= n; ++i)
-        tmp[i] = offsets[i] - b0;
-    PH_HIP(hipMemcpy(doff.p, tmp.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    if (nbytes)
-        PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
-    return POLYHIP_OK;
-}
-
 int polyhip_santalucia_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double primer_conc,
                              double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
 {
     if (n == 0)
         return POLYHIP_OK;
     PH_REQUIRE(tm && dH && dS, "polyhip_santalucia_batch: null pointer");
-    DevBuf dseq, doff, dtm, ddh, dds;
-    int rc = stage_batch(seqs, offsets, n, "polyhip_santalucia_batch", true, dseq, doff);
-    if (rc != POLYHIP_OK)
+    if (int rc = check_batch(seqs, offsets, n, "polyhip_santalucia_batch", true))
         return rc;
-    PH_HIP(dtm.alloc(n * 8));
-    PH_HIP(ddh.alloc(n * 8));
-    PH_HIP(dds.alloc(n * 8));
-    rc = polyhip_santalucia_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, primer_conc, salt_conc, mg_conc,
-                                      dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(tm, dtm.p, n * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(dH, ddh.p, n * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(dS, dds.p, n * 8, hipMemcpyDeviceToHost));
-    return POLYHIP_OK;
+    double *const outs[3] = {tm, dH, dS};
+    return run_batch_host<3>(seqs, offsets, n, outs,
+                             [&](const uint8_t *ds, const uint64_t *dof, uint64_t m, double *(&d)[3], hipStream_t st) {
+                                 return polyhip_santalucia_batch_dev(ds, dof, m, primer_conc, salt_conc, mg_conc, d[0], d[1], d[2], st);
+                             });
 }
 
 int polyhip_marmurdoty_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, double *d_tm,
@@ -595,17 +620,13 @@ int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets, uint6
     if (n == 0)
         return POLYHIP_OK;
     PH_REQUIRE(tm, "polyhip_marmurdoty_batch: null pointer");
-    DevBuf dseq, doff, dtm;
-    int rc = stage_batch(seqs, offsets, n, "polyhip_marmurdoty_batch", false, dseq, doff);
-    if (rc != POLYHIP_OK)
+    if (int rc = check_batch(seqs, offsets, n, "polyhip_marmurdoty_batch", false))
         return rc;
-    PH_HIP(dtm.alloc(n * 8));
-    rc = polyhip_marmurdoty_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, dtm.as<double>(), nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(tm, dtm.p, n * 8, hipMemcpyDeviceToHost));
-    return POLYHIP_OK;
+    double *const outs[1] = {tm};
+    return run_batch_host<1>(seqs, offsets, n, outs,
+                             [&](const uint8_t *ds, const uint64_t *dof, uint64_t m, double *(&d)[1], hipStream_t st) {
+                                 return polyhip_marmurdoty_batch_dev(ds, dof, m, d[0], st);
+                             });
 }
 
 } // extern "C"

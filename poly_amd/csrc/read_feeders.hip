@@ -40,6 +40,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "host_pipeline.h"
 
 namespace polyhip {
 namespace fq {
@@ -691,20 +692,27 @@ int polyhip_fastq_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs, uint
     PH_HIP(dres.alloc(4 * 8));
     const size_t wb = polyhip_fastq_workspace_bytes(nbytes);
     PH_HIP(dwork.alloc(wb));
+    // the calling thread's own streams (host_pipeline.h), never the null stream: the parse is one pass over the whole
+    // image, so there is nothing to overlap the upload with, but the two result copies travel side by side
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
     if (nbytes)
-        PH_HIP(hipMemcpy(dfile.p, file, nbytes, hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpyAsync(dfile.p, file, nbytes, hipMemcpyHostToDevice, hs.s[0]));
     int rc = polyhip_fastq_pack_dev(dfile.as<uint8_t>(), nbytes, dseqs.as<uint8_t>(), doffs.as<uint64_t>(),
-                                    drec.as<uint64_t>(), max_records, dres.as<uint64_t>(), dwork.p, wb, nullptr);
-    if (rc != POLYHIP_OK)
+                                    drec.as<uint64_t>(), max_records, dres.as<uint64_t>(), dwork.p, wb, hs.s[0]);
+    if (rc != POLYHIP_OK) {
+        (void)hs.sync_both();
         return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(result, dres.p, 4 * 8, hipMemcpyDeviceToHost));
+    }
+    PH_HIP(hipMemcpyAsync(result, dres.p, 4 * 8, hipMemcpyDeviceToHost, hs.s[0]));
+    PH_HIP(hipStreamSynchronize(hs.s[0]));
     const uint64_t n = result[0];
-    PH_HIP(hipMemcpy(offsets, doffs.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpyAsync(offsets, doffs.p, (n + 1) * 8, hipMemcpyDeviceToHost, hs.s[1]));
     if (rec_start && n)
-        PH_HIP(hipMemcpy(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost));
+        PH_HIP(hipMemcpyAsync(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost, hs.s[1]));
     if (result[3])
-        PH_HIP(hipMemcpy(seqs, dseqs.p, result[3], hipMemcpyDeviceToHost));
+        PH_HIP(hipMemcpyAsync(seqs, dseqs.p, result[3], hipMemcpyDeviceToHost, hs.s[0]));
+    PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }
 
@@ -777,21 +785,26 @@ int polyhip_fasta_pack(const uint8_t *file, uint64_t nbytes, uint8_t *seqs, uint
     PH_HIP(dres.alloc(4 * 8));
     const size_t wb = polyhip_fasta_workspace_bytes(nbytes);
     PH_HIP(dwork.alloc(wb));
+    HostStreams &hs = host_streams(); // the calling thread's own streams, never the null stream (see polyhip_fastq_pack)
+    PH_HIP(hs.init());
     if (nbytes)
-        PH_HIP(hipMemcpy(dfile.p, file, nbytes, hipMemcpyHostToDevice));
-    PH_HIP(hipMemset(doffs.p, 0, 16));
+        PH_HIP(hipMemcpyAsync(dfile.p, file, nbytes, hipMemcpyHostToDevice, hs.s[0]));
+    PH_HIP(hipMemsetAsync(doffs.p, 0, 16, hs.s[0]));
     int rc = polyhip_fasta_pack_dev(dfile.as<uint8_t>(), nbytes, dseqs.as<uint8_t>(), doffs.as<uint64_t>(),
-                                    drec.as<uint64_t>(), max_records, dres.as<uint64_t>(), dwork.p, wb, nullptr);
-    if (rc != POLYHIP_OK)
+                                    drec.as<uint64_t>(), max_records, dres.as<uint64_t>(), dwork.p, wb, hs.s[0]);
+    if (rc != POLYHIP_OK) {
+        (void)hs.sync_both();
         return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(result, dres.p, 4 * 8, hipMemcpyDeviceToHost));
+    }
+    PH_HIP(hipMemcpyAsync(result, dres.p, 4 * 8, hipMemcpyDeviceToHost, hs.s[0]));
+    PH_HIP(hipStreamSynchronize(hs.s[0]));
     const uint64_t n = result[0];
-    PH_HIP(hipMemcpy(offsets, doffs.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpyAsync(offsets, doffs.p, (n + 1) * 8, hipMemcpyDeviceToHost, hs.s[1]));
     if (rec_start && n)
-        PH_HIP(hipMemcpy(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost));
+        PH_HIP(hipMemcpyAsync(rec_start, drec.p, n * 8, hipMemcpyDeviceToHost, hs.s[1]));
     if (result[2])
-        PH_HIP(hipMemcpy(seqs, dseqs.p, result[2], hipMemcpyDeviceToHost));
+        PH_HIP(hipMemcpyAsync(seqs, dseqs.p, result[2], hipMemcpyDeviceToHost, hs.s[0]));
+    PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }
 

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_pipeline.h"
 
 namespace polyhip {
 namespace s2 {
@@ -580,26 +581,40 @@ int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t
     for (uint64_t i = 0; i < nbytes; ++i)
         PH_REQUIRE(seqs[b0 + i] < 0x80, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
                    seqs[b0 + i], (unsigned long long)i);
-    DevBuf dseq, doff, dout, derr, dwork;
-    PH_HIP(dseq.alloc(nbytes));
-    PH_HIP(doff.alloc((n + 1) * 8));
-    PH_HIP(dout.alloc(n * 72));
-    PH_HIP(derr.alloc(n * 4));
-    std::vector<uint64_t> tmp(n + 1);
-    for (uint64_t i = 0; i <= n; ++i)
-        tmp[i] = offsets[i] - b0;
-    PH_HIP(hipMemcpy(doff.p, tmp.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    if (nbytes)
-        PH_HIP(hipMemcpy(dseq.p, seqs + b0, nbytes, hipMemcpyHostToDevice));
-    const size_t wb = polyhip_seqhash_workspace_bytes(n, nbytes, circular, double_stranded);
-    PH_HIP(dwork.alloc(wb));
-    int rc = polyhip_seqhash_batch_dev(dseq.as<uint8_t>(), doff.as<uint64_t>(), n, nbytes, max_len, seq_type, circular,
-                                       double_stranded, dout.as<char>(), derr.as<uint32_t>(), dwork.p, wb, nullptr);
-    if (rc != POLYHIP_OK)
-        return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(out, dout.p, n * 72, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(err, derr.p, n * 4, hipMemcpyDeviceToHost));
+    // chunks of ~64 MB through two slots on the calling thread's two streams: chunk c is uploaded and hashed while the
+    // seqhashes of chunk c-1 travel back
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    const Chunks ch = cut_packed(offsets, n, 76, HOST_CHUNK_BYTES);
+    struct Slot {
+        PackedSlot in;
+        DevBuf dout, derr, dwork;
+    } slot[2];
+    const size_t wb = polyhip_seqhash_workspace_bytes(ch.max_items, ch.max_bytes, circular, double_stranded);
+    for (size_t q = 0; q < std::min<size_t>(2, ch.count()); ++q) {
+        PH_HIP(slot[q].in.alloc(ch, hs.s[q]));
+        PH_HIP(slot[q].dout.alloc(ch.max_items * 72));
+        PH_HIP(slot[q].derr.alloc(ch.max_items * 4));
+        PH_HIP(slot[q].dwork.alloc(wb));
+    }
+    for (size_t c = 0; c < ch.count(); ++c) {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0, cb = offsets[i0 + m] - offsets[i0];
+        PH_HIP(hipStreamSynchronize(S.in.st)); // chunk c-2 has left this slot
+        PH_HIP(S.in.upload(seqs, offsets, i0, m));
+        uint64_t ml = 0;
+        for (uint64_t i = 0; i < m; ++i)
+            ml = std::max(ml, offsets[i0 + i + 1] - offsets[i0 + i]);
+        const int rc = polyhip_seqhash_batch_dev(S.in.dseq.as<uint8_t>(), S.in.doff.as<uint64_t>(), m, cb, ml, seq_type, circular,
+                                                 double_stranded, S.dout.as<char>(), S.derr.as<uint32_t>(), S.dwork.p, wb, S.in.st);
+        if (rc != POLYHIP_OK) {
+            (void)hs.sync_both();
+            return rc;
+        }
+        PH_HIP(hipMemcpyAsync(out + i0 * 72, S.dout.p, m * 72, hipMemcpyDeviceToHost, S.in.st));
+        PH_HIP(hipMemcpyAsync(err + i0, S.derr.p, m * 4, hipMemcpyDeviceToHost, S.in.st));
+    }
+    PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }
 

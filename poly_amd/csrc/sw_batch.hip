@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_pipeline.h"
 
 #include "sw_scoring.h"
 
@@ -843,9 +844,14 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && endA && endB && err, "polyhip_sw_batch: null pointer");
+    HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
+    PH_HIP(hs.init());
+    hipStream_t st = hs.s[0];
     PairStage in;
-    if (int rc0 = in.load("polyhip_sw_batch", A, offA, npairs, B, offB, lenB))
+    if (int rc0 = in.load("polyhip_sw_batch", A, offA, npairs, B, offB, lenB, st)) {
+        (void)hipStreamSynchronize(st);
         return rc0;
+    }
     const uint64_t maxA = in.maxA, maxB = in.maxB;
     DevBuf dscore, dea, deb, derr, dwork;
     PH_HIP(dscore.alloc(npairs * 8));
@@ -856,14 +862,16 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t
     PH_HIP(dwork.alloc(wb));
     int rc = polyhip_sw_batch_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
                                   dscore.as<int64_t>(), dea.as<uint32_t>(), deb.as<uint32_t>(), derr.as<uint32_t>(), dwork.p,
-                                  wb, nullptr);
-    if (rc != POLYHIP_OK)
+                                  wb, st);
+    if (rc != POLYHIP_OK) {
+        (void)hipStreamSynchronize(st);
         return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(endA, dea.p, npairs * 4, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
+    }
+    PH_HIP(hipMemcpyAsync(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(endA, dea.p, npairs * 4, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(err, derr.p, npairs * 4, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
     return POLYHIP_OK;
 }
 

@@ -135,6 +135,7 @@ namespace polyhip {
 // rebased to 0, and reports the longest A / B.  Shared by polyhip_sw_batch, polyhip_sw_align_batch, polyhip_nw_align_batch.
 struct PairStage {
     DevBuf dA, doA, dB, doB;
+    std::vector<uint64_t> hoA, hoB; // rebased offsets: they must outlive the asynchronous uploads
     uint64_t maxA = 0, maxB = 0;
     bool per_pair_B = false;
 
@@ -143,8 +144,10 @@ struct PairStage {
     const uint8_t *B() const { return dB.as<uint8_t>(); }
     const uint64_t *offB() const { return per_pair_B ? doB.as<uint64_t>() : nullptr; }
 
+    // uploads are enqueued on `st` (one of the calling thread's own streams, host_pipeline.h -- never the null stream);
+    // the caller synchronises `st` before this object goes away
     int load(const char *who, const uint8_t *A_, const uint64_t *offA_, uint64_t npairs, const uint8_t *B_,
-             const uint64_t *offB_, uint64_t lenB)
+             const uint64_t *offB_, uint64_t lenB, hipStream_t st)
     {
         per_pair_B = offB_ != nullptr;
         maxA = 0;
@@ -164,19 +167,20 @@ struct PairStage {
         PH_HIP(dA.alloc(abytes + 16));
         PH_HIP(doA.alloc((npairs + 1) * 8));
         PH_HIP(dB.alloc(bbytes + 16));
-        std::vector<uint64_t> tmp(npairs + 1);
+        hoA.resize(npairs + 1);
         for (uint64_t i = 0; i <= npairs; ++i)
-            tmp[i] = offA_[i] - a0;
-        PH_HIP(hipMemcpy(doA.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+            hoA[i] = offA_[i] - a0;
+        PH_HIP(hipMemcpyAsync(doA.p, hoA.data(), (npairs + 1) * 8, hipMemcpyHostToDevice, st));
         if (abytes)
-            PH_HIP(hipMemcpy(dA.p, A_ + a0, abytes, hipMemcpyHostToDevice));
+            PH_HIP(hipMemcpyAsync(dA.p, A_ + a0, abytes, hipMemcpyHostToDevice, st));
         if (bbytes)
-            PH_HIP(hipMemcpy(dB.p, B_ + b0, bbytes, hipMemcpyHostToDevice));
+            PH_HIP(hipMemcpyAsync(dB.p, B_ + b0, bbytes, hipMemcpyHostToDevice, st));
         if (offB_) {
             PH_HIP(doB.alloc((npairs + 1) * 8));
+            hoB.resize(npairs + 1);
             for (uint64_t i = 0; i <= npairs; ++i)
-                tmp[i] = offB_[i] - b0;
-            PH_HIP(hipMemcpy(doB.p, tmp.data(), (npairs + 1) * 8, hipMemcpyHostToDevice));
+                hoB[i] = offB_[i] - b0;
+            PH_HIP(hipMemcpyAsync(doB.p, hoB.data(), (npairs + 1) * 8, hipMemcpyHostToDevice, st));
         }
         return POLYHIP_OK;
     }

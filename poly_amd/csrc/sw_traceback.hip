@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "common.h"
+#include "host_pipeline.h"
 #include "sw_scoring.h"
 
 namespace polyhip {
@@ -356,10 +357,12 @@ __global__ __launch_bounds__(THREADS) void tb_prof_kernel(
     // The score pass may have left the end cell to this kernel (k3p::SW_END_DEFERRED): eB is then the last column of
     // the ONE block of four columns that holds the maximum, and the first cell worth M in row-major order is found
     // while that block -- the last of the window -- is swept.  The window is sized with lenA for the unknown end row.
-    const bool locate = active && eA == k3p::SW_END_DEFERRED;
+    // `wide` bit 1: the caller is the fused entry point, whose score pass may have deferred end cells; without it the
+    // end arrays are the caller's read-only input, a sentinel (or any row beyond the read) there means "no alignment"
+    const bool locate = active && (wide & 2) && eA == k3p::SW_END_DEFERRED;
     const uint32_t rowsA = locate ? lenA : eA;
-    const bool work = active && rowsA > 0 && eB > 0 && M > 0 && lenA <= RA;
-    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide) + (locate ? 4u : 0u)) : 0u;
+    const bool work = active && rowsA > 0 && rowsA <= lenA && eB > 0 && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide & 1) + (locate ? 4u : 0u)) : 0u;
     const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u; // first column (1-based) of my window
     const uint32_t jb0 = (c_s - 1u) & ~3u;                               // 0-based, on a block boundary
     const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u;        // <= nblk_alloc
@@ -686,10 +689,10 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
             M = score[pair];
         }
     }
-    const bool locate = active && eA == k3p::SW_END_DEFERRED; // as tb_prof_kernel
+    const bool locate = active && (wide & 2) && eA == k3p::SW_END_DEFERRED; // as tb_prof_kernel
     const uint32_t rowsA = locate ? lenA : eA;
-    const bool work = active && rowsA > 0 && eB > 0 && M > 0 && lenA <= RA;
-    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide) + (locate ? 4u : 0u)) : 0u;
+    const bool work = active && rowsA > 0 && rowsA <= lenA && eB > 0 && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide & 1) + (locate ? 4u : 0u)) : 0u;
     const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u;
     const uint32_t jb0 = (c_s - 1u) & ~3u;
     const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u; // <= nblk_alloc - 1
@@ -1708,7 +1711,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
                           uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err,
                           const int64_t *d_score, uint8_t *d_alnA,
                           uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
-                          polyhip_stream_t stream)
+                          polyhip_stream_t stream, int deferred)
 {
     PH_REQUIRE(sc, "polyhip_sw_traceback: null scoring");
     if (npairs == 0)
@@ -1726,7 +1729,11 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
                           !env_is("POLYHIP_TB_PROF", '0'); // testing aid: the table kernel for a shared reference
     const bool use_wave = !use_prof && (p.ra == 0 || p.ra == 256) && wave_ok;
     k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
-    const int wide = env_is("POLYHIP_TB_WIDE", '1'); // testing aid: the conservative per-pair window
+    // only the byte-profile kernels know a deferred end cell: the fused entry point decided with traceback_uses_prof();
+    // should the two conditions ever drift apart, fail here instead of walking from row 4e9
+    PH_REQUIRE(!deferred || use_prof, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
+    // bit 0: the conservative per-pair window (POLYHIP_TB_WIDE=1, testing aid); bit 1: deferred end cells allowed
+    const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0);
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
@@ -1763,8 +1770,21 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     }
     const hipStream_t caller_st = st;
     AuxStream &aux = aux_stream();
-    if (overlap)
+    // whatever way this function is left after the fork, the caller's stream waits for the library's
+    struct Joiner {
+        AuxStream &a;
+        hipStream_t caller;
+        bool armed = false;
+        ~Joiner()
+        {
+            if (armed)
+                (void)a.join(caller);
+        }
+    } joiner{aux, caller_st};
+    if (overlap) {
         PH_HIP(aux.fork(caller_st)); // the profile table (and everything before this call) is ready
+        joiner.armed = true;
+    }
     uint64_t chunk_no = 0;
     for (uint64_t p0 = 0; p0 < npairs; p0 += chunk, ++chunk_no) {
         const uint64_t p1 = std::min(npairs, p0 + chunk);
@@ -1876,8 +1896,10 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
 #undef PH_TB_LAUNCH
         PH_HIP(hipGetLastError());
     }
-    if (overlap) // the caller's stream continues after both
+    if (overlap) { // the caller's stream continues after both
+        joiner.armed = false;
         PH_HIP(aux.join(caller_st));
+    }
     return POLYHIP_OK;
 }
 
@@ -1888,10 +1910,10 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A, cons
                              uint8_t *d_alnB, uint32_t *d_alnLen, uint32_t aln_stride, void *d_work, size_t work_bytes,
                              polyhip_stream_t stream)
 {
-    // (nothing is deferred in ends that come from polyhip_sw_batch_dev: the arrays are only read)
+    // deferred = 0: the kernels never write the end arrays (a sentinel or an end row beyond the read means "no alignment")
     return traceback_impl(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, lenB, const_cast<uint32_t *>(d_endA),
                           const_cast<uint32_t *>(d_endB), const_cast<uint32_t *>(d_err), d_score, d_alnA, d_alnB, d_alnLen,
-                          aln_stride, d_work, work_bytes, stream);
+                          aln_stride, d_work, work_bytes, stream, 0);
 }
 
 // The whole SmithWaterman on device pointers: score pass + traceback in one call.  For batches that take the packed
@@ -1914,9 +1936,8 @@ int polyhip_sw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
                                      work_bytes, stream, want_defer, &deferred);
     if (rc != POLYHIP_OK)
         return rc;
-    (void)deferred;
     return traceback_impl(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, lenB, d_endA, d_endB, d_err, d_score, d_alnA, d_alnB,
-                          d_alnLen, aln_stride, d_tb_work, tb_work_bytes, stream);
+                          d_alnLen, aln_stride, d_tb_work, tb_work_bytes, stream, deferred);
 }
 
 int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
@@ -1928,9 +1949,13 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && endA && endB && err && alnA && alnB && alnLen, "polyhip_sw_align_batch: null pointer");
+    HostStreams &hs = host_streams(); // the calling thread's two streams carry the two slots (never the null stream)
+    PH_HIP(hs.init());
     PairStage in;
-    if (int rc0 = in.load("polyhip_sw_align_batch", A, offA, npairs, B, offB, lenB))
+    if (int rc0 = in.load("polyhip_sw_align_batch", A, offA, npairs, B, offB, lenB, hs.s[0])) {
+        (void)hipStreamSynchronize(hs.s[0]);
         return rc0;
+    }
     const uint64_t maxA = in.maxA, maxB = in.maxB;
     // Chunks of pairs through two slots, each with its own stream, outputs and workspaces: the strings of chunk c cross
     // PCIe (1 GB for config 4, as long as the kernels take) while chunk c + 1 is being aligned.  The reads and the
@@ -1956,10 +1981,8 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
         hipStream_t st = nullptr;
         ~Slot()
         {
-            if (st) {
-                (void)hipStreamSynchronize(st);
-                (void)hipStreamDestroy(st);
-            }
+            if (st)
+                (void)hipStreamSynchronize(st); // the buffers are freed next
         }
     } slot[2];
     const size_t wb = polyhip_sw_workspace_bytes(sc, per, (uint32_t)maxA, maxB, offB == nullptr);
@@ -1975,10 +1998,9 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
         PH_HIP(S.dalB.alloc(per * (size_t)aln_stride));
         PH_HIP(S.dwork.alloc(wb));
         PH_HIP(S.dtb.alloc(tb));
-        if (nchunks > 1)
-            PH_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+        S.st = hs.s[q];
     }
-    PH_HIP(hipStreamSynchronize(nullptr)); // PairStage's uploads
+    PH_HIP(hipStreamSynchronize(hs.s[0])); // PairStage's uploads: both slots read them
     auto download = [&](uint64_t c) -> hipError_t {
         Slot &S = slot[c & 1];
         const uint64_t i0 = c * per, m = std::min(per, npairs - i0);
@@ -2000,8 +2022,7 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     for (uint64_t c = 0; c < nchunks; ++c) {
         Slot &S = slot[c & 1];
         const uint64_t i0 = c * per, m = std::min(per, npairs - i0);
-        if (S.st)
-            PH_HIP(hipStreamSynchronize(S.st)); // chunk c - 2 has left this slot
+        PH_HIP(hipStreamSynchronize(S.st)); // chunk c - 2 has left this slot
         const int rc = polyhip_sw_align_batch_dev(sc, in.A(), in.offA() + i0, m, (uint32_t)maxA, in.B(), in.offB() ? in.offB() + i0 : nullptr,
                                                   maxB, S.dscore.as<int64_t>(), S.dea.as<uint32_t>(), S.deb.as<uint32_t>(),
                                                   S.derr.as<uint32_t>(), S.dalA.as<uint8_t>(), S.dalB.as<uint8_t>(),
@@ -2131,9 +2152,14 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && err && alnA && alnB && alnLen, "polyhip_nw_align_batch: null pointer");
+    HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
+    PH_HIP(hs.init());
+    hipStream_t hst = hs.s[0];
     PairStage in;
-    if (int rc0 = in.load("polyhip_nw_align_batch", A, offA, npairs, B, offB, lenB))
+    if (int rc0 = in.load("polyhip_nw_align_batch", A, offA, npairs, B, offB, lenB, hst)) {
+        (void)hipStreamSynchronize(hst);
         return rc0;
+    }
     const uint64_t maxA = in.maxA, maxB = in.maxB;
     PH_REQUIRE(maxB < 0xFFFFFFFFull, "polyhip_nw_align_batch: sequence longer than 2^32");
     DevBuf dscore, derr, dalA, dalB, dlen, dwork;
@@ -2147,17 +2173,21 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     int rc = polyhip_nw_align_batch_dev(sc, in.A(), in.offA(), npairs, (uint32_t)maxA, in.B(), in.offB(), maxB,
                                         dscore.as<int64_t>(), derr.as<uint32_t>(),
                                         dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(), aln_stride, dwork.p, wb,
-                                        nullptr);
-    if (rc != POLYHIP_OK)
+                                        hst);
+    if (rc != POLYHIP_OK) {
+        (void)hipStreamSynchronize(hst);
         return rc;
-    PH_HIP(hipStreamSynchronize(nullptr));
-    PH_HIP(hipMemcpy(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost));
-    PH_HIP(hipMemcpy(err, derr.p, npairs * 4, hipMemcpyDeviceToHost));
-    if (aln_stride) {
-        PH_HIP(hipMemcpy(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
-        PH_HIP(hipMemcpy(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost));
     }
-    PH_HIP(hipMemcpy(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost));
+    PH_HIP(hipMemcpyAsync(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost, hst));
+    PH_HIP(hipMemcpyAsync(err, derr.p, npairs * 4, hipMemcpyDeviceToHost, hst));
+    if (aln_stride) { // the two string planes side by side on the thread's two streams
+        PH_HIP(hipEventRecord(hs.ev, hst));
+        PH_HIP(hipStreamWaitEvent(hs.s[1], hs.ev, 0));
+        PH_HIP(hipMemcpyAsync(alnA, dalA.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost, hst));
+        PH_HIP(hipMemcpyAsync(alnB, dalB.p, npairs * (size_t)aln_stride, hipMemcpyDeviceToHost, hs.s[1]));
+    }
+    PH_HIP(hipMemcpyAsync(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost, hst));
+    PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }
 

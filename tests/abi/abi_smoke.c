@@ -71,9 +71,17 @@ static void test_mash(void)
     sketch(s2, 17, 10, h1);
     sketch(s1, 17, 5, h2);
     CHECK(distance(h1, 10, h2, 5) == 0.0, "last TestMash distance"); /* :59 */
-    /* s < 2: the reference indexes Sketches[-1] */
-    uint64_t off[2] = {0, 62};
-    CHECK(polyhip_mash_sketch_batch((const uint8_t *)s1, off, 1, 17, 1, f1) == POLYHIP_ERR_PANIC, "s = 1 must be a panic");
+    /* s == 1: the reference indexes Sketches[-1] (mash.go:98) iff a later window hashes below the first one.  A
+     * homopolymer never does (every window hashes alike: murmur3("A" x 17) = 0x295dfd60, this repo's restatement) and
+     * leaves that hash in Sketches[0]; both 62-mers above have a smaller hash further on and panic */
+    uint64_t off[2] = {0, 62}, offa[2] = {0, 40};
+    uint32_t one = 0;
+    CHECK(polyhip_mash_sketch_batch((const uint8_t *)"AAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAAA", offa, 1, 17, 1, &one) == POLYHIP_OK &&
+              one == 0x295dfd60u,
+          "s = 1 on a homopolymer: %08x (%s)", one, polyhip_last_error());
+    CHECK(polyhip_mash_sketch_batch((const uint8_t *)s1, off, 1, 17, 1, &one) == POLYHIP_ERR_PANIC, "s = 1 must be a panic here");
+    CHECK(polyhip_mash_sketch_batch((const uint8_t *)s2, off, 1, 17, 1, &one) == POLYHIP_ERR_PANIC, "s = 1 must be a panic here");
+    CHECK(polyhip_mash_sketch_batch((const uint8_t *)s2, off, 1, 17, 0, &one) == POLYHIP_ERR_PANIC, "s = 0 with a window must be a panic");
 }
 
 static polyhip_scoring *nuc_scoring(int match, int mismatch, int gap)

@@ -44,10 +44,16 @@ def test_product_does_not_import_oracle():
 
 def test_argument_errors_without_gpu():
     from poly_amd import _lib, mash
-    with pytest.raises(_lib.GoPanic):  # s < 2: the reference indexes Sketches[-1]
-        mash.sketch_batch_packed(np.frombuffer(b"ACGT" * 10, np.uint8), np.array([0, 40], np.uint64), 3, 1)
-    with pytest.raises(_lib.PolyhipError):
-        mash.sketch_batch_packed(np.frombuffer(b"ACGT" * 10, np.uint8), np.array([0, 40], np.uint64), 3, 100000)
+    import torch
+    seq, offs = np.frombuffer(b"ACGT" * 10, np.uint8), np.array([0, 40], np.uint64)
+    with pytest.raises(_lib.PolyhipError) as ei:  # SketchSize beyond 2^24: rejected before any device call
+        mash.sketch_batch_packed(seq, offs, 3, (1 << 24) + 1, out=np.zeros((1, (1 << 24) + 1), np.uint32))
+    assert ei.value.status == _lib.ERR_INVALID
+    if not torch.cuda.is_available():
+        # s < 2 is decided read by read ON THE DEVICE (mash.go:96,98): without one it is a device error, never a guess
+        with pytest.raises(_lib.PolyhipError) as ei:
+            mash.sketch_batch_packed(seq, offs, 3, 1)
+        assert ei.value.status == _lib.ERR_HIP
 
 
 def test_no_cpu_fallback():

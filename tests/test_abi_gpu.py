@@ -25,3 +25,14 @@ def test_c_harness_without_torch():
     assert "abi_smoke: ok" in res.stdout
     rt = [ln for ln in res.stdout.splitlines() if "HIP runtime" in ln]
     assert rt and "torch" not in rt[0] and "/opt/rocm" in rt[0], rt
+
+
+def test_eight_threads_in_mixed_entry_points():
+    """tests/abi/abi_threads.c: cgo calls arrive on arbitrary OS threads, several at once -- 8 pthreads x 6 rounds x 7
+    host-pointer entry points (one scoring handle shared by all), every result equal to the serial run"""
+    from poly_amd import build
+    exe = build.build_abi_threads()
+    res = subprocess.run([exe, "8", "6"], capture_output=True, text=True, timeout=600)
+    print(res.stdout, res.stderr)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "abi_threads ok: 8 threads" in res.stdout

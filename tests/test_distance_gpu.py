@@ -205,6 +205,33 @@ def test_rows_with_many_relatives_overflow_to_merge(mash, join_kind):
         assert (got[i] == _oracle_counts(S[i:i + 1], S)[0]).all()
 
 
+def test_column_stripes_beyond_one_index(mash, monkeypatch):
+    """Y sets of 2^32 hashes and more are joined in column stripes (one index each, side by side in the matrix); the bound
+    is lowered here so that the striping runs on a small input: ragged last stripe, ld > ny, irregular sketches, the
+    host-pointer flavour with distances"""
+    import torch
+    rng = np.random.default_rng(21)
+    S = _families(rng, 9, 7, 1200, 0.02, 21, 150)           # 63 sketches of 150
+    S[10] = rng.integers(0, 1 << 30, 150, dtype=np.uint32)  # unsorted: the merge loop's pairs, in whichever stripe
+    X = np.ascontiguousarray(S[5:40])
+    want = _oracle_counts(X, S)
+    monkeypatch.setenv("POLYHIP_K2_MAX_ITEMS", str(150 * 16 + 7))   # 16 sketches per stripe: 4 stripes, the last of 15
+    dev = torch.device("cuda:0")
+    Xt, Yt = (torch.from_numpy(a.view(np.int32)).to(dev) for a in (X, S))
+    ct = torch.full((35, 80), -1, dtype=torch.int16, device=dev)
+    work = torch.empty(mash.shared_counts_workspace_bytes(35, 150, 63, 150), dtype=torch.uint8, device=dev)
+    mash.shared_counts_dev(Xt, Yt, ct[:, :63], work)
+    torch.cuda.synchronize()
+    got = ct.cpu().numpy().view(np.uint16)
+    assert (got[:, :63] == want).all() and (got[:, 63:] == 0xFFFF).all()
+    counts, dist = mash.distance_matrix_packed(X, S)
+    assert (counts == want).all()
+    assert (dist.view(np.uint64) == _oracle_dist(X, S).view(np.uint64)).all()
+    monkeypatch.delenv("POLYHIP_K2_MAX_ITEMS")
+    small = mash.shared_counts_workspace_bytes(35, 150, 16, 150)
+    assert work.numel() == small    # the workspace is sized for a stripe, not for the whole set
+
+
 def test_c_abi_allgather_one_rank(mash):
     """R1 through the C ABI (polyhip_comm_*: RCCL resolved at run time) on a 1-rank communicator"""
     import ctypes as C

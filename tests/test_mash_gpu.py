@@ -140,12 +140,102 @@ def test_sketch_is_idempotent_and_order_free(mash):
     assert (b.Sketches == first).all()
 
 
-def test_error_paths(mash):
+def test_sketchsize_below_two_is_the_reference_read_by_read(mash):
+    """mash.go:96,98 index Sketches[-1]: with s == 0 a sequence panics iff it has a window; with s == 1 window 0 fills
+    Sketches[0] and the sequence panics iff a LATER window hashes below it.  The batch call reports the FIRST such
+    sequence and writes the rows of the ones that do not panic exactly as the reference leaves them."""
     from poly_amd import _lib
+    k = 21
+    rng = np.random.default_rng(5)
+    blob = orc.synth_dna(0x51, 200_000).tobytes()
+
+    def ref(seq, s, prior):
+        m = orc.Mash(k, s)
+        m.Sketches[:] = prior
+        try:
+            m.Sketch(seq)
+        except orc.GoPanic:
+            return None
+        return m.Sketches.copy()
+
+    # ---- s == 1: reads whose FIRST window holds the smallest hash do not panic
+    safe, unsafe = [], []
+    for i in range(400):
+        L = int(rng.integers(k + 2, 400))
+        a = int(rng.integers(0, len(blob) - L))
+        q = blob[a:a + L]
+        hs = [orc.murmur3_32(q[w:w + k]) for w in range(L - k)]
+        (safe if min(hs) == hs[0] else unsafe).append(q)
+    short = [b"", b"ACGT", blob[:k], blob[:k + 1]]          # no window (x3), exactly one window
+    assert len(safe) >= 3 and len(unsafe) >= 3
+    batch = safe + short
+    prior = rng.integers(1, 1 << 32, (len(batch), 1), dtype=np.uint32)
+    buf, offs = _pack(batch)
+    got = mash.sketch_batch_packed(buf, offs, k, 1, out=prior.copy())
+    for i, q in enumerate(batch):
+        want = ref(q, 1, prior[i])
+        assert want is not None and got[i, 0] == want[0], i
+    mixed = safe[:2] + [unsafe[0]] + safe[2:] + [unsafe[1]]
+    buf, offs = _pack(mixed)
+    with pytest.raises(_lib.GoPanic) as ei:
+        mash.sketch_batch_packed(buf, offs, k, 1)
+    assert "sequence 2 " in str(ei.value) and "mash.go:98" in str(ei.value)   # the first one the reference panics on
+    assert ref(mixed[2], 1, 0) is None and ref(mixed[0], 1, 0) is not None
+    # ---- s == 0: only sequences with a window panic
+    none = [b"", b"A" * k, blob[:5]]
+    buf, offs = _pack(none)
+    mash.sketch_batch_packed(buf, offs, k, 0, out=np.zeros((3, 0), np.uint32))     # len <= k everywhere: fine
+    for q in none:
+        assert ref(q, 0, 0) is not None
+    buf, offs = _pack(none + [blob[:k + 1]])
+    with pytest.raises(_lib.GoPanic) as ei:
+        mash.sketch_batch_packed(buf, offs, k, 0, out=np.zeros((4, 0), np.uint32))
+    assert "sequence 3 " in str(ei.value) and "mash.go:96" in str(ei.value)
+    assert ref(blob[:k + 1], 0, 0) is None
+    # the single-call API: the reference's own panics
     with pytest.raises(_lib.GoPanic):
-        mash.New(21, 1).Sketch("ACGT" * 100)
+        mash.New(21, 1).Sketch(unsafe[0])
     with pytest.raises(_lib.GoPanic):
         mash.New(21, 0).Sketch("ACGT" * 100)
+    one = mash.New(21, 1)
+    one.Sketch(safe[0])
+    assert one.Sketches[0] == orc.murmur3_32(safe[0][:k])
+
+
+@pytest.mark.parametrize("k,s", [(21, 8193), (21, 10000), (21, 65535), (17, 20000), (4097, 1000), (10000, 64), (5000, 9000),
+                                 (4096, 8192), (31, 16384)])
+def test_sketch_and_kmer_sizes_beyond_the_lds_kernels(mash, k, s):
+    """mash.New(21, 10000) is ordinary usage and the reference takes any KmerSize: what the LDS-resident kernels cannot
+    hold goes through the wide kernel (windows hashed from global memory, candidates in a stream-ordered scratch) --
+    same sketches as the oracle, incl. reads with fewer windows than SketchSize, duplicates and dirty prior state."""
+    rng = np.random.default_rng(k * 131 + s)
+    blob = orc.synth_dna(k + s, 400_000).tobytes()
+    L1 = k + s + 5000
+    seqs = [blob[:L1 + 120_000], blob[7:7 + L1], blob[3:3 + k + s], blob[11:11 + k + s - 1], blob[:k], blob[:k + 1], b"",
+            (b"ACGTTGCA" * ((L1 + 40_000) // 8 + 1))[:L1 + 40_000],            # period 8: at most 8 distinct hashes
+            b"A" * (k + s + 300)]                                              # one hash, s + 300 times
+    prior = rng.integers(0, 1 << 32, (len(seqs), s), dtype=np.uint32)
+    _check_batch(mash, seqs, k, s, prior=prior)
+
+
+def test_wide_kernel_device_resident(mash):
+    """the _dev flavour of the wide path (stream-ordered scratch) on many reads at once"""
+    import torch
+    dev = torch.device("cuda:0")
+    n, L, k, s = 300, 30_000, 21, 10_000
+    seqs = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC7, seqs)
+    offs = torch.arange(0, (n + 1) * L, L, dtype=torch.int64, device=dev)
+    out = torch.zeros((n, s), dtype=torch.int32, device=dev)
+    mash.sketch_batch_dev(seqs, offs, k, s, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    host = orc.synth_dna(0xC7, n * L)
+    rows = [0, 1, 150, 299]
+    for r in rows:
+        want = orc.mash_sketch_batch(host[r * L:(r + 1) * L], np.array([0, L], np.uint64), k, s)
+        assert (got[r] == want[0]).all()
+    assert (np.diff(got.astype(np.int64), axis=1) >= 0).all()
 
 
 def test_full_size_config2_properties(mash):
