@@ -166,6 +166,14 @@ int polyhip_mash_index_part_spans(uint64_t ny, uint32_t sy, uint32_t nparts,
                                   polyhip_stream_t stream);
 int polyhip_mash_index_finalize_dev(uint64_t ny, uint32_t sy, void *d_work,
                                     size_t work_bytes, polyhip_stream_t stream);
+/* Bytes per item of the index in d_work (synchronous read-back; tests, profiling, sizing an exchange): 8 = (value, sketch
+ * id | occurrence number); 4 = the compact form the build picks ON THE DEVICE when the join to come is the one-stripe dense
+ * join (up to ~113k columns of 10-bit counters) and the value's bits below its bucket plus the largest multiplicity of a
+ * hash inside one sketch fit 11 bits: the item then carries the LDS counter it bumps (dword and field), so the join's
+ * inner step is subtract, compare, two shifts, and, ds_add.  An index built on its own assumes X sets of Y's SketchSize;
+ * a join that does not fit that assumption rebuilds the index with 8-byte items first.  POLYHIP_K2_COMPACT=0 keeps the
+ * 8-byte items (testing aid). */
+int polyhip_mash_index_format_dev(const void *d_work, uint32_t *item_bytes);
 int polyhip_mash_index_allgather_dev(struct polyhip_comm *c, uint64_t ny,
                                      uint32_t sy, void *d_work,
                                      size_t work_bytes, polyhip_stream_t stream);

@@ -381,14 +381,22 @@ def e2e(dev) -> dict:
     hs_ = skd.cpu().numpy().view(np.uint32)
     del skd
     X = np.ascontiguousarray(hs_[:4000])
-    ms_c = _wall(lambda: mash.distance_matrix_packed(X, hs_, True, False), 3, 1)
-    ms_cd = _wall(lambda: mash.distance_matrix_packed(X, hs_, True, True), 3, 1)
+    # results go into buffers that already exist (as for the SW strings above: fresh numpy / Go memory adds first-touch page
+    # faults at a few GB/s, which is the allocator's time, not the library's)
+    o_c, o_d = np.zeros((4000, 20000), np.uint16), np.zeros((4000, 20000), np.float64)
+
+    def dm(with_dist):
+        _lib.check(L_.polyhip_mash_distance_matrix(X.ctypes.data, 4000, 1000, hs_.ctypes.data, 20000, 1000, o_c.ctypes.data,
+                                                   o_d.ctypes.data if with_dist else None))
+    ms_c = _wall(lambda: dm(False), 3, 1)
+    ms_cd = _wall(lambda: dm(True), 3, 1)
     out["mash_distance_matrix"] = {"workload": "polyhip_mash_distance_matrix, 4000 x 20000 sketches of s = 1000, host pointers "
                                                "(row blocks of ~64 MB: block b joined while block b-1 crosses PCIe)",
                                    "pairs_per_s_counts": 4000 * 20000 / ms_c * 1e3, "ms_counts": ms_c,
                                    "pairs_per_s_counts_and_fp64": 4000 * 20000 / ms_cd * 1e3, "ms_counts_and_fp64": ms_cd,
+                                   "pcie_GBs_counts": (4000 * 20000 * 2 + hs_.nbytes) / ms_c * 1e3 / 1e9,
                                    "pcie_GBs_counts_and_fp64": (4000 * 20000 * 10 + hs_.nbytes) / ms_cd * 1e3 / 1e9}
-    del hs_, X
+    del hs_, X, o_c, o_d
     # K5 / S2: 100k circular sequences of 5 kb (500 MB in; rotated: 500 MB out; seqhash: 7.2 MB out)
     nq, Lq = 100_000, 5000
     dq = torch.empty(nq * Lq, dtype=torch.uint8, device=dev)
@@ -396,17 +404,24 @@ def e2e(dev) -> dict:
     hq = dq.cpu().numpy()
     del dq
     oq = np.arange(0, (nq + 1) * Lq, Lq, dtype=np.uint64)
-    ms = _wall(lambda: seqhash.least_rotation_batch_packed(hq, oq, True), 3, 1)
+    o_rot, o_seq = np.zeros(nq, np.uint64), np.zeros(nq * Lq, np.uint8)
+    ms = _wall(lambda: _lib.check(L_.polyhip_least_rotation_batch(hq.ctypes.data, oq.ctypes.data, nq, o_rot.ctypes.data,
+                                                                  o_seq.ctypes.data)), 3, 1)
     out["least_rotation"] = {"workload": f"polyhip_least_rotation_batch, {nq} x {Lq} bp, host pointers, rotated sequences back",
                              "bases_per_s": nq * Lq / ms * 1e3, "ms": ms, "pcie_GBs": 2 * nq * Lq / ms * 1e3 / 1e9}
-    ms = _wall(lambda: seqhash.seqhash_batch_packed(hq, oq, 0, True, True), 3, 1)
+    del o_seq
+    o_h, o_e = np.zeros(nq * 72, np.uint8), np.zeros(nq, np.uint32)
+    ms = _wall(lambda: _lib.check(L_.polyhip_seqhash_batch(hq.ctypes.data, oq.ctypes.data, nq, 0, 1, 1, o_h.ctypes.data,
+                                                           o_e.ctypes.data)), 3, 1)
     out["seqhash"] = {"workload": f"polyhip_seqhash_batch, {nq} x {Lq} bp (DNA, circular, double-stranded), host pointers",
                       "sequences_per_s": nq / ms * 1e3, "ms": ms, "pcie_GBs": nq * Lq / ms * 1e3 / 1e9}
-    # K4 batch: 4M primers of 24 nt (96 MB in, 96 MB out)
+    # K4 batch: 4M primers of 24 nt (96 MB in + 32 MB of offsets, 96 MB out)
     npz = 4_000_000
     hp = hq[: npz * 24]
     op = np.arange(0, (npz + 1) * 24, 24, dtype=np.uint64)
-    ms = _wall(lambda: primers.santalucia_batch_packed(hp, op, 500e-9, 50e-3, 0.0), 3, 1)
+    o_t = [np.zeros(npz, np.float64) for _ in range(3)]
+    ms = _wall(lambda: _lib.check(L_.polyhip_santalucia_batch(hp.ctypes.data, op.ctypes.data, npz, 500e-9, 50e-3, 0.0,
+                                                              *(t.ctypes.data for t in o_t))), 3, 1)
     out["santalucia_batch"] = {"workload": f"polyhip_santalucia_batch, {npz} primers of 24 nt, host pointers",
                                "primers_per_s": npz / ms * 1e3, "ms": ms}
     return out

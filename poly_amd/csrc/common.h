@@ -58,6 +58,25 @@ inline bool env_is(const char *name, char value)
 
 inline hipStream_t as_stream(polyhip_stream_t s) { return static_cast<hipStream_t>(s); }
 
+// Index of the first byte >= 0x80 in p[0, n), or n.  The host flavours refuse such input where the Go code would treat it
+// as UTF-8; a byte-by-byte loop with an early exit does not vectorise (0.2 s per GB), this OR-reduction over 4 KB blocks
+// does (the compiler turns it into SIMD ors) and only a failing block is searched byte by byte.
+inline uint64_t first_non_ascii(const uint8_t *p, uint64_t n)
+{
+    uint64_t i = 0;
+    for (; i + 4096 <= n; i += 4096) {
+        uint8_t acc = 0;
+        for (int j = 0; j < 4096; ++j)
+            acc |= p[i + j];
+        if (acc & 0x80)
+            break;
+    }
+    for (; i < n; ++i)
+        if (p[i] >= 0x80)
+            return i;
+    return n;
+}
+
 // A second stream the library keeps per calling thread, for entry points that run sub-batches of one call side by side
 // (the end of one sub-batch's kernels -- waves finish at different times -- overlaps the start of the next).  fork():
 // the aux stream waits for everything enqueued on the caller's stream so far; join(): the caller's stream waits for the

@@ -41,6 +41,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <vector>
 
@@ -65,7 +66,13 @@ constexpr int JOIN_U = 8;             // buckets a wave keeps in flight
 #define PH_K2_NCLOG 10 // log2 of the most coarse buckets of the index build
 #endif
 
-enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_pad, H_EST_LO, H_EST_HI, H_WORDS = 16 };
+enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_MAXMULT, H_EST_LO, H_EST_HI, H_FMT, H_WORDS = 16 };
+// H_FMT: 0 = 8-byte items (value, sketch id | occurrence number << id_bits); 1 = COMPACT 4-byte items, written when the
+// join is known to be the one-stripe dense join and the bits fit (decided on the device, lists_kernel):
+//     [ value's bits below the bucket : shift | occurrence number : 11 - shift | counter dword : 16 | field shift : 5 ]
+// -- the LDS counter a shared hash bumps (dword = column % ndw, field = column / ndw) is worked out ONCE, when the index is
+// built, instead of once per visit: the join's inner step becomes subtract, compare, shift, shift, and, ds_add.
+constexpr uint32_t CK_LOW = 21; // bits below the occurrence number
 enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
 
 struct Layout {
@@ -124,7 +131,7 @@ __global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restri
 {
     const uint64_t q = blockIdx.x;
     const uint32_t *p = sk + q * s;
-    uint32_t v = 0;
+    uint32_t v = 0, mult = 0;
     bool bad = force_irregular != 0;
     for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
         const uint32_t x = p[e];
@@ -133,17 +140,29 @@ __global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restri
             bad = true;
         if (e > max_occ && p[e - max_occ - 1u] == x) // more equal values in one sketch than an item can number
             bad = true;
+        if (track_max && (e == 0 || p[e - 1] != x)) { // first copy of a value: how many are there?
+            uint32_t a = 1;
+            while (e + a < s && p[e + a] == x)
+                ++a;
+            mult = max(mult, a);
+        }
     }
     if (bad)
         flags[q] = 1;
     if (track_max) {
+        const int anybad = __syncthreads_or(bad ? 1 : 0); // an irregular sketch never enters the index
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1)
+        for (int d = 32; d >= 1; d >>= 1) {
             v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+            mult = max(mult, (uint32_t)__shfl_xor((int)mult, d, 64));
+        }
         // nearly every wave sees a maximum that is already recorded: read before the atomic
-        if ((threadIdx.x & 63) == 0 &&
-            v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&hdr[H_MAXVAL], v);
+        if ((threadIdx.x & 63) == 0) {
+            if (v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&hdr[H_MAXVAL], v);
+            if (!anybad && mult > __hip_atomic_load(&hdr[H_MAXMULT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMax(&hdr[H_MAXMULT], mult);
+        }
     }
 }
 
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
                                                        const uint8_t *__restrict__ flagsY, uint64_t ny,
                                                        uint32_t *__restrict__ irrX, uint32_t *__restrict__ regX,
                                                        uint32_t *__restrict__ irrY, uint32_t *__restrict__ hdr,
-                                                       uint32_t nbk_log2)
+                                                       uint32_t nbk_log2, int allow_compact)
 {
     const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (t < nx) {
@@ -166,7 +185,12 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
     if (t == 0) {
         const uint32_t mv = hdr[H_MAXVAL];
         const uint32_t bits = 32u - (uint32_t)__builtin_clz(mv | 1u);
-        hdr[H_SHIFT] = bits > nbk_log2 ? bits - nbk_log2 : 0u;
+        const uint32_t shift = bits > nbk_log2 ? bits - nbk_log2 : 0u;
+        hdr[H_SHIFT] = shift;
+        // compact items: the value's low bits and the occurrence number share 11 bits (the all-ones occurrence number
+        // stays free: it is the join's "no item" marker)
+        if (allow_compact >= 0)
+            hdr[H_FMT] = (allow_compact && shift <= 10u && hdr[H_MAXMULT] <= (1u << (11u - shift)) - 1u) ? 1u : 0u;
     }
 }
 
@@ -390,12 +414,16 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
 __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__ citems,
                                                       const uint32_t *__restrict__ cstart, uint32_t cfirst, uint32_t nc,
                                                       uint32_t fpc_log2, uint32_t *__restrict__ hdr,
-                                                      uint32_t *__restrict__ start, uint2 *__restrict__ items)
+                                                      uint32_t *__restrict__ start, uint2 *__restrict__ items,
+                                                      uint32_t id_bits, uint32_t ndw, uint32_t field_bits)
 {
     __shared__ uint32_t cnt[FPC_MAX];
     __shared__ uint32_t ws[4];
     const uint32_t fpc = 1u << fpc_log2;
     const uint32_t shift = hdr[H_SHIFT];
+    const bool compact = hdr[H_FMT] != 0u;
+    uint32_t *items32 = reinterpret_cast<uint32_t *>(items);
+    const uint32_t id_mask = (1u << id_bits) - 1u, low_mask = (1u << shift) - 1u, kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
     const int tid = threadIdx.x;
     unsigned long long sq = 0;
     for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) { // coarse buckets [cfirst, nc)
@@ -461,8 +489,16 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
                 at[u] = t0 + u * THREADS < hi ? atomicAdd(&cnt[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (t0 + u * THREADS < hi)
-                    items[at[u]] = it[u];
+                if (t0 + u * THREADS < hi) {
+                    if (compact) {
+                        const uint32_t col = it[u].y & id_mask, occ = it[u].y >> id_bits;
+                        const uint32_t k = __umulhi(col, kmul); // col / ndw (exact: see rowjoin_dense_kernel)
+                        const uint32_t hi_part = shift ? (((it[u].x & low_mask) << (32u - shift)) | (occ << CK_LOW)) : (occ << CK_LOW);
+                        items32[at[u]] = hi_part | ((col - k * ndw) << 5) | (k * field_bits);
+                    } else {
+                        items[at[u]] = it[u];
+                    }
+                }
         }
     }
 #pragma unroll
@@ -630,11 +666,11 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int BITS>
+template <int BITS, bool COMPACT>
 __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
                                                                const uint8_t *__restrict__ flagsX,
                                                                const uint32_t *__restrict__ start,
-                                                               const uint2 *__restrict__ items, uint32_t nbk,
+                                                               const void *__restrict__ items_v, uint32_t nbk,
                                                                const uint32_t *__restrict__ hdr,
                                                                const uint32_t *__restrict__ rows, uint64_t ny,
                                                                uint32_t stripe_dwords, uint32_t id_bits,
@@ -642,13 +678,20 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
 {
     if (hdr[H_MODE] != MODE_SPARSE)
         return;
+    if ((hdr[H_FMT] != 0u) != COMPACT) // the index says which item format it holds; the other instantiation has nothing to do
+        return;
     constexpr uint32_t PER = 32 / BITS, FMASK = (1u << BITS) - 1u;
+    // 8-byte items (value, id | occurrence number) or compact 4-byte ones (H_FMT)
+    typedef typename std::conditional<COMPACT, uint32_t, uint2>::type Item;
+    const Item *__restrict__ items = static_cast<const Item *>(items_v);
+    // the counters come FIRST: their LDS address is then the item's own byte offset plus a constant the instruction carries
     extern __shared__ __attribute__((aligned(16))) uint32_t dyn[];
-    uint32_t *xv = dyn, *dval = dyn + sx, *dmul = dyn + 2 * (size_t)sx, *dbeg = dyn + 3 * (size_t)sx,
-             *dend = dyn + 4 * (size_t)sx, *dense = dyn + ((5 * (size_t)sx + 3) & ~(size_t)3);
+    uint32_t *dense = dyn, *xv = dyn + stripe_dwords, *dval = xv + sx, *dmul = xv + 2 * (size_t)sx, *dbeg = xv + 3 * (size_t)sx,
+             *dend = xv + 4 * (size_t)sx;
     __shared__ uint32_t ndist;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t shift = hdr[H_SHIFT], id_mask = (1u << id_bits) - 1u;
+    const uint32_t low_mask = (1u << shift) - 1u, occ_cap = (1u << (11u - (COMPACT ? shift : 0u))) - 1u; // compact: shift <= 10
     const uint64_t nrows = rows ? hdr[H_NOVF] : nx;
     const uint32_t stripe_cols = stripe_dwords * PER;
     const bool one_stripe = ny <= stripe_cols;
@@ -752,7 +795,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             // k = col / ndw by one multiply-high: kmul = ceil(2^32 / ndw) is exact for col < PER * ndw while PER * ndw^2 < 2^32
             // (the host caps the stripe accordingly)
             const uint32_t kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
-            auto consume = [&](const uint2 it, uint32_t v, uint32_t alim) {
+            auto consume_wide = [&](const uint2 it, uint32_t v, uint32_t alim) {
                 // alim = multiplicity << id_bits: "occurrence number < multiplicity" is one compare of the whole word
                 // ((0, 0xFFFFFFFF) = no item fails it)
                 if (it.x != v || it.y >= alim)
@@ -766,6 +809,24 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 const uint32_t k = __umulhi(col, kmul);
                 atomicAdd(&dense[col - k * ndw], 1u << (BITS * k));
             };
+            // compact: key = the row value's low bits in the item's top field, alim = multiplicity << CK_LOW; "same value
+            // and occurrence number < multiplicity" is ONE subtract and ONE compare (an item of another value wraps or
+            // overshoots; 0xFFFFFFFF = no item fails too), the counter's byte offset and field shift are in the item
+            auto consume_compact = [&](const uint32_t it, uint32_t key, uint32_t alim) {
+                if (it - key < alim)
+                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dense) + ((it >> 3) & 0x3FFFCu)), 1u << (it & 31u));
+            };
+            auto consume = [&](const Item it, uint32_t v, uint32_t alim) {
+                if constexpr (COMPACT)
+                    consume_compact(it, v, alim);
+                else
+                    consume_wide(it, v, alim);
+            };
+            Item none;
+            if constexpr (COMPACT)
+                none = 0xFFFFFFFFu;
+            else
+                none = make_uint2(0u, 0xFFFFFFFFu);
             // Wave w owns the distinct values w, w + 16, w + 32, ...: lane l keeps the descriptor of the wave's l-th one
             // in registers (one LDS pass per 64 buckets) and the walk takes them from there by v_readlane -- bucket
             // bounds, value and multiplicity are scalars, no LDS round trip stands between two buckets.  DENSE_U
@@ -778,19 +839,24 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 if (mine < nd) {
                     const uint32_t a = dmul[mine];
                     mval = dval[mine];
-                    mlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
+                    if (COMPACT) {
+                        mval = shift ? (mval & low_mask) << (32u - shift) : 0u;
+                        mlim = min(a, occ_cap) << CK_LOW;
+                    } else {
+                        mlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
+                    }
                     mbeg = dbeg[mine];
                     mend = dend[mine];
                 }
                 const uint32_t cnt = min(64u, (nd - wave - NW * jb + NW - 1) / NW); // my buckets in this chunk
                 for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
-                    uint2 it[DENSE_U][2];
+                    Item it[DENSE_U][2];
                     uint32_t beg[DENSE_U], end[DENSE_U];
 #pragma unroll
                     for (int u = 0; u < DENSE_U; ++u) {
                         beg[u] = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
                         end[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u));
-                        it[u][0] = it[u][1] = make_uint2(0u, 0xFFFFFFFFu);
+                        it[u][0] = it[u][1] = none;
                         const uint32_t t = beg[u] + lane;
                         if (t < end[u])
                             it[u][0] = items[t];
@@ -1044,12 +1110,48 @@ static __global__ void reset_x_kernel(uint32_t *__restrict__ hdr)
     hdr[k2::H_MODE] = k2::MODE_SPARSE;
 }
 
+// dense join geometry: counter width from the largest possible count, stripe from what LDS holds next to the row
+struct DenseGeom {
+    int bits;
+    uint32_t per, stripe_dwords, ndw; // ndw: counter dwords of a one-stripe join over all ny columns
+    uint64_t stripe_cols, stripes;
+    size_t row_bytes;
+    bool force;      // every pair through the merge (ids beyond 24 bits, X rows beyond the LDS stage)
+    bool dense_all;  // the dense join takes every regular row
+    bool compact_ok; // ... in one stripe whose counter addresses fit a compact item
+};
+static DenseGeom dense_geom(uint32_t sx, uint32_t sy, uint64_t ny)
+{
+    DenseGeom g;
+    g.force = ny > (1ull << k2::ID_BITS_MAX) || sx > k2::S_MAX;
+    g.bits = std::min(sx, sy) <= 1023u ? 10 : 16;
+    g.per = 32u / (uint32_t)g.bits;
+    g.row_bytes = (((size_t)5 * sx + 3) & ~(size_t)3) * 4;
+    const size_t lds_max = 160 * 1024 - 256;
+    // <= 37832 dwords with three fields (the kernel's multiply-high `column / ndw` is exact for 3 * ndw^2 < 2^32)
+    const size_t sdw_cap = g.per == 3 ? 37832u : 46328u;
+    g.stripe_dwords =
+        g.row_bytes + 4096 <= lds_max ? (uint32_t)std::min<size_t>(((lds_max - g.row_bytes) / 4) & ~(size_t)7, sdw_cap) : 0u;
+    g.stripe_cols = (uint64_t)g.stripe_dwords * g.per;
+    g.stripes = g.stripe_cols ? (ny + g.stripe_cols - 1) / g.stripe_cols : ~0ull;
+    g.ndw = (uint32_t)std::min<uint64_t>((((ny + g.per - 1) / g.per) + 7) & ~7ull, 0xFFFFFFFFull);
+    // Up to two stripes the dense join takes EVERY regular row: it reads each bucket at most twice, bumps one LDS counter
+    // per shared hash and writes the row's counts once, zeros included -- no zero-fill of the matrix, no hash probing.
+    // Beyond that (hundreds of thousands of columns) rows go through the sparse join first and only the ones whose
+    // table overflows come here.  POLYHIP_K2_DENSE=0 keeps the sparse join in front, POLYHIP_K2_COMPACT=0 the 8-byte
+    // items (testing aids).
+    g.dense_all = !g.force && g.stripes <= 2 && !env_is("POLYHIP_K2_DENSE", '0');
+    g.compact_ok = g.dense_all && g.stripes == 1 && g.ndw < 65536u && !env_is("POLYHIP_K2_COMPACT", '0');
+    return g;
+}
+
 // what: 1 = build the index of Y, 2 = join X against the index in the workspace, 3 = both
 static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
                               uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
                               polyhip_stream_t stream, uint32_t part = 0, uint32_t nparts = 1)
 {
-    const bool build = what & 1, join = what & 2;
+    bool build = what & 1;
+    const bool join = what & 2;
     if ((join && sx == 0) || sy == 0)
         return set_error(POLYHIP_ERR_PANIC,
                          "mash.Similarity with SketchSize 0 indexes Sketches[-1] (mash.go:117): the reference panics");
@@ -1079,10 +1181,23 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
 
     // the join packs the Y sketch id into 24 bits and stages an X row in LDS
     const int force = (ny > (1ull << k2::ID_BITS_MAX) || sx > k2::S_MAX) ? 1 : 0;
+    (void)stripe_sketches;
     uint32_t id_bits = 1; // bits of a Y sketch id; the rest of an item's second dword numbers the copies of a value
     while ((1ull << id_bits) < ny && id_bits < k2::ID_BITS_MAX)
         ++id_bits;
     const uint32_t max_occ = (1u << (32 - id_bits)) - 2u; // all-ones stays free (the join's "no item" marker)
+
+    // Item format.  An index built on its own assumes that the X sets to come have Y's SketchSize (an all-vs-all, a
+    // database of one sketch size); built together with a join it takes that join's geometry.  If a later join does not
+    // fit what the build assumed (another counter width, more than one stripe), the index is rebuilt with 8-byte items
+    // first -- correct, at the price of a build.
+    const DenseGeom gJ = dense_geom(join ? sx : sy, sy, ny), gY = dense_geom(sy, sy, ny);
+    bool allow_compact = (join && build) ? gJ.compact_ok : gY.compact_ok;
+    if (join && !build && gY.compact_ok && !(gJ.compact_ok && gJ.bits == gY.bits)) {
+        build = true;
+        allow_compact = false;
+    }
+    const DenseGeom &gB = (join && (what & 1)) ? gJ : gY; // the geometry compact items are made for
 
     if (build) {
         // header, Y flags and the histogram start at zero
@@ -1091,7 +1206,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         hipLaunchKernelGGL(k2::check_kernel, dim3((unsigned)ny), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1,
                            max_occ);
         hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
-                           flagsX, (uint64_t)0, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2);
+                           flagsX, (uint64_t)0, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2, allow_compact ? 1 : 0);
         // ---- inverted index of the Y side: two-level partition by value
         const uint32_t per_batch = std::max<uint32_t>(1u, k2::BATCH_ITEMS / sy);
         const unsigned batches = (unsigned)((ny + per_batch - 1) / per_batch);
@@ -1123,7 +1238,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         }
         if (c1 > c0)
             hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::THREADS), 0, st, citems,
-                               cstart, c0, c1, L.fpc_log2, hdr, start, items);
+                               cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
         PH_HIP(hipGetLastError());
     }
     if (!join)
@@ -1136,7 +1251,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     hipLaunchKernelGGL(k2::check_kernel, dim3((unsigned)nx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0,
                        0xFFFFFFFEu);
     hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nx + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
-                       flagsX, nx, flagsY, (uint64_t)0, irrX, regX, irrY, hdr, L.nbk_log2);
+                       flagsX, nx, flagsY, (uint64_t)0, irrX, regX, irrY, hdr, L.nbk_log2, -1);
     // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
     // value with its whole bucket: about (nx*sx/(ny*sy)) * sum_b cntY_b^2 compares when X is
     // distributed like Y (exact for the all-vs-all).  The join only loses on huge buckets.
@@ -1144,37 +1259,35 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     const double generic_cost = (double)nx * (double)ny * (double)(sx + sy) * 4.0;
     hipLaunchKernelGGL(k2::decide_kernel, dim3(1), dim3(1), 0, st, hdr, est_scale, generic_cost);
 
-    // dense join geometry: counter width from the largest possible count, stripe from what LDS holds next to the row
-    const int bits = std::min(sx, sy) <= 1023u ? 10 : 16;
-    const uint32_t per = 32u / (uint32_t)bits;
-    const size_t row_bytes = (((size_t)5 * sx + 3) & ~(size_t)3) * 4, lds_max = 160 * 1024 - 256;
-    // <= 37832 dwords with three fields (the kernel's multiply-high `column / ndw` is exact for 3 * ndw^2 < 2^32)
-    const size_t sdw_cap = per == 3 ? 37832u : 46328u;
-    const uint32_t stripe_dwords =
-        row_bytes + 4096 <= lds_max ? (uint32_t)std::min<size_t>(((lds_max - row_bytes) / 4) & ~(size_t)7, sdw_cap) : 0u;
-    const uint64_t stripe_cols = (uint64_t)stripe_dwords * per;
-    const uint64_t stripes = stripe_cols ? (ny + stripe_cols - 1) / stripe_cols : ~0ull;
+    const int bits = gJ.bits;
+    const uint32_t per = gJ.per, stripe_dwords = gJ.stripe_dwords;
+    const size_t row_bytes = gJ.row_bytes;
+    const uint64_t stripe_cols = gJ.stripe_cols;
     auto launch_dense = [&](const uint32_t *rows, unsigned blocks) -> int {
         const uint32_t sdw = (uint32_t)std::min<uint64_t>(stripe_dwords, (((ny + per - 1) / per) + 7) & ~7ull);
         const size_t smem = row_bytes + (size_t)sdw * 4;
+#define PH_K2_DENSE_LAUNCH(BITS_, COMPACT_)                                                                                   \
+    do {                                                                                                                      \
+        auto kern = k2::rowjoin_dense_kernel<BITS_, COMPACT_>;                                                                \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX, start,                 \
+                           static_cast<const void *>(items), L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);               \
+    } while (0)
+        // both item formats are launched when the index MAY be compact: the device decided (H_FMT), the instantiation
+        // that does not match returns at once
         if (bits == 10) {
-            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<10>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k2::rowjoin_dense_kernel<10>, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX,
-                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);
+            PH_K2_DENSE_LAUNCH(10, false);
+            if (allow_compact && rows == nullptr)
+                PH_K2_DENSE_LAUNCH(10, true);
         } else {
-            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::rowjoin_dense_kernel<16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k2::rowjoin_dense_kernel<16>, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX,
-                               start, items, L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);
+            PH_K2_DENSE_LAUNCH(16, false);
+            if (allow_compact && rows == nullptr)
+                PH_K2_DENSE_LAUNCH(16, true);
         }
+#undef PH_K2_DENSE_LAUNCH
         return POLYHIP_OK;
     };
-    // Up to two stripes the dense join takes EVERY regular row: it reads each bucket at most twice, bumps one LDS counter
-    // per shared hash and writes the row's counts once, zeros included -- no zero-fill of the matrix, no hash probing.
-    // Beyond that (hundreds of thousands of columns) rows go through the sparse join first and only the ones whose
-    // table overflows come here.  POLYHIP_K2_DENSE=0 keeps the sparse join in front (testing aid).
-    const bool dense_all = !force && stripes <= 2 && !env_is("POLYHIP_K2_DENSE", '0');
+    const bool dense_all = gJ.dense_all;
     int ovf_done = 0;
     if (dense_all) {
         if (int rc = launch_dense(nullptr, (unsigned)std::min<uint64_t>(nx, 256ull)))
@@ -1253,13 +1366,25 @@ int polyhip_mash_index_part_spans(uint64_t ny, uint32_t sy, uint32_t nparts, con
     PH_REQUIRE(work_bytes >= L.off_flagsX, "polyhip_mash_index_part_spans: workspace too small");
     const uint8_t *w = static_cast<const uint8_t *>(d_work);
     std::vector<uint32_t> hc(L.nc + 1), b(nparts + 1);
+    uint32_t h[k2::H_WORDS];
     PH_HIP(hipMemcpyAsync(hc.data(), w + L.off_cstart, (size_t)(L.nc + 1) * 4, hipMemcpyDeviceToHost, as_stream(stream)));
+    PH_HIP(hipMemcpyAsync(h, w, sizeof h, hipMemcpyDeviceToHost, as_stream(stream)));
     PH_HIP(hipStreamSynchronize(as_stream(stream)));
     k2::part_bounds(hc.data(), L.nc, nparts, b.data());
+    const uint64_t item_bytes = h[k2::H_FMT] ? 4 : 8; // compact items are half the size (and half the all-gather)
     for (uint32_t p = 0; p <= nparts; ++p) {
-        item_spans[p] = L.off_items + (uint64_t)hc[b[p]] * 8;
+        item_spans[p] = L.off_items + (uint64_t)hc[b[p]] * item_bytes;
         start_spans[p] = L.off_start + ((uint64_t)b[p] << L.fpc_log2) * 4;
     }
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_index_format_dev(const void *d_work, uint32_t *item_bytes)
+{
+    PH_REQUIRE(d_work && item_bytes, "polyhip_mash_index_format: null pointer");
+    uint32_t h[k2::H_WORDS];
+    PH_HIP(hipMemcpy(h, d_work, sizeof h, hipMemcpyDeviceToHost));
+    *item_bytes = h[k2::H_FMT] ? 4u : 8u;
     return POLYHIP_OK;
 }
 

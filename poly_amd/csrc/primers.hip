@@ -364,10 +364,10 @@ using namespace polyhip;
 
 static int validate_ascii(const uint8_t *p, uint64_t n, const char *who)
 {
-    for (uint64_t i = 0; i < n; ++i)
-        if (p[i] >= 0x80)
-            return set_error(POLYHIP_ERR_INVALID, "%s: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
-                             who, p[i], (unsigned long long)i);
+    const uint64_t i = first_non_ascii(p, n);
+    if (i < n)
+        return set_error(POLYHIP_ERR_INVALID, "%s: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)", who, p[i],
+                         (unsigned long long)i);
     return POLYHIP_OK;
 }
 

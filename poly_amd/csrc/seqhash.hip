@@ -578,9 +578,11 @@ int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t
         max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
     }
     const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
-    for (uint64_t i = 0; i < nbytes; ++i)
-        PH_REQUIRE(seqs[b0 + i] < 0x80, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
-                   seqs[b0 + i], (unsigned long long)i);
+    {
+        const uint64_t i = first_non_ascii(seqs + b0, nbytes);
+        PH_REQUIRE(i == nbytes, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)", seqs[b0 + i],
+                   (unsigned long long)i);
+    }
     // chunks of ~64 MB through two slots on the calling thread's two streams: chunk c is uploaded and hashed while the
     // seqhashes of chunk c-1 travel back
     HostStreams &hs = host_streams();

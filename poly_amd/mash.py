@@ -176,6 +176,14 @@ def index_part_spans(ny: int, sy: int, nparts: int, work_t, stream=None):
     return it, st
 
 
+def index_item_bytes(work_t) -> int:
+    """8 (value, id | occurrence) or 4 (compact: the item carries the LDS counter it bumps) -- polyhip_mash_index_format_dev"""
+    import ctypes as C
+    b = C.c_uint32()
+    _lib.check(_lib.lib().polyhip_mash_index_format_dev(work_t.data_ptr(), C.addressof(b)))
+    return int(b.value)
+
+
 def index_finalize_dev(ny: int, sy: int, work_t, stream=None) -> None:
     _lib.check(_lib.lib().polyhip_mash_index_finalize_dev(ny, sy, work_t.data_ptr(),
                                                           work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))

@@ -21,17 +21,19 @@ def mash():
     return mash
 
 
-@pytest.fixture(autouse=True, params=["dense", "sparse"])
+@pytest.fixture(autouse=True, params=["dense", "sparse", "wide"])
 def join_kind(request, monkeypatch):
     """every test runs twice: with the dense join in front (a counter per column in LDS; the default up to two
     stripes of columns; index built with the LDS-staged level-1 scatter) and with POLYHIP_K2_DENSE=0 (sparse LDS hash
     join, dense join only for overflowing rows) + POLYHIP_K2_STAGE=0 (the index's direct level-1 scatter)"""
+    monkeypatch.delenv("POLYHIP_K2_DENSE", raising=False)
+    monkeypatch.delenv("POLYHIP_K2_STAGE", raising=False)
+    monkeypatch.delenv("POLYHIP_K2_COMPACT", raising=False)
     if request.param == "sparse":
         monkeypatch.setenv("POLYHIP_K2_DENSE", "0")
         monkeypatch.setenv("POLYHIP_K2_STAGE", "0")
-    else:
-        monkeypatch.delenv("POLYHIP_K2_DENSE", raising=False)
-        monkeypatch.delenv("POLYHIP_K2_STAGE", raising=False)
+    elif request.param == "wide":   # the dense join on 8-byte items (the default picks compact 4-byte items where they fit)
+        monkeypatch.setenv("POLYHIP_K2_COMPACT", "0")
     return request.param
 
 
@@ -230,6 +232,85 @@ def test_column_stripes_beyond_one_index(mash, monkeypatch):
     monkeypatch.delenv("POLYHIP_K2_MAX_ITEMS")
     small = mash.shared_counts_workspace_bytes(35, 150, 16, 150)
     assert work.numel() == small    # the workspace is sized for a stripe, not for the whole set
+
+
+def _small_valued_families(rng, nfam, copies, s, bits=19, sub=0.1):
+    """related ascending sketches whose hashes stay below 2^bits: a few thousand of them already have fine buckets (the
+    value's bits below its bucket are few), which is what lets a SMALL test reach the compact item format"""
+    out = []
+    for _ in range(nfam):
+        base = rng.choice(1 << bits, s, replace=False).astype(np.uint32)
+        for _ in range(copies):
+            m = base.copy()
+            hit = rng.random(s) < sub
+            m[hit] = rng.integers(0, 1 << bits, int(hit.sum()), dtype=np.uint32)
+            m.sort()
+            out.append(m)
+    return np.stack(out)
+
+
+def test_compact_items_where_they_fit_and_a_rebuild_where_not(mash, join_kind):
+    """The index build picks 4-byte items on the device when the join to come is the one-stripe dense join and the bits
+    fit; a hash repeated many times inside one sketch, or a later join with another counter width, gets 8-byte items
+    (the latter by a silent rebuild) -- same counts either way"""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(33)
+    S = _small_valued_families(rng, 12, 10, 300)
+    St = torch.from_numpy(S.view(np.int32)).to(dev)
+    N = len(S)
+    work = torch.zeros(mash.shared_counts_workspace_bytes(N, 1200, N, 300), dtype=torch.uint8, device=dev)
+    mash.index_build_dev(St, work)
+    torch.cuda.synchronize()
+    assert mash.index_item_bytes(work) == (4 if join_kind == "dense" else 8)
+    ct = torch.zeros((N, N), dtype=torch.int16, device=dev)
+    mash.shared_counts_reuse_dev(St, St, ct, work)
+    torch.cuda.synchronize()
+    assert (ct.cpu().numpy().view(np.uint16) == _oracle_counts(S, S)).all()
+    # X of SketchSize 1200 against the same index: the counts cannot pass 300, same 10-bit counters -> the index stays
+    X = np.sort(np.concatenate([S[:20], rng.integers(0, 1 << 19, (20, 900), dtype=np.uint32)], axis=1), axis=1)
+    Xt = torch.from_numpy(X.view(np.int32)).to(dev)
+    cx = torch.zeros((20, N), dtype=torch.int16, device=dev)
+    mash.shared_counts_reuse_dev(Xt, St, cx, work)
+    torch.cuda.synchronize()
+    assert mash.index_item_bytes(work) == (4 if join_kind == "dense" else 8)
+    assert (cx.cpu().numpy().view(np.uint16) == _oracle_counts(X, S)).all()
+    # an index of 1100-hash sketches assumes 16-bit counters; X sketches of 300 hashes need 10-bit ones: not what the
+    # build assumed -> rebuilt with 8-byte items, still right
+    Y = _small_valued_families(rng, 6, 5, 1100)
+    Yt = torch.from_numpy(Y.view(np.int32)).to(dev)
+    wY = torch.zeros(mash.shared_counts_workspace_bytes(N, 300, len(Y), 1100), dtype=torch.uint8, device=dev)
+    mash.index_build_dev(Yt, wY)
+    torch.cuda.synchronize()
+    assert mash.index_item_bytes(wY) == (4 if join_kind == "dense" else 8)
+    cyy = torch.zeros((len(Y), len(Y)), dtype=torch.int16, device=dev)
+    mash.shared_counts_reuse_dev(Yt, Yt, cyy, wY)          # 16-bit counters, compact items
+    torch.cuda.synchronize()
+    assert (cyy.cpu().numpy().view(np.uint16) == _oracle_counts(Y, Y)).all()
+    cy = torch.zeros((N, len(Y)), dtype=torch.int16, device=dev)
+    mash.shared_counts_reuse_dev(St, Yt, cy, wY)
+    torch.cuda.synchronize()
+    assert mash.index_item_bytes(wY) == 8
+    assert (cy.cpu().numpy().view(np.uint16) == _oracle_counts(S, Y)).all()
+    # a sketch that repeats one hash 200 times: occurrence numbers beyond what a compact item holds -> 8-byte items
+    S2 = S.copy()
+    S2[7, :200] = S2[7, 0]
+    S2[8, :150] = S2[7, 0]
+    S2t = torch.from_numpy(S2.view(np.int32)).to(dev)
+    mash.shared_counts_dev(S2t, S2t, ct, work)
+    torch.cuda.synchronize()
+    assert mash.index_item_bytes(work) == 8
+    assert (ct.cpu().numpy().view(np.uint16) == _oracle_counts(S2, S2)).all()
+    # a few copies (what the 11 - shift bits number) stay compact
+    S3 = S.copy()
+    S3[7, :3] = S3[7, 0]
+    S3[8, :2] = S3[7, 0]
+    S3.sort(axis=1)
+    S3t = torch.from_numpy(S3.view(np.int32)).to(dev)
+    mash.shared_counts_dev(S3t, S3t, ct, work)
+    torch.cuda.synchronize()
+    assert mash.index_item_bytes(work) == (4 if join_kind == "dense" else 8)
+    assert (ct.cpu().numpy().view(np.uint16) == _oracle_counts(S3, S3)).all()
 
 
 def test_c_abi_allgather_one_rank(mash):
