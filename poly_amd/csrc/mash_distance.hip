@@ -70,8 +70,9 @@ enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_MAXMU
 // H_FMT: 0 = 8-byte items (value, sketch id | occurrence number << id_bits); 1 = COMPACT 4-byte items, written when the
 // join is known to be the one-stripe dense join and the bits fit (decided on the device, lists_kernel):
 //     [ value's bits below the bucket : shift | occurrence number : 11 - shift | counter dword : 16 | field shift : 5 ]
-// -- the LDS counter a shared hash bumps (dword = column % ndw, field = column / ndw) is worked out ONCE, when the index is
-// built, instead of once per visit: the join's inner step becomes subtract, compare, shift, shift, and, ds_add.
+// (occurrence number stored + 1, so that the all-zero word is "no item") -- the LDS counter a shared hash bumps (dword =
+// column % ndw, field = column / ndw) is worked out ONCE, when the index is built, instead of once per visit: the join's
+// inner step becomes subtract, compare, shift, shift, and, ds_add, and its loads are buffer loads bounded by the bucket.
 constexpr uint32_t CK_LOW = 21; // bits below the occurrence number
 enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
 
@@ -174,21 +175,29 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
                                                        uint32_t nbk_log2, int allow_compact)
 {
     const uint64_t t = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    if (t < nx) {
-        if (flagsX[t])
-            irrX[atomicAdd(&hdr[H_NIRRX], 1u)] = (uint32_t)t;
-        else
-            regX[atomicAdd(&hdr[H_NREGX], 1u)] = (uint32_t)t;
-    }
-    if (t < ny && flagsY[t])
-        irrY[atomicAdd(&hdr[H_NIRRY], 1u)] = (uint32_t)t;
+    // one atomic per wave and list, not one per sketch: 100k increments of one word took as long as the join of 600 rows
+    auto append = [&](bool mine, uint32_t *counter, uint32_t *list) {
+        const uint64_t m = __ballot(mine);
+        if (m == 0ull)
+            return;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m))
+            base = atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (mine)
+            list[base + (uint32_t)__builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] = (uint32_t)t;
+    };
+    const bool inX = t < nx, badX = inX && flagsX[t] != 0;
+    append(badX, &hdr[H_NIRRX], irrX);
+    append(inX && !badX, &hdr[H_NREGX], regX);
+    append(t < ny && flagsY[t] != 0, &hdr[H_NIRRY], irrY);
     if (t == 0) {
         const uint32_t mv = hdr[H_MAXVAL];
         const uint32_t bits = 32u - (uint32_t)__builtin_clz(mv | 1u);
         const uint32_t shift = bits > nbk_log2 ? bits - nbk_log2 : 0u;
         hdr[H_SHIFT] = shift;
-        // compact items: the value's low bits and the occurrence number share 11 bits (the all-ones occurrence number
-        // stays free: it is the join's "no item" marker)
+        // compact items: the value's low bits and the occurrence number + 1 share 11 bits (the all-zero word is the join's
+        // "no item": what a buffer load returns beyond the end of a bucket)
         if (allow_compact >= 0)
             hdr[H_FMT] = (allow_compact && shift <= 10u && hdr[H_MAXMULT] <= (1u << (11u - shift)) - 1u) ? 1u : 0u;
     }
@@ -493,7 +502,10 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
                     if (compact) {
                         const uint32_t col = it[u].y & id_mask, occ = it[u].y >> id_bits;
                         const uint32_t k = __umulhi(col, kmul); // col / ndw (exact: see rowjoin_dense_kernel)
-                        const uint32_t hi_part = shift ? (((it[u].x & low_mask) << (32u - shift)) | (occ << CK_LOW)) : (occ << CK_LOW);
+                        // occurrence number + 1: an all-zero word is then no item at all -- what a buffer load returns
+                        // beyond the end of a bucket, so the join needs no bounds test
+                        const uint32_t occ1 = (occ + 1u) << CK_LOW;
+                        const uint32_t hi_part = shift ? (((it[u].x & low_mask) << (32u - shift)) | occ1) : occ1;
                         items32[at[u]] = hi_part | ((col - k * ndw) << 5) | (k * field_bits);
                     } else {
                         items[at[u]] = it[u];
@@ -811,22 +823,11 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             };
             // compact: key = the row value's low bits in the item's top field, alim = multiplicity << CK_LOW; "same value
             // and occurrence number < multiplicity" is ONE subtract and ONE compare (an item of another value wraps or
-            // overshoots; 0xFFFFFFFF = no item fails too), the counter's byte offset and field shift are in the item
+            // overshoots; the all-zero word = no item fails too), the counter's byte offset and field shift are in the item
             auto consume_compact = [&](const uint32_t it, uint32_t key, uint32_t alim) {
                 if (it - key < alim)
                     atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dense) + ((it >> 3) & 0x3FFFCu)), 1u << (it & 31u));
             };
-            auto consume = [&](const Item it, uint32_t v, uint32_t alim) {
-                if constexpr (COMPACT)
-                    consume_compact(it, v, alim);
-                else
-                    consume_wide(it, v, alim);
-            };
-            Item none;
-            if constexpr (COMPACT)
-                none = 0xFFFFFFFFu;
-            else
-                none = make_uint2(0u, 0xFFFFFFFFu);
             // Wave w owns the distinct values w, w + 16, w + 32, ...: lane l keeps the descriptor of the wave's l-th one
             // in registers (one LDS pass per 64 buckets) and the walk takes them from there by v_readlane -- bucket
             // bounds, value and multiplicity are scalars, no LDS round trip stands between two buckets.  DENSE_U
@@ -840,7 +841,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                     const uint32_t a = dmul[mine];
                     mval = dval[mine];
                     if (COMPACT) {
-                        mval = shift ? (mval & low_mask) << (32u - shift) : 0u;
+                        // key = the value's low bits in the item's top field, + 1 in the occurrence field (items store
+                        // occurrence + 1); multiplicity capped at what the field numbers
+                        mval = (shift ? (mval & low_mask) << (32u - shift) : 0u) + (1u << CK_LOW);
                         mlim = min(a, occ_cap) << CK_LOW;
                     } else {
                         mlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
@@ -849,29 +852,59 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                     mend = dend[mine];
                 }
                 const uint32_t cnt = min(64u, (nd - wave - NW * jb + NW - 1) / NW); // my buckets in this chunk
-                for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
-                    Item it[DENSE_U][2];
-                    uint32_t beg[DENSE_U], end[DENSE_U];
+                if constexpr (COMPACT) {
+                    // Buffer loads: a bucket is its own little buffer (base and size are scalars built on the scalar
+                    // unit), every lane reads at the constant offset 4 * lane, and a lane beyond the bucket's end gets 0 =
+                    // no item -- no address arithmetic, no bounds compare, no select on the vector unit.
+                    const uint32_t lane4 = (uint32_t)lane * 4u;
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
+                        uint32_t it[DENSE_U][2], len[DENSE_U];
+                        __amdgpu_buffer_rsrc_t rs[DENSE_U];
 #pragma unroll
-                    for (int u = 0; u < DENSE_U; ++u) {
-                        beg[u] = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
-                        end[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u));
-                        it[u][0] = it[u][1] = none;
-                        const uint32_t t = beg[u] + lane;
-                        if (t < end[u])
-                            it[u][0] = items[t];
-                        if (t + 64 < end[u])
-                            it[u][1] = items[t + 64];
+                        for (int u = 0; u < DENSE_U; ++u) {
+                            const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
+                            len[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u)) - b;
+                            rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(items + b), 0, (int)(len[u] * 4u), 0x00020000);
+                            it[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 0, 0);
+                            it[u][1] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 256, 0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < DENSE_U; ++u) {
+                            const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
+                            const uint32_t alim = (uint32_t)__builtin_amdgcn_readlane((int)mlim, (int)(j0 + u));
+                            consume_compact(it[u][0], key, alim);
+                            if (len[u] > 64u) { // wave-uniform
+                                consume_compact(it[u][1], key, alim);
+                                for (uint32_t t = 128; t < len[u]; t += 64) // rest of a long bucket
+                                    consume_compact(__builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, (int)(t * 4u), 0), key, alim);
+                            }
+                        }
                     }
+                } else {
+                    for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
+                        uint2 it[DENSE_U][2];
+                        uint32_t beg[DENSE_U], end[DENSE_U];
 #pragma unroll
-                    for (int u = 0; u < DENSE_U; ++u) {
-                        const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
-                        const uint32_t alim = (uint32_t)__builtin_amdgcn_readlane((int)mlim, (int)(j0 + u));
-                        consume(it[u][0], v, alim);
-                        if (end[u] - beg[u] > 64u) { // wave-uniform
-                            consume(it[u][1], v, alim);
-                            for (uint32_t t = beg[u] + 128 + lane; t < end[u]; t += 64) // rest of a long bucket
-                                consume(items[t], v, alim);
+                        for (int u = 0; u < DENSE_U; ++u) {
+                            beg[u] = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
+                            end[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u));
+                            it[u][0] = it[u][1] = make_uint2(0u, 0xFFFFFFFFu);
+                            const uint32_t t = beg[u] + lane;
+                            if (t < end[u])
+                                it[u][0] = items[t];
+                            if (t + 64 < end[u])
+                                it[u][1] = items[t + 64];
+                        }
+#pragma unroll
+                        for (int u = 0; u < DENSE_U; ++u) {
+                            const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
+                            const uint32_t alim = (uint32_t)__builtin_amdgcn_readlane((int)mlim, (int)(j0 + u));
+                            consume_wide(it[u][0], v, alim);
+                            if (end[u] - beg[u] > 64u) { // wave-uniform
+                                consume_wide(it[u][1], v, alim);
+                                for (uint32_t t = beg[u] + 128 + lane; t < end[u]; t += 64) // rest of a long bucket
+                                    consume_wide(items[t], v, alim);
+                            }
                         }
                     }
                 }
@@ -880,6 +913,41 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             // flush the stripe whole, zeros included: field k of dwords [0, ndw) = columns [k * ndw, (k + 1) * ndw)
             uint16_t *crow = counts + i * ld + c0;
             const uint32_t al = (uint32_t)(((uintptr_t)crow) & 15u);
+            if (al == 0) {
+                // aligned rows (every row of a matrix whose stride is a multiple of 8): ONE pass -- a thread reads eight
+                // counter dwords once, clears them, and sends each of their PER fields to its own run of eight columns
+                // (field k = columns [k * ndw, (k + 1) * ndw), k * ndw a multiple of 8: all stores 16-byte aligned)
+                typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+                for (uint32_t t = tid * 8; t < ndw; t += DENSE_THREADS * 8) {
+                    const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
+                    const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
+                    *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4 *>(dense + t + 4) = make_uint4(0, 0, 0, 0);
+                    const uint32_t d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                    for (uint32_t k = 0; k < PER; ++k) {
+                        const uint32_t cb = k * ndw;
+                        if (cb + t >= ncols)
+                            break;
+                        uint32_t f[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            f[q] = (d[q] >> (BITS * k)) & FMASK;
+                        if (cb + t + 8 <= ncols) {
+                            // written once, never read here: nontemporal, so the 2 B per pair do not push the index out of L2
+                            const u32x4_t o = {f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16)};
+                            __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(crow + cb + t));
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q)
+                                if (cb + t + q < ncols)
+                                    crow[cb + t + q] = (uint16_t)f[q];
+                        }
+                    }
+                }
+                lds_barrier();
+                continue;
+            }
 #pragma unroll
             for (uint32_t k = 0; k < PER; ++k) {
                 const uint32_t cb = k * ndw; // a multiple of 8: crow + cb keeps crow's alignment
@@ -890,7 +958,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 // every pass: no barrier needed in between)
                 const bool last = cb + ndw >= ncols;
                 const uint32_t lim = last ? ndw : n;
-                if (al == 0) { // eight columns per 16-byte store
+                if (al == 0) { // eight columns per 16-byte store (kept for reference: aligned rows take the single pass above)
                     for (uint32_t t = tid * 8; t < lim; t += DENSE_THREADS * 8) {
                         const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
                         const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
