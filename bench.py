@@ -222,6 +222,29 @@ def cpu_baseline_extra():
     return out
 
 
+def valu_issue_ceiling(kmers_per_s: float) -> dict:
+    """K1's VALU-issue ceiling: instructions per k-mer from the SQ_INSTS_VALU counter (profiles/k1_issue.json), times the
+    average issue cost of the kernel's own instruction mix -- its disassembly histogram priced with the two measured issue
+    classes, 2 cycles for plain add/sub/and/or/xor/lshr, 4 for everything else (scripts/valu_mix.py ->
+    profiles/r03_valu_mix.json) -- at the clock the kernel actually sustains (SQ_BUSY_CYCLES / duration of the same counter
+    pass: a VALU-dense kernel does not hold the 2.4 GHz peak clock).  None of it is measured by this run; `source` says so."""
+    try:
+        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))
+        cyc = mix["kernels"]["K1 polyhip::k1::sketch_slab_kernel<21>"]["cycles_per_valu_instruction"]
+        ki = json.load(open(os.path.join(ROOT, "profiles", "k1_issue.json")))
+        ipk, clock = ki["valu_instructions_per_kmer"], ki["clock_GHz"] * 1e9
+    except Exception as e:  # the line must not die with a missing profile
+        return {"error": f"{type(e).__name__}: {e}"}
+    ceiling = 1024 * clock * 64 / (ipk * cyc)
+    return {"instructions_per_kmer": ipk, "cycles_per_instruction": cyc, "clock_GHz": clock / 1e9, "simds": 1024,
+            "ceiling_kmers_per_s": ceiling, "frac": kmers_per_s / ceiling,
+            "ceiling_at_peak_clock_kmers_per_s": 1024 * 2.4e9 * 64 / (ipk * cyc),
+            "source": f"{ki.get('source')}; instruction mix: profiles/r03_valu_mix.json (scripts/valu_mix.py: "
+                      f"{mix['kernels']['K1 polyhip::k1::sketch_slab_kernel<21>']['valu_full_rate']} full-rate + "
+                      f"{mix['kernels']['K1 polyhip::k1::sketch_slab_kernel<21>']['valu_half_rate']} half-rate VALU instructions in the "
+                      "kernel's per-read loop); NOT measured by this run"}
+
+
 def timed_steps(step, steps: int, warmup: int, sync_all, world: int, dev):
     """W untimed steps, then EXACTLY K steps between barrier + synchronize; (elapsed MAX over ranks, mean
     per-launch ms from HIP events recorded on the launch stream)."""
@@ -554,12 +577,8 @@ def main() -> int:
                      "kernel": "polyhip::k1::sketch_slab_kernel<21>", "kernel_ms": kern_ms,
                      "kernel_ms_median": kern_ms_median,
                      "algorithmic_bytes_per_launch": alg_bytes,
-                     # what actually bounds K1: VALU issue.  43.8 VALU instructions per k-mer
-                     # (profiles/r02_k1_issue.md: SQ_INSTS_VALU / k-mers), of which MurmurHash3 itself needs ~25; one
-                     # 64-lane instruction per 4 cycles per SIMD, 1024 SIMDs at the 2.4 GHz peak clock
-                     "valu_issue": {"instructions_per_kmer": 43.8, "source": "profiles/r02_k1_issue.md (counters, NOT measured by this run)",
-                                    "ceiling_kmers_per_s": 1024 * 2.4e9 / 4 * 64 / 43.8,
-                                    "frac": (kmers_per_step / (kern_ms * 1e-3)) / (1024 * 2.4e9 / 4 * 64 / 43.8)}},
+                     # what actually bounds K1: VALU issue -- priced by valu_issue_ceiling() below
+                     "valu_issue": valu_issue_ceiling(kmers_per_step / (kern_ms * 1e-3))},
         "parity_spot_check": parity,
     }
     if strong is not None:

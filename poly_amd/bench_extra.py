@@ -78,8 +78,21 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
     work = torch.empty(align.sw_workspace_bytes(sc, n, LA, LB, True), dtype=torch.uint8, device=dev)
     ms_score = _time(lambda: align.sw_batch_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, work), 3)
     half = align.last_packed_half()  # gfx950's half-float cell (scores < 2048): 17 instructions per row and block, else 22
-    per_blk = 17 if half else 22
-    ceiling = 1024 * 2.4e9 * 512 / (4 * per_blk)
+    # VALU-issue ceiling: the kernel's own instruction count per row and 4-column block (counter-measured for the
+    # half-float cell, profiles/k3_issue.json; every instruction of the packed recurrence is a 4-cycle one,
+    # profiles/r03_valu_mix.json) at the clock the kernel sustains; beside it the ceiling of the 14-instruction recurrence
+    # floor, which says how far the stream is from the algorithm, not from its own issue rate
+    import json as _json
+    import os as _os
+    _root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+    try:
+        _k3 = _json.load(open(_os.path.join(_root, "profiles", "k3_issue.json")))
+    except Exception:
+        _k3 = {"valu_instructions_per_row_block": 17.15, "clock_GHz": 2.343, "floor_instructions_per_row_block": 14, "source": "defaults"}
+    per_blk = _k3["valu_instructions_per_row_block"] if half else 22
+    clock = _k3["clock_GHz"] * 1e9
+    ceiling = 1024 * clock * 512 / (4 * per_blk)
+    ceiling_floor = 1024 * clock * 512 / (4 * _k3["floor_instructions_per_row_block"])
     stride = align.sw_traceback_stride(sc, LA, LB)
     tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, LA, LB), dtype=torch.uint8, device=dev)
     alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
@@ -105,7 +118,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         "align_one_call_ms": ms_fused, "cell_updates_per_s_align_one_call": cells / ms_fused * 1e3,
         "algorithmic_GBs_score_pass": alg / ms_score * 1e3 / 1e9,
         # the bound that matters for K3: VALU issue.  The packed kernel spends `per_blk` instructions of four
-        # issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns); 1024 SIMDs at ~2.4 GHz.
+        # issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns) on 1024 SIMDs at the clock it sustains.
         "packed_cell": "half-float (v_pk_maximum3_f16)" if half else "int16",
         "valu_issue_ceiling_cell_updates_per_s": ceiling,
         "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / ceiling,
@@ -113,8 +126,12 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
                      "unit": "T cell updates/s", "frac": cells / ms_score * 1e3 / ceiling,
                      "kernel": f"polyhip::k3p::sw_pk_kernel<152,false,{'true' if half else 'false'}> (+ locate + tie wave, all inside score_pass_ms)",
                      "derivation": f"packed {'half-float' if half else 'int16'} recurrence: {per_blk} VALU instructions = "
-                                   f"{4 * per_blk} issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x 2.4 GHz; "
-                                   "HBM is not the bound (166 B per 750,000 cells)",
+                                   f"{4 * per_blk:.1f} issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x "
+                                   f"{clock / 1e9:.3f} GHz (the clock the kernel sustains); HBM is not the bound (166 B per 750,000 cells)",
+                     "source": _k3.get("source"),
+                     "floor": {"instructions_per_row_block": _k3["floor_instructions_per_row_block"],
+                               "ceiling_T_cell_updates_per_s": ceiling_floor / 1e12,
+                               "frac": cells / ms_score * 1e3 / ceiling_floor},
                      "hbm_achieved_GBs": alg / ms_score * 1e3 / 1e9},
         "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
     }

@@ -415,19 +415,25 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
     for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
         const uint2 it = stage[t];
         const uint32_t c = it.x >> cshift;
-        citems[gbase[c] + (t - lstart[c])] = it;
+        citems[gbase[c] + (t - lstart[c])] = it; // (values and ids in two arrays halve level 2's counting pass but cost
+                                                  // level 1 more than that: 0.64 -> 0.87 ms, two half-length runs per bucket)
     }
 }
 
 // level 2: one workgroup per coarse bucket -> fine start[] + final item order (+ self-join size)
-__global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__ citems,
-                                                      const uint32_t *__restrict__ cstart, uint32_t cfirst, uint32_t nc,
-                                                      uint32_t fpc_log2, uint32_t *__restrict__ hdr,
-                                                      uint32_t *__restrict__ start, uint2 *__restrict__ items,
-                                                      uint32_t id_bits, uint32_t ndw, uint32_t field_bits)
+#ifndef PH_K2_FINE_THREADS
+#define PH_K2_FINE_THREADS 512
+#endif
+constexpr int FINE_THREADS = PH_K2_FINE_THREADS; // a coarse bucket is a chain of memory round trips: 8 waves per SIMD hide more of them
+__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const uint2 *__restrict__ citems,
+                                                           const uint32_t *__restrict__ cstart, uint32_t cfirst, uint32_t nc,
+                                                           uint32_t fpc_log2, uint32_t *__restrict__ hdr,
+                                                           uint32_t *__restrict__ start, uint2 *__restrict__ items,
+                                                           uint32_t id_bits, uint32_t ndw, uint32_t field_bits)
 {
+    constexpr int T = FINE_THREADS;
     __shared__ uint32_t cnt[FPC_MAX];
-    __shared__ uint32_t ws[4];
+    __shared__ uint32_t ws[T / 64];
     const uint32_t fpc = 1u << fpc_log2;
     const uint32_t shift = hdr[H_SHIFT];
     const bool compact = hdr[H_FMT] != 0u;
@@ -438,27 +444,28 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
     for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) { // coarse buckets [cfirst, nc)
         const uint32_t lo = cstart[c], hi = cstart[c + 1];
         __syncthreads();
-        for (uint32_t f = tid; f < fpc; f += THREADS)
+        for (uint32_t f = tid; f < fpc; f += T)
             cnt[f] = 0;
         __syncthreads();
         // eight loads in flight per thread: the loop is a chain of memory round trips otherwise (96 % of the wave
         // cycles were s_waitcnt, profiles/r02_k2_pmc_sq.md)
-        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * THREADS) {
+        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * T) {
             uint32_t x[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                x[u] = t0 + u * THREADS < hi ? citems[t0 + u * THREADS].x : 0u;
+                x[u] = t0 + u * T < hi ? citems[t0 + u * T].x : 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (t0 + u * THREADS < hi)
+                if (t0 + u * T < hi)
                     atomicAdd(&cnt[(x[u] >> shift) & (fpc - 1u)], 1u);
         }
         __syncthreads();
         // exclusive scan of cnt[0..fpc): PER consecutive entries per thread
-        const uint32_t per = (fpc + THREADS - 1) / THREADS; // <= 32
-        uint32_t v[32], sum = 0;
+        constexpr int PERMAX = (int)(FPC_MAX / T);
+        const uint32_t per = (fpc + T - 1) / T; // <= PERMAX
+        uint32_t v[PERMAX], sum = 0;
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < PERMAX; ++i) {
             const uint32_t f = tid * per + i;
             v[i] = ((uint32_t)i < per && f < fpc) ? cnt[f] : 0u;
             sum += v[i];
@@ -478,7 +485,7 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
         for (int w = 0; w < (tid >> 6); ++w)
             run += ws[w];
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < PERMAX; ++i) {
             const uint32_t f = tid * per + i;
             if ((uint32_t)i < per && f < fpc) {
                 start[((size_t)c << fpc_log2) + f] = run;
@@ -487,18 +494,18 @@ __global__ __launch_bounds__(THREADS) void fine_kernel(const uint2 *__restrict__
             run += v[i];
         }
         __syncthreads();
-        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * THREADS) {
+        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * T) {
             uint2 it[8];
             uint32_t at[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                it[u] = t0 + u * THREADS < hi ? citems[t0 + u * THREADS] : make_uint2(0u, 0u);
+                it[u] = t0 + u * T < hi ? citems[t0 + u * T] : make_uint2(0u, 0u);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                at[u] = t0 + u * THREADS < hi ? atomicAdd(&cnt[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
+                at[u] = t0 + u * T < hi ? atomicAdd(&cnt[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                if (t0 + u * THREADS < hi) {
+                if (t0 + u * T < hi) {
                     if (compact) {
                         const uint32_t col = it[u].y & id_mask, occ = it[u].y >> id_bits;
                         const uint32_t k = __umulhi(col, kmul); // col / ndw (exact: see rowjoin_dense_kernel)
@@ -1305,7 +1312,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
                                flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems);
         }
         if (c1 > c0)
-            hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::THREADS), 0, st, citems,
+            hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st, citems,
                                cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
         PH_HIP(hipGetLastError());
     }
