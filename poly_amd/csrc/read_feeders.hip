@@ -225,11 +225,16 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ a
 }
 
 // newlines per 4096-byte window
+// (also leaves every 16-byte chunk's newline mask -- 2 bytes per 16 of file -- so that the ranked write below does not read
+// the file a second time: 51 MB instead of 408 MB for the bench's image)
 __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ abase, uint32_t mis,
-                                                                uint64_t nbytes, uint32_t *__restrict__ counts)
+                                                                uint64_t nbytes, uint32_t *__restrict__ counts,
+                                                                uint16_t *__restrict__ masks)
 {
     __shared__ uint32_t ws[THREADS / 64];
-    uint32_t c = (uint32_t)__popc(newline_mask16(abase, (uint64_t)blockIdx.x * THREADS + threadIdx.x, mis, nbytes));
+    const uint32_t mk = newline_mask16(abase, (uint64_t)blockIdx.x * THREADS + threadIdx.x, mis, nbytes);
+    masks[(uint64_t)blockIdx.x * THREADS + threadIdx.x] = (uint16_t)mk;
+    uint32_t c = (uint32_t)__popc(mk);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         c += (uint32_t)__shfl_xor((int)c, d, 64);
@@ -241,13 +246,13 @@ __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *
 }
 
 // line_end[k] = file-relative position of the k-th '\n'
-__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const uint8_t *__restrict__ abase, uint32_t mis,
-                                                                uint64_t nbytes, const uint64_t *__restrict__ block_off,
+__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const uint16_t *__restrict__ masks, uint32_t mis,
+                                                                const uint64_t *__restrict__ block_off,
                                                                 uint64_t *__restrict__ line_end)
 {
     __shared__ uint32_t ws[THREADS / 64];
     const uint64_t chunk = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    uint32_t m = newline_mask16(abase, chunk, mis, nbytes);
+    uint32_t m = masks[chunk];
     const uint32_t c = (uint32_t)__popc(m);
     uint32_t incl = c; // inclusive scan over the wave, then over the 4 waves
 #pragma unroll
@@ -542,8 +547,122 @@ __global__ void fasta_finish_kernel(const uint8_t *__restrict__ file, uint64_t n
     res[F_NHEADERS] = H;
 }
 
+// ---- FASTA gather: sequence lines of the kept records -> packed buffer ------------------------------------------------
+// OUTPUT-driven (round 3).  Consecutive sequence lines land back to back in the output, so a wave takes 64 consecutive
+// lines (lane l loads line l's start, length and destination: three coalesced loads), and then produces the whole
+// contiguous output range of those lines with ALIGNED, fully coalesced 16-byte stores -- 1 KB per store instruction
+// whatever the line width.  A lane finds the line its output dword belongs to from the block's mean line length, corrected by a
+// short walk over the 64 destinations (in LDS), and reads the four source bytes with one unaligned dword load when they lie in one line (19 of 20
+// dwords of an 80-column file), byte by byte across a line end.  The per-line form it replaces (8 lanes per line, whole
+// dwords funnelled to the destination's alignment) wrote 32-byte pieces at line-sized strides and stayed at 2.3 TB/s of
+// traffic however many lines a group kept in flight (0.36 ms for the 408 MB image; four lines per group: the same);
+// a workgroup-per-file-window compaction through LDS drowned in per-byte arithmetic (28 vector instructions per byte).
+// POLYHIP_FASTA_STREAM=0 keeps the per-line kernel (testing aid; tests/test_fasta_gpu.py runs both).
+__global__ __launch_bounds__(THREADS) void fasta_gather_stream_kernel(const uint8_t *__restrict__ file,
+                                                                     const uint64_t *__restrict__ line_end,
+                                                                     const uint64_t *__restrict__ nlines_dev,
+                                                                     const uint32_t *__restrict__ seq_len,
+                                                                     const uint64_t *__restrict__ dst,
+                                                                     const unsigned long long *__restrict__ res,
+                                                                     uint8_t *__restrict__ seqs)
+{
+    __shared__ uint64_t dls[THREADS / 64][64], els[THREADS / 64][64], sls[THREADS / 64][64];
+    const uint64_t nl = *nlines_dev, total = res[F_SEQBYTES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t *dl = dls[wv], *el = els[wv], *sl = sls[wv];
+    const uint64_t wave = ((uint64_t)blockIdx.x * THREADS + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (THREADS / 64);
+    for (uint64_t kA = wave * 64; kA < nl; kA += nwaves * 64) {
+        const uint64_t k = kA + lane;
+        uint64_t len = 0, d = ~0ull, st = 0;
+        if (k < nl) {
+            len = seq_len[k];
+            d = dst[k];
+            st = k == 0 ? 0 : line_end[k - 1] + 1;
+            if (d >= total) { // behind the kept records
+                len = 0;
+                d = ~0ull;
+            }
+        }
+        const uint64_t kept = __ballot(len != 0);
+        if (kept == 0ull)
+            continue; // wave-uniform
+        dl[lane] = d;
+        el[lane] = d + len; // (d = ~0: never looked at)
+        sl[lane] = st;
+        const int first = __builtin_ctzll(kept), last = 63 - __builtin_clzll(kept);
+        const uint64_t Dlo = __shfl(d, first, 64), Dhi = __shfl(d + len, last, 64);
+        __builtin_amdgcn_wave_barrier(); // the LDS rows are this wave's own; DS operations of a wave execute in order
+        // line of output position o: the last one whose destination is <= o (zero-length lines in front of it share its
+        // destination and lose; lines behind the kept records carry ~0)
+        // (a guess from the block's mean line length -- exact to within a line or two for the usual fixed-width files --
+        // corrected by walking the table; the walk is what makes it exact for any widths)
+        const float per_byte = (float)(last - first + 1) / (float)(Dhi - Dlo);
+        auto line_of = [&](uint64_t o) {
+            int kk = first + min(last - first, (int)((float)(o - Dlo) * per_byte));
+            while (dl[kk] > o)
+                --kk;
+            while (kk < last && dl[kk + 1] <= o)
+                ++kk;
+            return kk;
+        };
+        auto byte_at = [&](uint64_t o, int kk) -> uint32_t { // o in [Dlo, Dhi); kk = a line at or before o's
+            while (o >= el[kk])
+                ++kk;
+            return file[sl[kk] + (o - dl[kk])];
+        };
+        uint8_t *out = seqs;
+        // first output position on a 16-byte boundary of the destination, and the whole 16-byte pieces from there
+        const uint64_t oa = Dlo + ((16u - (uint32_t)((uintptr_t)(out + Dlo) & 15u)) & 15u);
+        if (oa >= Dhi) { // not one aligned piece: bytes
+            if (Dlo + lane < Dhi)
+                out[Dlo + lane] = (uint8_t)byte_at(Dlo + lane, first);
+            continue;
+        }
+        if (Dlo + lane < oa) // head bytes (at most 15)
+            out[Dlo + lane] = (uint8_t)byte_at(Dlo + lane, first);
+        const uint64_t n16 = (Dhi - oa) >> 4;
+        for (uint64_t w = lane; w < n16; w += 64) {
+            const uint64_t o = oa + 16 * w;
+            int kk = line_of(o);
+            uint4 piece;
+            if (o + 16 <= el[kk]) {
+                __builtin_memcpy(&piece, file + sl[kk] + (o - dl[kk]), 16); // one line: (unaligned) dword loads
+            } else { // a line ends inside the piece: dword by dword, byte by byte across the end
+                uint32_t wd[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t oq = o + 4 * q;
+                    while (oq >= el[kk])
+                        ++kk;
+                    if (oq + 4 <= el[kk])
+                        __builtin_memcpy(&wd[q], file + sl[kk] + (oq - dl[kk]), 4);
+                    else
+                        wd[q] = byte_at(oq, kk) | (byte_at(oq + 1, kk) << 8) | (byte_at(oq + 2, kk) << 16) | (byte_at(oq + 3, kk) << 24);
+                }
+                piece = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+            }
+            *reinterpret_cast<uint4 *>(out + o) = piece;
+        }
+        const uint64_t ot = oa + 16 * n16; // tail bytes (at most 15)
+        if (ot + lane < Dhi)
+            out[ot + lane] = (uint8_t)byte_at(ot + lane, line_of(ot + lane));
+        __builtin_amdgcn_wave_barrier(); // the rows are rewritten by the next block of lines
+    }
+}
+
 // 8 lanes per line (grid-stride; 4 / 8 / 16 / 32 lanes measured 0.80 / 0.75 / 0.89 / 1.07 ms on 80-column lines): sequence
-// lines of the kept records -> packed buffer, whole dwords
+// lines of the kept records -> packed buffer, whole dwords.
+// Round 3: a group takes GU lines per iteration and keeps them in flight TOGETHER -- all their (line_end, seq_len, dst)
+// loads are issued back to back, then all their source dwords, then the stores.  One line per iteration was two dependent
+// memory round trips for 80 bytes per group (the kernel moved 0.8 GB at 2.3 TB/s with every wave slot taken: latency
+// bound); a workgroup-per-file-window version that compacted the kept bytes through LDS was tried first and lost to its
+// own per-byte arithmetic (28 vector instructions per byte, 0.36-0.84 ms).
+#ifndef PH_FASTA_G
+#define PH_FASTA_G 8
+#endif
+#ifndef PH_FASTA_GU
+#define PH_FASTA_GU 4
+#endif
 __global__ __launch_bounds__(THREADS) void fasta_gather_kernel(const uint8_t *__restrict__ file,
                                                               const uint64_t *__restrict__ line_end,
                                                               const uint64_t *__restrict__ nlines_dev,
@@ -552,25 +671,76 @@ __global__ __launch_bounds__(THREADS) void fasta_gather_kernel(const uint8_t *__
                                                               const unsigned long long *__restrict__ res,
                                                               uint8_t *__restrict__ seqs)
 {
-#ifndef PH_FASTA_G
-#define PH_FASTA_G 8
-#endif
-    constexpr int G = PH_FASTA_G;
+    constexpr int G = PH_FASTA_G, GU = PH_FASTA_GU;
     const uint64_t nl = *nlines_dev;
     const uint64_t total = res[F_SEQBYTES];
     const int gl = threadIdx.x & (G - 1);
     const uint64_t group = ((uint64_t)blockIdx.x * THREADS + threadIdx.x) / G, ngroups = (uint64_t)gridDim.x * (THREADS / G);
-    for (uint64_t k = group; k < nl; k += ngroups) {
-        const uint64_t len = seq_len[k], d = dst[k];
-        if (len == 0 || d >= total)
-            continue;
-        group_copy<G>(seqs + d, file + (k == 0 ? 0 : line_end[k - 1] + 1), len, gl);
+    for (uint64_t k0 = group * GU; k0 < nl; k0 += ngroups * GU) { // GU CONSECUTIVE lines: their metadata shares cache lines
+        // ---- all the lines' metadata
+        uint64_t len[GU], d[GU], st[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const uint64_t k = k0 + u;
+            len[u] = 0;
+            d[u] = 0;
+            st[u] = 0;
+            if (k < nl) {
+                len[u] = seq_len[k];
+                d[u] = dst[k];
+                st[u] = k == 0 ? 0 : line_end[k - 1] + 1;
+            }
+        }
+        // ---- geometry of each copy: head bytes up to the destination's dword boundary, whole dwords, tail bytes
+        uint32_t head[GU], sh[GU];
+        uint64_t ndw[GU];
+        const uint32_t *s4[GU];
+        uint32_t *d4[GU];
+        uint64_t maxdw = 0;
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            if (len[u] == 0 || d[u] >= total)
+                len[u] = 0;
+            uint8_t *dp = seqs + d[u];
+            const uint8_t *sp = file + st[u];
+            head[u] = (uint32_t)min(len[u], (uint64_t)((4u - (uint32_t)((uintptr_t)dp & 3u)) & 3u));
+            if ((uint32_t)gl < head[u])
+                dp[gl] = sp[gl];
+            dp += head[u];
+            sp += head[u];
+            const uint64_t rest = len[u] - head[u];
+            ndw[u] = rest >> 2;
+            sh[u] = (uint32_t)((uintptr_t)sp & 3u);
+            s4[u] = reinterpret_cast<const uint32_t *>(sp - sh[u]);
+            d4[u] = reinterpret_cast<uint32_t *>(dp);
+            const uint32_t tail = (uint32_t)(rest & 3u);
+            if ((uint32_t)gl < tail)
+                dp[4 * ndw[u] + gl] = sp[4 * ndw[u] + gl];
+            maxdw = max(maxdw, ndw[u]);
+        }
+        // ---- the dwords: every line's loads of a round before any store
+        for (uint64_t w = gl; w < maxdw; w += G) {
+            uint32_t lo[GU], hi[GU];
+#pragma unroll
+            for (int u = 0; u < GU; ++u) {
+                lo[u] = hi[u] = 0;
+                if (w < ndw[u]) {
+                    lo[u] = s4[u][w];
+                    if (sh[u])
+                        hi[u] = s4[u][w + 1]; // holds a byte of the source: in bounds
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GU; ++u)
+                if (w < ndw[u])
+                    d4[u][w] = sh[u] ? __builtin_amdgcn_alignbyte(hi[u], lo[u], sh[u]) : lo[u];
+        }
     }
 }
 
 struct Layout {
     uint64_t nblocks, max_lines;
-    size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, off_scanpart, total;
+    size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, off_scanpart, off_masks, total;
     size_t off_ishdr, off_hrank, off_dst; // FASTA (per line)
 };
 
@@ -585,6 +755,7 @@ static Layout layout(uint64_t nbytes)
     L.off_res = o; o += al(R_WORDS * 8);
     L.off_scanpart = o; o += al(SCAN_SEGS * 8);
     L.off_counts = o; o += al(L.nblocks * 4);
+    L.off_masks = o; o += al(L.nblocks * (size_t)THREADS * 2);
     L.off_blockoff = o; o += al((L.nblocks + 1) * 8);
     L.off_lineend = o; o += al((L.max_lines + 1) * 8);
     L.off_seqlen = o; o += al((L.max_lines / 4 + 1) * 4);
@@ -655,10 +826,12 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(res + fq::R_FIRSTBAD, 0xFF, 8, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
     const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
-    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts);
+    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts,
+                       reinterpret_cast<uint16_t *>(w + L.off_masks));
     if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
-    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes,
+    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st,
+                       reinterpret_cast<const uint16_t *>(w + L.off_masks), mis,
                        blockoff, line_end);
     // The line count exists only on the device (blockoff[nblocks]); the record kernels are launched for
     // the most records the file could hold and read the real count there.  The shortest record is 7 bytes: the
@@ -745,10 +918,12 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(dst, 0, 16, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
     const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
-    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts);
+    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts,
+                       reinterpret_cast<uint16_t *>(w + L.off_masks));
     if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
-    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes,
+    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st,
+                       reinterpret_cast<const uint16_t *>(w + L.off_masks), mis,
                        blockoff, line_end);
     const uint64_t *nlines_dev = blockoff + L.nblocks; // the line count exists only on the device
     // per-line kernels: as many workgroups as keep the chip busy, each striding over the lines (their count exists only on the device)
@@ -765,8 +940,12 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     hipLaunchKernelGGL(fq::fasta_empty_kernel, dim3(gl), dim3(fq::THREADS), 0, st, hrank, nlines_dev, d_offsets, res);
     hipLaunchKernelGGL(fq::fasta_finish_kernel, dim3(1), dim3(1), 0, st, d_file, nbytes, line_end, nlines_dev, hrank, d_offsets,
                        max_records, res);
-    hipLaunchKernelGGL(fq::fasta_gather_kernel, dim3((unsigned)std::min<uint64_t>(gl, 256ull * 32ull)), dim3(fq::THREADS), 0, st,
-                       d_file, line_end, nlines_dev, seq_len, dst, res, d_seqs);
+    if (env_is("POLYHIP_FASTA_STREAM", '0'))
+        hipLaunchKernelGGL(fq::fasta_gather_kernel, dim3((unsigned)std::min<uint64_t>(gl, 256ull * 32ull)), dim3(fq::THREADS), 0, st,
+                           d_file, line_end, nlines_dev, seq_len, dst, res, d_seqs);
+    else
+        hipLaunchKernelGGL(fq::fasta_gather_stream_kernel, dim3((unsigned)std::min<uint64_t>(gl, 256ull * 32ull)), dim3(fq::THREADS), 0,
+                           st, d_file, line_end, nlines_dev, seq_len, dst, res, d_seqs);
     PH_HIP(hipGetLastError());
     PH_HIP(hipMemcpyAsync(d_result, res, 4 * 8, hipMemcpyDeviceToDevice, st));
     return POLYHIP_OK;

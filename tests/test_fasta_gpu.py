@@ -13,6 +13,17 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "fasta")
 
 
+@pytest.fixture(autouse=True, params=["stream", "lines"])
+def gather_kind(request, monkeypatch):
+    """every test runs with the output-driven gather (a wave writes the contiguous output range of 64 lines with aligned
+    dword stores: the default) and with POLYHIP_FASTA_STREAM=0 (one 8-lane group per line)"""
+    if request.param == "lines":
+        monkeypatch.setenv("POLYHIP_FASTA_STREAM", "0")
+    else:
+        monkeypatch.delenv("POLYHIP_FASTA_STREAM", raising=False)
+    return request.param
+
+
 def _check(data: bytes):
     from poly_amd import fasta
     want, code = fr.parse_all(data)
@@ -65,6 +76,20 @@ def test_quirks_and_random_files():
         seq = bytes(rng.choice(list(b"ACGT"), int(rng.integers(1, 900))).astype(np.uint8))
         recs.append(b">seq%d desc\n" % i + b"\n".join(seq[j:j + 70] for j in range(0, len(seq), 70)) + b"\n")
     _check(b"".join(recs))
+
+
+def test_lines_longer_than_a_window_and_stretches_without_sequence():
+    """single-line records of tens of kilobytes, long header / comment stretches (nothing kept for kilobytes), one-byte
+    lines (thousands of lines per 4 KB), lines of 4095 / 4096 / 4097 bytes, and a dropped tail"""
+    rng = np.random.default_rng(77)
+    big = bytes(rng.choice(list(b"ACGT"), 50_000).astype(np.uint8))
+    parts = [b">long one\n" + big + b"\n", b">" + b"h" * 9000 + b"\n" + big[:13_001] + b"\n", b";" + b"c" * 10_000 + b"\n",
+             b">tiny\n" + b"\n".join(bytes([c]) for c in big[:6000]) + b"\n", b">x\n" + big[:4095] + b"\n>y\n" + big[:4096] + b"\n",
+             b">z\n" + big[:4097] + b"\n"]
+    data = b"".join(parts)
+    _check(data)
+    _check(data + b">dropped\n" + big[:9000])      # unterminated last line: the record is dropped
+    _check(b"junk before\n" * 700 + data)
 
 
 def test_large_file_goes_through_the_multi_workgroup_scan():
