@@ -668,6 +668,8 @@ constexpr int DENSE_THREADS = 1024; // one workgroup per CU (its LDS is the whol
 #define PH_K2_PIPE 1
 #endif
 constexpr int DENSE_U = PH_K2_DENSE_U; // buckets a wave loads back to back, 128 items of each
+static_assert(64 % DENSE_U == 0, "a chunk of 64 bucket descriptors (one per lane) is walked DENSE_U at a time by v_readlane: "
+                                 "DENSE_U must divide 64 (12 read lanes 64..71 = lanes 0..7 again and counted buckets twice)");
 
 // ---- dense join: a counter per COLUMN in LDS ------------------------------------------------------------
 // Same bucket walk as rowjoin_kernel, but the accumulator is a dense array of BITS-bit counters in LDS, one per
