@@ -89,10 +89,17 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
 {
     Layout L;
     (void)sx;
-    // ~32 Y items per bucket; a bucket is a value range of one width (a power of two)
+    // ~PH_K2_BUCKET_ITEMS Y items per bucket; a bucket is a value range of one width (a power of two).  A row's bucket holds
+    // the copies of ITS hash in the row's family (~80 at config 3) plus whatever else falls into the value range: 32 per
+    // bucket made a quarter of the walk's items foreign ones.  Measured at config 3 (join per row block / index / full
+    // matrix): 64 -> 1.76 / 2.12 / 15.4 ms, 32 -> 1.35 / 2.11 / 13.0, 16 -> 1.26 / 2.15 / 11.9, 8 -> 1.21 / 2.74 / 12.1
+    // (2^24 buckets need 2048 coarse ones, which the LDS-staged level-1 scatter does not hold).
+#ifndef PH_K2_BUCKET_ITEMS
+#define PH_K2_BUCKET_ITEMS 16
+#endif
     const uint64_t itemsY = ny * (uint64_t)sy;
     uint32_t nbk = 2048;
-    while (nbk < (1u << 23) && (uint64_t)nbk * 32 < itemsY)
+    while (nbk < (1u << 24) && (uint64_t)nbk * PH_K2_BUCKET_ITEMS < itemsY)
         nbk <<= 1;
     L.nbk = nbk;
     L.nbk_log2 = 0;
