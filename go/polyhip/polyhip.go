@@ -114,43 +114,46 @@ type AlignResult struct {
 	EndA, EndB   uint32
 }
 
-// SWAlignBatch: every A against one shared B (offB == nil) or pairwise.
+// SWAlignBatch: every A against one shared B (offB == nil) or pairwise.  The strings come back PACKED
+// (polyhip_sw_align_batch_packed: only their own bytes cross PCIe, 0.3 GB instead of 1.05 GB per million 150-bp reads);
+// a batch whose strings outgrow the first guess is run once more with the size the library reports.
 func (s *Scoring) SWAlignBatch(A []byte, offA []uint64, B []byte, offB []uint64, maxLenA int) ([]AlignResult, error) {
 	n := len(offA) - 1
-	lenB := uint64(len(B))
 	var pOffB *C.uint64_t
+	shared := C.uint64_t(len(B))
 	if offB != nil {
 		pOffB = (*C.uint64_t)(unsafe.Pointer(&offB[0]))
-		lenB = 0
-		for i := 0; i < n; i++ {
-			if d := offB[i+1] - offB[i]; d > lenB {
-				lenB = d
-			}
-		}
+		shared = 0
 	}
-	stride := int(C.polyhip_sw_traceback_stride(s.h, C.uint32_t(maxLenA), C.uint64_t(lenB)))
-	score := make([]int64, n)
-	endA, endB, errs, alen := make([]uint32, n), make([]uint32, n), make([]uint32, n), make([]uint32, n)
-	alnA, alnB := make([]byte, n*stride+1), make([]byte, n*stride+1)
-	err := call(func() C.int {
-		shared := C.uint64_t(0)
-		if offB == nil {
-			shared = C.uint64_t(len(B))
+	score := make([]int64, n+1)
+	endA, endB, errs := make([]uint32, n+1), make([]uint32, n+1), make([]uint32, n+1)
+	off := make([]uint64, n+1)
+	capacity := uint64(len(A)) + uint64(len(A))/4 + 65536
+	var alnA, alnB []byte
+	for attempt := 0; ; attempt++ {
+		alnA, alnB = make([]byte, capacity+1), make([]byte, capacity+1)
+		var status C.int
+		err := call(func() C.int {
+			status = C.polyhip_sw_align_batch_packed(s.h, (*C.uint8_t)(unsafe.Pointer(&A[0])), (*C.uint64_t)(unsafe.Pointer(&offA[0])),
+				C.uint64_t(n), (*C.uint8_t)(unsafe.Pointer(&B[0])), pOffB, shared, (*C.int64_t)(unsafe.Pointer(&score[0])),
+				(*C.uint32_t)(unsafe.Pointer(&endA[0])), (*C.uint32_t)(unsafe.Pointer(&endB[0])),
+				(*C.uint32_t)(unsafe.Pointer(&errs[0])), (*C.uint8_t)(unsafe.Pointer(&alnA[0])),
+				(*C.uint8_t)(unsafe.Pointer(&alnB[0])), (*C.uint64_t)(unsafe.Pointer(&off[0])), C.uint64_t(capacity))
+			return status
+		})
+		if err != nil && attempt == 0 && status == C.POLYHIP_ERR_INVALID && off[n] > capacity {
+			capacity = off[n] // the strings did not fit: alnOff[npairs] is what they need
+			continue
 		}
-		return C.polyhip_sw_align_batch(s.h, (*C.uint8_t)(unsafe.Pointer(&A[0])), (*C.uint64_t)(unsafe.Pointer(&offA[0])),
-			C.uint64_t(n), (*C.uint8_t)(unsafe.Pointer(&B[0])), pOffB, shared, (*C.int64_t)(unsafe.Pointer(&score[0])),
-			(*C.uint32_t)(unsafe.Pointer(&endA[0])), (*C.uint32_t)(unsafe.Pointer(&endB[0])),
-			(*C.uint32_t)(unsafe.Pointer(&errs[0])), (*C.uint8_t)(unsafe.Pointer(&alnA[0])),
-			(*C.uint8_t)(unsafe.Pointer(&alnB[0])), (*C.uint32_t)(unsafe.Pointer(&alen[0])), C.uint32_t(stride))
-	})
-	if err != nil {
-		return nil, err
+		if err != nil {
+			return nil, err
+		}
+		break
 	}
+	_ = maxLenA
 	res := make([]AlignResult, n)
 	for p := 0; p < n; p++ {
-		hi := (p + 1) * stride
-		lo := hi - int(alen[p])
-		res[p] = AlignResult{Score: score[p], AlignA: string(alnA[lo:hi]), AlignB: string(alnB[lo:hi]), Err: errs[p],
+		res[p] = AlignResult{Score: score[p], AlignA: string(alnA[off[p]:off[p+1]]), AlignB: string(alnB[off[p]:off[p+1]]), Err: errs[p],
 			EndA: endA[p], EndB: endB[p]}
 	}
 	return res, nil

@@ -320,6 +320,19 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A,
                            uint32_t *endB, uint32_t *err, uint8_t *alnA,
                            uint8_t *alnB, uint32_t *alnLen,
                            uint32_t aln_stride);
+/* The same with PACKED strings -- what a cgo caller wants (Go strings are made from slices, not from fixed-stride slots):
+ * alignA_p = alnA[alnOff[p] .. alnOff[p+1]), alignB_p = the same range of alnB (the two strings of a pair have one
+ * length); alnOff has npairs + 1 entries.  A pair's strings are a few hundred of its slot's bytes (151 of 525 at BASELINE
+ * config 4), so compacting them on the device cuts the PCIe traffic of 1M reads from 1.05 GB to 0.3 GB.  aln_capacity =
+ * bytes each of alnA / alnB holds; if the strings need more, the call returns POLYHIP_ERR_INVALID after filling score,
+ * endA, endB, err and alnOff (alnOff[npairs] = the bytes needed).  Chunked through two slots like the call above. */
+int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A,
+                                  const uint64_t *offA, uint64_t npairs,
+                                  const uint8_t *B, const uint64_t *offB,
+                                  uint64_t lenB, int64_t *score, uint32_t *endA,
+                                  uint32_t *endB, uint32_t *err, uint8_t *alnA,
+                                  uint8_t *alnB, uint64_t *alnOff,
+                                  uint64_t aln_capacity);
 /* ---- search/align NeedlemanWunsch  (search/align/align.go:100-166) -------------- */
 /*
  * Global alignment of every pair (A_p, B_p) (B shared when d_offB == NULL): score

@@ -71,6 +71,7 @@ SIGNATURES = {
     "polyhip_sw_align_batch_dev": (C.c_int, [_vp, _vp, _vp, _u64, _u32, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32,
                                              _vp, C.c_size_t, _vp, C.c_size_t, _vp]),
     "polyhip_sw_align_batch": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32]),
+    "polyhip_sw_align_batch_packed": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u64]),
     "polyhip_santalucia_scan_dev": (C.c_int, [_vp, _u64, _u64, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp,
                                               _u64, _vp]),
     "polyhip_santalucia_scan": (C.c_int, [_vp, _u64, _u32, _u32, _dbl, _dbl, _dbl, _vp, _vp, _vp]),

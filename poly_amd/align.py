@@ -181,6 +181,39 @@ def sw_align_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.nda
     return score, endA, endB, err, sa, sb
 
 
+def sw_align_strings_packed(scoring: Scoring, A: np.ndarray, offA: np.ndarray, B: np.ndarray, offB: np.ndarray | None = None,
+                            capacity: int | None = None):
+    """Host-pointer entry point with PACKED strings (polyhip_sw_align_batch_packed: only the strings' own bytes cross
+    PCIe): (score, endA, endB, err, alignA list[bytes], alignB list[bytes]).  `capacity` bytes per string buffer
+    (default: 1.25 x the reads' bytes + 64 KB; a batch that needs more is run again with the exact size)."""
+    n = len(offA) - 1
+    A = np.ascontiguousarray(A, dtype=np.uint8)
+    B = np.ascontiguousarray(B, dtype=np.uint8)
+    offA = np.ascontiguousarray(offA, dtype=np.uint64)
+    if offB is not None:
+        offB = np.ascontiguousarray(offB, dtype=np.uint64)
+    score = np.zeros(n, dtype=np.int64)
+    endA, endB, err = (np.zeros(n, dtype=np.uint32) for _ in range(3))
+    off = np.zeros(n + 1, dtype=np.uint64)
+    cap = int(capacity) if capacity is not None else int(int(offA[n] - offA[0]) * 1.25) + (64 << 10)
+    for _ in range(2):
+        alnA, alnB = np.zeros(max(cap, 1), dtype=np.uint8), np.zeros(max(cap, 1), dtype=np.uint8)
+        rc = _lib.lib().polyhip_sw_align_batch_packed(
+            scoring.handle(), A.ctypes.data, offA.ctypes.data, n, B.ctypes.data,
+            offB.ctypes.data if offB is not None else None, len(B) if offB is None else 0,
+            score.ctypes.data, endA.ctypes.data, endB.ctypes.data, err.ctypes.data, alnA.ctypes.data, alnB.ctypes.data,
+            off.ctypes.data, cap)
+        if rc == _lib.ERR_INVALID and int(off[n]) > cap:   # the strings did not fit: off[n] says what they need
+            cap = int(off[n])
+            continue
+        _lib.check(rc)
+        break
+    o = off.astype(np.int64)
+    sa = [alnA[o[p]:o[p + 1]].tobytes() for p in range(n)]
+    sb = [alnB[o[p]:o[p + 1]].tobytes() for p in range(n)]
+    return score, endA, endB, err, sa, sb
+
+
 def SmithWaterman(stringA, stringB, scoring: Scoring):
     """align.go:171-232 -> (score, alignA, alignB); raises alphabet.Error like the reference's err."""
     A, offA = _pack([stringA])
@@ -196,7 +229,7 @@ def SmithWatermanBatch(reads, ref, scoring: Scoring):
     list of (score, alignA, alignB) or alphabet.Error instances."""
     A, offA = _pack(reads)
     B, _ = _pack([ref])
-    score, _, _, err, sa, sb = sw_align_packed(scoring, A, offA, B, None)
+    score, _, _, err, sa, sb = sw_align_strings_packed(scoring, A, offA, B, None)
     out = []
     for p in range(len(reads)):
         if err[p]:

@@ -367,6 +367,20 @@ def e2e(dev) -> dict:
                     f"{stride}-byte slots (2 x {n * stride / 1e6:.0f} MB cross PCIe into existing pageable buffers)",
         "cell_updates_per_s": n * LA * LB / ms * 1e3, "ms": ms, "mean_alignment_len": float(o_len.mean())}
     del o_alnA, o_alnB
+    # the same with PACKED strings (polyhip_sw_align_batch_packed): 0.3 GB instead of 1.05 GB over PCIe
+    cap = n * 200
+    p_a, p_b, p_off = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8), np.zeros(n + 1, np.uint64)
+
+    def sw_packed():
+        _lib.check(L_.polyhip_sw_align_batch_packed(sc.handle(), hA.ctypes.data, offA.ctypes.data, n, hB.ctypes.data, None, LB,
+                                                    o_score.ctypes.data, o_ea.ctypes.data, o_eb.ctypes.data, o_er.ctypes.data,
+                                                    p_a.ctypes.data, p_b.ctypes.data, p_off.ctypes.data, cap))
+    ms = _wall(sw_packed, 3, 1)
+    out["smith_waterman_with_packed_strings"] = {
+        "workload": f"polyhip_sw_align_batch_packed, {n} x {LA} bp reads vs one {LB} bp reference, host pointers, aligned strings "
+                    f"compacted on the device ({int(p_off[n]) * 2 / 1e6:.0f} MB cross PCIe)",
+        "cell_updates_per_s": n * LA * LB / ms * 1e3, "ms": ms, "string_bytes": int(p_off[n]) * 2}
+    del p_a, p_b
     # K4: configs[4], 5 Mb genome in, three fp64 planes (1.56 GB) out into buffers that already exist (a caller that
     # scans more than one genome reuses them; fresh numpy / Go memory adds ~0.1 s of first-touch page faults)
     g = torch.empty(5_000_000, dtype=torch.uint8, device=dev)

@@ -1662,6 +1662,131 @@ static uint64_t nw_per_pair(uint32_t max_lenA, uint64_t max_lenB)
     return std::max<uint64_t>(std::max(std::max(generic, reg), wave), 8);
 }
 
+
+// ---- packed strings: the last alnLen[p] bytes of pair p's two slots -> [off[p], off[p] + alnLen[p]) of two packed buffers ----
+constexpr int PACK_BLOCK = 1024; // pairs per scan block
+
+__global__ __launch_bounds__(256) void pack_sums_kernel(const uint32_t *__restrict__ alnLen, uint64_t n, uint64_t *__restrict__ bsum)
+{
+    __shared__ uint64_t ws[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * PACK_BLOCK;
+    uint64_t v = 0;
+    for (uint32_t t = threadIdx.x; t < PACK_BLOCK; t += 256)
+        if (i0 + t < n)
+            v += alnLen[i0 + t];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0)
+        ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+// exclusive scan of the block sums in place (one workgroup; nb <= a few thousand), total behind them
+__global__ __launch_bounds__(1024) void pack_scan_kernel(uint64_t *__restrict__ bsum, uint32_t nb)
+{
+    __shared__ uint64_t ws[16];
+    __shared__ uint64_t carry;
+    const int tid = threadIdx.x;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+        const uint32_t i = b0 + tid;
+        const uint64_t v = i < nb ? bsum[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            ws[tid >> 6] = incl;
+        __syncthreads();
+        uint64_t pre = carry;
+        for (int w = 0; w < (tid >> 6); ++w)
+            pre += ws[w];
+        if (i < nb)
+            bsum[i] = pre + incl - v;
+        __syncthreads();
+        if (tid == 1023)
+            carry = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0)
+        bsum[nb] = carry;
+}
+
+// offsets (global: + base) and the copies; 16 lanes per pair, unaligned dwords
+__global__ __launch_bounds__(256) void pack_copy_kernel(const uint32_t *__restrict__ alnLen, uint64_t n, const uint64_t *__restrict__ bsum,
+                                                       uint64_t base, const uint8_t *__restrict__ slotA, const uint8_t *__restrict__ slotB,
+                                                       uint32_t stride, uint64_t *__restrict__ off, uint8_t *__restrict__ outA,
+                                                       uint8_t *__restrict__ outB)
+{
+    __shared__ uint32_t lens[PACK_BLOCK];
+    __shared__ uint64_t offs[PACK_BLOCK];
+    __shared__ uint64_t ws[4];
+    const uint64_t i0 = (uint64_t)blockIdx.x * PACK_BLOCK;
+    const int tid = threadIdx.x;
+    // the block's own exclusive scan: 4 pairs per thread
+    uint32_t l[4];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t p = i0 + 4 * tid + q;
+        l[q] = p < n ? alnLen[p] : 0u;
+        sum += l[q];
+    }
+    uint64_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d)
+            incl += t;
+    }
+    if ((tid & 63) == 63)
+        ws[tid >> 6] = incl;
+    __syncthreads();
+    uint64_t run = bsum[blockIdx.x] + incl - sum; // chunk-local
+    for (int w = 0; w < (tid >> 6); ++w)
+        run += ws[w];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint64_t p = i0 + 4 * tid + q;
+        lens[4 * tid + q] = l[q];
+        offs[4 * tid + q] = run;
+        if (p < n)
+            off[p] = base + run;
+        run += l[q];
+    }
+    if (blockIdx.x == gridDim.x - 1 && tid == 255)
+        off[n] = base + bsum[gridDim.x]; // = base + the chunk's total
+    __syncthreads();
+    const int g = tid >> 4, gl = tid & 15; // 16 groups of 16 lanes
+    for (uint32_t j = g; j < PACK_BLOCK && i0 + j < n; j += 16) {
+        const uint32_t len = lens[j];
+        if (len == 0)
+            continue;
+        const uint64_t p = i0 + j;
+        const uint8_t *sa = slotA + (p + 1) * (uint64_t)stride - len, *sb = slotB + (p + 1) * (uint64_t)stride - len;
+        uint8_t *da = outA + offs[j], *db = outB + offs[j];
+        const uint32_t nd = len >> 2;
+        for (uint32_t w = gl; w < nd; w += 16) {
+            uint32_t x, y;
+            __builtin_memcpy(&x, sa + 4 * w, 4);
+            __builtin_memcpy(&y, sb + 4 * w, 4);
+            __builtin_memcpy(da + 4 * w, &x, 4);
+            __builtin_memcpy(db + 4 * w, &y, 4);
+        }
+        if ((uint32_t)gl < (len & 3u)) {
+            da[4 * nd + gl] = sa[4 * nd + gl];
+            db[4 * nd + gl] = sb[4 * nd + gl];
+        }
+    }
+}
 } // namespace k3t
 } // namespace polyhip
 
@@ -2038,7 +2163,148 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     return POLYHIP_OK;
 }
 
+// The same with PACKED strings: a pair's strings are a few hundred bytes of its aln_stride-byte slots (151 of 525 at
+// config 4), and the slots are what crossed PCIe above (1.05 GB per 1M reads).  Here each chunk's strings are compacted
+// on the device (scan of the lengths, 16 lanes per pair) and only the packed bytes travel (0.3 GB): alignA_p =
+// alnA[alnOff[p] .. alnOff[p + 1]), alignB_p the same range of alnB (the two strings of a pair have one length).
+int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                                  const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                                  uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint64_t *alnOff,
+                                  uint64_t aln_capacity)
+{
+    PH_REQUIRE(sc, "polyhip_sw_align_batch_packed: null scoring");
+    PH_REQUIRE(alnOff, "polyhip_sw_align_batch_packed: null pointer");
+    alnOff[0] = 0;
+    if (npairs == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(offA && score && endA && endB && err && (aln_capacity == 0 || (alnA && alnB)), "polyhip_sw_align_batch_packed: null pointer");
+    HostStreams &hs = host_streams(); // the calling thread's two streams carry the two slots (never the null stream)
+    PH_HIP(hs.init());
+    PairStage in;
+    if (int rc0 = in.load("polyhip_sw_align_batch_packed", A, offA, npairs, B, offB, lenB, hs.s[0])) {
+        (void)hipStreamSynchronize(hs.s[0]);
+        return rc0;
+    }
+    const uint64_t maxA = in.maxA, maxB = in.maxB;
+    const uint32_t aln_stride = polyhip_sw_traceback_stride(sc, (uint32_t)maxA, maxB);
+    // Chunks of pairs through two slots, each with its own stream, outputs and workspaces: the strings of chunk c cross
+    // PCIe (1 GB for config 4, as long as the kernels take) while chunk c + 1 is being aligned.  The reads and the
+    // reference are on the device already (PairStage); a chunk is a window of offA.  Shared reference only -- per-pair
+    // references keep the single shot.
+    // Chunk = a multiple of 262,144 pairs (one full round of the packed pass: 512 workgroups of 512 pairs), at most
+    // eight chunks, none when the strings are below ~200 MB.
+    const uint64_t out_bytes = npairs * (2ull * aln_stride + 24);
+    uint64_t per = npairs;
+    if (!offB) {
+        const uint64_t unit = 262144;
+        if (out_bytes >= (192ull << 20) && npairs > unit)
+            per = ((npairs + 7) / 8 + unit - 1) / unit * unit;
+        if (const char *e = getenv("POLYHIP_SW_HOST_CHUNKS")) // testing aid: 0 / 1 = single shot, 2..8 = that many chunks
+            if (e[0] >= '0' && e[0] <= '8') {
+                const uint64_t want = std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)(e[0] - '0'), npairs));
+                per = (npairs + want - 1) / want;
+            }
+    }
+    const uint64_t nchunks = (npairs + per - 1) / per;
+    struct Slot {
+        DevBuf dscore, dea, deb, derr, dwork, dalA, dalB, dlen, dtb, dpA, dpB, doff, dbsum;
+        hipStream_t st = nullptr;
+        ~Slot()
+        {
+            if (st)
+                (void)hipStreamSynchronize(st); // the buffers are freed next
+        }
+    } slot[2];
+    const size_t wb = polyhip_sw_workspace_bytes(sc, per, (uint32_t)maxA, maxB, offB == nullptr);
+    const size_t tb = polyhip_sw_traceback_workspace_bytes(sc, per, (uint32_t)maxA, maxB);
+    for (uint64_t q = 0; q < std::min<uint64_t>(2, nchunks); ++q) {
+        Slot &S = slot[q];
+        PH_HIP(S.dscore.alloc(per * 8));
+        PH_HIP(S.dea.alloc(per * 4));
+        PH_HIP(S.deb.alloc(per * 4));
+        PH_HIP(S.derr.alloc(per * 4));
+        PH_HIP(S.dlen.alloc(per * 4));
+        PH_HIP(S.dalA.alloc(per * (size_t)aln_stride));
+        PH_HIP(S.dalB.alloc(per * (size_t)aln_stride));
+        PH_HIP(S.dwork.alloc(wb));
+        PH_HIP(S.dtb.alloc(tb));
+        PH_HIP(S.dpA.alloc(per * (size_t)aln_stride));
+        PH_HIP(S.dpB.alloc(per * (size_t)aln_stride));
+        PH_HIP(S.doff.alloc((per + 1) * 8));
+        PH_HIP(S.dbsum.alloc(((per + k3t::PACK_BLOCK - 1) / k3t::PACK_BLOCK + 2) * 8));
+        S.st = hs.s[q];
+    }
+    PH_HIP(hipStreamSynchronize(hs.s[0])); // PairStage's uploads: both slots read them
+    uint64_t base = 0;     // packed bytes of the chunks finished so far
+    bool overflow = false; // the caller's string buffers are too small: offsets and scores still complete
+    // chunk c's results -> host: its total first (the one thing the host has to wait for), then exactly that many bytes
+    auto finish = [&](uint64_t c, uint64_t cbase, uint64_t &total) -> hipError_t {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = c * per, m = std::min(per, npairs - i0);
+        hipError_t e;
+        uint64_t last = 0;
+        if ((e = hipMemcpyAsync(&last, S.doff.as<uint64_t>() + m, 8, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipStreamSynchronize(S.st)) != hipSuccess)
+            return e;
+        total = last - cbase;
+        if ((e = hipMemcpyAsync(score + i0, S.dscore.p, m * 8, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(endA + i0, S.dea.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(endB + i0, S.deb.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(err + i0, S.derr.p, m * 4, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+            (e = hipMemcpyAsync(alnOff + i0, S.doff.p, (m + 1) * 8, hipMemcpyDeviceToHost, S.st)) != hipSuccess)
+            return e;
+        if (cbase + total > aln_capacity) {
+            overflow = true;
+            return hipSuccess;
+        }
+        if (total && ((e = hipMemcpyAsync(alnA + cbase, S.dpA.p, total, hipMemcpyDeviceToHost, S.st)) != hipSuccess ||
+                      (e = hipMemcpyAsync(alnB + cbase, S.dpB.p, total, hipMemcpyDeviceToHost, S.st)) != hipSuccess))
+            return e;
+        return hipSuccess;
+    };
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = c * per, m = std::min(per, npairs - i0);
+        PH_HIP(hipStreamSynchronize(S.st)); // chunk c - 2 has left this slot
+        const int rc = polyhip_sw_align_batch_dev(sc, in.A(), in.offA() + i0, m, (uint32_t)maxA, in.B(), in.offB() ? in.offB() + i0 : nullptr,
+                                                  maxB, S.dscore.as<int64_t>(), S.dea.as<uint32_t>(), S.deb.as<uint32_t>(),
+                                                  S.derr.as<uint32_t>(), S.dalA.as<uint8_t>(), S.dalB.as<uint8_t>(),
+                                                  S.dlen.as<uint32_t>(), aln_stride, S.dwork.p, wb, S.dtb.p, tb, S.st);
+        if (rc != POLYHIP_OK) {
+            (void)hs.sync_both();
+            return rc;
+        }
+        if (c > 0) { // the host waits here for chunk c - 1's total while chunk c's kernels run
+            uint64_t t = 0;
+            PH_HIP(finish(c - 1, base, t));
+            base += t;
+        }
+        // compact chunk c's strings behind everything before it
+        const unsigned nb = (unsigned)((m + k3t::PACK_BLOCK - 1) / k3t::PACK_BLOCK);
+        hipLaunchKernelGGL(k3t::pack_sums_kernel, dim3(nb), dim3(256), 0, S.st, S.dlen.as<uint32_t>(), m, S.dbsum.as<uint64_t>());
+        hipLaunchKernelGGL(k3t::pack_scan_kernel, dim3(1), dim3(1024), 0, S.st, S.dbsum.as<uint64_t>(), nb);
+        hipLaunchKernelGGL(k3t::pack_copy_kernel, dim3(nb), dim3(256), 0, S.st, S.dlen.as<uint32_t>(), m, S.dbsum.as<uint64_t>(), base,
+                           S.dalA.as<uint8_t>(), S.dalB.as<uint8_t>(), aln_stride, S.doff.as<uint64_t>(), S.dpA.as<uint8_t>(),
+                           S.dpB.as<uint8_t>());
+        PH_HIP(hipGetLastError());
+    }
+    {
+        uint64_t t = 0;
+        PH_HIP(finish(nchunks - 1, base, t));
+        base += t;
+    }
+    PH_HIP(hs.sync_both());
+    if (overflow)
+        return set_error(POLYHIP_ERR_INVALID,
+                         "polyhip_sw_align_batch_packed: the strings need %llu bytes per buffer, aln_capacity is %llu (scores, ends and "
+                         "alnOff are complete: call again with buffers of alnOff[npairs] bytes)",
+                         (unsigned long long)base, (unsigned long long)aln_capacity);
+    return POLYHIP_OK;
+}
+
+
 } // extern "C"
+
 
 extern "C" {
 

@@ -111,6 +111,19 @@ static void sw(polyhip_scoring *sc, const char *a, const char *b, long want, con
     CHECK(score == want && err == 0, "SW(%s, %s) score %ld err %u", a, b, (long)score, err);
     CHECK(len == strlen(wa) && !memcmp(alnA + 64 - len, wa, len) && !memcmp(alnB + 64 - len, wb, len),
           "SW(%s, %s) strings %.*s / %.*s", a, b, (int)len, alnA + 64 - len, (int)len, alnB + 64 - len);
+    /* the packed-strings flavour the Go binding calls: same answer, strings at alnOff[0] .. alnOff[1] */
+    uint64_t off[2] = {7, 7};
+    uint8_t pa[64], pb[64];
+    score = -1;
+    OK(polyhip_sw_align_batch_packed(sc, (const uint8_t *)a, offA, 1, (const uint8_t *)b, NULL, strlen(b), &score, &ea, &eb, &err, pa, pb,
+                                     off, 64));
+    CHECK(score == want && off[0] == 0 && off[1] == strlen(wa) && !memcmp(pa, wa, off[1]) && !memcmp(pb, wb, off[1]),
+          "SW packed(%s, %s): score %ld, %llu bytes", a, b, (long)score, (unsigned long long)off[1]);
+    if (strlen(wa) > 2) { /* a buffer that is too small is an error that says what is needed */
+        CHECK(polyhip_sw_align_batch_packed(sc, (const uint8_t *)a, offA, 1, (const uint8_t *)b, NULL, strlen(b), &score, &ea, &eb, &err, pa,
+                                            pb, off, 2) == POLYHIP_ERR_INVALID && off[1] == strlen(wa) && score == want,
+              "SW packed with a 2-byte buffer: off[1] = %llu", (unsigned long long)off[1]);
+    }
 }
 
 static void test_align(void)

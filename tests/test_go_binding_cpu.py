@@ -144,7 +144,7 @@ def test_every_cgo_call_matches_the_header():
                 assert ok, f"{fn}: C.{name} argument {k} `{a}` is {got}, the header wants {w}"
             seen.add(name)
     # the binding covers the host-pointer entry point of every operation the four packages need, and the multi-rank calls
-    for need in ("polyhip_mash_sketch_batch", "polyhip_mash_distance_matrix", "polyhip_sw_align_batch", "polyhip_nw_align_batch",
+    for need in ("polyhip_mash_sketch_batch", "polyhip_mash_distance_matrix", "polyhip_sw_align_batch_packed", "polyhip_nw_align_batch",
                  "polyhip_santalucia_batch", "polyhip_santalucia_scan", "polyhip_santalucia_scan_first", "polyhip_marmurdoty_batch",
                  "polyhip_least_rotation_batch", "polyhip_seqhash_batch", "polyhip_fastq_pack", "polyhip_fasta_pack",
                  "polyhip_comm_unique_id", "polyhip_comm_init_rank", "polyhip_allgather_sketches_dev", "polyhip_allgatherv_dev",

@@ -150,6 +150,46 @@ def test_host_flavour_chunk_pipeline_equals_single_shot(al, monkeypatch, chunks)
         assert (int(got[0][p]), got[4][p], got[5][p]) == (s_, sa, sb), p
 
 
+@pytest.mark.parametrize("chunks", ["1", "3", "8"])
+def test_packed_strings_equal_the_slots(al, monkeypatch, chunks):
+    """polyhip_sw_align_batch_packed (strings compacted on the device, only their own bytes cross PCIe) against the
+    fixed-stride-slot flavour on a ragged batch with bad symbols, empty reads and zero-score pairs -- same scores, end cells,
+    errors and strings whatever the chunk count; a capacity that is too small is reported with the size needed and the
+    Python wrapper's second attempt succeeds; per-pair references too"""
+    align = al[0]
+    rng = np.random.default_rng(100 + int(chunks))
+    ref = orc.synth_dna(0xC4, 3000).tobytes()
+    reads = []
+    for i in range(20_003):
+        p = int(rng.integers(0, 3000 - 150))
+        r = _mutate(rng, ref[p:p + int(rng.integers(1, 151))])[:152]
+        if i % 997 == 0:
+            r = b"" if i % 2 else r[:5] + b"N" + r[6:]
+        if i % 1499 == 0:
+            r = b"-" * 30                      # scores nothing against NUC_4: an empty alignment
+        reads.append(r)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    A, offA = _pack(reads)
+    B, _ = _pack([ref])
+    monkeypatch.setenv("POLYHIP_SW_HOST_CHUNKS", chunks)
+    slots = align.sw_align_packed(sc, A, offA, B, None)
+    packed = align.sw_align_strings_packed(sc, A, offA, B, None)
+    for g, w in zip(packed[:4], slots[:4]):
+        assert (g == w).all()
+    assert packed[4] == slots[4] and packed[5] == slots[5]
+    tight = align.sw_align_strings_packed(sc, A, offA, B, None, capacity=1000)   # far too small: the retry path
+    assert tight[4] == slots[4] and tight[5] == slots[5]
+    # reads against reads (per-pair references: the single-shot path)
+    n = 300
+    pa, oa = _pack(reads[:n])
+    pb, ob = _pack(reads[n:2 * n])
+    s2 = align.sw_align_packed(sc, pa, oa, pb, ob)
+    p2 = align.sw_align_strings_packed(sc, pa, oa, pb, ob)
+    for g, w in zip(p2[:4], s2[:4]):
+        assert (g == w).all()
+    assert p2[4] == s2[4] and p2[5] == s2[5]
+
+
 @pytest.mark.parametrize("maxlen,reflen", [(64, 300), (152, 1500), (256, 2100), (40, 3), (10, 1)])
 def test_ragged(al, maxlen, reflen):
     rng = np.random.default_rng(maxlen * 7 + reflen)
