@@ -33,21 +33,44 @@
 namespace polyhip {
 namespace k5 {
 
-constexpr int THREADS = 256;
+#ifndef PH_K5_THREADS
+#define PH_K5_THREADS 256
+#endif
+constexpr int THREADS = PH_K5_THREADS;
 constexpr uint32_t LIST_CAP = 1024;      // candidates kept in LDS (random DNA: ~n/256 after the first word)
 constexpr uint32_t MAX_ROUNDS = 64;      // 4 bytes per round before the serial fallback
 constexpr uint32_t LDS_SEQ_MAX = 120 * 1024;
+constexpr uint32_t WRAP = 24; // bytes of s[0..] staged again behind s[n-1]: a 16-byte output piece + its funnel dword never wrap
 
-__device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t *red)
+// least value of a wave, in every lane: the DPP ladder (pairs, quads, rows of 16 by rotation, then the two row broadcasts
+// land the result in lane 63) -- six v_min with no LDS round trip
+__device__ __forceinline__ uint32_t wave_min(uint32_t v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        v = min(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    __syncthreads(); // red[] free again
+#define PH_DPP_MIN(ctrl, rows) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false))
+    PH_DPP_MIN(0xb1, 0xf);  // quad_perm [1,0,3,2]
+    PH_DPP_MIN(0x4e, 0xf);  // quad_perm [2,3,0,1]
+    PH_DPP_MIN(0x124, 0xf); // row_ror 4
+    PH_DPP_MIN(0x128, 0xf); // row_ror 8
+    PH_DPP_MIN(0x142, 0xa); // row_bcast15 into rows 1, 3
+    PH_DPP_MIN(0x143, 0xc); // row_bcast31 into rows 2, 3
+#undef PH_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// least value of the work group; ONE barrier: the per-wave slots alternate between two sets (`par`, block-uniform, flips
+// per call), so the next call's writes cannot overtake this call's reads
+__device__ __forceinline__ uint32_t block_min(uint32_t v, uint32_t (*red)[THREADS / 64], uint32_t &par)
+{
+    v = wave_min(v);
+    par ^= 1u;
     if ((threadIdx.x & 63) == 0)
-        red[threadIdx.x >> 6] = v;
+        red[par][threadIdx.x >> 6] = v;
     __syncthreads();
-    return min(min(red[0], red[1]), min(red[2], red[3]));
+    uint32_t r = red[par][0];
+#pragma unroll
+    for (int w = 1; w < THREADS / 64; ++w)
+        r = min(r, red[par][w]);
+    return r;
 }
 
 // big-endian word of the 4 bytes at cyclic position p (p < n); the staged copy
@@ -90,8 +113,14 @@ template <class Ptr> __device__ uint64_t two_pointer_wave(Ptr s, uint64_t n)
     return i < j ? i : j;
 }
 
+// big-endian word at byte K of the 8-byte window {d1:d0}: one v_perm_b32
+template <uint32_t K> __device__ __forceinline__ uint32_t word_k(uint32_t d0, uint32_t d1)
+{
+    return __builtin_amdgcn_perm(d1, d0, (K << 24) | ((K + 1) << 16) | ((K + 2) << 8) | (K + 3));
+}
+
 // 4 bytes of an LDS-staged sequence at byte position p as a big-endian word: two aligned dwords, a
-// funnel shift and a byte swap (the staged copy carries 8 wrapped bytes behind s[n-1])
+// funnel shift and a byte swap (the staged copy carries WRAP wrapped bytes behind s[n-1])
 __device__ __forceinline__ uint32_t word_lds(const uint32_t *__restrict__ L, uint32_t p)
 {
     const uint32_t d0 = L[p >> 2], d1 = L[(p >> 2) + 1];
@@ -107,11 +136,12 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t listA[LIST_CAP], listB[LIST_CAP];
-    __shared__ uint32_t red[4];
-    __shared__ uint32_t cnt;
+    __shared__ uint32_t red[2][THREADS / 64];
+    __shared__ uint32_t cnt, cntq;
     __shared__ uint64_t answer;
     const int tid = threadIdx.x;
     uint32_t *L = reinterpret_cast<uint32_t *>(lds);
+    uint32_t par = 0;
 
     for (uint64_t q = blockIdx.x; q < nseq; q += gridDim.x) {
         const uint64_t o0 = offs[q];
@@ -124,31 +154,30 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                 rotated[o0] = g[0];
             continue;
         }
-        if (IN_LDS && n + 8 > lds_seq_bytes)
+        if (IN_LDS && n + WRAP > lds_seq_bytes)
             continue; // the global-memory launch handles this one
-        if (!IN_LDS && n + 8 <= lds_seq_bytes)
+        if (!IN_LDS && n + WRAP <= lds_seq_bytes)
             continue;
 
-        // ---- stage the sequence (+ 8 wrapped bytes so a word never wraps), a dword per thread and step:
-        // aligned global dwords funnelled to the sequence's own alignment; the last dword index is clamped
-        // (the bytes it would add lie behind the sequence)
+        // ---- stage the sequence (+ WRAP wrapped bytes so a word or an output piece never wraps): 16 bytes per thread
+        // and step, read from the sequence's own (unaligned) address, written to aligned LDS; the last n % 16 singly
         __syncthreads();
         if (IN_LDS) {
-            const uintptr_t addr = reinterpret_cast<uintptr_t>(g);
-            const uint32_t sh = (uint32_t)(addr & 3u);
-            const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
-            const uint64_t last_dw = (sh + n - 1) >> 2; // dword holding s[n-1]
-            const uint64_t ndw = (n + 3) >> 2;
-            for (uint64_t t = tid; t < ndw; t += THREADS) {
-                const uint32_t d0 = gd[t], d1 = gd[t + 1 <= last_dw ? t + 1 : last_dw];
-                L[t] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            const uint32_t n32 = (uint32_t)n, n16 = n32 >> 4;
+            uint4 *L4 = reinterpret_cast<uint4 *>(lds);
+            for (uint32_t t = tid; t < n16; t += THREADS) {
+                uint4 v;
+                __builtin_memcpy(&v, g + 16u * t, 16);
+                L4[t] = v;
             }
-            __syncthreads();
-            if (tid < 8) // s[0..7] again behind s[n-1] (n may be tiny: cyclic)
-                lds[n + tid] = lds[(uint64_t)tid % n];
+            if ((uint32_t)tid < (n32 & 15u))
+                lds[16u * n16 + tid] = g[16u * n16 + tid];
+            if (tid < (int)WRAP) // s[0..] again behind s[n-1] (n may be tiny: cyclic)
+                lds[n32 + tid] = g[n32 >= WRAP ? (uint32_t)tid : (uint32_t)tid % n32];
         }
         if (tid == 0) {
             cnt = 0;
+            cntq = 0;
             answer = ~0ull;
         }
         __syncthreads();
@@ -166,7 +195,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
             if (IN_LDS) {
                 if (n >= 4)
                     return word_lds(L, (uint32_t)p);
-                return word_at(lds, p); // n = 2, 3: the 8 wrapped bytes cover it
+                return word_at(lds, p); // n = 2, 3: the wrapped bytes cover it
             }
             return ((uint32_t)g[p] << 24) | ((uint32_t)g[(p + 1) % n] << 16) | ((uint32_t)g[(p + 2) % n] << 8) |
                    (uint32_t)g[(p + 3) % n];
@@ -181,36 +210,68 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         uint32_t m = 0xFFFFFFFFu;
         bool serial = false, homo = false;
         if (IN_LDS && ne >= 8) {
-            const uint64_t nquad = (ne + 3) >> 2;
-            for (uint64_t t = tid; t < nquad; t += THREADS) {
+            // whole quads of positions from two dwords each, the ne % 4 positions behind them singly
+            const uint32_t ne32 = (uint32_t)ne, nfull = ne32 >> 2, ntail = ne32 & 3u;
+            for (uint32_t t = tid; t < nfull; t += THREADS) {
                 const uint32_t d0 = L[t], d1 = L[t + 1];
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k)
-                    if (4 * t + k < ne)
-                        m = min(m, __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, k)));
+                m = min(min(m, word_k<0>(d0, d1)), word_k<1>(d0, d1));
+                m = min(min(m, word_k<2>(d0, d1)), word_k<3>(d0, d1));
             }
-            m = block_min(m, red);
-            homo = ne >= 4 && (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
-            for (uint64_t t0 = 0; t0 < nquad; t0 += THREADS) {
-                const uint64_t t = t0 + tid;
-                if (t < nquad) {
+            if ((uint32_t)tid < ntail)
+                m = min(m, word(4u * nfull + tid));
+            m = block_min(m, red, par);
+            homo = (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
+            auto push = [&](uint32_t p) {
+                if (homo && word(p ? p - 1 : ne32 - 1) == m)
+                    return; // inside a run of the least byte: the run's first position beats it
+                const uint32_t slot = atomicAdd(&cnt, 1u);
+                if (slot < LIST_CAP)
+                    listA[slot] = p;
+            };
+            // the quads that hold the least word at all (random DNA: one in 64) go on a list first, so that the pass over
+            // every position stays a handful of instructions; the positions come from the list
+            for (uint32_t t = tid; t < nfull; t += THREADS) {
+                const uint32_t d0 = L[t], d1 = L[t + 1];
+                const uint32_t lo = min(min(word_k<0>(d0, d1), word_k<1>(d0, d1)), min(word_k<2>(d0, d1), word_k<3>(d0, d1)));
+                if (lo == m) {
+                    const uint32_t slot = atomicAdd(&cntq, 1u);
+                    if (slot < LIST_CAP)
+                        listB[slot] = t;
+                }
+            }
+            if ((uint32_t)tid < ntail && word(4u * nfull + tid) == m)
+                push(4u * nfull + tid);
+            __syncthreads();
+            const uint32_t cq = cntq;
+            if (cq <= LIST_CAP) {
+                for (uint32_t e = tid; e < cq; e += THREADS) {
+                    const uint32_t t = listB[e], d0 = L[t], d1 = L[t + 1];
+                    if (word_k<0>(d0, d1) == m)
+                        push(4u * t);
+                    if (word_k<1>(d0, d1) == m)
+                        push(4u * t + 1);
+                    if (word_k<2>(d0, d1) == m)
+                        push(4u * t + 2);
+                    if (word_k<3>(d0, d1) == m)
+                        push(4u * t + 3);
+                }
+            } else { // low complexity: more quads than the list holds, every position is looked at directly
+                for (uint32_t t = tid; t < nfull; t += THREADS) {
                     const uint32_t d0 = L[t], d1 = L[t + 1];
-#pragma unroll
-                    for (uint32_t k = 0; k < 4; ++k)
-                        if (4 * t + k < ne && __builtin_bswap32(__builtin_amdgcn_alignbyte(d1, d0, k)) == m) {
-                            const uint64_t p = 4 * t + k;
-                            if (homo && word(p ? p - 1 : ne - 1) == m)
-                                continue; // inside a run of the least byte: the run's first position beats it
-                            const uint32_t slot = atomicAdd(&cnt, 1u);
-                            if (slot < LIST_CAP)
-                                listA[slot] = (uint32_t)p;
-                        }
+                    if (word_k<0>(d0, d1) == m)
+                        push(4u * t);
+                    if (word_k<1>(d0, d1) == m)
+                        push(4u * t + 1);
+                    if (word_k<2>(d0, d1) == m)
+                        push(4u * t + 2);
+                    if (word_k<3>(d0, d1) == m)
+                        push(4u * t + 3);
                 }
             }
         } else {
             for (uint64_t p = tid; p < ne; p += THREADS)
                 m = min(m, word(p));
-            m = block_min(m, red);
+            m = block_min(m, red, par);
             homo = ne >= 4 && (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
             for (uint64_t p0 = 0; p0 < ne; p0 += THREADS) {
                 const uint64_t p = p0 + tid;
@@ -223,21 +284,27 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
             }
         }
         __syncthreads();
-        uint32_t c = cnt;
+        uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
         // c occurrences of the least word, evenly spread if the sequence is periodic: is it a repetition of its first
-        // ne / c bytes?  (ONE parallel pass; short-period tandem repeats used to sit in the rounds below until the serial
-        // fallback took over: 6.6 ms per 100k sequences against 0.5 ms for random DNA)
-        if (c >= 2 && ne % c == 0 && ne <= 0xFFFFFFFFull) {
-            const uint64_t d = ne / c;
-            bool differs = false;
-            for (uint64_t p = tid; p < ne && !differs; p += THREADS)
-                differs = byte_at(p) != byte_at(p + d >= ne ? p + d - ne : p + d);
+        // ne / c bytes?  (short-period tandem repeats used to sit in the rounds below until the serial fallback took
+        // over: 6.6 ms per 100k sequences against 0.5 ms for random DNA.)  One mismatch anywhere rules it out, so a
+        // first look takes one byte per thread -- random sequence leaves here -- and only then the whole length
+        if (c >= 2 && ne <= 0xFFFFFFFFull && (uint32_t)ne % c == 0) {
+            const uint32_t ne32 = (uint32_t)ne, d = ne32 / c;
+            auto differs_at = [&](uint32_t p) { return byte_at(p) != byte_at(p + d >= ne32 ? p + d - ne32 : p + d); };
+            bool differs = (uint32_t)tid < ne32 && differs_at(tid);
             if (!__syncthreads_or(differs ? 1 : 0)) {
-                ne = d; // block-uniform
-                if (tid == 0)
-                    cnt = 0;
-                __syncthreads();
-                goto search; // again, on one block
+                for (uint32_t p = tid + THREADS; p < ne32 && !differs; p += THREADS)
+                    differs = differs_at(p);
+                if (!__syncthreads_or(differs ? 1 : 0)) {
+                    ne = d; // block-uniform
+                    if (tid == 0) {
+                        cnt = 0;
+                        cntq = 0;
+                    }
+                    __syncthreads();
+                    goto search; // again, on one block
+                }
             }
         }
         if (c > LIST_CAP || ne > 0xFFFFFFFFull)
@@ -253,7 +320,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         uint32_t *cur = listA, *nxt = listB;
         uint64_t depth = 4;
         uint32_t rounds = 0;
-        while (!serial && c > 1 && depth < ne) {
+        while (!serial && c > 64 && depth < ne) { // work-group rounds while a wave cannot hold the candidates
             if (++rounds > MAX_ROUNDS) {
                 serial = true;
                 break;
@@ -261,7 +328,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
             uint32_t mm = 0xFFFFFFFFu;
             for (uint32_t e = tid; e < c; e += THREADS)
                 mm = min(mm, word((uint64_t)cur[e] + depth));
-            mm = block_min(mm, red);
+            mm = block_min(mm, red, par);
             if (tid == 0)
                 cnt = 0;
             __syncthreads();
@@ -271,7 +338,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                     nxt[atomicAdd(&cnt, 1u)] = p;
             }
             __syncthreads();
-            c = cnt;
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
             uint32_t *t = cur;
             cur = nxt;
             nxt = t;
@@ -289,12 +356,37 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                 if (tid == 0)
                     answer = r;
             }
-        } else {
-            // survivors are equal rotations (or a single one): the smallest index wins
+        } else if (c <= 64) {
+            // one candidate per lane of wave 0, the rounds go on without a barrier; what is left when the compared depth
+            // reaches ne are equal rotations (or a single one): the smallest index wins
+            if (tid < 64) {
+                bool alive = (uint32_t)tid < c;
+                const uint32_t p = alive ? cur[tid] : 0u;
+                bool wserial = false;
+                while (c > 1 && depth < ne) {
+                    if (++rounds > MAX_ROUNDS) {
+                        wserial = true;
+                        break;
+                    }
+                    const uint32_t w = alive ? word((uint64_t)p + depth) : 0xFFFFFFFFu;
+                    const uint32_t mm = wave_min(w);
+                    alive = alive && w == mm;
+                    c = (uint32_t)__builtin_popcountll(__ballot(alive));
+                    depth += 4;
+                }
+                uint64_t r;
+                if (wserial)
+                    r = IN_LDS ? two_pointer_wave(lds, ne) : two_pointer_wave(g, ne);
+                else
+                    r = wave_min(alive ? p : 0xFFFFFFFFu);
+                if (tid == 0)
+                    answer = r;
+            }
+        } else { // more than a wave of equal rotations
             uint32_t best = 0xFFFFFFFFu;
             for (uint32_t e = tid; e < c; e += THREADS)
                 best = min(best, cur[e]);
-            best = block_min(best, red);
+            best = block_min(best, red, par);
             if (tid == 0)
                 answer = best;
         }
@@ -304,22 +396,30 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
             rot[q] = r;
         if (rotated) { // RotateSequence: (s + s)[r : r + n], seqhash.go:131-137
             uint8_t *out = rotated + o0;
-            if (IN_LDS && n >= 8) {
-                // bytes up to the first aligned output dword and behind the last one singly, whole dwords between
-                const uint64_t head = (4 - (reinterpret_cast<uintptr_t>(out) & 3u)) & 3u;
-                const uint64_t nd = (n - head) >> 2, tail0 = head + 4 * nd;
-                if ((uint64_t)tid < head)
+            if (IN_LDS && n >= 32) {
+                // bytes up to the first 16-byte-aligned output address and behind the last whole piece singly; between
+                // them 16 bytes per thread and step: five aligned LDS dwords funnelled to the rotation's byte phase
+                const uint32_t n32 = (uint32_t)n, r32 = (uint32_t)r;
+                const uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u)) & 15u;
+                const uint32_t nd = (n32 - head) >> 4, tail0 = head + 16u * nd;
+                if ((uint32_t)tid < head)
                     out[tid] = (uint8_t)byte_at((uint64_t)tid + r);
-                if ((uint64_t)tid < n - tail0)
-                    out[tail0 + tid] = (uint8_t)byte_at(tail0 + tid + r);
-                uint32_t *od = reinterpret_cast<uint32_t *>(out + head);
-                for (uint64_t t = tid; t < nd; t += THREADS) {
-                    uint64_t p = head + 4 * t + r;
-                    p -= p >= n ? n : 0;
-                    // p + 3 may run past s[n-1]: the wrapped bytes behind it continue with s[0..]
-                    const uint32_t d0 = L[p >> 2], d1 = L[(p >> 2) + 1];
-                    const uint32_t w = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)(p & 3u));
-                    od[t] = w;
+                if ((uint32_t)tid < n32 - tail0)
+                    out[tail0 + tid] = (uint8_t)byte_at((uint64_t)tail0 + tid + r);
+                uint4 *od = reinterpret_cast<uint4 *>(out + head);
+                for (uint32_t t = tid; t < nd; t += THREADS) {
+                    uint32_t p = head + 16u * t + r32;
+                    p -= p >= n32 ? n32 : 0;
+                    // p + 15 may run past s[n-1]: the wrapped bytes behind it continue with s[0..]
+                    const uint32_t *src = L + (p >> 2);
+                    const uint32_t sh = p & 3u;
+                    const uint32_t a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4];
+                    uint4 v;
+                    v.x = __builtin_amdgcn_alignbyte(a1, a0, sh);
+                    v.y = __builtin_amdgcn_alignbyte(a2, a1, sh);
+                    v.z = __builtin_amdgcn_alignbyte(a3, a2, sh);
+                    v.w = __builtin_amdgcn_alignbyte(a4, a3, sh);
+                    od[t] = v;
                 }
             } else {
                 for (uint64_t t = tid; t < n; t += THREADS) {
@@ -347,7 +447,7 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
     PH_REQUIRE(d_seqs && d_offsets && d_rot_index, "polyhip_least_rotation_batch: null pointer");
     hipStream_t st = as_stream(stream);
     // LDS holds sequences up to LDS_SEQ_MAX; size the allocation to the batch's longest
-    uint64_t lds_seq = max_len + 8;
+    uint64_t lds_seq = max_len + k5::WRAP;
     if (lds_seq > k5::LDS_SEQ_MAX)
         lds_seq = k5::LDS_SEQ_MAX;
     lds_seq = (lds_seq + 15) & ~15ull;
@@ -358,7 +458,7 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
     hipLaunchKernelGGL(kl, dim3(blocks), dim3(k5::THREADS), lds_seq, st, d_seqs, d_offsets, n, lds_seq, d_rot_index,
                        d_rotated);
     PH_HIP(hipGetLastError());
-    if (max_len + 8 > lds_seq) {
+    if (max_len + k5::WRAP > lds_seq) {
         hipLaunchKernelGGL((k5::least_rotation_kernel<false>), dim3(blocks), dim3(k5::THREADS), 0, st, d_seqs, d_offsets,
                            n, lds_seq, d_rot_index, d_rotated);
         PH_HIP(hipGetLastError());
