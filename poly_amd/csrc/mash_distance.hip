@@ -132,46 +132,122 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     return L;
 }
 
-// ---- check: ascending? occurrence number representable? max value.  One block per sketch.
-__global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restrict__ sk, uint32_t s,
-                                                       uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
-                                                       int force_irregular, int track_max, uint32_t max_occ)
+// ---- the largest value of the Y side: an ascending sketch ends with its largest value, and a sketch that is not
+// ascending never enters the index -- one load per sketch gives the bucket shift before the sketches are read at all
+__global__ __launch_bounds__(THREADS) void maxlast_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
+                                                         uint32_t *__restrict__ hdr)
 {
-    const uint64_t q = blockIdx.x;
-    const uint32_t *p = sk + q * s;
-    uint32_t v = 0, mult = 0;
-    bool bad = force_irregular != 0;
-    for (uint32_t e = threadIdx.x; e < s; e += THREADS) {
-        const uint32_t x = p[e];
-        v = max(v, x);
-        if (e + 1 < s && x > p[e + 1])
-            bad = true;
-        if (e > max_occ && p[e - max_occ - 1u] == x) // more equal values in one sketch than an item can number
-            bad = true;
-        if (track_max && (e == 0 || p[e - 1] != x)) { // first copy of a value: how many are there?
-            uint32_t a = 1;
-            while (e + a < s && p[e + a] == x)
-                ++a;
-            mult = max(mult, a);
-        }
-    }
-    if (bad)
-        flags[q] = 1;
-    if (track_max) {
-        const int anybad = __syncthreads_or(bad ? 1 : 0); // an irregular sketch never enters the index
+    const uint64_t q = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    uint32_t v = q < n ? sk[q * s + (s - 1)] : 0u;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-            mult = max(mult, (uint32_t)__shfl_xor((int)mult, d, 64));
+    for (int d = 32; d >= 1; d >>= 1)
+        v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&hdr[H_MAXVAL], v);
+}
+
+__device__ __forceinline__ uint32_t bucket_shift(uint32_t maxval, uint32_t nbk_log2)
+{
+    const uint32_t bits = 32u - (uint32_t)__builtin_clz(maxval | 1u);
+    return bits > nbk_log2 ? bits - nbk_log2 : 0u;
+}
+
+// ---- check: ascending? occurrence number representable?  One WAVE per sketch, grid-stride, no barrier: up to 1024
+// elements of the sketch sit in the lanes' registers from one round of loads, the right-hand neighbour comes from the next
+// lane (the last lane loads its own), and an ascending sketch without a repeated value -- nearly all -- is done after 16
+// compares.  (A workgroup per sketch, one element per trip: 0.42 ms for 100k sketches of 1000.)  On the Y side the same
+// pass counts the regular sketches' items per coarse bucket from those registers: the separate counting pass over Y
+// (0.09 ms) and its read of the flags are gone.
+template <bool YSIDE>
+__global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
+                                                       uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
+                                                       int force_irregular, uint32_t max_occ, uint32_t nbk_log2,
+                                                       uint32_t cshift_extra, uint32_t nc, uint32_t *__restrict__ gcount)
+{
+    extern __shared__ uint32_t lh[]; // YSIDE: nc coarse counters
+    uint32_t cshift = 0;
+    if (YSIDE) {
+        for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+            lh[c] = 0;
+        cshift = bucket_shift(hdr[H_MAXVAL], nbk_log2) + cshift_extra;
+        __syncthreads();
+    }
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * THREADS + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (THREADS / 64);
+    uint32_t multmax = 0; // over this wave's regular sketches
+    for (uint64_t q = wave; q < n; q += nwaves) {
+        const uint32_t *p = sk + q * s;
+        bool bad = force_irregular != 0, anyeq = false;
+        uint32_t x[16];
+        for (uint32_t e0 = 0; e0 < s; e0 += 1024) {
+            uint32_t edge[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t e = e0 + u * 64 + lane;
+                x[u] = e < s ? p[e] : 0u;
+                edge[u] = (lane == 63u && e + 1 < s) ? p[e + 1] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t e = e0 + u * 64 + lane;
+                uint32_t nx = (uint32_t)__shfl_down((int)x[u], 1, 64);
+                if (lane == 63u)
+                    nx = edge[u];
+                const bool has = e + 1 < s;
+                bad = bad || (has && x[u] > nx);
+                anyeq = anyeq || (has && x[u] == nx);
+            }
         }
-        // nearly every wave sees a maximum that is already recorded: read before the atomic
-        if ((threadIdx.x & 63) == 0) {
-            if (v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&hdr[H_MAXVAL], v);
-            if (!anybad && mult > __hip_atomic_load(&hdr[H_MAXMULT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                atomicMax(&hdr[H_MAXMULT], mult);
+        bool anybad = __ballot(bad) != 0ull; // an irregular sketch never enters the index
+        uint32_t mult = 1;
+        if (YSIDE && !anybad && __ballot(anyeq) != 0ull) {
+            // repeated values inside an ascending sketch (rare): the longest run, a first copy counting its own
+            mult = 0;
+            for (uint32_t e = lane; e < s; e += 64) {
+                const uint32_t x0 = p[e];
+                if (e == 0 || p[e - 1] != x0) {
+                    uint32_t a = 1;
+                    while (e + a < s && p[e + a] == x0)
+                        ++a;
+                    mult = max(mult, a);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1)
+                mult = max(mult, (uint32_t)__shfl_xor((int)mult, d, 64));
+            if (mult - 1u > max_occ) // more equal values in one sketch than an item can number
+                anybad = true;
+        }
+        if (anybad && lane == 0)
+            flags[q] = 1;
+        if (YSIDE && !anybad) {
+            multmax = max(multmax, mult);
+            if (s <= 1024) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (u * 64 + lane < s)
+                        atomicAdd(&lh[x[u] >> cshift], 1u);
+            } else {
+                for (uint32_t e = lane; e < s; e += 64)
+                    atomicAdd(&lh[p[e] >> cshift], 1u);
+            }
         }
     }
+    if (YSIDE) {
+        // nearly every wave sees a maximum that is already recorded: read before the atomic
+        if (lane == 0 && multmax > __hip_atomic_load(&hdr[H_MAXMULT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&hdr[H_MAXMULT], multmax);
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+            if (lh[c])
+                atomicAdd(&gcount[c], lh[c]);
+    }
+}
+
+static inline unsigned check_grid(uint64_t n) // a wave per sketch, at most 8 workgroups per CU
+{
+    const uint64_t wg = (n + THREADS / 64 - 1) / (THREADS / 64);
+    return (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(wg, 256ull * 8ull));
 }
 
 // ---- lists of irregular / regular sketches, bucket shift ---------------------------
@@ -199,9 +275,7 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
     append(inX && !badX, &hdr[H_NREGX], regX);
     append(t < ny && flagsY[t] != 0, &hdr[H_NIRRY], irrY);
     if (t == 0) {
-        const uint32_t mv = hdr[H_MAXVAL];
-        const uint32_t bits = 32u - (uint32_t)__builtin_clz(mv | 1u);
-        const uint32_t shift = bits > nbk_log2 ? bits - nbk_log2 : 0u;
+        const uint32_t shift = bucket_shift(hdr[H_MAXVAL], nbk_log2);
         hdr[H_SHIFT] = shift;
         // compact items: the value's low bits and the occurrence number + 1 share 11 bits (the all-zero word is the join's
         // "no item": what a buffer load returns beyond the end of a bucket)
@@ -219,32 +293,6 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
 
 constexpr uint32_t FPC_MAX = 8192;   // fine buckets per coarse bucket
 constexpr uint32_t BATCH_ITEMS = 65536; // items a level-1 workgroup takes at a time
-
-// coarse histogram: gcount[c] += items of my batch in coarse bucket c
-__global__ __launch_bounds__(THREADS) void coarse_count_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
-                                                              const uint8_t *__restrict__ flags,
-                                                              const uint32_t *__restrict__ hdr, uint32_t cshift_extra,
-                                                              uint32_t nc, uint32_t per_batch,
-                                                              uint32_t *__restrict__ gcount)
-{
-    extern __shared__ uint32_t lh[]; // nc
-    const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
-    for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
-        lh[c] = 0;
-    __syncthreads();
-    const uint64_t q0 = (uint64_t)blockIdx.x * per_batch, q1 = min(n, q0 + per_batch);
-    for (uint64_t q = q0; q < q1; ++q) {
-        if (flags[q])
-            continue;
-        const uint32_t *p = sk + q * s;
-        for (uint32_t e = threadIdx.x; e < s; e += THREADS)
-            atomicAdd(&lh[p[e] >> cshift], 1u);
-    }
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
-        if (lh[c])
-            atomicAdd(&gcount[c], lh[c]);
-}
 
 // exclusive scan of gcount[nc] (nc <= 4096) -> cstart[nc + 1], gcur = copy; one workgroup
 __global__ __launch_bounds__(1024) void coarse_scan_kernel(const uint32_t *__restrict__ gcount, uint32_t nc,
@@ -347,7 +395,10 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
 #endif
 constexpr uint32_t STAGE_ITEMS = PH_K2_STAGE_ITEMS;
 constexpr int STAGE_THREADS = PH_K2_STAGE_THREADS;
-__global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
+#ifndef PH_K2_STAGE_MINW
+#define PH_K2_STAGE_MINW 8
+#endif
+__global__ __launch_bounds__(STAGE_THREADS, PH_K2_STAGE_MINW) void coarse_scatter_staged_kernel(
     const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags,
     const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t nc, uint32_t per_batch, uint32_t id_bits,
     uint32_t c0, uint32_t c1, uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
@@ -363,14 +414,35 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
         cnt[c] = 0;
     __syncthreads();
     const uint64_t q0 = (uint64_t)blockIdx.x * per_batch, q1 = min(n, q0 + per_batch);
-    for (uint64_t q = q0; q < q1; ++q) {
-        if (flags[q])
-            continue;
-        const uint32_t *p = sk + q * s;
-        for (uint32_t e = tid; e < s; e += STAGE_THREADS) {
-            const uint32_t c = p[e] >> cshift;
-            if (c - c0 < c1 - c0) // a part of the index takes the coarse buckets [c0, c1) only
-                atomicAdd(&cnt[c], 1u);
+    // The batch's sketches are one contiguous array of at most STAGE_ITEMS values: a thread keeps its SPT items in
+    // registers from ONE round of loads (value, the value in front of it for the occurrence number, the sketch's flag) --
+    // a sketch at a time the kernel was a chain of ~20 dependent round trips per workgroup, 83 % of the wave cycles
+    // waiting (profiles/r03_k2_pmc_sq.md) -- and the counting atomic's return value IS the item's rank inside its
+    // bucket, so the items are placed without a second atomic pass.
+    constexpr int SPT = (int)(STAGE_ITEMS / STAGE_THREADS);
+    const uint32_t *base = sk + q0 * s;
+    const uint32_t nb = (uint32_t)(q1 - q0) * s; // <= STAGE_ITEMS
+    const uint32_t sinv = (uint32_t)(((1ull << 32) + s - 1) / s); // i / s by multiply-high: exact for i < 2^16 <= 2^32 / s
+    uint32_t v[SPT], rk[SPT], in = 0, dup = 0; // masks: item u is mine / has its own value in front of it in its sketch
+    {
+        uint32_t pv[SPT];
+        uint8_t fl[SPT];
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const uint32_t i = tid + u * STAGE_THREADS;
+            const bool ok = i < nb;
+            const uint32_t qi = s > 1 ? __umulhi(i, sinv) : i;
+            v[u] = ok ? base[i] : 0u;
+            pv[u] = (ok && i > qi * s) ? base[i - 1] : ~v[u]; // the value in front of it in the same sketch
+            fl[u] = ok ? flags[q0 + qi] : (uint8_t)1;
+        }
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            const uint32_t c = v[u] >> cshift;
+            const bool mine = !fl[u] && c - c0 < c1 - c0; // a part of the index takes the coarse buckets [c0, c1) only
+            in |= (mine ? 1u : 0u) << u;
+            dup |= (pv[u] == v[u] ? 1u : 0u) << u;
+            rk[u] = mine ? atomicAdd(&cnt[c], 1u) : 0u;
         }
     }
     __syncthreads();
@@ -397,28 +469,46 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
         }
         if (c < nc) {
             lstart[c] = pre + incl - v;
+#ifdef PH_K2_X_NOGCUR /* timing experiment only: wrong slices */
+            gbase[c] = gcur[c] + blockIdx.x * 8u;
+#else
             gbase[c] = v ? atomicAdd(&gcur[c], v) : 0u;
+#endif
             cnt[c] = 0;
         }
         carry += tot;
         __syncthreads();
     }
     const uint32_t nitems = carry;
-    for (uint64_t q = q0; q < q1; ++q) {
-        if (flags[q])
-            continue;
-        const uint32_t *p = sk + q * s;
-        for (uint32_t e = tid; e < s; e += STAGE_THREADS) {
-            const uint32_t v = p[e];
+#if defined(PH_K2_X_ABL) && PH_K2_X_ABL == 2 /* timing experiment: stop after the scan */
+    if (nitems == 0xFFFFFFFFu)
+        citems[0] = make_uint2(rk[0] + rk[7], gbase[tid & 1023]);
+    return;
+#endif
+#pragma unroll
+    for (int u = 0; u < SPT; ++u)
+        if (in >> u & 1u) {
+            const uint32_t i = tid + u * STAGE_THREADS, qi = s > 1 ? __umulhi(i, sinv) : i;
             uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
-            while (occ < e && p[e - occ - 1] == v)
-                ++occ;
-            const uint32_t c = v >> cshift;
-            if (c - c0 < c1 - c0)
-                stage[lstart[c] + atomicAdd(&cnt[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
+            if (dup >> u & 1u) {
+                const uint32_t e = i - qi * s;
+                occ = 1;
+                while (occ < e && base[i - occ - 1] == v[u])
+                    ++occ;
+            }
+            stage[lstart[v[u] >> cshift] + rk[u]] = make_uint2(v[u], (uint32_t)(q0 + qi) | (occ << id_bits));
         }
-    }
     __syncthreads();
+#if defined(PH_K2_X_ABL) && PH_K2_X_ABL == 3 /* timing experiment: no write-out */
+    if (nitems == 0xFFFFFFFFu)
+        citems[0] = stage[tid];
+    return;
+#endif
+#if defined(PH_K2_X_ABL) && PH_K2_X_ABL == 4 /* timing experiment: write-out to the workgroup's own contiguous range */
+    for (uint32_t t = tid; t < nitems; t += STAGE_THREADS)
+        citems[(size_t)blockIdx.x * STAGE_ITEMS + t] = stage[t];
+    return;
+#endif
     for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
         const uint2 it = stage[t];
         const uint32_t c = it.x >> cshift;
@@ -432,7 +522,10 @@ __global__ __launch_bounds__(STAGE_THREADS) void coarse_scatter_staged_kernel(
 #define PH_K2_FINE_THREADS 512
 #endif
 constexpr int FINE_THREADS = PH_K2_FINE_THREADS; // a coarse bucket is a chain of memory round trips: 8 waves per SIMD hide more of them
-__global__ __launch_bounds__(FINE_THREADS) void fine_kernel(const uint2 *__restrict__ citems,
+#ifndef PH_K2_FINE_MINW
+#define PH_K2_FINE_MINW 8
+#endif
+__global__ __launch_bounds__(FINE_THREADS, PH_K2_FINE_MINW) void fine_kernel(const uint2 *__restrict__ citems,
                                                            const uint32_t *__restrict__ cstart, uint32_t cfirst, uint32_t nc,
                                                            uint32_t fpc_log2, uint32_t *__restrict__ hdr,
                                                            uint32_t *__restrict__ start, uint2 *__restrict__ items,
@@ -1287,15 +1380,15 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         // header, Y flags and the histogram start at zero
         PH_HIP(hipMemsetAsync(w, 0, L.off_irrY, st));
         PH_HIP(hipMemsetAsync(gcount, 0, (size_t)L.nc * 4, st));
-        hipLaunchKernelGGL(k2::check_kernel, dim3((unsigned)ny), dim3(k2::THREADS), 0, st, d_Y, sy, flagsY, hdr, force, 1,
-                           max_occ);
+        hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st, d_Y,
+                           ny, sy, hdr);
+        hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(ny)), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy,
+                           flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount);
         hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                            flagsX, (uint64_t)0, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2, allow_compact ? 1 : 0);
         // ---- inverted index of the Y side: two-level partition by value
         const uint32_t per_batch = std::max<uint32_t>(1u, k2::BATCH_ITEMS / sy);
         const unsigned batches = (unsigned)((ny + per_batch - 1) / per_batch);
-        hipLaunchKernelGGL(k2::coarse_count_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy, flagsY,
-                           hdr, L.fpc_log2, L.nc, per_batch, gcount);
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, gcount, L.nc, cstart, gcur, start, L.nbk);
         // one part of the index (multi-rank build): the coarse buckets [c0, c1) only, every item at its final place.  The
         // bounds come from the coarse histogram -- the one point where the host has to look at device data.
@@ -1332,8 +1425,8 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     if (!build)
         hipLaunchKernelGGL(reset_x_kernel, dim3(1), dim3(1), 0, st, hdr);
     PH_HIP(hipMemsetAsync(flagsX, 0, nx, st));
-    hipLaunchKernelGGL(k2::check_kernel, dim3((unsigned)nx), dim3(k2::THREADS), 0, st, d_X, sx, flagsX, hdr, force, 0,
-                       0xFFFFFFFEu);
+    hipLaunchKernelGGL(k2::check_kernel<false>, dim3(k2::check_grid(nx)), dim3(k2::THREADS), 0, st, d_X, nx, sx, flagsX, hdr, force,
+                       0xFFFFFFFEu, 0u, 0u, 0u, (uint32_t *)nullptr);
     hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nx + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                        flagsX, nx, flagsY, (uint64_t)0, irrX, regX, irrY, hdr, L.nbk_log2, -1);
     // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
