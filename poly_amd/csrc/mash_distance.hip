@@ -393,7 +393,21 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
 #ifndef PH_K2_STAGE_THREADS
 #define PH_K2_STAGE_THREADS 1024
 #endif
+#ifndef PH_K2_STAGE_GRID
+#define PH_K2_STAGE_GRID 512ull // two 1024-thread workgroups per CU
+#endif
 constexpr uint32_t STAGE_ITEMS = PH_K2_STAGE_ITEMS;
+// A wave places items of consecutive buckets: slots ~8 items (64 bytes) apart, four bank groups for 64 lanes.  Flipping an
+// item's low three slot bits by bits 5..7 of its slot spreads such a stride over all banks; a run read back in order
+// stays inside its own 8 slots.
+__device__ __forceinline__ uint32_t stage_swz(uint32_t pos)
+{
+#ifdef PH_K2_NO_SWZ
+    return pos;
+#else
+    return pos ^ ((pos >> 5) & 7u);
+#endif
+}
 constexpr int STAGE_THREADS = PH_K2_STAGE_THREADS;
 #ifndef PH_K2_STAGE_MINW
 #define PH_K2_STAGE_MINW 8
@@ -410,110 +424,96 @@ __global__ __launch_bounds__(STAGE_THREADS, PH_K2_STAGE_MINW) void coarse_scatte
     __shared__ uint32_t wsum[STAGE_THREADS / 64];
     const int tid = threadIdx.x;
     const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
-    for (uint32_t c = tid; c < nc; c += STAGE_THREADS)
-        cnt[c] = 0;
-    __syncthreads();
-    const uint64_t q0 = (uint64_t)blockIdx.x * per_batch, q1 = min(n, q0 + per_batch);
-    // The batch's sketches are one contiguous array of at most STAGE_ITEMS values: a thread keeps its SPT items in
-    // registers from ONE round of loads (value, the value in front of it for the occurrence number, the sketch's flag) --
-    // a sketch at a time the kernel was a chain of ~20 dependent round trips per workgroup, 83 % of the wave cycles
-    // waiting (profiles/r03_k2_pmc_sq.md) -- and the counting atomic's return value IS the item's rank inside its
-    // bucket, so the items are placed without a second atomic pass.
-    constexpr int SPT = (int)(STAGE_ITEMS / STAGE_THREADS);
-    const uint32_t *base = sk + q0 * s;
-    const uint32_t nb = (uint32_t)(q1 - q0) * s; // <= STAGE_ITEMS
-    const uint32_t sinv = (uint32_t)(((1ull << 32) + s - 1) / s); // i / s by multiply-high: exact for i < 2^16 <= 2^32 / s
-    uint32_t v[SPT], rk[SPT], in = 0, dup = 0; // masks: item u is mine / has its own value in front of it in its sketch
-    {
-        uint32_t pv[SPT];
-        uint8_t fl[SPT];
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const uint32_t i = tid + u * STAGE_THREADS;
-            const bool ok = i < nb;
-            const uint32_t qi = s > 1 ? __umulhi(i, sinv) : i;
-            v[u] = ok ? base[i] : 0u;
-            pv[u] = (ok && i > qi * s) ? base[i - 1] : ~v[u]; // the value in front of it in the same sketch
-            fl[u] = ok ? flags[q0 + qi] : (uint8_t)1;
-        }
-#pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            const uint32_t c = v[u] >> cshift;
-            const bool mine = !fl[u] && c - c0 < c1 - c0; // a part of the index takes the coarse buckets [c0, c1) only
-            in |= (mine ? 1u : 0u) << u;
-            dup |= (pv[u] == v[u] ? 1u : 0u) << u;
-            rk[u] = mine ? atomicAdd(&cnt[c], 1u) : 0u;
-        }
-    }
-    __syncthreads();
-    // exclusive scan of cnt[0..nc) -> lstart; my slice of every coarse bucket -> gbase; cnt becomes the cursor
-    uint32_t carry = 0;
-    for (uint32_t c0 = 0; c0 < nc; c0 += STAGE_THREADS) {
-        const uint32_t c = c0 + tid;
-        const uint32_t v = c < nc ? cnt[c] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d)
-                incl += t;
-        }
-        if ((tid & 63) == 63)
-            wsum[tid >> 6] = incl;
-        __syncthreads();
-        uint32_t pre = carry, tot = 0;
-        for (int w = 0; w < STAGE_THREADS / 64; ++w) {
-            if (w < (tid >> 6))
-                pre += wsum[w];
-            tot += wsum[w];
-        }
-        if (c < nc) {
-            lstart[c] = pre + incl - v;
-#ifdef PH_K2_X_NOGCUR /* timing experiment only: wrong slices */
-            gbase[c] = gcur[c] + blockIdx.x * 8u;
-#else
-            gbase[c] = v ? atomicAdd(&gcur[c], v) : 0u;
-#endif
+    // persistent workgroups, a batch per turn: 12,500 launches of 1024 threads each cost more than the turns' one barrier
+    // (the barrier behind the zeroing also keeps a fast wave out of the stage while a slow one still writes it out)
+    for (uint64_t batch = blockIdx.x; batch * per_batch < n; batch += gridDim.x) {
+        for (uint32_t c = tid; c < nc; c += STAGE_THREADS)
             cnt[c] = 0;
-        }
-        carry += tot;
         __syncthreads();
-    }
-    const uint32_t nitems = carry;
-#if defined(PH_K2_X_ABL) && PH_K2_X_ABL == 2 /* timing experiment: stop after the scan */
-    if (nitems == 0xFFFFFFFFu)
-        citems[0] = make_uint2(rk[0] + rk[7], gbase[tid & 1023]);
-    return;
-#endif
+        const uint64_t q0 = batch * per_batch, q1 = min(n, q0 + per_batch);
+        // The batch's sketches are one contiguous array of at most STAGE_ITEMS values: a thread keeps its SPT items in
+        // registers from ONE round of loads (value, the value in front of it for the occurrence number, the sketch's flag) --
+        // a sketch at a time the kernel was a chain of ~20 dependent round trips per workgroup, 83 % of the wave cycles
+        // waiting (profiles/r03_k2_pmc_sq.md) -- and the counting atomic's return value IS the item's rank inside its
+        // bucket, so the items are placed without a second atomic pass.
+        constexpr int SPT = (int)(STAGE_ITEMS / STAGE_THREADS);
+        const uint32_t *base = sk + q0 * s;
+        const uint32_t nb = (uint32_t)(q1 - q0) * s; // <= STAGE_ITEMS
+        const uint32_t sinv = (uint32_t)(((1ull << 32) + s - 1) / s); // i / s by multiply-high: exact for i < 2^16 <= 2^32 / s
+        uint32_t v[SPT], rk[SPT], in = 0, dup = 0; // masks: item u is mine / has its own value in front of it in its sketch
+        {
+            uint32_t pv[SPT];
+            uint8_t fl[SPT];
 #pragma unroll
-    for (int u = 0; u < SPT; ++u)
-        if (in >> u & 1u) {
-            const uint32_t i = tid + u * STAGE_THREADS, qi = s > 1 ? __umulhi(i, sinv) : i;
-            uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
-            if (dup >> u & 1u) {
-                const uint32_t e = i - qi * s;
-                occ = 1;
-                while (occ < e && base[i - occ - 1] == v[u])
-                    ++occ;
+            for (int u = 0; u < SPT; ++u) {
+                const uint32_t i = tid + u * STAGE_THREADS;
+                const bool ok = i < nb;
+                const uint32_t qi = s > 1 ? __umulhi(i, sinv) : i;
+                v[u] = ok ? base[i] : 0u;
+                pv[u] = (ok && i > qi * s) ? base[i - 1] : ~v[u]; // the value in front of it in the same sketch
+                fl[u] = ok ? flags[q0 + qi] : (uint8_t)1;
             }
-            stage[lstart[v[u] >> cshift] + rk[u]] = make_uint2(v[u], (uint32_t)(q0 + qi) | (occ << id_bits));
+#pragma unroll
+            for (int u = 0; u < SPT; ++u) {
+                const uint32_t c = v[u] >> cshift;
+                const bool mine = !fl[u] && c - c0 < c1 - c0; // a part of the index takes the coarse buckets [c0, c1) only
+                in |= (mine ? 1u : 0u) << u;
+                dup |= (pv[u] == v[u] ? 1u : 0u) << u;
+                rk[u] = mine ? atomicAdd(&cnt[c], 1u) : 0u;
+            }
         }
-    __syncthreads();
-#if defined(PH_K2_X_ABL) && PH_K2_X_ABL == 3 /* timing experiment: no write-out */
-    if (nitems == 0xFFFFFFFFu)
-        citems[0] = stage[tid];
-    return;
-#endif
-#if defined(PH_K2_X_ABL) && PH_K2_X_ABL == 4 /* timing experiment: write-out to the workgroup's own contiguous range */
-    for (uint32_t t = tid; t < nitems; t += STAGE_THREADS)
-        citems[(size_t)blockIdx.x * STAGE_ITEMS + t] = stage[t];
-    return;
-#endif
-    for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
-        const uint2 it = stage[t];
-        const uint32_t c = it.x >> cshift;
-        citems[gbase[c] + (t - lstart[c])] = it; // (values and ids in two arrays halve level 2's counting pass but cost
-                                                  // level 1 more than that: 0.64 -> 0.87 ms, two half-length runs per bucket)
+        __syncthreads();
+        // exclusive scan of cnt[0..nc) -> lstart; my slice of every coarse bucket -> gbase; cnt becomes the cursor
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < nc; c0 += STAGE_THREADS) {
+            const uint32_t c = c0 + tid;
+            const uint32_t v = c < nc ? cnt[c] : 0u;
+            // my slice of the bucket: the atomic's round trip runs under the scan, its result is not needed before the write-out
+            const uint32_t slice = v ? atomicAdd(&gcur[c], v) : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if ((tid & 63) >= d)
+                    incl += t;
+            }
+            if ((tid & 63) == 63)
+                wsum[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t pre = carry, tot = 0;
+            for (int w = 0; w < STAGE_THREADS / 64; ++w) {
+                if (w < (tid >> 6))
+                    pre += wsum[w];
+                tot += wsum[w];
+            }
+            if (c < nc) {
+                lstart[c] = pre + incl - v;
+                gbase[c] = slice;
+            }
+            carry += tot;
+            __syncthreads();
+        }
+        const uint32_t nitems = carry;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u)
+            if (in >> u & 1u) {
+                const uint32_t i = tid + u * STAGE_THREADS, qi = s > 1 ? __umulhi(i, sinv) : i;
+                uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
+                if (dup >> u & 1u) {
+                    const uint32_t e = i - qi * s;
+                    occ = 1;
+                    while (occ < e && base[i - occ - 1] == v[u])
+                        ++occ;
+                }
+                stage[stage_swz(lstart[v[u] >> cshift] + rk[u])] = make_uint2(v[u], (uint32_t)(q0 + qi) | (occ << id_bits));
+            }
+        __syncthreads();
+        for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
+            const uint2 it = stage[stage_swz(t)];
+            const uint32_t c = it.x >> cshift;
+            citems[gbase[c] + (t - lstart[c])] = it; // (values and ids in two arrays halve level 2's counting pass but cost
+                                                      // level 1 more than that: 0.64 -> 0.87 ms, two half-length runs per bucket)
+        }
     }
 }
 
@@ -1407,7 +1407,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k2::coarse_scatter_staged_kernel, dim3((unsigned)((ny + pb - 1) / pb)), dim3(k2::STAGE_THREADS),
+            hipLaunchKernelGGL(k2::coarse_scatter_staged_kernel, dim3((unsigned)std::min<uint64_t>((ny + pb - 1) / pb, PH_K2_STAGE_GRID)), dim3(k2::STAGE_THREADS),
                                smem, st, d_Y, ny, sy, flagsY, hdr, L.fpc_log2, L.nc, pb, id_bits, c0, c1, gcur, citems);
         } else {
             hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
