@@ -7,8 +7,11 @@
 // periodic strings) -- and, optionally, the rotated sequence itself.
 //
 // Booth's algorithm is a serial scan with a 2n-entry failure table.  On a GPU
-// the same answer comes from candidate elimination, one workgroup per sequence
-// with the sequence staged in LDS:
+// the same answer comes from candidate elimination with the sequence staged in
+// LDS -- one WAVE per sequence up to 8 kB (least_rotation_wave_kernel: no
+// barrier, four sequences per workgroup), one workgroup per sequence beyond
+// that (least_rotation_kernel<true>), reading global memory when LDS cannot
+// hold it (<false>):
 //   1. every position's first 4 bytes as one big-endian word; block-wide min;
 //      the candidates are the positions that attain it (for DNA: ~n/256 of them)
 //   2. rounds of 4 more bytes: min of the next word over the surviving
@@ -19,12 +22,15 @@
 //      than the LDS list holds, or too many rounds) is finished by wave 0 with
 //      the exact two-pointer minimal-rotation algorithm, its match-extension
 //      loop vectorised 64 bytes per step with a ballot.
-// Sequences too long for LDS run the same code reading global memory.
+//   An exact repetition of a block of d bytes (c evenly spread candidates, one
+//   pass comparing s[p] with s[p + n/c]) restarts the search on that block.
 //
 // Byte compare / integer work, no MFMA.  Algorithmic HBM bytes per sequence:
 // n (read) [+ n if the rotated sequence is written] + 8.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -40,6 +46,9 @@ constexpr int THREADS = PH_K5_THREADS;
 constexpr uint32_t LIST_CAP = 1024;      // candidates kept in LDS (random DNA: ~n/256 after the first word)
 constexpr uint32_t MAX_ROUNDS = 64;      // 4 bytes per round before the serial fallback
 constexpr uint32_t LDS_SEQ_MAX = 120 * 1024;
+constexpr uint64_t MARK = ~0ull;       // rot[q] of a sequence the wave kernel leaves to the workgroup kernels
+constexpr uint64_t WAVE_SEQ_MAX = 8192; // longest sequence a wave takes alone
+constexpr uint32_t WLIST = 1024;       // candidates one wave keeps, as 16-bit positions (random DNA: n / 256 after the first word)
 constexpr uint32_t WRAP = 24; // bytes of s[0..] staged again behind s[n-1]: a 16-byte output piece + its funnel dword never wrap
 
 // least value of a wave, in every lane: the DPP ladder (pairs, quads, rows of 16 by rotation, then the two row broadcasts
@@ -132,7 +141,7 @@ template <bool IN_LDS>
 __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *__restrict__ seqs,
                                                                 const uint64_t *__restrict__ offs, uint64_t nseq,
                                                                 uint64_t lds_seq_bytes, uint64_t *__restrict__ rot,
-                                                                uint8_t *__restrict__ rotated)
+                                                                uint8_t *__restrict__ rotated, uint32_t chunk)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ uint32_t listA[LIST_CAP], listB[LIST_CAP];
@@ -143,7 +152,22 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
     uint32_t *L = reinterpret_cast<uint32_t *>(lds);
     uint32_t par = 0;
 
-    for (uint64_t q = blockIdx.x; q < nseq; q += gridDim.x) {
+    // The wave kernel ran first and MARKed what it left (sequences too long for a wave's LDS share): a
+    // workgroup looks at `chunk` consecutive rot[] entries at a time (one coalesced load) and works through the marked ones.
+    __shared__ uint32_t marked[THREADS];
+    __shared__ uint32_t nmark;
+    for (uint64_t base = (uint64_t)blockIdx.x * chunk; base < nseq; base += (uint64_t)gridDim.x * chunk)
+    {
+        __syncthreads(); // the list of the chunk before is used up
+        if (tid == 0)
+            nmark = 0;
+        __syncthreads();
+        if ((uint32_t)tid < chunk && base + tid < nseq && rot[base + tid] == MARK)
+            marked[atomicAdd(&nmark, 1u)] = (uint32_t)tid;
+        __syncthreads();
+        const uint32_t nm = nmark;
+    for (uint32_t km = 0; km < nm; ++km) {
+        const uint64_t q = base + marked[km];
         const uint64_t o0 = offs[q];
         const uint64_t n = offs[q + 1] - o0;
         const uint8_t *g = seqs + o0;
@@ -430,6 +454,262 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
             }
         }
     }
+    }
+}
+
+
+// ---- one WAVE per sequence (sequences up to a few kB): the same search with no barrier at all.  The workgroup kernel
+// spends most of a 5 kb sequence's time on its fixed part -- a dozen barriers, every wave running the one-candidate
+// bookkeeping (4.3 us per sequence and workgroup slot whatever the length: 2.5M sequences of 200 bp took 5.3 ms) --;
+// here four waves of a workgroup work on four sequences, lists are appended to with ballots on a scalar count instead of LDS
+// atomics, lists hold 16-bit positions; a sequence that does not fit the wave's LDS share is MARKed for the workgroup
+// kernels that run behind this one.
+__device__ __forceinline__ void wave_sync() // LDS written by one lane, read by another of the same wave
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) // set bits of mask below this lane
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t *__restrict__ seqs,
+                                                                 const uint64_t *__restrict__ offs, uint64_t nseq,
+                                                                 uint32_t lds_seq_bytes, uint64_t *__restrict__ rot,
+                                                                 uint8_t *__restrict__ rotated)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint8_t *lds = lds_all + (size_t)wv * (lds_seq_bytes + 2u * WLIST * 2u);
+    uint32_t *L = reinterpret_cast<uint32_t *>(lds);
+    uint16_t *listA = reinterpret_cast<uint16_t *>(lds + lds_seq_bytes), *listB = listA + WLIST; // positions < 2^16
+
+    for (uint64_t q = (uint64_t)blockIdx.x * 4 + wv; q < nseq; q += (uint64_t)gridDim.x * 4) {
+        const uint64_t o0 = offs[q];
+        const uint64_t n = offs[q + 1] - o0;
+        const uint8_t *g = seqs + o0;
+        if (n <= 1) {
+            if (lane == 0)
+                rot[q] = 0;
+            if (rotated && n == 1 && lane == 0)
+                rotated[o0] = g[0];
+            continue;
+        }
+        if (n + WRAP > lds_seq_bytes) {
+            if (lane == 0)
+                rot[q] = MARK;
+            continue;
+        }
+        const uint32_t n32 = (uint32_t)n;
+        // ---- stage (+ WRAP wrapped bytes), 16 bytes per lane and step
+        wave_sync();
+        {
+            const uint32_t n16 = n32 >> 4;
+            uint4 *L4 = reinterpret_cast<uint4 *>(lds);
+            for (uint32_t t = lane; t < n16; t += 64) {
+                uint4 v;
+                __builtin_memcpy(&v, g + 16u * t, 16);
+                L4[t] = v;
+            }
+            if (lane < (n32 & 15u))
+                lds[16u * n16 + lane] = g[16u * n16 + lane];
+            if (lane < WRAP)
+                lds[n32 + lane] = g[n32 >= WRAP ? lane : lane % n32];
+        }
+        wave_sync();
+
+        uint32_t ne = n32; // the length the search runs on (an exact repetition restarts on its first block)
+        auto byte_at = [&](uint32_t p) -> uint32_t { return lds[p >= n32 ? p - n32 : p]; }; // cyclic position p < 2n
+        auto word = [&](uint32_t p) -> uint32_t { // big-endian 4 bytes at cyclic position p < 2 * ne
+            p -= p >= ne ? ne : 0;
+            return n32 >= 4 ? word_lds(L, p) : word_at(lds, (uint64_t)p);
+        };
+        uint32_t c, m;
+        bool homo;
+    search:
+        c = 0;
+        m = 0xFFFFFFFFu;
+        {
+            // a list grows by a ballot: the lanes that add write behind the scalar count, in lane order
+            auto push_if = [&](bool is, uint32_t p) {
+                const uint64_t mask = __ballot(is);
+                if (mask != 0ull) {
+                    const uint32_t slot = c + lanes_below(mask);
+                    if (is && slot < WLIST)
+                        listA[slot] = (uint16_t)p;
+                    c += (uint32_t)__builtin_popcountll(mask);
+                }
+            };
+            if (ne >= 8) {
+                const uint32_t nfull = ne >> 2, ntail = ne & 3u;
+                for (uint32_t t = lane; t < nfull; t += 64) {
+                    const uint32_t d0 = L[t], d1 = L[t + 1];
+                    m = min(min(m, word_k<0>(d0, d1)), word_k<1>(d0, d1));
+                    m = min(min(m, word_k<2>(d0, d1)), word_k<3>(d0, d1));
+                }
+                if (lane < ntail)
+                    m = min(m, word(4u * nfull + lane));
+                m = wave_min(m);
+                homo = (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
+                // inside a run of the least byte the run's first position beats the others (see the workgroup kernel)
+                auto is_cand = [&](uint32_t w, uint32_t p) { return w == m && !(homo && word(p ? p - 1 : ne - 1) == m); };
+                // the quads that hold the least word at all, then the positions inside them
+                uint32_t cq = 0;
+                for (uint32_t t0 = 0; t0 < nfull; t0 += 64) {
+                    const uint32_t t = t0 + lane;
+                    bool hit = false;
+                    if (t < nfull) {
+                        const uint32_t d0 = L[t], d1 = L[t + 1];
+                        hit = min(min(word_k<0>(d0, d1), word_k<1>(d0, d1)), min(word_k<2>(d0, d1), word_k<3>(d0, d1))) == m;
+                    }
+                    const uint64_t mask = __ballot(hit);
+                    if (mask != 0ull) {
+                        const uint32_t slot = cq + lanes_below(mask);
+                        if (hit && slot < WLIST)
+                            listB[slot] = (uint16_t)t;
+                        cq += (uint32_t)__builtin_popcountll(mask);
+                    }
+                }
+                wave_sync();
+                {
+                    const uint32_t p = 4u * nfull + lane;
+                    push_if(lane < ntail && is_cand(word(p), p), p);
+                }
+                if (cq <= WLIST) {
+                    for (uint32_t e0 = 0; e0 < cq; e0 += 64) {
+                        const bool valid = e0 + lane < cq;
+                        const uint32_t t = valid ? listB[e0 + lane] : 0u, d0 = L[t], d1 = L[t + 1];
+                        push_if(valid && is_cand(word_k<0>(d0, d1), 4u * t), 4u * t);
+                        push_if(valid && is_cand(word_k<1>(d0, d1), 4u * t + 1), 4u * t + 1);
+                        push_if(valid && is_cand(word_k<2>(d0, d1), 4u * t + 2), 4u * t + 2);
+                        push_if(valid && is_cand(word_k<3>(d0, d1), 4u * t + 3), 4u * t + 3);
+                    }
+                } else { // low complexity: every position is looked at directly
+                    for (uint32_t t0 = 0; t0 < nfull; t0 += 64) { // (to the end: c stays exact for the period test)
+                        const bool valid = t0 + lane < nfull;
+                        const uint32_t t = valid ? t0 + lane : 0u, d0 = L[t], d1 = L[t + 1];
+                        push_if(valid && is_cand(word_k<0>(d0, d1), 4u * t), 4u * t);
+                        push_if(valid && is_cand(word_k<1>(d0, d1), 4u * t + 1), 4u * t + 1);
+                        push_if(valid && is_cand(word_k<2>(d0, d1), 4u * t + 2), 4u * t + 2);
+                        push_if(valid && is_cand(word_k<3>(d0, d1), 4u * t + 3), 4u * t + 3);
+                    }
+                }
+            } else { // a handful of positions
+                if (lane < ne)
+                    m = word(lane);
+                m = wave_min(m);
+                homo = ne >= 4 && (m & 0xFFFFu) == (m >> 16) && (m & 0xFFu) == ((m >> 8) & 0xFFu);
+                push_if(lane < ne && word(lane) == m && !(homo && word(lane ? lane - 1 : ne - 1) == m), lane);
+            }
+        }
+        wave_sync();
+        // c occurrences of the least word, evenly spread if the sequence is periodic: a repetition of its first ne / c bytes?
+        // (c is exact even when the list is full)
+        if (c >= 2 && ne % c == 0) {
+            const uint32_t d = ne / c;
+            auto differs_at = [&](uint32_t p) { return byte_at(p) != byte_at(p + d >= ne ? p + d - ne : p + d); };
+            if (__ballot(lane < ne && differs_at(lane)) == 0ull) {
+                bool differs = false;
+                for (uint32_t p0 = 64; p0 < ne && !differs; p0 += 64)
+                    differs = __ballot(p0 + lane < ne && differs_at(p0 + lane)) != 0ull;
+                if (!differs) {
+                    ne = d;
+                    goto search; // again, on one block
+                }
+            }
+        }
+        uint64_t r = 0; // c == 0: a homopolymer, all rotations equal, the smallest index is 0
+        if (c != 0) {
+            uint16_t *cur = listA, *nxt = listB;
+            uint32_t depth = 4, rounds = 0, stalled = 0;
+            bool serial = c > WLIST; // more candidates than the list holds: the exact two-pointer search below
+            while (!serial && c > 64 && depth < ne) { // rounds over the list while the lanes cannot hold the candidates
+                // a tandem repeat that does not close on itself keeps all its candidates until the seam comes into view:
+                // three rounds without a loss and the two-pointer search takes over (it runs through a period in one step)
+                if (++rounds > MAX_ROUNDS || stalled >= 3) {
+                    serial = true;
+                    break;
+                }
+                uint32_t mm = 0xFFFFFFFFu;
+                for (uint32_t e = lane; e < c; e += 64)
+                    mm = min(mm, word(cur[e] + depth));
+                mm = wave_min(mm);
+                uint32_t c2 = 0;
+                for (uint32_t e0 = 0; e0 < c; e0 += 64) {
+                    const bool valid = e0 + lane < c;
+                    const uint32_t p = valid ? cur[e0 + lane] : 0u;
+                    const bool keep = valid && word(p + depth) == mm;
+                    const uint64_t mask = __ballot(keep);
+                    if (keep)
+                        nxt[c2 + lanes_below(mask)] = (uint16_t)p;
+                    c2 += (uint32_t)__builtin_popcountll(mask);
+                }
+                wave_sync();
+                stalled = c2 == c ? stalled + 1 : 0;
+                c = c2;
+                uint16_t *t = cur;
+                cur = nxt;
+                nxt = t;
+                depth += 4;
+            }
+            if (!serial && c <= 64) { // one candidate per lane
+                bool alive = lane < c;
+                const uint32_t p = alive ? cur[lane] : 0u;
+                while (c > 1 && depth < ne) {
+                    if (++rounds > MAX_ROUNDS) {
+                        serial = true;
+                        break;
+                    }
+                    const uint32_t w = alive ? word(p + depth) : 0xFFFFFFFFu;
+                    const uint32_t mm = wave_min(w);
+                    alive = alive && w == mm;
+                    c = (uint32_t)__builtin_popcountll(__ballot(alive));
+                    depth += 4;
+                }
+                if (!serial)
+                    r = wave_min(alive ? p : 0xFFFFFFFFu); // equal rotations (or a single one): the smallest index
+            } else if (!serial) { // more than a wave of equal rotations
+                uint32_t best = 0xFFFFFFFFu;
+                for (uint32_t e = lane; e < c; e += 64)
+                    best = min(best, cur[e]);
+                r = wave_min(best);
+            }
+            if (serial)
+                r = two_pointer_wave(lds, (uint64_t)ne);
+        }
+        if (lane == 0)
+            rot[q] = r;
+        if (rotated) { // RotateSequence: (s + s)[r : r + n], seqhash.go:131-137
+            uint8_t *out = rotated + o0;
+            const uint32_t r32 = (uint32_t)r;
+            if (n32 >= 32) {
+                const uint32_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u)) & 15u;
+                const uint32_t nd = (n32 - head) >> 4, tail0 = head + 16u * nd;
+                if (lane < head)
+                    out[lane] = (uint8_t)byte_at(lane + r32);
+                if (lane < n32 - tail0)
+                    out[tail0 + lane] = (uint8_t)byte_at(tail0 + lane + r32);
+                uint4 *od = reinterpret_cast<uint4 *>(out + head);
+                for (uint32_t t = lane; t < nd; t += 64) {
+                    uint32_t p = head + 16u * t + r32;
+                    p -= p >= n32 ? n32 : 0;
+                    const uint32_t *src = L + (p >> 2);
+                    const uint32_t sh = p & 3u;
+                    const uint32_t a0 = src[0], a1 = src[1], a2 = src[2], a3 = src[3], a4 = src[4];
+                    uint4 v;
+                    v.x = __builtin_amdgcn_alignbyte(a1, a0, sh);
+                    v.y = __builtin_amdgcn_alignbyte(a2, a1, sh);
+                    v.z = __builtin_amdgcn_alignbyte(a3, a2, sh);
+                    v.w = __builtin_amdgcn_alignbyte(a4, a3, sh);
+                    od[t] = v;
+                }
+            } else if (lane < n32) {
+                out[lane] = (uint8_t)byte_at(lane + r32);
+            }
+        }
+    }
 }
 
 } // namespace k5
@@ -446,21 +726,42 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
         return POLYHIP_OK;
     PH_REQUIRE(d_seqs && d_offsets && d_rot_index, "polyhip_least_rotation_batch: null pointer");
     hipStream_t st = as_stream(stream);
-    // LDS holds sequences up to LDS_SEQ_MAX; size the allocation to the batch's longest
+    // 1. a wave per sequence for everything up to WAVE_SEQ_MAX bytes (POLYHIP_K5_WAVE_MAX overrides; testing aid): what it
+    //    leaves -- longer sequences -- carries MARK in d_rot_index
+    uint64_t wave_max = k5::WAVE_SEQ_MAX;
+    if (const char *e = getenv("POLYHIP_K5_WAVE_MAX"))
+        wave_max = std::min<uint64_t>(strtoull(e, nullptr, 10), 32768);
+    uint32_t lds_w = (uint32_t)std::min<uint64_t>(max_len, wave_max) + k5::WRAP;
+    lds_w = (lds_w + 15u) & ~15u;
+    {
+        const size_t smem = 4 * ((size_t)lds_w + 2 * k5::WLIST * 2);
+        const unsigned blocks = (unsigned)std::min<uint64_t>((n + 3) / 4, 256ull * 8ull);
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k5::least_rotation_wave_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(k5::least_rotation_wave_kernel, dim3(blocks), dim3(256), smem, st, d_seqs, d_offsets, n, lds_w,
+                           d_rot_index, d_rotated);
+        PH_HIP(hipGetLastError());
+    }
+    if (max_len + k5::WRAP <= lds_w)
+        return POLYHIP_OK; // nothing was left
+    // 2. a workgroup per marked sequence, staged in LDS up to LDS_SEQ_MAX (the allocation is sized to the batch's longest)
     uint64_t lds_seq = max_len + k5::WRAP;
     if (lds_seq > k5::LDS_SEQ_MAX)
         lds_seq = k5::LDS_SEQ_MAX;
     lds_seq = (lds_seq + 15) & ~15ull;
-    const unsigned blocks = (unsigned)(n < 256ull * 32ull ? n : 256ull * 32ull);
+    // a workgroup reads `chunk` marks at a time: few sequences -> small chunks, so that the marked ones spread over the chip
+    const uint32_t chunk = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(k5::THREADS, n / (256ull * 32ull)));
+    const unsigned blocks = (unsigned)std::min<uint64_t>((n + chunk - 1) / chunk, 256ull * 32ull);
     auto kl = k5::least_rotation_kernel<true>;
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds_seq));
     hipLaunchKernelGGL(kl, dim3(blocks), dim3(k5::THREADS), lds_seq, st, d_seqs, d_offsets, n, lds_seq, d_rot_index,
-                       d_rotated);
+                       d_rotated, chunk);
     PH_HIP(hipGetLastError());
+    // 3. the same search reading global memory for what LDS cannot hold
     if (max_len + k5::WRAP > lds_seq) {
         hipLaunchKernelGGL((k5::least_rotation_kernel<false>), dim3(blocks), dim3(k5::THREADS), 0, st, d_seqs, d_offsets,
-                           n, lds_seq, d_rot_index, d_rotated);
+                           n, lds_seq, d_rot_index, d_rotated, chunk);
         PH_HIP(hipGetLastError());
     }
     return POLYHIP_OK;
