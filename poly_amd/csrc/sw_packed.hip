@@ -353,6 +353,165 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
     }
 }
 
+// ---- the same sweep with ONE wave per workgroup and the current block's table at a FIXED LDS address --------------
+// A row's table entry then sits at (code-pair index << 4) + an immediate: ONE vector instruction (an SDWA shift of the
+// packed index byte) instead of two (SDWA add of the block base, shift), 16 instead of 17 per row and 4-column block.
+// A workgroup of one wave owns its LDS allocation, so the slot is LDS address 0 for every wave and no barrier guards
+// it: when a block starts the wave sends the next block's table (at most 64 entries of 16 bytes, one per lane,
+// L2-resident) from global memory straight into a staging area of LDS (global_load_lds: no register is held under the
+// rows, where the allocator is at its limit), and copies it over the slot when the block's last row has read its entry --
+// LDS runs a wave's instructions in order, so the next block's first read sees the new table.  No chunk staging, no
+// __syncthreads in the sweep.  Half-float cells only (F16), tables of up to 64 code pairs (ncp <= 8).
+#define PH_PK1_ISSUE(dst, rp, SEL)                                                                                   \
+    do {                                                                                                           \
+        uint32_t ad_;                                                                                              \
+        asm volatile("v_lshlrev_b32_sdwa %0, 4, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL \
+                     : "=v"(ad_)                                                                                   \
+                     : "v"(rp));                                                                                   \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(ad_));                                                \
+    } while (0)
+
+template <int RA, bool SKIP>
+__global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                      uint64_t npairs, const uint32_t *__restrict__ prof2, uint32_t nq,
+                                                      uint32_t tab_bytes, int ncp, const uint8_t *__restrict__ codeA,
+                                                      int ncodes, int gapabs, uint32_t *__restrict__ infoM,
+                                                      uint32_t *__restrict__ infoQ)
+{
+    static_assert(RA % 4 == 0 && RA <= 152, "RA");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_pk[]; // [0, 1024) the table slot, [1024, 1280) the code bytes,
+    uint8_t *codeL = lds_pk + 1024;                                  // [1280, 2304) the next block's table arriving
+    const uint32_t lane = threadIdx.x;
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk)) != 0u)
+        __builtin_trap(); // the sweep addresses the slot by immediate
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        codeL[lane + 64 * u] = codeA[lane + 64 * u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // my two pairs
+    const uint64_t base = (uint64_t)blockIdx.x * 128;
+    const uint64_t p0 = base + lane, p1 = base + 64 + lane;
+    const uint8_t *ap0 = A, *ap1 = A;
+    uint32_t len0 = 0, len1 = 0;
+    if (p0 < npairs) {
+        const uint64_t o = offA[p0], l = offA[p0 + 1] - o;
+        ap0 = A + o;
+        len0 = l > (uint64_t)RA ? 0u : (uint32_t)l; // too long: no score here, the locate kernel reports it
+    }
+    if (p1 < npairs) {
+        const uint64_t o = offA[p1], l = offA[p1 + 1] - o;
+        ap1 = A + o;
+        len1 = l > (uint64_t)RA ? 0u : (uint32_t)l;
+    }
+    uint32_t rpk[RA / 4]; // index of row i's code pair inside a block's table, four rows per register
+#pragma unroll
+    for (int w = 0; w < RA / 4; ++w) {
+        uint32_t pk = 0;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int i = 4 * w + h;
+            const uint32_t c0 = row_code(ap0, len0, i, codeL, (uint32_t)ncodes);
+            const uint32_t c1 = row_code(ap1, len1, i, codeL, (uint32_t)ncodes);
+            pk |= (c0 * (uint32_t)ncp + c1) << (8 * h);
+        }
+        rpk[w] = pk;
+    }
+    uint32_t H[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+        H[i] = 0;
+    int ng = RA / 4;
+    if (SKIP) {
+        uint32_t wl = max(len0, len1);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+        ng = __builtin_amdgcn_readfirstlane((int)((wl + 3u) >> 2));
+    }
+    const uint32_t gh = half_bits(-gapabs);
+    const uint32_t gap2 = gh | (gh << 16); // -|gap| * 2^-11 in both halves
+    uint32_t best = 0, bestq = 0, ties = 0;
+
+    // table of block 0 into the slot; lane l owns entry l
+    const uint32_t nent = tab_bytes >> 4;
+    const bool mine = lane < nent;
+    const uint32_t slot = lane << 4;
+    const uint8_t *tabp = reinterpret_cast<const uint8_t *>(prof2) + slot; // my entry of block t
+    if (mine)
+        reinterpret_cast<uint4 *>(lds_pk)[lane] = *reinterpret_cast<const uint4 *>(tabp);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = 0; t < nq; ++t) {
+        tabp += tab_bytes;
+        // the next block's table: global memory -> the staging area behind the codes, no register held under the rows
+        if (mine && t + 1 < nq)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)tabp,
+                                             (__attribute__((address_space(3))) void *)(lds_pk + 1280), 16, 0, 0);
+        uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = gap2, bm = 0; // 0 - |gap| (PH_PKF_ROW)
+        uint32_t pg0 = 0, pg1 = 0, pg2 = 0, pg3 = 0;
+        (void)pr3;
+        u32x4 wa, wb;
+        PH_PK1_ISSUE(wa, rpk[0], "BYTE_0");
+#pragma unroll
+        for (int g = 0; g < RA / 4; ++g) {
+            if (!SKIP || g < ng) { // wave-uniform
+                PH_PK1_ISSUE(wb, rpk[g], "BYTE_1");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PKF_ROW(4 * g, wa);
+                PH_PK1_ISSUE(wa, rpk[g], "BYTE_2");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                PH_PKF_ROW(4 * g + 1, wb);
+                PH_PK1_ISSUE(wb, rpk[g], "BYTE_3");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PKF_ROW(4 * g + 2, wa);
+                if (g + 1 < RA / 4) {
+                    PH_PK1_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                }
+                PH_PKF_ROW(4 * g + 3, wb);
+            }
+        }
+        if (SKIP)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa)); // the read issued ahead of a skipped group
+        if (mine && t + 1 < nq) { // every row of this block has its entry: the slot takes the next table
+            u32x4 tmp;
+            asm volatile("s_waitcnt vmcnt(0)\n\tds_read_b128 %0, %1 offset:1280\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b128 %1, %0"
+                         : "=&v"(tmp)
+                         : "v"(slot)
+                         : "memory");
+        }
+        // block maximum against the running one, per half; a block reaching the maximum AGAIN is a tie
+        const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
+        if (blo > mlo) {
+            best = (best & 0xFFFF0000u) | blo;
+            bestq = (bestq & 0xFFFF0000u) | t;
+            ties &= ~1u;
+        } else if (blo == mlo && blo != 0u) {
+            ties |= 1u;
+        }
+        if (bhi > mhi) {
+            best = (best & 0xFFFFu) | (bhi << 16);
+            bestq = (bestq & 0xFFFFu) | (t << 16);
+            ties &= ~0x10000u;
+        } else if (bhi == mhi && bhi != 0u) {
+            ties |= 0x10000u;
+        }
+    }
+    const uint32_t m0 = half_score(best & 0xFFFFu), m1 = half_score(best >> 16);
+    if (p0 < npairs) {
+        infoM[p0] = m0;
+        infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+    }
+    if (p1 < npairs) {
+        infoM[p1] = m1;
+        infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+    }
+}
+
 // ---- reads of 153 .. 256 rows: K lanes per pair ------------------------------------------------------
 // One lane cannot hold more than 152 packed rows at two workgroups per CU, and at one workgroup per CU the
 // dependent packed chain stands exposed (measured: 256 rows in one lane run no faster than the 32-bit kernel).
@@ -1029,6 +1188,8 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     p.nq = p.lenB_pad / 4;
     p.jcb = std::max<uint32_t>(1, std::min<uint32_t>(64, 36864u / p.tab_bytes));
     p.pk_smem = (size_t)(p.jcb + p.k - 1) * p.tab_bytes + 256;
+    // one wave per workgroup, the block's table at a fixed LDS address (POLYHIP_SW_PK1=0: the chunk-staged kernel)
+    p.pk1 = p.f16 && p.k == 1 && p.ncp * p.ncp <= 64 && !env_is("POLYHIP_SW_PK1", '0');
     p.locate_smem = (size_t)p.lenB_pad * 8 + 256;
     if (p.ra <= 256 && p.locate_smem > 160 * 1024)
         return false; // the byte profile of the reference has to sit whole in LDS for step 2
@@ -1056,7 +1217,15 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                            sc->d_lutc, sc->ncodes, p.ncp, prof2, (int)p.f16, (int)(-sc->gap));
         PH_HIP(hipGetLastError());
     }
-    if constexpr (K == 1) {
+    if (K == 1 && p.pk1) {
+        if constexpr (K == 1) {
+            auto kern = p.skip_rows ? sw_pk1_kernel<RA, true> : sw_pk1_kernel<RA, false>;
+            const uint64_t blocks = (npairs + 127) / 128;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), 1024 + 256 + 1024, st, d_A, d_offA, npairs, prof2, p.nq,
+                               p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
+            PH_HIP(hipGetLastError());
+        }
+    } else if constexpr (K == 1) {
         auto kern = p.f16 ? (p.skip_rows ? sw_pk_kernel<RA, true, true> : sw_pk_kernel<RA, false, true>)
                           : (p.skip_rows ? sw_pk_kernel<RA, true, false> : sw_pk_kernel<RA, false, false>);
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,

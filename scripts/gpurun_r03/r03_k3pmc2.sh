@@ -1,0 +1,11 @@
+#!/bin/bash
+ROOT=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+export POLYHIP_SW_OVERLAP=0 POLYHIP_TB_OVERLAP=0
+tag=r03_k3_pmc_lds
+out=$ROOT/gpurun_out/prof_$tag; rm -rf $out; mkdir -p $out
+( cd $ROOT && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAIT_INST_LDS --kernel-trace -d $out -o x -- python scripts/quick_k3tb.py ) > $out/run.log 2>&1
+f=$(find $out -name "*results.db" | head -1)
+if [ -n "$f" ]; then ( cd $ROOT && python scripts/rocpd_summary.py $f "$tag" > gpurun_out/$tag.md 2>&1 ); else echo "no db"; tail -5 $out/run.log; fi
+rm -rf $out
+grep "sw_pk1_kernel" $ROOT/gpurun_out/$tag.md | cut -c1-160
