@@ -201,6 +201,22 @@ __device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) // bit 7 of ever
     return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
 }
 
+// bit j of the result = byte j of the four dwords equals the byte repeated in `pat`
+__device__ __forceinline__ uint32_t eq_mask16(const uint32_t (&w)[4], uint32_t pat)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t f = zero_byte_flags(w[q] ^ pat); // 0x80 per matching byte
+        // gather the four flag bits into a nibble: bit 7 -> 0, 15 -> 1, 23 -> 2, 31 -> 3
+        m |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * q);
+    }
+    return m;
+}
+
+// low 16 bits: the newlines of one aligned 16-byte chunk; SPEC: high 16 bits: its '>' and ';' bytes (the only bytes that
+// make a FASTA line anything but sequence when they stand first)
+template <bool SPEC>
 __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ abase, uint64_t chunk, uint32_t mis,
                                                    uint64_t nbytes)
 {
@@ -210,31 +226,29 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ a
         return 0u;
     const uint4 v = *reinterpret_cast<const uint4 *>(abase + chunk * 16);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t f = zero_byte_flags(w[q] ^ 0x0A0A0A0Au); // 0x80 per newline byte
-        // gather the four flag bits into a nibble: bit 7 -> 0, 15 -> 1, 23 -> 2, 31 -> 3
-        m |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * q);
-    }
+    uint32_t m = eq_mask16(w, 0x0A0A0A0Au);
+    if (SPEC)
+        m |= (eq_mask16(w, 0x3E3E3E3Eu) | eq_mask16(w, 0x3B3B3B3Bu)) << 16;
+    uint32_t keep = 0xFFFFu;
     if (p0 < 0)
-        m &= 0xFFFFu << (uint32_t)(-p0);
+        keep &= 0xFFFFu << (uint32_t)(-p0);
     if (p0 + 16 > (int64_t)nbytes)
-        m &= 0xFFFFu >> (uint32_t)(p0 + 16 - (int64_t)nbytes);
-    return m;
+        keep &= 0xFFFFu >> (uint32_t)(p0 + 16 - (int64_t)nbytes);
+    return m & (keep | (keep << 16));
 }
 
 // newlines per 4096-byte window
-// (also leaves every 16-byte chunk's newline mask -- 2 bytes per 16 of file -- so that the ranked write below does not read
-// the file a second time: 51 MB instead of 408 MB for the bench's image)
+// (also leaves every 16-byte chunk's masks -- 2 (FASTQ) or 4 (FASTA) bytes per 16 of file -- so that the ranked write below
+// does not read the file a second time: 51 MB instead of 408 MB for the bench's image)
+template <bool SPEC, class MaskT>
 __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ abase, uint32_t mis,
                                                                 uint64_t nbytes, uint32_t *__restrict__ counts,
-                                                                uint16_t *__restrict__ masks)
+                                                                MaskT *__restrict__ masks)
 {
     __shared__ uint32_t ws[THREADS / 64];
-    const uint32_t mk = newline_mask16(abase, (uint64_t)blockIdx.x * THREADS + threadIdx.x, mis, nbytes);
-    masks[(uint64_t)blockIdx.x * THREADS + threadIdx.x] = (uint16_t)mk;
-    uint32_t c = (uint32_t)__popc(mk);
+    const uint32_t mk = newline_mask16<SPEC>(abase, (uint64_t)blockIdx.x * THREADS + threadIdx.x, mis, nbytes);
+    masks[(uint64_t)blockIdx.x * THREADS + threadIdx.x] = (MaskT)mk;
+    uint32_t c = (uint32_t)__popc(mk & 0xFFFFu);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         c += (uint32_t)__shfl_xor((int)c, d, 64);
@@ -245,33 +259,48 @@ __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *
         counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// line_end[k] = file-relative position of the k-th '\n'
-__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const uint16_t *__restrict__ masks, uint32_t mis,
-                                                                const uint64_t *__restrict__ block_off,
-                                                                uint64_t *__restrict__ line_end)
+// line_end[k] = file-relative position of the k-th '\n'.  A wave per 4096-byte window (the unit the counts were scanned in), four
+// 16-byte chunks per lane: one scan step per 64 bytes of file instead of one per 16 (a thread per chunk: 0.07 ms for the
+// bench's FASTA image, as long as reading the image itself took).
+// SPEC (FASTA): kind[k] = 1 if line k starts with '>' or ';' -- the byte behind the newline that ends line k - 1, read off
+// the chunk masks, so that the per-line classification does not have to gather every line's first byte from the file.
+template <bool SPEC, class MaskT>
+__global__ __launch_bounds__(THREADS) void write_newlines_kernel(const MaskT *__restrict__ masks, uint64_t nchunks, uint32_t mis,
+                                                                const uint64_t *__restrict__ block_off, uint64_t nwindows,
+                                                                uint64_t *__restrict__ line_end, uint8_t *__restrict__ kind)
 {
-    __shared__ uint32_t ws[THREADS / 64];
-    const uint64_t chunk = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    uint32_t m = masks[chunk];
-    const uint32_t c = (uint32_t)__popc(m);
-    uint32_t incl = c; // inclusive scan over the wave, then over the 4 waves
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t window = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6);
+    if (window >= nwindows)
+        return;
+    const uint64_t chunk0 = window * THREADS + 4u * lane; // THREADS chunks per window
+    uint32_t m[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+        m[j] = (chunk0 + j < nchunks && (j < 4 || SPEC)) ? (uint32_t)masks[chunk0 + j] : 0u;
+    const uint32_t c = (uint32_t)(__popc(m[0] & 0xFFFFu) + __popc(m[1] & 0xFFFFu) + __popc(m[2] & 0xFFFFu) + __popc(m[3] & 0xFFFFu));
+    uint32_t incl = c; // inclusive scan over the wave
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
-        if ((threadIdx.x & 63) >= d)
+        if (lane >= (uint32_t)d)
             incl += t;
     }
-    if ((threadIdx.x & 63) == 63)
-        ws[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    uint64_t at = block_off[blockIdx.x] + incl - c;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w)
-        at += ws[w];
-    const int64_t p0 = (int64_t)(chunk * 16) - (int64_t)mis;
-    while (m) {
-        const int k = __builtin_ctz(m);
-        m &= m - 1u;
-        line_end[at++] = (uint64_t)(p0 + k);
+    uint64_t at = block_off[window] + incl - c;
+    if (SPEC && chunk0 == 0) // line 0 starts with the file
+        kind[0] = (uint8_t)((m[0] >> (16u + mis)) & 1u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t p0 = (int64_t)((chunk0 + j) * 16) - (int64_t)mis;
+        uint32_t nl = m[j] & 0xFFFFu;
+        const uint32_t sp = SPEC ? ((m[j] >> 16) | ((m[j + 1] >> 16) << 16)) : 0u; // special bytes of this chunk and the next
+        while (nl) {
+            const int k = __builtin_ctz(nl);
+            nl &= nl - 1u;
+            if (SPEC)
+                kind[at + 1] = (uint8_t)((sp >> (k + 1)) & 1u);
+            line_end[at++] = (uint64_t)(p0 + k);
+        }
     }
 }
 
@@ -420,6 +449,7 @@ enum { F_NREC = 0, F_CODE = 1, F_SEQBYTES = 2, F_NHEADERS = 3, F_FIRSTEMPTY = 4,
 __global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *__restrict__ file,
                                                                 const uint64_t *__restrict__ line_end,
                                                                 const uint64_t *__restrict__ nlines_dev,
+                                                                const uint8_t *__restrict__ kind,
                                                                 uint32_t *__restrict__ is_header,
                                                                 uint32_t *__restrict__ seq_len)
 {
@@ -427,7 +457,9 @@ __global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *
     for (uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x; k < nl; k += (uint64_t)gridDim.x * THREADS) {
     const uint64_t start = k == 0 ? 0 : line_end[k - 1] + 1;
     const uint64_t len = line_end[k] - start;
-    const uint8_t b = len ? file[start] : 0;
+    // only a line that starts with '>' or ';' (its kind, from the chunk masks) has its first byte looked at: one line in
+    // fifty of a usual file, instead of a gather of every line's first byte (0.3 GB of sectors for the bench's image)
+    const uint8_t b = (len && kind[k]) ? file[start] : 0;
     bool header = false;
     if (len && b == '>') {
         // position inside the run of consecutive '>' lines that ends here: odd = header
@@ -741,7 +773,7 @@ __global__ __launch_bounds__(THREADS) void fasta_gather_kernel(const uint8_t *__
 struct Layout {
     uint64_t nblocks, max_lines;
     size_t off_counts, off_blockoff, off_lineend, off_seqlen, off_seqstart, off_res, off_scanpart, off_masks, total;
-    size_t off_ishdr, off_hrank, off_dst; // FASTA (per line)
+    size_t off_ishdr, off_hrank, off_dst, off_kind; // FASTA (per line)
 };
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -755,13 +787,13 @@ static Layout layout(uint64_t nbytes)
     L.off_res = o; o += al(R_WORDS * 8);
     L.off_scanpart = o; o += al(SCAN_SEGS * 8);
     L.off_counts = o; o += al(L.nblocks * 4);
-    L.off_masks = o; o += al(L.nblocks * (size_t)THREADS * 2);
+    L.off_masks = o; o += al(L.nblocks * (size_t)THREADS * 4 + 16); // 2 bytes per chunk (FASTQ), 4 (FASTA)
     L.off_blockoff = o; o += al((L.nblocks + 1) * 8);
     L.off_lineend = o; o += al((L.max_lines + 1) * 8);
     L.off_seqlen = o; o += al((L.max_lines / 4 + 1) * 4);
     L.off_seqstart = o; o += al((L.max_lines / 4 + 1) * 8);
     L.total = o;
-    L.off_ishdr = L.off_hrank = L.off_dst = 0;
+    L.off_ishdr = L.off_hrank = L.off_dst = L.off_kind = 0;
     return L;
 }
 
@@ -774,6 +806,7 @@ static Layout layout_fasta(uint64_t nbytes)
     L.off_ishdr = o; o += al((L.max_lines + 1) * 4);
     L.off_hrank = o; o += al((L.max_lines + 2) * 8);
     L.off_dst = o; o += al((L.max_lines + 2) * 8);
+    L.off_kind = o; o += al(L.max_lines + 2);
     L.off_seqstart = 0;
     L.total = o;
     return L;
@@ -826,13 +859,13 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(res + fq::R_FIRSTBAD, 0xFF, 8, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
     const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
-    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts,
-                       reinterpret_cast<uint16_t *>(w + L.off_masks));
+    hipLaunchKernelGGL((fq::count_newlines_kernel<false, uint16_t>), dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis,
+                       nbytes, counts, reinterpret_cast<uint16_t *>(w + L.off_masks));
     if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
-    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st,
-                       reinterpret_cast<const uint16_t *>(w + L.off_masks), mis,
-                       blockoff, line_end);
+    hipLaunchKernelGGL((fq::write_newlines_kernel<false, uint16_t>), dim3((unsigned)((L.nblocks + 3) / 4)), dim3(fq::THREADS), 0, st,
+                       reinterpret_cast<const uint16_t *>(w + L.off_masks), (uint64_t)L.nblocks * fq::THREADS, mis, blockoff,
+                       (uint64_t)L.nblocks, line_end, (uint8_t *)nullptr);
     // The line count exists only on the device (blockoff[nblocks]); the record kernels are launched for
     // the most records the file could hold and read the real count there.  The shortest record is 7 bytes: the
     // reference reads the third line without looking at it (fastq.go:182), so "@\nA\n\nI\n" parses.
@@ -911,6 +944,7 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     uint32_t *is_header = reinterpret_cast<uint32_t *>(w + L.off_ishdr);
     uint64_t *hrank = reinterpret_cast<uint64_t *>(w + L.off_hrank);
     uint64_t *dst = reinterpret_cast<uint64_t *>(w + L.off_dst);
+    uint8_t *kind = w + L.off_kind;
 
     PH_HIP(hipMemsetAsync(res, 0, fq::F_WORDS * 8, st));
     PH_HIP(hipMemsetAsync(res + fq::F_FIRSTEMPTY, 0xFF, 8, st));
@@ -918,18 +952,18 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(dst, 0, 16, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
     const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
-    hipLaunchKernelGGL(fq::count_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis, nbytes, counts,
-                       reinterpret_cast<uint16_t *>(w + L.off_masks));
+    hipLaunchKernelGGL((fq::count_newlines_kernel<true, uint32_t>), dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis,
+                       nbytes, counts, reinterpret_cast<uint32_t *>(w + L.off_masks));
     if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
-    hipLaunchKernelGGL(fq::write_newlines_kernel, dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st,
-                       reinterpret_cast<const uint16_t *>(w + L.off_masks), mis,
-                       blockoff, line_end);
+    hipLaunchKernelGGL((fq::write_newlines_kernel<true, uint32_t>), dim3((unsigned)((L.nblocks + 3) / 4)), dim3(fq::THREADS), 0, st,
+                       reinterpret_cast<const uint32_t *>(w + L.off_masks), (uint64_t)L.nblocks * fq::THREADS, mis, blockoff,
+                       (uint64_t)L.nblocks, line_end, kind);
     const uint64_t *nlines_dev = blockoff + L.nblocks; // the line count exists only on the device
     // per-line kernels: as many workgroups as keep the chip busy, each striding over the lines (their count exists only on the device)
     const unsigned gl = (unsigned)std::min<uint64_t>((nbytes + fq::THREADS - 1) / fq::THREADS + 1, 256ull * 16ull);
-    hipLaunchKernelGGL(fq::fasta_classify_kernel, dim3(gl), dim3(fq::THREADS), 0, st, d_file, line_end, nlines_dev, is_header,
-                       seq_len);
+    hipLaunchKernelGGL(fq::fasta_classify_kernel, dim3(gl), dim3(fq::THREADS), 0, st, d_file, line_end, nlines_dev, kind,
+                       is_header, seq_len);
     if (int rc = scan_u32(is_header, 0, nlines_dev, 1, nbytes + 1, hrank, scanpart, st))
         return rc;
     hipLaunchKernelGGL(fq::fasta_prefix_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, hrank, seq_len);
