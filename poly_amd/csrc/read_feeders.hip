@@ -196,26 +196,20 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *__rest
 // A workgroup takes one 4096-byte window of the file's 16-byte-ALIGNED address space (the file itself may start
 // anywhere: `mis` = its offset inside the first window); every lane loads one uint4 and turns it into a 16-bit
 // mask of the bytes that are '\n' and lie inside the file.
-__device__ __forceinline__ uint32_t zero_byte_flags(uint32_t x) // bit 7 of every byte of x that is 0x00 (exact)
+
+// 0x01 in every byte of x that is NOT zero
+__device__ __forceinline__ uint32_t nonzero_bytes(uint32_t x)
 {
-    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+    return ((((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7) & 0x01010101u;
 }
 
-// bit j of the result = byte j of the four dwords equals the byte repeated in `pat`
-__device__ __forceinline__ uint32_t eq_mask16(const uint32_t (&w)[4], uint32_t pat)
-{
-    uint32_t m = 0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t f = zero_byte_flags(w[q] ^ pat); // 0x80 per matching byte
-        // gather the four flag bits into a nibble: bit 7 -> 0, 15 -> 1, 23 -> 2, 31 -> 3
-        m |= (((f >> 7) & 1u) | ((f >> 14) & 2u) | ((f >> 21) & 4u) | ((f >> 28) & 8u)) << (4 * q);
-    }
-    return m;
-}
-
-// low 16 bits: the newlines of one aligned 16-byte chunk; SPEC: high 16 bits: its '>' and ';' bytes (the only bytes that
-// make a FASTA line anything but sequence when they stand first)
+// low 16 bits: the newlines of one aligned 16-byte chunk; SPEC: high 16 bits: its ':' ';' '>' '?' bytes -- one compare
+// finds the four (0x3A | bits 0 and 2), and only '>' and ';' make a FASTA line anything but sequence when they stand
+// first: whoever acts on the bit looks at the byte itself.
+// The four flag bits of a dword (bits 0, 8, 16, 24) are gathered into a nibble by one multiply: every partial product
+// of 0x00204081 lands on a bit of its own, the nibble stands at bits 21..24; the second set of flags rides along four
+// bits higher (nibble at 25..28) -- the per-bit shifts of the plain gather made the FASTA count pass compute-bound
+// (0.154 ms against 0.10 ms for the newlines alone).
 template <bool SPEC>
 __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ abase, uint64_t chunk, uint32_t mis,
                                                    uint64_t nbytes)
@@ -226,15 +220,23 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ a
         return 0u;
     const uint4 v = *reinterpret_cast<const uint4 *>(abase + chunk * 16);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t m = eq_mask16(w, 0x0A0A0A0Au);
-    if (SPEC)
-        m |= (eq_mask16(w, 0x3E3E3E3Eu) | eq_mask16(w, 0x3B3B3B3Bu)) << 16;
+    uint32_t other = 0; // bytes that are NOT a newline (low half) / NOT one of the four (high half)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint32_t z = nonzero_bytes(w[q] ^ 0x0A0A0A0Au);
+        if (SPEC)
+            z |= nonzero_bytes((w[q] & 0xFAFAFAFAu) ^ 0x3A3A3A3Au) << 4;
+        const uint32_t g = z * 0x00204081u;
+        other |= ((g >> 21) & 0xFu) << (4 * q);
+        if (SPEC)
+            other |= ((g >> 25) & 0xFu) << (16 + 4 * q);
+    }
     uint32_t keep = 0xFFFFu;
     if (p0 < 0)
         keep &= 0xFFFFu << (uint32_t)(-p0);
     if (p0 + 16 > (int64_t)nbytes)
         keep &= 0xFFFFu >> (uint32_t)(p0 + 16 - (int64_t)nbytes);
-    return m & (keep | (keep << 16));
+    return ~other & (SPEC ? (keep | (keep << 16)) : keep);
 }
 
 // newlines per 4096-byte window
