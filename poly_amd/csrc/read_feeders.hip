@@ -192,6 +192,203 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(const uint32_t *__rest
     }
 }
 
+// ---- two exclusive scans in one pass (FASTA: headers before a line, sequence bytes before a line) -----------------
+// a[] holds 0 / 1 flags, b[] lengths; b[i] counts as 0 in front of the first set flag (lines before the first header carry no
+// sequence: the rule that used to sit between the two scans as a kernel of its own) and is written back as 0 there.  Four
+// consecutive elements per thread (one 16-byte load per array), so a chunk of 4096 elements costs one round of wave
+// scans and two barriers.  outA[n] / outB[n] = the totals.
+__global__ __launch_bounds__(1024) void scan2_sums_kernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b,
+                                                         const uint64_t *__restrict__ n_dev, uint64_t *__restrict__ partial)
+{
+    // per segment: [0] flags set, [1] sum of b behind the segment's first flag, [2] sum of b in front of it (all of b if the
+    // segment has no flag), [3] index of that first flag (~0: none) -- where the file's first header is, and with it which
+    // lines count, is only known once every segment has looked
+    const uint64_t n = *n_dev;
+    uint64_t lo, hi;
+    scan_segment(n, lo, hi);
+    __shared__ uint64_t ws[3][16];
+    __shared__ unsigned long long firstl;
+    if (threadIdx.x == 0)
+        firstl = ~0ull;
+    __syncthreads();
+    uint64_t mine = ~0ull;
+    for (uint64_t i0 = lo + 4ull * threadIdx.x; i0 < hi && mine == ~0ull; i0 += 4096) {
+        const uint4 va = *reinterpret_cast<const uint4 *>(a + i0);
+        const uint32_t xa[4] = {va.x, va.y, va.z, va.w};
+#pragma unroll
+        for (int u = 3; u >= 0; --u)
+            if (i0 + u < hi && xa[u])
+                mine = i0 + u;
+    }
+    if (mine != ~0ull)
+        atomicMin(&firstl, (unsigned long long)mine);
+    __syncthreads();
+    const uint64_t first = firstl;
+    uint64_t sa = 0, sb = 0, sf = 0;
+    for (uint64_t i0 = lo + 4ull * threadIdx.x; i0 < hi; i0 += 4096) {
+        const uint4 va = *reinterpret_cast<const uint4 *>(a + i0), vb = *reinterpret_cast<const uint4 *>(b + i0);
+        const uint32_t xa[4] = {va.x, va.y, va.z, va.w}, xb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u < hi) {
+                sa += xa[u];
+                if (i0 + u < first)
+                    sf += xb[u];
+                else
+                    sb += xb[u];
+            }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sa += __shfl_xor(sa, d, 64);
+        sb += __shfl_xor(sb, d, 64);
+        sf += __shfl_xor(sf, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        ws[0][threadIdx.x >> 6] = sa;
+        ws[1][threadIdx.x >> 6] = sb;
+        ws[2][threadIdx.x >> 6] = sf;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint64_t t = 0;
+        for (int w = 0; w < 16; ++w)
+            t += ws[threadIdx.x][w];
+        partial[threadIdx.x * SCAN_SEGS + blockIdx.x] = t;
+    }
+    if (threadIdx.x == 3)
+        partial[3 * SCAN_SEGS + blockIdx.x] = first;
+}
+
+__global__ __launch_bounds__(2 * SCAN_SEGS) void scan2_offsets_kernel(uint64_t *__restrict__ partial,
+                                                                     const uint64_t *__restrict__ n_dev,
+                                                                     uint64_t *__restrict__ outA, uint64_t *__restrict__ outB,
+                                                                     unsigned long long *__restrict__ first_out)
+{
+    __shared__ uint64_t ws[2 * SCAN_SEGS / 64];
+    __shared__ unsigned long long gfirst;
+    const int tid = threadIdx.x, half = tid / SCAN_SEGS, t = tid % SCAN_SEGS; // the two arrays side by side
+    if (tid == 0)
+        gfirst = ~0ull;
+    __syncthreads();
+    if (half == 0 && partial[3 * SCAN_SEGS + t] != ~0ull)
+        atomicMin(&gfirst, (unsigned long long)partial[3 * SCAN_SEGS + t]);
+    __syncthreads();
+    const uint64_t first = gfirst;
+    if (tid == 0)
+        *first_out = first;
+    // lines in front of the file's first header carry no sequence: a segment in front of it adds nothing, the segment that
+    // holds it what lies behind its own first flag (which is the file's), the segments behind it all they have
+    uint64_t v;
+    if (half == 0) {
+        v = partial[t];
+    } else {
+        const uint64_t n = *n_dev;
+        const uint64_t per = ((n + SCAN_SEGS - 1) / SCAN_SEGS + 1023) / 1024 * 1024; // scan_segment's
+        const uint64_t lo = min(n, (uint64_t)t * per);
+        const uint64_t after = partial[SCAN_SEGS + t], before = partial[2 * SCAN_SEGS + t];
+        if (first == ~0ull)
+            v = 0;
+        else if (lo > first)
+            v = after + before;
+        else if (partial[3 * SCAN_SEGS + t] == first)
+            v = after;
+        else
+            v = 0;
+    }
+    uint64_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t x = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d)
+            incl += x;
+    }
+    if ((tid & 63) == 63)
+        ws[tid >> 6] = incl;
+    __syncthreads();
+    uint64_t pre = 0;
+    for (int w = half * (SCAN_SEGS / 64); w < (tid >> 6); ++w)
+        pre += ws[w];
+    __syncthreads(); // every thread has read what it needs of partial[]
+    partial[tid] = pre + incl - v; // exclusive: where segment t starts
+    if (t == SCAN_SEGS - 1)
+        (half ? outB : outA)[*n_dev] = pre + incl;
+}
+
+__global__ __launch_bounds__(1024) void scan2_apply_kernel(const uint32_t *__restrict__ a, uint32_t *__restrict__ b,
+                                                          const uint64_t *__restrict__ n_dev,
+                                                          const unsigned long long *__restrict__ first_p,
+                                                          const uint64_t *__restrict__ partial, uint64_t *__restrict__ outA,
+                                                          uint64_t *__restrict__ outB)
+{
+    const uint64_t n = *n_dev, first = *first_p;
+    uint64_t lo, hi;
+    scan_segment(n, lo, hi);
+    __shared__ uint64_t wsum[2][16];
+    const int tid = threadIdx.x;
+    uint64_t carryA = partial[blockIdx.x], carryB = partial[SCAN_SEGS + blockIdx.x];
+    for (uint64_t base = lo; base < hi; base += 4096) {
+        const uint64_t i0 = base + 4ull * tid;
+        uint32_t xa[4] = {0u, 0u, 0u, 0u}, xb[4] = {0u, 0u, 0u, 0u};
+        if (i0 < hi) {
+            const uint4 va = *reinterpret_cast<const uint4 *>(a + i0), vb = *reinterpret_cast<const uint4 *>(b + i0);
+            xa[0] = va.x, xa[1] = va.y, xa[2] = va.z, xa[3] = va.w;
+            xb[0] = vb.x, xb[1] = vb.y, xb[2] = vb.z, xb[3] = vb.w;
+            bool cut = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u >= hi) {
+                    xa[u] = 0;
+                    xb[u] = 0;
+                } else if (i0 + u < first && xb[u]) {
+                    xb[u] = 0;
+                    cut = true;
+                }
+            if (cut) { // (rare: sequence-like lines in front of the first header)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < hi && i0 + u < first)
+                        b[i0 + u] = 0;
+            }
+        }
+        const uint64_t ta = (uint64_t)xa[0] + xa[1] + xa[2] + xa[3], tb = (uint64_t)xb[0] + xb[1] + xb[2] + xb[3];
+        uint64_t ia = ta, ib = tb; // inclusive over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t ua = __shfl_up(ia, d, 64), ub = __shfl_up(ib, d, 64);
+            if ((tid & 63) >= d) {
+                ia += ua;
+                ib += ub;
+            }
+        }
+        __syncthreads(); // wsum of the chunk before is used up
+        if ((tid & 63) == 63) {
+            wsum[0][tid >> 6] = ia;
+            wsum[1][tid >> 6] = ib;
+        }
+        __syncthreads();
+        uint64_t pa = carryA + ia - ta, pb = carryB + ib - tb, totA = 0, totB = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < (tid >> 6)) {
+                pa += wsum[0][w];
+                pb += wsum[1][w];
+            }
+            totA += wsum[0][w];
+            totB += wsum[1][w];
+        }
+        carryA += totA;
+        carryB += totB;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u < hi) {
+                outA[i0 + u] = pa;
+                outB[i0 + u] = pb;
+                pa += xa[u];
+                pb += xb[u];
+            }
+    }
+}
+
 // ---- newline compaction, 16 bytes per lane ---------------------------------------------------------
 // A workgroup takes one 4096-byte window of the file's 16-byte-ALIGNED address space (the file itself may start
 // anywhere: `mis` = its offset inside the first window); every lane loads one uint4 and turns it into a 16-bit
@@ -445,7 +642,7 @@ __global__ __launch_bounds__(THREADS) void gather_kernel(const uint8_t *__restri
 }
 
 // ---- FASTA ----------------------------------------------------------------------------------------
-enum { F_NREC = 0, F_CODE = 1, F_SEQBYTES = 2, F_NHEADERS = 3, F_FIRSTEMPTY = 4, F_WORDS = 8 };
+enum { F_NREC = 0, F_CODE = 1, F_SEQBYTES = 2, F_NHEADERS = 3, F_FIRSTEMPTY = 4, F_FIRSTHDR = 5, F_WORDS = 8 };
 
 // per complete line: is it a header?  how many sequence bytes does it contribute?
 __global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *__restrict__ file,
@@ -480,17 +677,6 @@ __global__ __launch_bounds__(THREADS) void fasta_classify_kernel(const uint8_t *
     is_header[k] = header ? 1u : 0u;
     seq_len[k] = (!header && !skippable) ? (uint32_t)len : 0u;
     }
-}
-
-// lines before the first header carry no sequence
-__global__ __launch_bounds__(THREADS) void fasta_prefix_kernel(const uint64_t *__restrict__ nlines_dev,
-                                                              const uint64_t *__restrict__ hrank,
-                                                              uint32_t *__restrict__ seq_len)
-{
-    const uint64_t nl = *nlines_dev;
-    for (uint64_t k = (uint64_t)blockIdx.x * THREADS + threadIdx.x; k < nl; k += (uint64_t)gridDim.x * THREADS)
-        if (hrank[k] == 0 && seq_len[k]) // hrank = headers strictly before line k
-            seq_len[k] = 0;
 }
 
 // offsets[r] = sequence bytes before record r's header; first record without sequence
@@ -787,7 +973,7 @@ static Layout layout(uint64_t nbytes)
     L.max_lines = nbytes; // every byte a newline
     size_t o = 0;
     L.off_res = o; o += al(R_WORDS * 8);
-    L.off_scanpart = o; o += al(SCAN_SEGS * 8);
+    L.off_scanpart = o; o += al(4 * SCAN_SEGS * 8);
     L.off_counts = o; o += al(L.nblocks * 4);
     L.off_masks = o; o += al(L.nblocks * (size_t)THREADS * 4 + 16); // 2 bytes per chunk (FASTQ), 4 (FASTA)
     L.off_blockoff = o; o += al((L.nblocks + 1) * 8);
@@ -949,7 +1135,7 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     uint8_t *kind = w + L.off_kind;
 
     PH_HIP(hipMemsetAsync(res, 0, fq::F_WORDS * 8, st));
-    PH_HIP(hipMemsetAsync(res + fq::F_FIRSTEMPTY, 0xFF, 8, st));
+    PH_HIP(hipMemsetAsync(res + fq::F_FIRSTEMPTY, 0xFF, 16, st)); // F_FIRSTEMPTY, F_FIRSTHDR: none yet
     PH_HIP(hipMemsetAsync(hrank, 0, 16, st));
     PH_HIP(hipMemsetAsync(dst, 0, 16, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
@@ -966,11 +1152,12 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     const unsigned gl = (unsigned)std::min<uint64_t>((nbytes + fq::THREADS - 1) / fq::THREADS + 1, 256ull * 16ull);
     hipLaunchKernelGGL(fq::fasta_classify_kernel, dim3(gl), dim3(fq::THREADS), 0, st, d_file, line_end, nlines_dev, kind,
                        is_header, seq_len);
-    if (int rc = scan_u32(is_header, 0, nlines_dev, 1, nbytes + 1, hrank, scanpart, st))
-        return rc;
-    hipLaunchKernelGGL(fq::fasta_prefix_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, hrank, seq_len);
-    if (int rc = scan_u32(seq_len, 0, nlines_dev, 1, nbytes + 1, dst, scanpart, st))
-        return rc;
+    // hrank[k] = headers before line k, dst[k] = sequence bytes before line k: one pass over both arrays
+    hipLaunchKernelGGL(fq::scan2_sums_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, is_header, seq_len, nlines_dev, scanpart);
+    hipLaunchKernelGGL(fq::scan2_offsets_kernel, dim3(1), dim3(2 * fq::SCAN_SEGS), 0, st, scanpart, nlines_dev, hrank, dst,
+                       res + fq::F_FIRSTHDR);
+    hipLaunchKernelGGL(fq::scan2_apply_kernel, dim3(fq::SCAN_SEGS), dim3(1024), 0, st, is_header, seq_len, nlines_dev,
+                       res + fq::F_FIRSTHDR, scanpart, hrank, dst);
     hipLaunchKernelGGL(fq::fasta_offsets_kernel, dim3(gl), dim3(fq::THREADS), 0, st, nlines_dev, is_header, hrank, dst, line_end,
                        d_offsets, d_rec_start);
     hipLaunchKernelGGL(fq::fasta_empty_kernel, dim3(gl), dim3(fq::THREADS), 0, st, hrank, nlines_dev, d_offsets, res);

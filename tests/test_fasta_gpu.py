@@ -92,6 +92,19 @@ def test_lines_longer_than_a_window_and_stretches_without_sequence():
     _check(b"junk before\n" * 700 + data)
 
 
+def test_sequence_like_lines_far_in_front_of_the_first_header():
+    """lines before the first header carry no sequence (`hrank == 0`); the two per-line scans run as ONE pass over segments of
+    whole 1024-line chunks, which learn where the first header is from each other: thousands of junk lines in front of it
+    (segments without any header), the header exactly on a segment edge, no header at all, a header only at the very end"""
+    rng = np.random.default_rng(9)
+    body = b"".join(b">r%d\n" % i + bytes(rng.choice(list(b"ACGT"), 150).astype(np.uint8)) + b"\n" for i in range(3000))
+    for njunk in (1023, 1024, 1025, 2048, 5000, 20_000):
+        _check(b"ACGTACGT\n" * njunk + body)
+    _check(b"ACGTACGT\n" * 9000)                       # no header anywhere
+    _check(b"ACGTACGT\n" * 9000 + b">only\nAC\n")      # the only header at the very end
+    _check(b";c\n" * 3000 + b"\n" * 3000 + body)       # comments and empty lines in front
+
+
 def test_large_file_goes_through_the_multi_workgroup_scan():
     """a ~1 MB FASTA image (tens of thousands of lines: past the single-workgroup scan's limit) with ragged line
     widths, comment lines and empty lines: same records as the restated parser"""
