@@ -393,30 +393,78 @@ __global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict
     // my two pairs
     const uint64_t base = (uint64_t)blockIdx.x * 128;
     const uint64_t p0 = base + lane, p1 = base + 64 + lane;
-    const uint8_t *ap0 = A, *ap1 = A;
+    uint64_t o0 = 0, o1 = 0;
     uint32_t len0 = 0, len1 = 0;
     if (p0 < npairs) {
-        const uint64_t o = offA[p0], l = offA[p0 + 1] - o;
-        ap0 = A + o;
+        o0 = offA[p0];
+        const uint64_t l = offA[p0 + 1] - o0;
         len0 = l > (uint64_t)RA ? 0u : (uint32_t)l; // too long: no score here, the locate kernel reports it
     }
     if (p1 < npairs) {
-        const uint64_t o = offA[p1], l = offA[p1 + 1] - o;
-        ap1 = A + o;
+        o1 = offA[p1];
+        const uint64_t l = offA[p1 + 1] - o1;
         len1 = l > (uint64_t)RA ? 0u : (uint32_t)l;
     }
-    uint32_t rpk[RA / 4]; // index of row i's code pair inside a block's table, four rows per register
+    // index of row i's code pair inside a block's table, four rows per register.  The reads' bytes come as RA / 4 + 1
+    // ALIGNED dwords per pair, all in flight at once, funnelled to the read's own alignment -- a byte at a time the prologue
+    // was 2 x RA dependent round trips, ~2 % of a wave's life with both waves of a SIMD in it together.  A buffer resource
+    // over the whole packed batch (rounded out to whole dwords: an aligned dword never crosses a page) bounds the loads;
+    // what lies beyond the batch reads as zero, what lies beyond the read is never looked at.  Batches of 4 GB and more
+    // keep the byte loads.
+    uint32_t rpk[RA / 4];
+    const uint64_t totalA = offA[npairs];
+    if (totalA < 0xFFFFFFF0ull) {
+        const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(A) & 3u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(A) - misA, 0,
+                                                                            (int)(((uint32_t)totalA + misA + 3u) & ~3u), 0x00020000);
+        uint32_t d0[RA / 4], d1[RA / 4];
+        {
+            const uint32_t b0 = (uint32_t)o0 + misA, b1 = (uint32_t)o1 + misA;
+            uint32_t a0[RA / 4 + 1], a1[RA / 4 + 1];
 #pragma unroll
-    for (int w = 0; w < RA / 4; ++w) {
-        uint32_t pk = 0;
+            for (int w = 0; w <= RA / 4; ++w) {
+                a0[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b0 & ~3u) + 4u * w), 0, 0);
+                a1[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b1 & ~3u) + 4u * w), 0, 0);
+            }
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int i = 4 * w + h;
-            const uint32_t c0 = row_code(ap0, len0, i, codeL, (uint32_t)ncodes);
-            const uint32_t c1 = row_code(ap1, len1, i, codeL, (uint32_t)ncodes);
-            pk |= (c0 * (uint32_t)ncp + c1) << (8 * h);
+            for (int w = 0; w < RA / 4; ++w) {
+                d0[w] = __builtin_amdgcn_alignbyte(a0[w + 1], a0[w], b0 & 3u);
+                d1[w] = __builtin_amdgcn_alignbyte(a1[w + 1], a1[w], b1 & 3u);
+            }
         }
-        rpk[w] = pk;
+#pragma unroll
+        for (int w = 0; w < RA / 4; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const uint32_t i = 4u * w + h;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes; // pad: no such row, or a byte outside FirstAlphabet
+                if (i < len0) {
+                    const uint32_t c = codeL[(d0[w] >> (8 * h)) & 0xFFu];
+                    c0 = c == 0xFFu ? c0 : c;
+                }
+                if (i < len1) {
+                    const uint32_t c = codeL[(d1[w] >> (8 * h)) & 0xFFu];
+                    c1 = c == 0xFFu ? c1 : c;
+                }
+                pk |= (c0 * (uint32_t)ncp + c1) << (8 * h);
+            }
+            rpk[w] = pk;
+        }
+    } else {
+        const uint8_t *ap0 = A + o0, *ap1 = A + o1;
+#pragma unroll
+        for (int w = 0; w < RA / 4; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int i = 4 * w + h;
+                const uint32_t c0 = row_code(ap0, len0, i, codeL, (uint32_t)ncodes);
+                const uint32_t c1 = row_code(ap1, len1, i, codeL, (uint32_t)ncodes);
+                pk |= (c0 * (uint32_t)ncp + c1) << (8 * h);
+            }
+            rpk[w] = pk;
+        }
     }
     uint32_t H[RA];
 #pragma unroll
