@@ -679,8 +679,10 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
     uint32_t lenA = 0, eA = 0, eB = 0;
     int64_t M = 0;
     const uint8_t *ap = A;
+    uint64_t oA = 0;
     if (active) {
         const uint64_t o0 = offA[pair];
+        oA = o0;
         lenA = (uint32_t)(offA[pair + 1] - o0);
         ap = A + o0;
         if (err[pair] == 0u) {
@@ -697,28 +699,69 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
     const uint32_t jb0 = (c_s - 1u) & ~3u;
     const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u; // <= nblk_alloc - 1
 
-    // byte offsets (code * 8) of my rows inside a profile block, four rows per register and band
+    // byte offsets (code * 8) of my rows inside a profile block, four rows per register and band.  The read's bytes come as
+    // RA / 4 + 1 aligned dwords, all in flight at once, through a buffer resource over this launch's reads (as
+    // sw_pk1_kernel does; a byte at a time the prologue was RA dependent round trips); 4 GB and more keep the byte loads.
     uint32_t apk0[RB / 4], apk1[RB / 4];
+    const uint64_t totalA = offA[pair1];
+    if (totalA < 0xFFFFFFF0ull) {
+        const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(A) & 3u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(A) - misA, 0,
+                                                                            (int)(((uint32_t)totalA + misA + 3u) & ~3u), 0x00020000);
+        const uint32_t b0 = (uint32_t)oA + misA;
+        uint32_t dd[RA / 4];
+        {
+            uint32_t aw[RA / 4 + 1];
 #pragma unroll
-    for (int w = 0; w < RB / 4; ++w) {
-        uint32_t k0 = 0, k1 = 0;
+            for (int w = 0; w <= RA / 4; ++w)
+                aw[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b0 & ~3u) + 4u * w), 0, 0);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int i0 = 4 * w + b, i1 = RB + 4 * w + b;
-            uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
-            if (work && (uint32_t)i0 < lenA) {
-                const uint32_t c = codeL[ap[i0]];
-                c0 = c == 0xFFu ? (uint32_t)ncodes : c;
-            }
-            if (work && (uint32_t)i1 < lenA) {
-                const uint32_t c = codeL[ap[i1]];
-                c1 = c == 0xFFu ? (uint32_t)ncodes : c;
-            }
-            k0 |= (c0 * 8u) << (8 * b);
-            k1 |= (c1 * 8u) << (8 * b);
+            for (int w = 0; w < RA / 4; ++w)
+                dd[w] = __builtin_amdgcn_alignbyte(aw[w + 1], aw[w], b0 & 3u);
         }
-        apk0[w] = k0;
-        apk1[w] = k1;
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i0 = 4 * w + b, i1 = RB + 4 * w + b;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+                if (work && (uint32_t)i0 < lenA) {
+                    const uint32_t c = codeL[(dd[w] >> (8 * b)) & 0xFFu];
+                    c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                if (work && (uint32_t)i1 < lenA) {
+                    const uint32_t c = codeL[(dd[RB / 4 + w] >> (8 * b)) & 0xFFu];
+                    c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                k0 |= (c0 * 8u) << (8 * b);
+                k1 |= (c1 * 8u) << (8 * b);
+            }
+            apk0[w] = k0;
+            apk1[w] = k1;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i0 = 4 * w + b, i1 = RB + 4 * w + b;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+                if (work && (uint32_t)i0 < lenA) {
+                    const uint32_t c = codeL[ap[i0]];
+                    c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                if (work && (uint32_t)i1 < lenA) {
+                    const uint32_t c = codeL[ap[i1]];
+                    c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                k0 |= (c0 * 8u) << (8 * b);
+                k1 |= (c1 * 8u) << (8 * b);
+            }
+            apk0[w] = k0;
+            apk1[w] = k1;
+        }
     }
 
     uint32_t H[RB];
