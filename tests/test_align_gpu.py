@@ -311,7 +311,7 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
     A = torch.from_numpy(flat.copy()).to(dev)
     offA = torch.from_numpy(offs).to(dev)
 
-    def run(refarr, packed, half=True):
+    def run(refarr, packed, half=True, fixed_slot=True):
         if packed:
             monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
         else:
@@ -320,12 +320,17 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
             monkeypatch.delenv("POLYHIP_SW_F16", raising=False)
         else:
             monkeypatch.setenv("POLYHIP_SW_F16", "0")
+        if fixed_slot:  # sw_pk1_kernel: one wave per workgroup, the block's table at a fixed LDS address (the default)
+            monkeypatch.delenv("POLYHIP_SW_PK1", raising=False)
+        else:           # sw_pk_kernel: four waves share 36 KB chunks of the profile
+            monkeypatch.setenv("POLYHIP_SW_PK1", "0")
         B = torch.from_numpy(refarr.copy()).to(dev)
         score = torch.full((n,), -7, dtype=torch.int64, device=dev)
         ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
         work = torch.empty(align.sw_workspace_bytes(sc, n, L, len(refarr)), dtype=torch.uint8, device=dev)
         align.sw_batch_dev(sc, A, offA, L, B, None, len(refarr), score, ea, eb, er, work)
         torch.cuda.synchronize()
+        monkeypatch.delenv("POLYHIP_SW_PK1", raising=False)
         return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path(), align.last_packed_half()
 
     refs = [ref]
@@ -339,11 +344,12 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         # the int16 cell (POLYHIP_SW_F16=0) and the exact 32-bit kernel are both run beside it
         got, path, half = run(refarr, True)
         got16, path16, half16 = run(refarr, True, half=False)
+        gotc, pathc, halfc = run(refarr, True, fixed_slot=False)
         want, path0, _ = run(refarr, False)
-        assert (path, path16, path0) == (3, 3, 1)
-        assert (half, half16) == (True, False)
-        for g, g16, w in zip(got, got16, want):
-            assert (g == w).all() and (g16 == w).all()
+        assert (path, path16, pathc, path0) == (3, 3, 3, 1)
+        assert (half, half16, halfc) == (True, False, True)
+        for g, g16, gc, w in zip(got, got16, gotc, want):
+            assert (g == w).all() and (g16 == w).all() and (gc == w).all()
         refb = refarr.tobytes()
         for p in range(0, n, 1501):
             a = flat[offs[p]:offs[p + 1]].tobytes()
