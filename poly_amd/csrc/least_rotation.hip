@@ -8,7 +8,7 @@
 //
 // Booth's algorithm is a serial scan with a 2n-entry failure table.  On a GPU
 // the same answer comes from candidate elimination with the sequence staged in
-// LDS -- one WAVE per sequence up to 8 kB (least_rotation_wave_kernel: no
+// LDS -- one WAVE per sequence up to 7 kB (least_rotation_wave_kernel: no
 // barrier, four sequences per workgroup), one workgroup per sequence beyond
 // that (least_rotation_kernel<true>), reading global memory when LDS cannot
 // hold it (<false>):
@@ -47,7 +47,7 @@ constexpr uint32_t LIST_CAP = 1024;      // candidates kept in LDS (random DNA: 
 constexpr uint32_t MAX_ROUNDS = 64;      // 4 bytes per round before the serial fallback
 constexpr uint32_t LDS_SEQ_MAX = 120 * 1024;
 constexpr uint64_t MARK = ~0ull;       // rot[q] of a sequence the wave kernel leaves to the workgroup kernels
-constexpr uint64_t WAVE_SEQ_MAX = 8192; // longest sequence a wave takes alone
+constexpr uint64_t WAVE_SEQ_MAX = 7168; // longest sequence a wave takes alone (8 kB: the workgroup kernel is ahead, 0.32 vs 0.36 ms per 0.5 GB; 6 kB: behind, 0.39 vs 0.29)
 constexpr uint32_t WLIST = 1024;       // candidates one wave keeps, as 16-bit positions (random DNA: n / 256 after the first word)
 constexpr uint32_t WRAP = 24; // bytes of s[0..] staged again behind s[n-1]: a 16-byte output piece + its funnel dword never wrap
 

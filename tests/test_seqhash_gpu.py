@@ -69,15 +69,15 @@ def test_random_periodic_and_edge_cases(sh):
     _check(sh, seqs)
 
 
-@pytest.mark.parametrize("wave_max", [None, "0", "100", "32768"])
+@pytest.mark.parametrize("wave_max", [None, "0", "100", "8192", "32768"])
 def test_wave_and_workgroup_kernels_agree(sh, wave_max):
-    """The wave-per-sequence kernel takes sequences up to 8 kB, the workgroup kernels what it marks (longer ones; beyond
+    """The wave-per-sequence kernel takes sequences up to 7 kB, the workgroup kernels what it marks (longer ones; beyond
     LDS from global memory).  POLYHIP_K5_WAVE_MAX moves the boundary: 0 = everything through the workgroup kernels,
-    100 / 32768 = other splits of the same batch.  Lengths on both sides of every boundary, > 1024 candidates of the
+    100 / 8192 / 32768 = other splits of the same batch.  Lengths on both sides of every boundary, > 1024 candidates of the
     least word (the list is full), tandem repeats that do and do not close, the least word wrapping around the origin."""
     rng = np.random.default_rng(5)
     seqs = [b"", b"G", b"CA"]
-    for L in (7, 8, 9, 75, 76, 77, 99, 100, 101, 8191, 8192, 8193, 8216, 20000, 32767, 32768, 32769):
+    for L in (7, 8, 9, 75, 76, 77, 99, 100, 101, 7167, 7168, 7169, 7192, 8191, 8192, 8193, 20000, 32767, 32768, 32769):
         seqs.append(bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8)))
     seqs.append(bytes(rng.choice(list(b"AC"), 8000).astype(np.uint8)) + b"CCCC")          # ~ 500 candidates, then rounds
     seqs.append(b"AAAC" * 1500)                                                          # 1500 candidates, closes on itself
