@@ -16,7 +16,8 @@
 //
 //   check    every sketch: ascending?  (a sketch of a sequence with fewer than
 //            s windows is positional/unsorted, mash.go:81-84)  -> per-sketch
-//            "irregular" flag; max Y value -> bucket shift
+//            "irregular" flag; largest last element of Y -> bucket shift; the
+//            same pass counts the regular sketches' items per coarse bucket
 //   index    the Y side becomes an inverted index: items (value, sketch id,
 //            occurrence number among equal values of that sketch) partitioned
 //            into NBK buckets by value >> shift (histogram, scan, scatter)

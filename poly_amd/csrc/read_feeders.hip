@@ -32,9 +32,12 @@
 //   * a last record that ends in an unterminated, non-skippable line is returned WITH io.EOF by
 //     ParseNext and therefore dropped by ParseN/ParseAll (fasta_test.go:139-142); an unterminated line of
 //     at most one byte, or one starting with ';', is skippable and changes nothing.
-// Device algorithm: the same newline compaction; one thread per line classifies it (the parity inside a
-// run of '>' lines by walking back over the run); two exclusive scans (header rank, sequence bytes) give
-// every line its record and its destination; one workgroup per line copies it.
+// Device algorithm: the same newline compaction, which also leaves per 16-byte chunk a mask of the bytes that could
+// make a line special ('>' / ';'), so that the ranked write knows every line's kind; one thread per line classifies
+// it (the parity inside a run of '>' lines by walking back over the run; the file is read only for special lines);
+// ONE pass of exclusive scans over (header flag, sequence bytes) gives every line its record and its destination
+// (lines in front of the first header count as empty); the gather is output-driven: a wave writes the contiguous
+// output range of 64 consecutive lines in aligned 16-byte pieces.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
