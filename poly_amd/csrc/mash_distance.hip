@@ -451,7 +451,7 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
             }
         }
         __syncthreads();
-        // exclusive scan of cnt[0..nc) -> lstart; my slice of every coarse bucket -> gbase; cnt becomes the cursor
+        // exclusive scan of cnt[0..nc) -> lstart; my slice of every coarse bucket (minus lstart) -> gbase
         uint32_t carry = 0;
         for (uint32_t c0 = 0; c0 < nc; c0 += STAGE_THREADS) {
             const uint32_t c = c0 + tid;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
             }
             if (c < nc) {
                 lstart[c] = pre + incl - v;
-                gbase[c] = slice;
+                gbase[c] = slice - (pre + incl - v); // slice start minus the run's place in the stage: the write-out adds t
             }
             carry += tot;
             __syncthreads();
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
         for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
             const uint2 it = stage[t];
             const uint32_t c = it.x >> cshift;
-            citems[gbase[c] + (t - lstart[c])] = it; // (values and ids in two arrays halve level 2's counting pass but cost
+            citems[gbase[c] + t] = it; // (values and ids in two arrays halve level 2's counting pass but cost
                                                       // level 1 more than that: 0.64 -> 0.87 ms, two half-length runs per bucket)
         }
     }
