@@ -398,6 +398,17 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
 #define PH_K2_STAGE_GRID 512ull // two 1024-thread workgroups per CU
 #endif
 constexpr uint32_t STAGE_ITEMS = PH_K2_STAGE_ITEMS;
+// A wave places items of consecutive buckets: slots ~8 items (64 bytes) apart, four bank groups for 64 lanes.  Flipping an
+// item's low three slot bits by bits 5..7 of its slot spreads such a stride over all banks; a run read back in order
+// stays inside its own 8 slots.
+__device__ __forceinline__ uint32_t stage_swz(uint32_t pos)
+{
+#ifdef PH_K2_NO_SWZ
+    return pos;
+#else
+    return pos ^ ((pos >> 5) & 7u);
+#endif
+}
 constexpr int STAGE_THREADS = PH_K2_STAGE_THREADS;
 __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel( // 64 registers: two workgroups per CU
    
@@ -493,11 +504,11 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
                     while (occ < e && base[i - occ - 1] == v[u])
                         ++occ;
                 }
-                stage[lstart[v[u] >> cshift] + rk[u]] = make_uint2(v[u], (uint32_t)(q0 + qi) | (occ << id_bits));
+                stage[stage_swz(lstart[v[u] >> cshift] + rk[u])] = make_uint2(v[u], (uint32_t)(q0 + qi) | (occ << id_bits));
             }
         __syncthreads();
         for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
-            const uint2 it = stage[t];
+            const uint2 it = stage[stage_swz(t)];
             const uint32_t c = it.x >> cshift;
             citems[gbase[c] + t] = it; // (values and ids in two arrays halve level 2's counting pass but cost
                                                       // level 1 more than that: 0.64 -> 0.87 ms, two half-length runs per bucket)
