@@ -127,3 +127,41 @@ def test_dense_join_column_division_bound():
     assert all(ok(n, 3) for n in range(8, 37832 + 1, 8))
     assert all(ok(n, 2) for n in range(8, 46328 + 1, 8))
     assert not all(ok(n, 3) for n in range(37840, 40000, 8))  # beyond the cap the trick does fail somewhere
+
+
+def test_level1_sketch_division_and_stage_swizzle():
+    """csrc/mash_distance.hip coarse_scatter_staged_kernel: a batch's flat item index i (< 8192) is split into sketch
+    i / s and element i % s by one multiply-high with sinv = ceil(2^32 / s), for EVERY s the staged scatter takes (1 < s <=
+    8192; s == 1 is special-cased); the stage-slot swizzle pos ^ ((pos >> 5) & 7) is a permutation that keeps every
+    aligned group of 8 slots in place (a run written out in order reads back its own slots)."""
+    i = np.arange(8192, dtype=np.uint64)
+    for s in range(2, 8193):
+        sinv = np.uint64(((1 << 32) + s - 1) // s) & np.uint64(0xFFFFFFFF)
+        assert ((i * sinv) >> np.uint64(32) == i // np.uint64(s)).all(), s
+    pos = np.arange(8192, dtype=np.uint32)
+    swz = pos ^ ((pos >> 5) & 7)
+    assert sorted(swz.tolist()) == pos.tolist()
+    assert ((swz >> 3) == (pos >> 3)).all()
+
+
+def test_feeder_chunk_masks_by_one_multiply():
+    """csrc/read_feeders.hip newline_mask16: the "byte is not X" flags of a dword (0x01 per byte, bits 0 / 8 / 16 / 24) are
+    gathered into a nibble by ONE multiply with 0x00204081 (nibble at bits 21..24), a second set of flags shifted up by 4
+    rides along (nibble at bits 25..28); ':' ';' '>' '?' are the bytes that equal 0x3A once bits 0 and 2 are cleared."""
+    rng = np.random.default_rng(3)
+    w = rng.integers(0, 1 << 32, 200_000, dtype=np.uint64)
+    special = np.frombuffer(b"\n>;:?\x0b\x1a\x3c\x7e\xba", np.uint8)
+    for k in range(4):      # plant the bytes of interest
+        hit = rng.random(len(w)) < 0.3
+        w[hit] = (w[hit] & ~np.uint64(0xFF << (8 * k))) | (rng.choice(special, int(hit.sum())).astype(np.uint64) << np.uint64(8 * k))
+
+    def nonzero_bytes(x):
+        return ((((x & np.uint64(0x7F7F7F7F)) + np.uint64(0x7F7F7F7F)) | x) >> np.uint64(7)) & np.uint64(0x01010101)
+
+    z = nonzero_bytes(w ^ np.uint64(0x0A0A0A0A)) | (nonzero_bytes((w & np.uint64(0xFAFAFAFA)) ^ np.uint64(0x3A3A3A3A)) << np.uint64(4))
+    g = (z * np.uint64(0x00204081)) & np.uint64(0xFFFFFFFF)
+    not_nl, not_sp = (g >> np.uint64(21)) & np.uint64(0xF), (g >> np.uint64(25)) & np.uint64(0xF)
+    for k in range(4):
+        byte = (w >> np.uint64(8 * k)) & np.uint64(0xFF)
+        assert ((((not_nl >> np.uint64(k)) & np.uint64(1)) == 0) == (byte == 0x0A)).all()
+        assert ((((not_sp >> np.uint64(k)) & np.uint64(1)) == 0) == np.isin(byte, [0x3A, 0x3B, 0x3E, 0x3F])).all()
