@@ -165,3 +165,56 @@ def test_feeder_chunk_masks_by_one_multiply():
         byte = (w >> np.uint64(8 * k)) & np.uint64(0xFF)
         assert ((((not_nl >> np.uint64(k)) & np.uint64(1)) == 0) == (byte == 0x0A)).all()
         assert ((((not_sp >> np.uint64(k)) & np.uint64(1)) == 0) == np.isin(byte, [0x3A, 0x3B, 0x3E, 0x3F])).all()
+
+
+def test_fasta_two_scans_in_one_pass_combination_rule():
+    """csrc/read_feeders.hip scan2_*: the per-line scans of (is_header, seq_len) run as ONE pass over segments of whole
+    1024-line chunks although seq_len counts only behind the file's first header.  Every segment reports (headers, bytes
+    behind its own first header, bytes in front of it, index of that header); the single-workgroup step in the middle
+    finds the file's first header and takes from a segment: nothing (it lies in front), the bytes behind its own first
+    header (it holds the file's first header), or everything (it starts behind it).  Restated in numpy against the plain
+    definition: dst[k] = sum of seq_len[j] for first_header <= j < k."""
+    SEGS = 512
+    rng = np.random.default_rng(17)
+    for n, first in [(0, None), (5, None), (5, 0), (5000, 4999), (5000, None), (600_000, 0), (600_000, 1023), (600_000, 1024),
+                     (600_000, 1025), (600_000, 2047), (600_000, 300_000), (600_000, 599_999), (1_100_000, 777_777)]:
+        is_header = np.zeros(n, np.uint64)
+        if first is not None:
+            is_header[first] = 1
+            later = rng.random(n) < 0.02
+            later[: first + 1] = False
+            is_header[later] = 1
+        seq_len = rng.integers(0, 200, n).astype(np.uint64)
+        seq_len[is_header == 1] = 0
+        per = ((n + SEGS - 1) // SEGS + 1023) // 1024 * 1024
+        cnt, after, before, firstl = [], [], [], []
+        for t in range(SEGS):
+            lo, hi = min(n, t * per), min(n, t * per + per)
+            h = np.flatnonzero(is_header[lo:hi])
+            f = lo + int(h[0]) if len(h) else None
+            cnt.append(int(is_header[lo:hi].sum()))
+            firstl.append(f)
+            cut = hi if f is None else f
+            before.append(int(seq_len[lo:cut].sum()))
+            after.append(int(seq_len[cut:hi].sum()))
+        gfirst = min((f for f in firstl if f is not None), default=None)
+        eff = []
+        for t in range(SEGS):
+            lo = min(n, t * per)
+            if gfirst is None:
+                eff.append(0)
+            elif lo > gfirst:
+                eff.append(after[t] + before[t])
+            elif firstl[t] == gfirst:
+                eff.append(after[t])
+            else:
+                eff.append(0)
+        seg_start = np.concatenate([[0], np.cumsum(eff)])
+        masked = seq_len.copy()
+        masked[: (n if gfirst is None else gfirst)] = 0
+        want = np.concatenate([[0], np.cumsum(masked)])
+        assert gfirst == first
+        for t in range(SEGS):
+            lo = min(n, t * per)
+            assert int(seg_start[t]) == int(want[lo]), (n, first, t)
+        assert int(seg_start[SEGS]) == int(want[n])
