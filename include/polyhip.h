@@ -63,6 +63,37 @@ int polyhip_set_device(int device);
 /* name of the current device's gcnArch (e.g. "gfx950:sramecc+:xnack-") */
 int polyhip_device_arch(char *buf, size_t buflen);
 
+/* ---- one host call over several GPUs  (polyhip_init(n_devices); 8e) ---- */
+/*
+ * The reference is single-threaded Go (search/mash/mash.go:68-140, search/align/align.go:171-232,
+ * primers/primers.go:70-128, seqhash/seqhash.go:127-224 are plain loops); a Go host that keeps that API has ONE call
+ * per batch, so the node's GPUs have to be reached from inside that call.  The library keeps one device list per
+ * process.  Empty (the default): every host-pointer entry point runs on the calling thread's current device.  With n
+ * entries the host-pointer entry points
+ *     polyhip_mash_sketch_batch, polyhip_mash_distance_matrix, polyhip_mash_sketch_distance_matrix,
+ *     polyhip_sw_batch, polyhip_sw_align_batch, polyhip_sw_align_batch_packed, polyhip_nw_align_batch,
+ *     polyhip_santalucia_scan, polyhip_santalucia_scan_first, polyhip_santalucia_batch, polyhip_marmurdoty_batch,
+ *     polyhip_least_rotation_batch, polyhip_seqhash_batch
+ * cut their batch into n contiguous shards balanced by bytes (reads, pairs, window starts, matrix rows: SURVEY 8e's
+ * partitioning; no data-path collective) and run shard q on a worker thread that lives on device ids[q], each with
+ * its own streams and two-slot upload / compute / download pipeline, results written straight into the caller's
+ * buffers.  Results, error codes and messages are those of the one-device call (the status reported is the lowest
+ * failing shard's, i.e. the first failure in batch order; positions in messages are positions of the whole batch).
+ * An id may appear more than once ("0,0,0"): the shards then share that GPU (testing on a one-GPU box).  The _dev
+ * entry points, the feeders and polyhip_scoring_create are not affected (a scoring handle is copied to the other
+ * devices of the list on first use).  polyhip_sw_last_path and friends describe calls on the calling thread only.
+ *   polyhip_set_devices(ids, n)  n = 0 clears the list.  Calls in flight finish on the list they started with.
+ *   polyhip_get_devices          -> the list's length (ids filled up to `capacity`).
+ *   polyhip_init(n)              = polyhip_set_devices({0 .. n-1}); n <= 0: every visible device.
+ *   polyhip_shutdown()           = polyhip_set_devices(NULL, 0).
+ *   POLYHIP_DEVICES=0,1,2 | all  in the environment: the list a process starts with (read once, at the first
+ *                                host-pointer call, unless polyhip_set_devices came first).
+ */
+int polyhip_set_devices(const int *ids, int n);
+int polyhip_get_devices(int *ids, int capacity);
+int polyhip_init(int n_devices);
+int polyhip_shutdown(void);
+
 /* ---- synthetic inputs (bench/test plumbing) ------------- */
 /* d_out[i] = "ACGT"[(x >> 2*(i&31)) & 3], x = splitmix64 output number
  * (first + i)/32 + 1 of the stream seeded with `seed`; `first` must be a

@@ -34,6 +34,10 @@ SIGNATURES = {
     "polyhip_device_count": (C.c_int, []),
     "polyhip_set_device": (C.c_int, [C.c_int]),
     "polyhip_device_arch": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "polyhip_set_devices": (C.c_int, [_vp, C.c_int]),
+    "polyhip_get_devices": (C.c_int, [_vp, C.c_int]),
+    "polyhip_init": (C.c_int, [C.c_int]),
+    "polyhip_shutdown": (C.c_int, []),
     "polyhip_synth_dna_dev": (C.c_int, [_u64, _u64, _vp, _u64, _vp]),
     "polyhip_mash_sketch_batch": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp]),
     "polyhip_mash_sketch_batch_dev": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp, _vp]),

@@ -45,6 +45,12 @@ struct DevBuf {
             (void)hipFree(p);
     }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    void reset()
+    {
+        if (p)
+            (void)hipFree(p);
+        p = nullptr;
+    }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 

@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "multi_device.h"
 
 namespace polyhip {
 

@@ -767,8 +767,9 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
     return POLYHIP_OK;
 }
 
-int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint64_t *rot_index,
-                                 uint8_t *rotated)
+// the single-device body; `rotated` is indexed by the caller's offsets (a shard passes the whole batch's buffers)
+static int least_rotation_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint64_t *rot_index,
+                                    uint8_t *rotated)
 {
     if (n == 0)
         return POLYHIP_OK;
@@ -776,7 +777,7 @@ int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets, u
     uint64_t max_len = 0;
     for (uint64_t i = 0; i < n; ++i) {
         PH_REQUIRE(offsets[i] <= offsets[i + 1], "polyhip_least_rotation_batch: offsets not ascending at %llu",
-                   (unsigned long long)i);
+                   (unsigned long long)(i + md::base().item));
         if (offsets[i + 1] - offsets[i] > max_len)
             max_len = offsets[i + 1] - offsets[i];
     }
@@ -814,6 +815,23 @@ int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets, u
     }
     PH_HIP(hs.sync_both());
     return POLYHIP_OK;
+}
+
+int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint64_t *rot_index,
+                                 uint8_t *rotated)
+{
+    std::shared_ptr<md::Pool> P = n ? md::pool() : nullptr;
+    if (!P)
+        return least_rotation_batch_one(seqs, offsets, n, rot_index, rotated);
+    // sequences are independent -- block split by bytes
+    PH_REQUIRE(seqs && offsets && rot_index, "polyhip_least_rotation_batch: null pointer");
+    const std::vector<uint64_t> cut =
+        md::split(n, md::size(*P), [&](uint64_t i) { return (offsets[i] - offsets[0]) * (rotated ? 2 : 1) + i * 8; });
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, offsets[i0] - offsets[0]);
+        return least_rotation_batch_one(seqs, offsets + i0, m, rot_index + i0, rotated);
+    });
 }
 
 } // extern "C"

@@ -1635,8 +1635,8 @@ int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts, uint64_t nx,
     return POLYHIP_OK;
 }
 
-int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,
-                                 uint16_t *counts, double *dist)
+static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,
+                               uint16_t *counts, double *dist)
 {
     if (sx == 0 || sy == 0)
         return polyhip_mash_shared_counts_dev(nullptr, nx, sx, nullptr, ny, sy, nullptr, 0, nullptr, 0, nullptr);
@@ -1706,6 +1706,26 @@ int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, co
         return rc;
     PH_HIP(e);
     return POLYHIP_OK;
+}
+
+int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,
+                                 uint16_t *counts, double *dist)
+{
+    std::shared_ptr<md::Pool> P = nx && ny && sx && sy ? md::pool() : nullptr;
+    if (!P)
+        return distance_matrix_one(X, nx, sx, Y, ny, sy, counts, dist);
+    // every device holds all of Y (uploaded over its own link: the host is the source, so N parallel uploads
+    // cost what one does) and its own index, and joins a contiguous block of X's rows; the row blocks go back to the
+    // host side by side.  No collective: the matrix stays sharded by rows all the way.
+    PH_REQUIRE(X && Y && (counts || dist), "polyhip_mash_distance_matrix: null pointer");
+    const size_t nsh = md::size(*P);
+    return md::run(*P, [&](size_t q) {
+        const uint64_t r0 = (uint64_t)(((unsigned __int128)nx * q) / nsh), r1 = (uint64_t)(((unsigned __int128)nx * (q + 1)) / nsh);
+        if (r0 == r1)
+            return (int)POLYHIP_OK;
+        return distance_matrix_one(X + r0 * (uint64_t)sx, r1 - r0, sx, Y, ny, sy, counts ? counts + r0 * ny : nullptr,
+                                   dist ? dist + r0 * ny : nullptr);
+    });
 }
 
 } // extern "C"

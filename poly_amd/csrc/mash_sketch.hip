@@ -34,6 +34,8 @@
 #include <algorithm>
 
 #include "common.h"
+#include "multi_device.h"
+#include <string>
 #include <vector>
 
 // PH_ABL != 0 only in scripts/ubench/k1_ablate.hip: knocks out one phase to measure its cost
@@ -1362,7 +1364,7 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
         if (h_first != ~0ull)
             return set_error(POLYHIP_ERR_PANIC,
                              "mash.Sketch with SketchSize %u indexes Sketches[-1] on sequence %llu (mash.go:%s): the reference panics",
-                             s, h_first, s == 0 ? "96" : "98");
+                             s, h_first + (unsigned long long)md::base().item, s == 0 ? "96" : "98");
         return POLYHIP_OK;
     }
     const k1::Launch L = k1::plan(k <= 4096 ? k : 4096, s <= 8192 ? s : 8192);
@@ -1397,8 +1399,8 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
     return POLYHIP_OK;
 }
 
-int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t s,
-                              uint32_t *out)
+// the single-device body: the calling thread's current device (a fan-out worker's, or the caller's own)
+static int sketch_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t s, uint32_t *out)
 {
     if (n == 0)
         return POLYHIP_OK;
@@ -1410,7 +1412,7 @@ int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint
     bool need_prior = false;
     for (uint64_t i = 0; i < n; ++i) {
         PH_REQUIRE(offsets[i] <= offsets[i + 1], "polyhip_mash_sketch_batch: offsets not ascending at %llu",
-                   (unsigned long long)i);
+                   (unsigned long long)(i + md::base().item));
         need_prior |= offsets[i + 1] - offsets[i] < (uint64_t)k + s;
     }
     // Chunks of about 256 MB (sequence bytes + sketch bytes) through two slots, each with its own stream:
@@ -1442,6 +1444,8 @@ int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint
         }
     } slot[2];
     const size_t nchunks = cut.size() - 1;
+    int first_panic = POLYHIP_OK;
+    std::string panic_text;
     for (size_t q = 0; q < std::min<size_t>(2, nchunks); ++q) {
         PH_HIP(slot[q].dseq.alloc(max_bytes + 16));
         PH_HIP(slot[q].doff.alloc((max_reads + 1) * sizeof(uint64_t)));
@@ -1464,17 +1468,47 @@ int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint
         PH_HIP(hipMemcpyAsync(S.dseq.p, seqs + b0, offsets[i0 + m] - b0, hipMemcpyHostToDevice, S.st));
         if (need_prior)
             PH_HIP(hipMemcpyAsync(S.dout.p, out + i0 * (uint64_t)s, m * row, hipMemcpyHostToDevice, S.st));
-        const int rc = polyhip_mash_sketch_batch_dev(S.dseq.as<uint8_t>(), S.doff.as<uint64_t>(), m, k, s,
-                                                     S.dout.as<uint32_t>(), S.st);
-        if (rc != POLYHIP_OK)
+        int rc;
+        {
+            md::BaseScope pos(i0, b0 - offsets[0]); // a message of this chunk names positions of the whole batch
+            rc = polyhip_mash_sketch_batch_dev(S.dseq.as<uint8_t>(), S.doff.as<uint64_t>(), m, k, s, S.dout.as<uint32_t>(), S.st);
+        }
+        if (rc == POLYHIP_ERR_PANIC && first_panic == POLYHIP_OK) {
+            // SketchSize < 2 is decided read by read (mash.go:96,98): the first panicking sequence is named, and the rows of
+            // the sequences that do not panic are written -- in the later chunks too
+            first_panic = rc;
+            panic_text = polyhip_last_error();
+        } else if (rc != POLYHIP_OK && rc != POLYHIP_ERR_PANIC) {
             return rc;
+        }
         if (c > 0)
             PH_HIP(download(c - 1));
     }
     PH_HIP(download(nchunks - 1));
     for (size_t q = 0; q < std::min<size_t>(2, nchunks); ++q)
         PH_HIP(hipStreamSynchronize(slot[q].st));
+    if (first_panic != POLYHIP_OK)
+        return set_error(first_panic, "%s", panic_text.c_str());
     return POLYHIP_OK;
+}
+
+int polyhip_mash_sketch_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t k, uint32_t s,
+                              uint32_t *out)
+{
+    std::shared_ptr<md::Pool> P = n ? md::pool() : nullptr;
+    if (!P)
+        return sketch_batch_one(seqs, offsets, n, k, s, out);
+    // reads are independent -- contiguous blocks of reads balanced by bytes (sequence + sketch row), one per
+    // device of the list, each through its own two-slot pipeline over its own PCIe link
+    PH_REQUIRE(seqs && offsets && (out || s == 0), "polyhip_mash_sketch_batch: null pointer");
+    const uint64_t row = (uint64_t)s * sizeof(uint32_t);
+    const std::vector<uint64_t> cut =
+        md::split(n, md::size(*P), [&](uint64_t i) { return offsets[i] - offsets[0] + i * row; });
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, offsets[i0] - offsets[0]);
+        return sketch_batch_one(seqs, offsets + i0, m, k, s, out ? out + i0 * (uint64_t)s : nullptr);
+    });
 }
 
 } // extern "C"

@@ -367,7 +367,7 @@ static int validate_ascii(const uint8_t *p, uint64_t n, const char *who)
     const uint64_t i = first_non_ascii(p, n);
     if (i < n)
         return set_error(POLYHIP_ERR_INVALID, "%s: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)", who, p[i],
-                         (unsigned long long)i);
+                         (unsigned long long)(i + md::base().byte));
     return POLYHIP_OK;
 }
 
@@ -376,10 +376,11 @@ static int check_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n,
 {
     PH_REQUIRE(seqs && offsets, "%s: null pointer", who);
     for (uint64_t i = 0; i < n; ++i) {
-        PH_REQUIRE(offsets[i] <= offsets[i + 1], "%s: offsets not ascending at %llu", who, (unsigned long long)i);
+        PH_REQUIRE(offsets[i] <= offsets[i + 1], "%s: offsets not ascending at %llu", who,
+                   (unsigned long long)(i + md::base().item));
         if (empty_panics && offsets[i] == offsets[i + 1])
             return set_error(POLYHIP_ERR_PANIC, "%s: sequence %llu is empty; primers.SantaLucia(\"\") panics (primers.go:89)",
-                             who, (unsigned long long)i);
+                             who, (unsigned long long)(i + md::base().item));
     }
     return validate_ascii(seqs + offsets[0], offsets[n] - offsets[0], who);
 }
@@ -483,45 +484,55 @@ int polyhip_santalucia_scan_first_dev(const uint8_t *d_seq, uint64_t len, uint64
                      target_tm, d_first_len, d_first_tm, stream);
 }
 
-int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uint32_t Lmax, double primer_conc,
-                            double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+// Starts [a, b) of the host flavour's scan on the calling thread's current device: the slice of the sequence those
+// windows touch (an (Lmax - 1)-byte halo on the right) goes up, the planes come back into columns [a, b) of
+// the caller's planes (row stride ld = the whole scan's number of starts).
+static int scan_range_one(const uint8_t *seq, uint64_t len, uint64_t a, uint64_t b, uint32_t Lmin, uint32_t Lmax,
+                          double primer_conc, double salt_conc, double mg_conc, double *tm, double *dH, double *dS, uint64_t ld)
 {
-    if (Lmin == 0)
-        return polyhip_santalucia_scan_dev(nullptr, 0, 0, 0, 0, Lmax, primer_conc, salt_conc, mg_conc, nullptr, nullptr,
-                                           nullptr, 0, nullptr);
-    PH_REQUIRE(Lmin <= Lmax, "polyhip_santalucia_scan: Lmin %u > Lmax %u", Lmin, Lmax);
-    if (len < Lmin)
-        return POLYHIP_OK; // no window fits
-    PH_REQUIRE(seq && tm && dH && dS, "polyhip_santalucia_scan: null pointer");
-    int rc = validate_ascii(seq, len, "polyhip_santalucia_scan");
+    if (a >= b)
+        return POLYHIP_OK;
+    const uint64_t nst = b - a, end = std::min<uint64_t>(len, b - 1 + Lmax), slen = end - a;
+    const uint32_t nl = Lmax - Lmin + 1;
+    int rc;
+    {
+        md::BaseScope pos(0, a);
+        rc = validate_ascii(seq + a, slen, "polyhip_santalucia_scan");
+    }
     if (rc != POLYHIP_OK)
         return rc;
-    const uint64_t nstarts = len - Lmin + 1;
-    const uint64_t nout = nstarts * (uint64_t)(Lmax - Lmin + 1);
+    const uint64_t nout = nst * (uint64_t)nl;
     DevBuf dseq, dtm, ddh, dds;
-    PH_HIP(dseq.alloc(len));
+    PH_HIP(dseq.alloc(slen));
     PH_HIP(dtm.alloc(nout * 8));
     PH_HIP(ddh.alloc(nout * 8));
     PH_HIP(dds.alloc(nout * 8));
     HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
     PH_HIP(hs.init());
-    PH_HIP(hipMemcpyAsync(dseq.p, seq, len, hipMemcpyHostToDevice, hs.s[0]));
-    rc = polyhip_santalucia_scan_dev(dseq.as<uint8_t>(), len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
-                                     dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nstarts, hs.s[0]);
+    PH_HIP(hipMemcpyAsync(dseq.p, seq + a, slen, hipMemcpyHostToDevice, hs.s[0]));
+    rc = polyhip_santalucia_scan_dev(dseq.as<uint8_t>(), slen, 0, nst, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
+                                     dtm.as<double>(), ddh.as<double>(), dds.as<double>(), nst, hs.s[0]);
     if (rc != POLYHIP_OK) {
         (void)hipStreamSynchronize(hs.s[0]);
         return rc;
     }
     PH_HIP(hipStreamSynchronize(hs.s[0]));
-    // three planes, three streams: one pageable download does not fill the link (a copy engine each does)
+    // three outputs, three streams: one pageable download does not fill the link (a copy engine each does).  The whole
+    // scan on one device (nst == ld) is one contiguous copy per output, a shard's columns one copy per length.
     hipStream_t cs[3] = {nullptr, nullptr, nullptr};
-    void *dstp[3] = {tm, dH, dS};
-    void *srcp[3] = {dtm.p, ddh.p, dds.p};
+    double *dstp[3] = {tm, dH, dS};
+    const double *srcp[3] = {dtm.as<double>(), ddh.as<double>(), dds.as<double>()};
     hipError_t e = hipSuccess;
     for (int q = 0; q < 3 && e == hipSuccess; ++q) {
         e = hipStreamCreateWithFlags(&cs[q], hipStreamNonBlocking);
-        if (e == hipSuccess)
+        if (e != hipSuccess)
+            break;
+        if (nst == ld) {
             e = hipMemcpyAsync(dstp[q], srcp[q], nout * 8, hipMemcpyDeviceToHost, cs[q]);
+        } else {
+            for (uint32_t l = 0; l < nl && e == hipSuccess; ++l)
+                e = hipMemcpyAsync(dstp[q] + (uint64_t)l * ld + a, srcp[q] + (uint64_t)l * nst, nst * 8, hipMemcpyDeviceToHost, cs[q]);
+        }
     }
     for (int q = 0; q < 3; ++q)
         if (cs[q]) {
@@ -534,6 +545,65 @@ int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uin
     return POLYHIP_OK;
 }
 
+int polyhip_santalucia_scan(const uint8_t *seq, uint64_t len, uint32_t Lmin, uint32_t Lmax, double primer_conc,
+                            double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+{
+    if (Lmin == 0)
+        return polyhip_santalucia_scan_dev(nullptr, 0, 0, 0, 0, Lmax, primer_conc, salt_conc, mg_conc, nullptr, nullptr,
+                                           nullptr, 0, nullptr);
+    PH_REQUIRE(Lmin <= Lmax, "polyhip_santalucia_scan: Lmin %u > Lmax %u", Lmin, Lmax);
+    PH_REQUIRE(Lmax <= (uint32_t)k4::LMAX_MAX, "polyhip_santalucia_scan: Lmax %u > %d is not implemented", Lmax, k4::LMAX_MAX);
+    if (len < Lmin)
+        return POLYHIP_OK; // no window fits
+    PH_REQUIRE(seq && tm && dH && dS, "polyhip_santalucia_scan: null pointer");
+    const uint64_t nstarts = len - Lmin + 1;
+    std::shared_ptr<md::Pool> P = md::pool();
+    if (!P)
+        return scan_range_one(seq, len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc, tm, dH, dS, nstarts);
+    // windows are independent -- contiguous ranges of starts, each with its halo
+    const size_t nsh = md::size(*P);
+    return md::run(*P, [&](size_t q) {
+        const uint64_t a = (uint64_t)(((unsigned __int128)nstarts * q) / nsh), b = (uint64_t)(((unsigned __int128)nstarts * (q + 1)) / nsh);
+        return scan_range_one(seq, len, a, b, Lmin, Lmax, primer_conc, salt_conc, mg_conc, tm, dH, dS, nstarts);
+    });
+}
+
+static int scan_first_range_one(const uint8_t *seq, uint64_t len, uint64_t a, uint64_t b, uint32_t Lmin, uint32_t Lmax,
+                                double primer_conc, double salt_conc, double mg_conc, double target_tm, uint16_t *first_len,
+                                double *first_tm)
+{
+    if (a >= b)
+        return POLYHIP_OK;
+    const uint64_t nst = b - a, end = std::min<uint64_t>(len, b - 1 + Lmax), slen = end - a;
+    int rc;
+    {
+        md::BaseScope pos(0, a);
+        rc = validate_ascii(seq + a, slen, "polyhip_santalucia_scan_first");
+    }
+    if (rc != POLYHIP_OK)
+        return rc;
+    DevBuf dseq, dlen, dtm;
+    PH_HIP(dseq.alloc(slen));
+    PH_HIP(dlen.alloc(nst * 2));
+    if (first_tm)
+        PH_HIP(dtm.alloc(nst * 8));
+    HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
+    PH_HIP(hs.init());
+    hipStream_t st = hs.s[0];
+    PH_HIP(hipMemcpyAsync(dseq.p, seq + a, slen, hipMemcpyHostToDevice, st));
+    rc = polyhip_santalucia_scan_first_dev(dseq.as<uint8_t>(), slen, 0, nst, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
+                                           target_tm, dlen.as<uint16_t>(), first_tm ? dtm.as<double>() : nullptr, st);
+    if (rc != POLYHIP_OK) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    PH_HIP(hipMemcpyAsync(first_len + a, dlen.p, nst * 2, hipMemcpyDeviceToHost, st));
+    if (first_tm)
+        PH_HIP(hipMemcpyAsync(first_tm + a, dtm.p, nst * 8, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
+    return POLYHIP_OK;
+}
+
 int polyhip_santalucia_scan_first(const uint8_t *seq, uint64_t len, uint32_t Lmin, uint32_t Lmax, double primer_conc,
                                   double salt_conc, double mg_conc, double target_tm, uint16_t *first_len, double *first_tm)
 {
@@ -541,33 +611,20 @@ int polyhip_santalucia_scan_first(const uint8_t *seq, uint64_t len, uint32_t Lmi
         return polyhip_santalucia_scan_dev(nullptr, 0, 0, 0, 0, Lmax, primer_conc, salt_conc, mg_conc, nullptr, nullptr,
                                            nullptr, 0, nullptr);
     PH_REQUIRE(Lmin <= Lmax, "polyhip_santalucia_scan_first: Lmin %u > Lmax %u", Lmin, Lmax);
+    PH_REQUIRE(Lmax <= (uint32_t)k4::LMAX_MAX, "polyhip_santalucia_scan: Lmax %u > %d is not implemented", Lmax, k4::LMAX_MAX);
     if (len < Lmin)
         return POLYHIP_OK; // no window fits
     PH_REQUIRE(seq && first_len, "polyhip_santalucia_scan_first: null pointer");
-    int rc = validate_ascii(seq, len, "polyhip_santalucia_scan_first");
-    if (rc != POLYHIP_OK)
-        return rc;
     const uint64_t nstarts = len - Lmin + 1;
-    DevBuf dseq, dlen, dtm;
-    PH_HIP(dseq.alloc(len));
-    PH_HIP(dlen.alloc(nstarts * 2));
-    if (first_tm)
-        PH_HIP(dtm.alloc(nstarts * 8));
-    HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
-    PH_HIP(hs.init());
-    hipStream_t st = hs.s[0];
-    PH_HIP(hipMemcpyAsync(dseq.p, seq, len, hipMemcpyHostToDevice, st));
-    rc = polyhip_santalucia_scan_first_dev(dseq.as<uint8_t>(), len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc,
-                                           target_tm, dlen.as<uint16_t>(), first_tm ? dtm.as<double>() : nullptr, st);
-    if (rc != POLYHIP_OK) {
-        (void)hipStreamSynchronize(st);
-        return rc;
-    }
-    PH_HIP(hipMemcpyAsync(first_len, dlen.p, nstarts * 2, hipMemcpyDeviceToHost, st));
-    if (first_tm)
-        PH_HIP(hipMemcpyAsync(first_tm, dtm.p, nstarts * 8, hipMemcpyDeviceToHost, st));
-    PH_HIP(hipStreamSynchronize(st));
-    return POLYHIP_OK;
+    std::shared_ptr<md::Pool> P = md::pool();
+    if (!P)
+        return scan_first_range_one(seq, len, 0, nstarts, Lmin, Lmax, primer_conc, salt_conc, mg_conc, target_tm, first_len,
+                                    first_tm);
+    const size_t nsh = md::size(*P);
+    return md::run(*P, [&](size_t q) {
+        const uint64_t a = (uint64_t)(((unsigned __int128)nstarts * q) / nsh), b = (uint64_t)(((unsigned __int128)nstarts * (q + 1)) / nsh);
+        return scan_first_range_one(seq, len, a, b, Lmin, Lmax, primer_conc, salt_conc, mg_conc, target_tm, first_len, first_tm);
+    });
 }
 
 int polyhip_santalucia_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, double primer_conc,
@@ -586,8 +643,8 @@ int polyhip_santalucia_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offset
     return POLYHIP_OK;
 }
 
-int polyhip_santalucia_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double primer_conc,
-                             double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+static int santalucia_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double primer_conc, double salt_conc,
+                                double mg_conc, double *tm, double *dH, double *dS)
 {
     if (n == 0)
         return POLYHIP_OK;
@@ -599,6 +656,21 @@ int polyhip_santalucia_batch(const uint8_t *seqs, const uint64_t *offsets, uint6
                              [&](const uint8_t *ds, const uint64_t *dof, uint64_t m, double *(&d)[3], hipStream_t st) {
                                  return polyhip_santalucia_batch_dev(ds, dof, m, primer_conc, salt_conc, mg_conc, d[0], d[1], d[2], st);
                              });
+}
+
+int polyhip_santalucia_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double primer_conc,
+                             double salt_conc, double mg_conc, double *tm, double *dH, double *dS)
+{
+    std::shared_ptr<md::Pool> P = n ? md::pool() : nullptr;
+    if (!P)
+        return santalucia_batch_one(seqs, offsets, n, primer_conc, salt_conc, mg_conc, tm, dH, dS);
+    PH_REQUIRE(seqs && offsets && tm && dH && dS, "polyhip_santalucia_batch: null pointer");
+    const std::vector<uint64_t> cut = md::split(n, md::size(*P), [&](uint64_t i) { return offsets[i] - offsets[0] + i * 24; });
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, offsets[i0] - offsets[0]);
+        return santalucia_batch_one(seqs, offsets + i0, m, primer_conc, salt_conc, mg_conc, tm + i0, dH + i0, dS + i0);
+    });
 }
 
 int polyhip_marmurdoty_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, double *d_tm,
@@ -615,7 +687,7 @@ int polyhip_marmurdoty_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offset
     return POLYHIP_OK;
 }
 
-int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double *tm)
+static int marmurdoty_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double *tm)
 {
     if (n == 0)
         return POLYHIP_OK;
@@ -627,6 +699,20 @@ int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets, uint6
                              [&](const uint8_t *ds, const uint64_t *dof, uint64_t m, double *(&d)[1], hipStream_t st) {
                                  return polyhip_marmurdoty_batch_dev(ds, dof, m, d[0], st);
                              });
+}
+
+int polyhip_marmurdoty_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, double *tm)
+{
+    std::shared_ptr<md::Pool> P = n ? md::pool() : nullptr;
+    if (!P)
+        return marmurdoty_batch_one(seqs, offsets, n, tm);
+    PH_REQUIRE(seqs && offsets && tm, "polyhip_marmurdoty_batch: null pointer");
+    const std::vector<uint64_t> cut = md::split(n, md::size(*P), [&](uint64_t i) { return offsets[i] - offsets[0] + i * 8; });
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, offsets[i0] - offsets[0]);
+        return marmurdoty_batch_one(seqs, offsets + i0, m, tm + i0);
+    });
 }
 
 } // extern "C"

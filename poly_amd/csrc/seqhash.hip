@@ -562,8 +562,8 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     return POLYHIP_OK;
 }
 
-int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int seq_type, int circular,
-                          int double_stranded, char *out, uint32_t *err)
+static int seqhash_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int seq_type, int circular,
+                             int double_stranded, char *out, uint32_t *err)
 {
     PH_REQUIRE(seq_type >= 0 && seq_type <= 2,
                "Only sequenceTypes of DNA, RNA, or PROTEIN allowed. Got sequenceType code: %d", seq_type);
@@ -574,14 +574,14 @@ int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t
     uint64_t max_len = 0;
     for (uint64_t i = 0; i < n; ++i) {
         PH_REQUIRE(offsets[i] <= offsets[i + 1], "polyhip_seqhash_batch: offsets not ascending at %llu",
-                   (unsigned long long)i);
+                   (unsigned long long)(i + md::base().item));
         max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
     }
     const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
     {
         const uint64_t i = first_non_ascii(seqs + b0, nbytes);
         PH_REQUIRE(i == nbytes, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)", seqs[b0 + i],
-                   (unsigned long long)i);
+                   (unsigned long long)(i + md::base().byte));
     }
     // chunks of ~64 MB through two slots on the calling thread's two streams: chunk c is uploaded and hashed while the
     // seqhashes of chunk c-1 travel back
@@ -618,6 +618,21 @@ int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t
     }
     PH_HIP(hs.sync_both());
     return POLYHIP_OK;
+}
+
+int polyhip_seqhash_batch(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int seq_type, int circular,
+                          int double_stranded, char *out, uint32_t *err)
+{
+    std::shared_ptr<md::Pool> P = n ? md::pool() : nullptr;
+    if (!P || seq_type < 0 || seq_type > 2 || (seq_type == 2 && double_stranded)) // argument errors: the one-device path words them
+        return seqhash_batch_one(seqs, offsets, n, seq_type, circular, double_stranded, out, err);
+    PH_REQUIRE(seqs && offsets && out && err, "polyhip_seqhash_batch: null pointer");
+    const std::vector<uint64_t> cut = md::split(n, md::size(*P), [&](uint64_t i) { return offsets[i] - offsets[0] + i * 76; });
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, offsets[i0] - offsets[0]);
+        return seqhash_batch_one(seqs, offsets + i0, m, seq_type, circular, double_stranded, out + i0 * 72, err + i0);
+    });
 }
 
 } // extern "C"

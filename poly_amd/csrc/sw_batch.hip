@@ -599,6 +599,8 @@ int polyhip_scoring_create(const int32_t *lut, const uint8_t *validA, const uint
     sc->d_codeA = nullptr;
     sc->d_lut = nullptr;
     sc->d_validA = sc->d_validB = nullptr;
+    sc->rep_m = new std::mutex();
+    sc->rep = new std::vector<polyhip_scoring *>();
 
     auto fail = [&](hipError_t e, const char *what) {
         polyhip_scoring_destroy(sc);
@@ -663,6 +665,11 @@ int polyhip_scoring_destroy(polyhip_scoring *sc)
     (void)hipFree(sc->d_lut);
     (void)hipFree(sc->d_validA);
     (void)hipFree(sc->d_validB);
+    if (sc->rep)
+        for (polyhip_scoring *r : *sc->rep)
+            polyhip_scoring_destroy(r);
+    delete sc->rep;
+    delete sc->rep_m;
     delete sc;
     return POLYHIP_OK;
 }
@@ -825,6 +832,27 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
     return POLYHIP_OK;
 }
 
+const polyhip_scoring *polyhip::scoring_here(const polyhip_scoring *sc)
+{
+    int dev = -1;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) {
+        set_error(POLYHIP_ERR_HIP, "hipGetDevice: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (dev == sc->device)
+        return sc;
+    std::lock_guard<std::mutex> lk(*sc->rep_m);
+    for (const polyhip_scoring *r : *sc->rep)
+        if (r->device == dev)
+            return r;
+    polyhip_scoring *r = nullptr; // the tables are rebuilt from the handle's host copies of the creation arguments
+    if (polyhip_scoring_create(sc->lut, sc->validA, sc->validB, sc->gap, &r) != POLYHIP_OK)
+        return nullptr;
+    sc->rep->push_back(r);
+    return r;
+}
+
 extern "C" {
 
 int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
@@ -836,14 +864,16 @@ int polyhip_sw_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, const ui
                                    work_bytes, stream, 0, nullptr);
 }
 
-int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
-                     const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
-                     uint32_t *endB, uint32_t *err)
+// the single-device body: the calling thread's current device (a fan-out worker's, or the caller's own)
+static int sw_batch_one(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs, const uint8_t *B,
+                        const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA, uint32_t *endB, uint32_t *err)
 {
     PH_REQUIRE(sc, "polyhip_sw_batch: null scoring");
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && endA && endB && err, "polyhip_sw_batch: null pointer");
+    if (!(sc = scoring_here(sc)))
+        return POLYHIP_ERR_HIP;
     HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
     PH_HIP(hs.init());
     hipStream_t st = hs.s[0];
@@ -873,6 +903,23 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t
     PH_HIP(hipMemcpyAsync(err, derr.p, npairs * 4, hipMemcpyDeviceToHost, st));
     PH_HIP(hipStreamSynchronize(st));
     return POLYHIP_OK;
+}
+
+int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                     const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                     uint32_t *endB, uint32_t *err)
+{
+    std::shared_ptr<md::Pool> P = npairs && sc ? md::pool() : nullptr;
+    if (!P)
+        return sw_batch_one(sc, A, offA, npairs, B, offB, lenB, score, endA, endB, err);
+    // pairs are independent -- the reads split by bytes, the shared reference goes to every device
+    PH_REQUIRE(offA && score && endA && endB && err, "polyhip_sw_batch: null pointer");
+    const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 24);
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, 0);
+        return sw_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0, err + i0);
+    });
 }
 
 } // extern "C"

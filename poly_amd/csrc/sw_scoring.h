@@ -30,6 +30,8 @@
                  : "vcc")
 
 #include <cstdint>
+#include <mutex>
+#include <vector>
 
 struct polyhip_scoring {
     int64_t gap;
@@ -51,7 +53,16 @@ struct polyhip_scoring {
     int32_t *d_lutcc;    // [ncodes + 1][ncodesB + 1] compact int32 table (last row/col: zeros for pad codes)
     int32_t *d_lut;      // [256][256]
     uint8_t *d_validA, *d_validB;
+    // copies of this handle on the other devices of the library's device list (multi_device.h): made by the first
+    // fan-out worker that needs one, owned and destroyed by this handle
+    std::mutex *rep_m;
+    std::vector<polyhip_scoring *> *rep;
 };
+
+namespace polyhip {
+// the handle (or its copy) whose tables live on the calling thread's current device; null + polyhip_last_error() on failure
+const polyhip_scoring *scoring_here(const polyhip_scoring *sc);
+} // namespace polyhip
 
 // ---- packed score pass (sw_packed.hip), driven from polyhip_sw_batch_dev (sw_batch.hip) ----------------
 #include <hip/hip_runtime.h>
@@ -129,8 +140,19 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
 #include <vector>
 
 #include "common.h"
+#include "multi_device.h"
 
 namespace polyhip {
+
+// Shards of a batch of pairs for the device list (pairs are independent): balanced by sequence bytes -- with
+// one shared reference a pair's cells are proportional to its read's length -- plus what comes back per pair.
+inline std::vector<uint64_t> split_pairs(const md::Pool &P, const uint64_t *offA, const uint64_t *offB, uint64_t npairs,
+                                         uint64_t out_per_pair)
+{
+    return md::split(npairs, md::size(P), [&](uint64_t i) {
+        return offA[i] - offA[0] + (offB ? offB[i] - offB[0] : 0) + i * out_per_pair;
+    });
+}
 
 // Validates a packed batch of pairs (offsets ascending, buffers present), copies it to the device with offsets
 // rebased to 0, and reports the longest A / B.  Shared by polyhip_sw_batch, polyhip_sw_align_batch, polyhip_nw_align_batch.
@@ -139,6 +161,13 @@ struct PairStage {
     std::vector<uint64_t> hoA, hoB; // rebased offsets: they must outlive the asynchronous uploads
     uint64_t maxA = 0, maxB = 0;
     bool per_pair_B = false;
+    hipStream_t up = nullptr; // the stream the uploads went to
+    // an early return of the entry point must not free the staging vectors and device buffers under uploads in flight
+    ~PairStage()
+    {
+        if (up)
+            (void)hipStreamSynchronize(up);
+    }
 
     const uint8_t *A() const { return dA.as<uint8_t>(); }
     const uint64_t *offA() const { return doA.as<uint64_t>(); }
@@ -151,13 +180,14 @@ struct PairStage {
              const uint64_t *offB_, uint64_t lenB, hipStream_t st)
     {
         per_pair_B = offB_ != nullptr;
+        up = st;
         maxA = 0;
         maxB = offB_ ? 0 : lenB;
         for (uint64_t i = 0; i < npairs; ++i) {
-            PH_REQUIRE(offA_[i] <= offA_[i + 1], "%s: offA not ascending at %llu", who, (unsigned long long)i);
+            PH_REQUIRE(offA_[i] <= offA_[i + 1], "%s: offA not ascending at %llu", who, (unsigned long long)(i + md::base().item));
             maxA = std::max(maxA, offA_[i + 1] - offA_[i]);
             if (offB_) {
-                PH_REQUIRE(offB_[i] <= offB_[i + 1], "%s: offB not ascending at %llu", who, (unsigned long long)i);
+                PH_REQUIRE(offB_[i] <= offB_[i + 1], "%s: offB not ascending at %llu", who, (unsigned long long)(i + md::base().item));
                 maxB = std::max(maxB, offB_[i + 1] - offB_[i]);
             }
         }

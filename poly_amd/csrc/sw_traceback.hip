@@ -1764,11 +1764,19 @@ __global__ __launch_bounds__(1024) void pack_scan_kernel(uint64_t *__restrict__ 
 }
 
 // offsets (global: + base) and the copies; 16 lanes per pair, unaligned dwords
+// base_ptr != nullptr (the multi-device shards, whose strings stay on the device until every shard's total is known): the
+// bytes in front of this chunk are read from the device -- the previous chunk's last offset -- and outA / outB are the
+// shard's whole buffers, so chunk after chunk is appended without the host waiting for a total.
 __global__ __launch_bounds__(256) void pack_copy_kernel(const uint32_t *__restrict__ alnLen, uint64_t n, const uint64_t *__restrict__ bsum,
                                                        uint64_t base, const uint8_t *__restrict__ slotA, const uint8_t *__restrict__ slotB,
                                                        uint32_t stride, uint64_t *__restrict__ off, uint8_t *__restrict__ outA,
-                                                       uint8_t *__restrict__ outB)
+                                                       uint8_t *__restrict__ outB, const uint64_t *base_ptr = nullptr)
 {
+    if (base_ptr) {
+        base = *base_ptr; // == off[0] of this chunk: written by the previous chunk's kernel, rewritten below with the same value
+        outA += base;
+        outB += base;
+    }
     __shared__ uint32_t lens[PACK_BLOCK];
     __shared__ uint64_t offs[PACK_BLOCK];
     __shared__ uint64_t ws[4];
@@ -2108,15 +2116,18 @@ int polyhip_sw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
                           d_alnLen, aln_stride, d_tb_work, tb_work_bytes, stream, deferred);
 }
 
-int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
-                           const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
-                           uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen,
-                           uint32_t aln_stride)
+// the single-device body: the calling thread's current device (a fan-out worker's, or the caller's own)
+static int sw_align_batch_one(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                              const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                              uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen,
+                              uint32_t aln_stride)
 {
     PH_REQUIRE(sc, "polyhip_sw_align_batch: null scoring");
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && endA && endB && err && alnA && alnB && alnLen, "polyhip_sw_align_batch: null pointer");
+    if (!(sc = scoring_here(sc)))
+        return POLYHIP_ERR_HIP;
     HostStreams &hs = host_streams(); // the calling thread's two streams carry the two slots (never the null stream)
     PH_HIP(hs.init());
     PairStage in;
@@ -2206,14 +2217,34 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     return POLYHIP_OK;
 }
 
+int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                           const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                           uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen,
+                           uint32_t aln_stride)
+{
+    std::shared_ptr<md::Pool> P = npairs && sc ? md::pool() : nullptr;
+    if (!P)
+        return sw_align_batch_one(sc, A, offA, npairs, B, offB, lenB, score, endA, endB, err, alnA, alnB, alnLen, aln_stride);
+    // pairs are independent; a shard's strings land in its own run of the caller's fixed-stride slots
+    PH_REQUIRE(offA && score && endA && endB && err && alnA && alnB && alnLen, "polyhip_sw_align_batch: null pointer");
+    const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 24 + 2ull * aln_stride);
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, 0);
+        return sw_align_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0,
+                                  err + i0, alnA + i0 * (size_t)aln_stride, alnB + i0 * (size_t)aln_stride, alnLen + i0,
+                                  aln_stride);
+    });
+}
+
 // The same with PACKED strings: a pair's strings are a few hundred bytes of its aln_stride-byte slots (151 of 525 at
 // config 4), and the slots are what crossed PCIe above (1.05 GB per 1M reads).  Here each chunk's strings are compacted
 // on the device (scan of the lengths, 16 lanes per pair) and only the packed bytes travel (0.3 GB): alignA_p =
 // alnA[alnOff[p] .. alnOff[p + 1]), alignB_p the same range of alnB (the two strings of a pair have one length).
-int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
-                                  const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
-                                  uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint64_t *alnOff,
-                                  uint64_t aln_capacity)
+static int sw_align_packed_one(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                               const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                               uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint64_t *alnOff,
+                               uint64_t aln_capacity)
 {
     PH_REQUIRE(sc, "polyhip_sw_align_batch_packed: null scoring");
     PH_REQUIRE(alnOff, "polyhip_sw_align_batch_packed: null pointer");
@@ -2221,6 +2252,8 @@ int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A, c
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && endA && endB && err && (aln_capacity == 0 || (alnA && alnB)), "polyhip_sw_align_batch_packed: null pointer");
+    if (!(sc = scoring_here(sc)))
+        return POLYHIP_ERR_HIP;
     HostStreams &hs = host_streams(); // the calling thread's two streams carry the two slots (never the null stream)
     PH_HIP(hs.init());
     PairStage in;
@@ -2345,6 +2378,140 @@ int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A, c
     return POLYHIP_OK;
 }
 
+// One shard of the packed call on a device list.  Where a shard's strings start in the caller's buffers depends on the
+// totals of all shards before it, so the call has two rounds.  Round A (all shards side by side): upload, align chunk
+// after chunk, compact every chunk's strings behind the previous one's in a buffer that STAYS on the device (the running
+// total is read from the device: no host wait between chunks), download scores / ends / errors to their final places
+// and the shard-local offsets to a private vector.  The caller turns the totals into bases.  Round B: the strings go to
+// alnA / alnB + base, the offsets to alnOff + base.
+struct PackedShard {
+    uint64_t i0 = 0, m = 0, total = 0;
+    DevBuf dpA, dpB;
+    std::vector<uint64_t> hoff;
+};
+
+static int packed_shard_align(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, const uint8_t *B, const uint64_t *offB,
+                              uint64_t lenB, int64_t *score, uint32_t *endA, uint32_t *endB, uint32_t *err, PackedShard &sh)
+{
+    const uint64_t npairs = sh.m;
+    sh.hoff.assign(npairs + 1, 0);
+    sh.total = 0;
+    if (npairs == 0)
+        return POLYHIP_OK;
+    if (!(sc = scoring_here(sc)))
+        return POLYHIP_ERR_HIP;
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    hipStream_t st = hs.s[0];
+    PairStage in;
+    if (int rc0 = in.load("polyhip_sw_align_batch_packed", A, offA, npairs, B, offB, lenB, st))
+        return rc0;
+    const uint64_t maxA = in.maxA, maxB = in.maxB;
+    const uint32_t aln_stride = polyhip_sw_traceback_stride(sc, (uint32_t)maxA, maxB);
+    // chunks bound the slots and the workspaces, not the transfers: 262,144 pairs is one full round of the packed pass
+    const uint64_t per = std::min<uint64_t>(npairs, 262144);
+    DevBuf dscore, dea, deb, derr, doff, dwork, dalA, dalB, dlen, dtb, dbsum;
+    PH_HIP(dscore.alloc(npairs * 8));
+    PH_HIP(dea.alloc(npairs * 4));
+    PH_HIP(deb.alloc(npairs * 4));
+    PH_HIP(derr.alloc(npairs * 4));
+    PH_HIP(doff.alloc((npairs + 1) * 8));
+    PH_HIP(sh.dpA.alloc(npairs * (size_t)aln_stride)); // upper bound: a pair's strings never exceed its slot
+    PH_HIP(sh.dpB.alloc(npairs * (size_t)aln_stride));
+    const size_t wb = polyhip_sw_workspace_bytes(sc, per, (uint32_t)maxA, maxB, offB == nullptr);
+    const size_t tb = polyhip_sw_traceback_workspace_bytes(sc, per, (uint32_t)maxA, maxB);
+    PH_HIP(dwork.alloc(wb));
+    PH_HIP(dtb.alloc(tb));
+    PH_HIP(dalA.alloc(per * (size_t)aln_stride));
+    PH_HIP(dalB.alloc(per * (size_t)aln_stride));
+    PH_HIP(dlen.alloc(per * 4));
+    PH_HIP(dbsum.alloc(((per + k3t::PACK_BLOCK - 1) / k3t::PACK_BLOCK + 2) * 8));
+    PH_HIP(hipMemsetAsync(doff.p, 0, 8, st)); // the first chunk's base
+    for (uint64_t i0 = 0; i0 < npairs; i0 += per) {
+        const uint64_t m = std::min(per, npairs - i0);
+        const int rc = polyhip_sw_align_batch_dev(sc, in.A(), in.offA() + i0, m, (uint32_t)maxA, in.B(), in.offB() ? in.offB() + i0 : nullptr,
+                                                  maxB, dscore.as<int64_t>() + i0, dea.as<uint32_t>() + i0, deb.as<uint32_t>() + i0,
+                                                  derr.as<uint32_t>() + i0, dalA.as<uint8_t>(), dalB.as<uint8_t>(), dlen.as<uint32_t>(),
+                                                  aln_stride, dwork.p, wb, dtb.p, tb, st);
+        if (rc != POLYHIP_OK) {
+            (void)hipStreamSynchronize(st);
+            return rc;
+        }
+        const unsigned nb = (unsigned)((m + k3t::PACK_BLOCK - 1) / k3t::PACK_BLOCK);
+        hipLaunchKernelGGL(k3t::pack_sums_kernel, dim3(nb), dim3(256), 0, st, dlen.as<uint32_t>(), m, dbsum.as<uint64_t>());
+        hipLaunchKernelGGL(k3t::pack_scan_kernel, dim3(1), dim3(1024), 0, st, dbsum.as<uint64_t>(), nb);
+        hipLaunchKernelGGL(k3t::pack_copy_kernel, dim3(nb), dim3(256), 0, st, dlen.as<uint32_t>(), m, dbsum.as<uint64_t>(), (uint64_t)0,
+                           dalA.as<uint8_t>(), dalB.as<uint8_t>(), aln_stride, doff.as<uint64_t>() + i0, sh.dpA.as<uint8_t>(),
+                           sh.dpB.as<uint8_t>(), doff.as<uint64_t>() + i0);
+        PH_HIP(hipGetLastError());
+    }
+    PH_HIP(hipMemcpyAsync(score, dscore.p, npairs * 8, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(endA, dea.p, npairs * 4, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(endB, deb.p, npairs * 4, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(err, derr.p, npairs * 4, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipMemcpyAsync(sh.hoff.data(), doff.p, (npairs + 1) * 8, hipMemcpyDeviceToHost, st));
+    PH_HIP(hipStreamSynchronize(st));
+    sh.total = sh.hoff[npairs];
+    return POLYHIP_OK;
+}
+
+static int packed_shard_deliver(PackedShard &sh, uint64_t base, bool fits, uint8_t *alnA, uint8_t *alnB, uint64_t *alnOff)
+{
+    for (uint64_t j = 1; j <= sh.m; ++j) // alnOff[i0] is the previous shard's last entry (or the caller's 0)
+        alnOff[sh.i0 + j] = base + sh.hoff[j];
+    if (fits && sh.total) {
+        HostStreams &hs = host_streams();
+        PH_HIP(hs.init());
+        PH_HIP(hipMemcpyAsync(alnA + base, sh.dpA.p, sh.total, hipMemcpyDeviceToHost, hs.s[0]));
+        PH_HIP(hipMemcpyAsync(alnB + base, sh.dpB.p, sh.total, hipMemcpyDeviceToHost, hs.s[1]));
+        PH_HIP(hs.sync_both());
+    }
+    return POLYHIP_OK;
+}
+
+int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                                  const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *endA,
+                                  uint32_t *endB, uint32_t *err, uint8_t *alnA, uint8_t *alnB, uint64_t *alnOff,
+                                  uint64_t aln_capacity)
+{
+    std::shared_ptr<md::Pool> P = npairs && sc && alnOff ? md::pool() : nullptr;
+    if (!P)
+        return sw_align_packed_one(sc, A, offA, npairs, B, offB, lenB, score, endA, endB, err, alnA, alnB, alnOff, aln_capacity);
+    PH_REQUIRE(offA && score && endA && endB && err && (aln_capacity == 0 || (alnA && alnB)), "polyhip_sw_align_batch_packed: null pointer");
+    alnOff[0] = 0;
+    const size_t nsh = md::size(*P);
+    const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 24 + 8 + 2 * 160);
+    std::vector<PackedShard> sh(nsh);
+    int rc = md::run(*P, [&](size_t q) {
+        sh[q].i0 = cut[q];
+        sh[q].m = cut[q + 1] - cut[q];
+        const uint64_t i0 = sh[q].i0;
+        md::BaseScope pos(i0, 0);
+        return packed_shard_align(sc, A, offA + i0, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0, err + i0,
+                                  sh[q]);
+    });
+    if (rc != POLYHIP_OK)
+        return rc; // the shards' device buffers go with `sh`
+    std::vector<uint64_t> base(nsh + 1, 0);
+    for (size_t q = 0; q < nsh; ++q)
+        base[q + 1] = base[q] + sh[q].total;
+    const bool fits = base[nsh] <= aln_capacity;
+    rc = md::run(*P, [&](size_t q) {
+        const int r = packed_shard_deliver(sh[q], base[q], fits, alnA, alnB, alnOff);
+        sh[q].dpA.reset(); // freed on the device's own worker
+        sh[q].dpB.reset();
+        return r;
+    });
+    if (rc != POLYHIP_OK)
+        return rc;
+    if (!fits)
+        return set_error(POLYHIP_ERR_INVALID,
+                         "polyhip_sw_align_batch_packed: the strings need %llu bytes per buffer, aln_capacity is %llu (scores, ends and "
+                         "alnOff are complete: call again with buffers of alnOff[npairs] bytes)",
+                         (unsigned long long)base[nsh], (unsigned long long)aln_capacity);
+    return POLYHIP_OK;
+}
+
 
 } // extern "C"
 
@@ -2453,14 +2620,16 @@ int polyhip_nw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A, co
     return POLYHIP_OK;
 }
 
-int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
-                           const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *err,
-                           uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen, uint32_t aln_stride)
+static int nw_align_batch_one(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                              const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *err,
+                              uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen, uint32_t aln_stride)
 {
     PH_REQUIRE(sc, "polyhip_nw_align_batch: null scoring");
     if (npairs == 0)
         return POLYHIP_OK;
     PH_REQUIRE(offA && score && err && alnA && alnB && alnLen, "polyhip_nw_align_batch: null pointer");
+    if (!(sc = scoring_here(sc)))
+        return POLYHIP_ERR_HIP;
     HostStreams &hs = host_streams(); // the calling thread's own stream, not the null stream
     PH_HIP(hs.init());
     hipStream_t hst = hs.s[0];
@@ -2498,6 +2667,23 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     PH_HIP(hipMemcpyAsync(alnLen, dlen.p, npairs * 4, hipMemcpyDeviceToHost, hst));
     PH_HIP(hs.sync_both());
     return POLYHIP_OK;
+}
+
+int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t *offA, uint64_t npairs,
+                           const uint8_t *B, const uint64_t *offB, uint64_t lenB, int64_t *score, uint32_t *err,
+                           uint8_t *alnA, uint8_t *alnB, uint32_t *alnLen, uint32_t aln_stride)
+{
+    std::shared_ptr<md::Pool> P = npairs && sc ? md::pool() : nullptr;
+    if (!P)
+        return nw_align_batch_one(sc, A, offA, npairs, B, offB, lenB, score, err, alnA, alnB, alnLen, aln_stride);
+    PH_REQUIRE(offA && score && err && alnA && alnB && alnLen, "polyhip_nw_align_batch: null pointer");
+    const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 16 + 2ull * aln_stride);
+    return md::run(*P, [&](size_t q) {
+        const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
+        md::BaseScope pos(i0, 0);
+        return nw_align_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, err + i0,
+                                  alnA + i0 * (size_t)aln_stride, alnB + i0 * (size_t)aln_stride, alnLen + i0, aln_stride);
+    });
 }
 
 } // extern "C"

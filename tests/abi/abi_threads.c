@@ -142,6 +142,14 @@ int main(int argc, char **argv)
         g_rounds = atoi(argv[2]);
     if (nt < 1 || nt > MAXT)
         return 2;
+    /* a device list from the environment (POLYHIP_DEVICES=0,0: two fan-out workers sharing the GPU) applies to the
+     * THREADS' calls only: the serial answers below are one-device answers */
+    int dev_ids[64];
+    const int ndev_list = polyhip_get_devices(dev_ids, 64);
+    if (ndev_list < 0 || polyhip_set_devices(NULL, 0) != POLYHIP_OK) {
+        fprintf(stderr, "device list: %s\n", polyhip_last_error());
+        return 1;
+    }
     /* NUC_4-like scoring through the public flatten contract: +5 / -4, gap -2, alphabet ACGT */
     static int32_t lut[65536];
     uint8_t va[256] = {0}, vb[256] = {0};
@@ -189,6 +197,11 @@ int main(int argc, char **argv)
                 return 1;
             }
     }
+    if (polyhip_set_devices(dev_ids, ndev_list > 64 ? 64 : ndev_list) != POLYHIP_OK) {
+        fprintf(stderr, "polyhip_set_devices: %s\n", polyhip_last_error());
+        return 1;
+    }
+    printf("device list: %d\n", ndev_list);
     pthread_t th[MAXT];
     for (long t = 0; t < nt; ++t)
         pthread_create(&th[t], NULL, thread_main, (void *)t);

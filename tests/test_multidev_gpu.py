@@ -1,0 +1,383 @@
+"""One host-pointer (cgo) call spread over a device list (include/polyhip.h "one host call over several GPUs";
+SURVEY 8b polyhip_init(n_devices), 8e's partitioning).  A list may name a device more than once, so the whole fan-out --
+byte-balanced ragged splits, empty shards, the packed strings' two rounds, error selection and positions in messages,
+scoring handles copied per device -- runs on this one-GPU box with [0, 0, 0] and friends.  Every entry point must give
+what the one-device call gives AND what the oracle gives (search/mash/mash.go:68-140, search/align/align.go:100-232,
+primers/primers.go:70-128, seqhash/seqhash.go:78-224)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+LISTS = [[0, 0, 0], [0, 0], [0] * 7, [0]]
+
+
+def _pack(seqs):
+    offs = np.zeros(len(seqs) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return np.frombuffer(b"".join(seqs), np.uint8).copy(), offs
+
+
+def _dna(rng, L):
+    return bytes(rng.choice(list(b"ACGT"), L).astype(np.uint8))
+
+
+@pytest.fixture(autouse=True)
+def _single_device_afterwards():
+    from poly_amd import devices
+    yield
+    devices.set_devices([])
+
+
+def test_device_list_roundtrip():
+    from poly_amd import _lib, devices
+    assert devices.get_devices() == []
+    devices.set_devices([0, 0, 0])
+    assert devices.get_devices() == [0, 0, 0]
+    devices.init(1)
+    assert devices.get_devices() == [0]
+    devices.shutdown()
+    assert devices.get_devices() == []
+    n = _lib.lib().polyhip_device_count()
+    with pytest.raises(_lib.PolyhipError) as e:
+        devices.set_devices([0, n])
+    assert "not one of" in str(e.value)
+    assert devices.get_devices() == []  # a refused list changes nothing
+    with devices.devices([0, 0]):
+        assert devices.get_devices() == [0, 0]
+    assert devices.get_devices() == []
+
+
+# ---- K1 mash.Sketch ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ids", LISTS)
+def test_sketch_ragged_batch(ids):
+    """reads of very different sizes (one of them most of the batch: the byte-balanced split leaves EMPTY shards), short
+    reads whose rows keep prior state (mash.go:81-84), empty reads"""
+    from poly_amd import devices, mash
+    rng = np.random.default_rng(len(ids))
+    k, s = 21, 200
+    reads = [_dna(rng, int(L)) for L in rng.integers(0, 3000, 300)]
+    reads[5] = _dna(rng, 400_000)
+    reads[17] = b""
+    reads[299] = _dna(rng, 30)
+    buf, offs = _pack(reads)
+    prior = rng.integers(0, 1 << 32, (len(reads), s), dtype=np.uint32)
+    one = mash.sketch_batch_packed(buf, offs, k, s, out=prior.copy())
+    want = orc.mash_sketch_batch(buf, offs, k, s, out=prior.copy())
+    with devices.devices(ids):
+        got = mash.sketch_batch_packed(buf, offs, k, s, out=prior.copy())
+    assert (got == one).all() and (got == want).all()
+
+
+def test_sketch_fewer_reads_than_devices():
+    from poly_amd import devices, mash
+    rng = np.random.default_rng(3)
+    reads = [_dna(rng, 5000), _dna(rng, 100)]
+    buf, offs = _pack(reads)
+    want = orc.mash_sketch_batch(buf, offs, 17, 64)
+    with devices.devices([0] * 5):
+        got = mash.sketch_batch_packed(buf, offs, 17, 64)
+        assert (got == want).all()
+        assert mash.sketch_batch_packed(np.zeros(0, np.uint8), np.zeros(1, np.uint64), 17, 64).shape == (0, 64)
+
+
+@pytest.mark.parametrize("s", [0, 1])
+def test_sketch_size_below_two_names_the_globally_first_sequence(s):
+    """mash.go:96,98 read by read: the panic names the FIRST panicking sequence of the whole batch (it sits in the last
+    shard here), the rows of the others are written as the reference leaves them"""
+    from poly_amd import _lib, devices, mash
+    rng = np.random.default_rng(40 + s)
+    k = 8
+    reads = [_dna(rng, 8) for _ in range(40)]  # len == k: no window, no panic
+    if s == 1:
+        # window 0 fills Sketches[0]; a later window hashing below it panics: find such a read and a monotone one
+        def panics(r):
+            h = [orc.murmur3_32(r[i:i + k]) for i in range(len(r) - k)]
+            return any(x < h[0] for x in h[1:])
+        bad = next(r for r in (_dna(rng, 40) for _ in range(1000)) if panics(r))
+        ok = next(r for r in (_dna(rng, 10) for _ in range(1000)) if not panics(r))
+        reads[3] = ok
+    else:
+        bad = _dna(rng, 12)
+    reads[37] = bad
+    reads[39] = bad
+    buf, offs = _pack(reads)
+    for ids in ([], [0, 0, 0]):
+        devices.set_devices(ids)
+        out = np.full((len(reads), max(s, 1)), 7, np.uint32)[:, :s].copy()
+        with pytest.raises(_lib.GoPanic) as e:
+            mash.sketch_batch_packed(buf, offs, k, s, out=out)
+        assert "on sequence 37 " in str(e.value), str(e.value)
+        if s == 1:
+            assert out[3, 0] == orc.murmur3_32(reads[3][:k])  # a sequence that does not panic has its row written
+
+
+def test_sketch_offsets_error_position_is_global():
+    from poly_amd import _lib, devices, mash
+    rng = np.random.default_rng(5)
+    reads = [_dna(rng, 500) for _ in range(60)]
+    buf, offs = _pack(reads)
+    offs[50] = offs[49] - 1
+    msgs = []
+    for ids in ([], [0, 0, 0]):
+        devices.set_devices(ids)
+        with pytest.raises(_lib.PolyhipError) as e:
+            mash.sketch_batch_packed(buf, offs, 21, 10)
+        msgs.append(e.value.message)
+    assert msgs[0] == msgs[1] and "at 49" in msgs[0]
+
+
+# ---- K2 distance matrix --------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ids", [[0, 0, 0], [0] * 7])
+def test_distance_matrix_rows_over_devices(ids):
+    from poly_amd import devices, mash
+    rng = np.random.default_rng(11)
+    s = 128
+    fam = [np.sort(rng.integers(0, 1 << 32, s, dtype=np.uint32)) for _ in range(10)]
+    rows = []
+    for i in range(230):
+        b = fam[i % 10].copy()
+        b[rng.integers(0, s, int(rng.integers(0, 40)))] = rng.integers(0, 1 << 32, 1, dtype=np.uint32)
+        b.sort()
+        rows.append(b)
+    Y = np.stack(rows)
+    X = Y[:101]
+    one_c, one_d = mash.distance_matrix_packed(X, Y)
+    with devices.devices(ids):
+        got_c, got_d = mash.distance_matrix_packed(X, Y)
+        few_c, _ = mash.distance_matrix_packed(Y[:2], Y, True, False)  # fewer rows than devices
+    want = orc.mash_distance_matrix(X, Y)
+    assert (got_c == one_c).all() and (got_d == one_d).all() and (got_d == want).all()
+    assert (few_c == one_c[:2]).all()
+
+
+# ---- K3 SmithWaterman / NeedlemanWunsch ----------------------------------------------------------------------------
+
+def _nuc4(gap=-2):
+    from poly_amd import align, alphabet, matrix
+    a = alphabet.NewAlphabet(list("-ACGT"))
+    return (align.NewScoring(matrix.NewSubstitutionMatrix(a, a, orc.NUC_4_SCORES), gap),
+            orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES), gap)
+
+
+def _reads_from(rng, ref, n, lo, hi, bad_every=0):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        p = int(rng.integers(0, max(1, len(ref) - L)))
+        r = bytearray(ref[p:p + L])
+        for j in rng.integers(0, max(1, L), max(1, L // 15)):
+            if L:
+                r[int(j)] = int(rng.choice(list(b"ACGT")))
+        if bad_every and i % bad_every == bad_every - 1 and L:
+            r[int(rng.integers(0, L))] = ord("N")  # "Symbol N not in alphabet" (align.go:189-191)
+        out.append(bytes(r))
+    return out
+
+
+def _oracle_sw(reads, refs, omat, gap):
+    res = []
+    for a, b in zip(reads, refs):
+        try:
+            res.append(orc.smith_waterman(a, b, omat, gap)[:3])
+        except orc.AlphabetError as e:
+            res.append(str(e))
+    return res
+
+
+@pytest.mark.parametrize("ids", [[0, 0, 0], [0] * 5])
+def test_sw_score_and_strings_shared_reference(ids):
+    from poly_amd import align, devices
+    sc, omat, gap = _nuc4()
+    rng = np.random.default_rng(21)
+    ref = _dna(rng, 700)
+    reads = _reads_from(rng, ref, 400, 0, 150, bad_every=37)
+    reads[0] = b""
+    A, offA = _pack(reads)
+    B, _ = _pack([ref])
+    one_s = align.sw_batch_packed(sc, A, offA, B)
+    one_f = align.sw_align_packed(sc, A, offA, B)
+    one_p = align.sw_align_strings_packed(sc, A, offA, B)
+    with devices.devices(ids):
+        got_s = align.sw_batch_packed(sc, A, offA, B)
+        got_f = align.sw_align_packed(sc, A, offA, B)
+        got_p = align.sw_align_strings_packed(sc, A, offA, B)
+        tight = align.sw_align_strings_packed(sc, A, offA, B, capacity=10)  # too small: the retry path gets the exact size
+    for g, o in zip(got_s, one_s):
+        assert (g == o).all()
+    for got, one in ((got_f, one_f), (got_p, one_p), (tight, one_p)):
+        for q in range(4):
+            assert (got[q] == one[q]).all()
+        assert got[4] == one[4] and got[5] == one[5]
+    want = _oracle_sw(reads, [ref] * len(reads), omat, gap)
+    for p, w in enumerate(want):
+        if isinstance(w, str):
+            assert got_p[3][p] != 0 and chr(int(got_p[3][p]) & 0xFF) == w.split(" ")[1]
+            assert got_p[4][p] == b"" and got_p[0][p] == 0
+        else:
+            assert (int(got_p[0][p]), got_p[4][p].decode(), got_p[5][p].decode()) == w
+
+
+def test_sw_packed_strings_in_chunks_on_a_device_list(monkeypatch):
+    """more pairs than one chunk of a shard (262,144): the running total stays on the device between chunks"""
+    from poly_amd import align, devices
+    sc, omat, gap = _nuc4()
+    rng = np.random.default_rng(22)
+    ref = _dna(rng, 120)
+    reads = _reads_from(rng, ref, 600_000, 20, 40)
+    A, offA = _pack(reads)
+    B, _ = _pack([ref])
+    one = align.sw_align_strings_packed(sc, A, offA, B)
+    with devices.devices([0, 0]):
+        got = align.sw_align_strings_packed(sc, A, offA, B)
+    for q in range(4):
+        assert (got[q] == one[q]).all()
+    assert got[4] == one[4] and got[5] == one[5]
+    for p in rng.integers(0, len(reads), 200):
+        assert (int(got[0][p]), got[4][p].decode(), got[5][p].decode()) == orc.smith_waterman(reads[p], ref, omat, gap)[:3]
+
+
+def test_sw_and_nw_per_pair_references():
+    from poly_amd import align, devices
+    sc, omat, gap = _nuc4(-3)
+    rng = np.random.default_rng(23)
+    refs = [_dna(rng, int(L)) for L in rng.integers(0, 90, 150)]
+    reads = [_reads_from(rng, r, 1, 0, max(1, len(r)))[0] if len(r) > 4 else _dna(rng, 7) for r in refs]
+    A, offA = _pack(reads)
+    B, offB = _pack(refs)
+    one_sw = align.sw_align_packed(sc, A, offA, B, offB)
+    one_nw = align.nw_align_packed(sc, A, offA, B, offB)
+    with devices.devices([0, 0, 0]):
+        got_sw = align.sw_align_packed(sc, A, offA, B, offB)
+        got_nw = align.nw_align_packed(sc, A, offA, B, offB)
+    for q in range(4):
+        assert (got_sw[q] == one_sw[q]).all()
+    assert got_sw[4] == one_sw[4] and got_sw[5] == one_sw[5]
+    assert (got_nw[0] == one_nw[0]).all() and (got_nw[1] == one_nw[1]).all() and got_nw[2:] == one_nw[2:]
+    for p in range(len(reads)):
+        assert (int(got_sw[0][p]), got_sw[4][p].decode(), got_sw[5][p].decode()) == orc.smith_waterman(reads[p], refs[p], omat, gap)[:3]
+        assert (int(got_nw[0][p]), got_nw[2][p].decode(), got_nw[3][p].decode()) == orc.needleman_wunsch(reads[p], refs[p], omat, gap)
+
+
+# ---- K4 primers ----------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ids", [[0, 0, 0], [0] * 7])
+def test_santalucia_scan_ranges_with_halo(ids):
+    from poly_amd import devices, primers
+    rng = np.random.default_rng(31)
+    genome = bytearray(_dna(rng, 5000))
+    genome[100:110] = b"acgtNNacgt"  # lower case folds, N contributes {0, 0} (primers.go:42-63,71)
+    genome = bytes(genome)
+    want = orc.santalucia_scan(genome, 18, 30, 500e-9, 50e-3, 0.0)
+    one = primers.SantaLuciaScan(genome, 18, 30)
+    one_first = primers.SantaLuciaScanFirst(genome, 18, 30, 55.0)
+    with devices.devices(ids):
+        got = primers.SantaLuciaScan(genome, 18, 30)
+        got_first = primers.SantaLuciaScanFirst(genome, 18, 30, 55.0)
+        tiny = primers.SantaLuciaScan(genome[:20], 18, 30)  # three starts over more devices
+    for g, o, w in zip(got, one, want):
+        assert np.array_equal(g, o, equal_nan=True) and np.array_equal(g, w, equal_nan=True)
+    assert (got_first[0] == one_first[0]).all() and np.array_equal(got_first[1], one_first[1], equal_nan=True)
+    assert np.array_equal(tiny[0], orc.santalucia_scan(genome[:20], 18, 30, 500e-9, 50e-3, 0.0)[0], equal_nan=True)
+
+
+def test_primer_batches_and_error_positions():
+    from poly_amd import _lib, devices, primers
+    rng = np.random.default_rng(32)
+    seqs = [_dna(rng, int(L)) for L in rng.integers(1, 60, 500)]
+    buf, offs = _pack(seqs)
+    one = primers.santalucia_batch_packed(buf, offs, 500e-9, 50e-3, 0.0)
+    one_md = primers.marmurdoty_batch_packed(buf, offs)
+    with devices.devices([0, 0, 0]):
+        got = primers.santalucia_batch_packed(buf, offs, 500e-9, 50e-3, 0.0)
+        got_md = primers.marmurdoty_batch_packed(buf, offs)
+    for g, o in zip(got, one):
+        assert (g == o).all()
+    assert (got_md == one_md).all()
+    for p in range(0, 500, 7):
+        assert (got[0][p], got[1][p], got[2][p]) == orc.santalucia(seqs[p], 500e-9, 50e-3, 0.0)
+        assert got_md[p] == orc.marmur_doty(seqs[p])
+    # SantaLucia("") panics (primers.go:89): sequence 480 sits in the last shard, a non-ASCII byte in the middle one
+    seqs[480] = b""
+    buf2, offs2 = _pack(seqs)
+    bad = buf.copy()
+    bad[int(offs[250]) + 1] = 0xC3
+    for ids in ([], [0, 0, 0]):
+        devices.set_devices(ids)
+        with pytest.raises(_lib.GoPanic) as e:
+            primers.santalucia_batch_packed(buf2, offs2, 500e-9, 50e-3, 0.0)
+        assert "sequence 480 is empty" in str(e.value)
+        with pytest.raises(_lib.PolyhipError) as e:
+            primers.marmurdoty_batch_packed(bad, offs)
+        assert f"at {int(offs[250]) + 1} is not ASCII" in str(e.value)
+
+
+# ---- K5 / S2 seqhash -----------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("ids", [[0, 0, 0], [0] * 6])
+def test_least_rotation_and_seqhash(ids):
+    from poly_amd import devices, seqhash
+    rng = np.random.default_rng(41)
+    seqs = [_dna(rng, int(L)) for L in rng.integers(0, 900, 240)]
+    seqs[7] = b"ACGT" * 500          # periodic: any period start is a least rotation, the reference's index is the smallest
+    seqs[100] = _dna(rng, 20_000)    # beyond the wave kernel
+    seqs[200] = b"ACGTXACGT"         # seqhash.go:157 "Got letter: X"
+    buf, offs = _pack(seqs)
+    one_rot, one_out = seqhash.least_rotation_batch_packed(buf, offs, True)
+    one_h = seqhash.seqhash_batch_packed(buf, offs, 0, True, True)
+    with devices.devices(ids):
+        got_rot, got_out = seqhash.least_rotation_batch_packed(buf, offs, True)
+        got_h = seqhash.seqhash_batch_packed(buf, offs, 0, True, True)
+    assert (got_rot == one_rot).all() and (got_out == one_out).all()
+    assert got_h[0] == one_h[0] and (got_h[1] == one_h[1]).all()
+    for p in list(range(0, 240, 9)) + [7, 100, 200]:
+        assert int(got_rot[p]) == orc.booth_least_rotation(seqs[p])
+        assert got_out[int(offs[p]):int(offs[p + 1])].tobytes() == orc.rotate_sequence(seqs[p])
+        try:
+            assert got_h[0][p] == orc.seqhash(seqs[p], "DNA", True, True)
+        except orc.SeqhashError as e:
+            assert got_h[0][p] == "" and chr(int(got_h[1][p]) & 0xFF) == str(e)[-1]
+
+
+# ---- the environment variable, concurrent callers ------------------------------------------------------------------
+
+def test_polyhip_devices_in_the_environment():
+    """POLYHIP_DEVICES=0,0,0 is the list a process starts with; a malformed list is refused by polyhip_set_devices'
+    parser and ignored at start-up"""
+    code = (
+        "import numpy as np, oracle as orc\n"
+        "from poly_amd import devices, mash\n"
+        "rng = np.random.default_rng(1)\n"
+        "reads = [bytes(rng.choice(list(b'ACGT'), int(L)).astype(np.uint8)) for L in rng.integers(100, 4000, 50)]\n"
+        "offs = np.zeros(51, np.uint64); offs[1:] = np.cumsum([len(r) for r in reads])\n"
+        "buf = np.frombuffer(b''.join(reads), np.uint8).copy()\n"
+        "got = mash.sketch_batch_packed(buf, offs, 21, 100)\n"
+        "assert (got == orc.mash_sketch_batch(buf, offs, 21, 100)).all()\n"
+        "print('devices', devices.get_devices())\n")
+    for value, want in (("0,0,0", "devices [0, 0, 0]"), ("all", "devices [0]"), ("0;1", "devices []")):
+        env = dict(os.environ, POLYHIP_DEVICES=value, PYTHONPATH=ROOT)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert want in res.stdout, res.stdout + res.stderr
+
+
+def test_two_caller_threads_on_two_aliased_devices():
+    """tests/abi/abi_threads.c with a device list: cgo calls from two OS threads at once, every call fanned out over two
+    workers that share the GPU; every result equal to the serial one-device run"""
+    from poly_amd import build
+    exe = build.build_abi_threads()
+    env = dict(os.environ, POLYHIP_DEVICES="0,0")
+    res = subprocess.run([exe, "2", "4"], env=env, capture_output=True, text=True, timeout=600)
+    print(res.stdout, res.stderr)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "abi_threads ok: 2 threads" in res.stdout
+    assert "device list: 2" in res.stdout
