@@ -231,6 +231,25 @@ int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts,
 int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx,
                                  const uint32_t *Y, uint64_t ny, uint32_t sy,
                                  uint16_t *counts, double *dist);
+/*
+ * BASELINE configs[2] in one host call: mash.New(k, s).Sketch(seq_i) for every sequence of a packed batch
+ * (mash.go:59-104), then X_i.Similarity(X_j) / X_i.Distance(X_j) for every ordered pair (mash.go:107-140) -- the two
+ * nested loops a caller of the reference writes.  The sketches stay in HBM between the two steps.
+ *   sketches  n * s in/out like polyhip_mash_sketch_batch's `out` (prior Sketches in, new ones out), or NULL: zeros in
+ *             (= mash.New), nothing out.
+ *   counts    n * n sameHashes (u16), and/or  dist  n * n float64 Distance; either may be NULL (both NULL: sketch only).
+ * On a device list (polyhip_set_devices) this is SURVEY 8e's flow inside one process: the reads shard by bytes, every
+ * device sketches its shard, the devices pull each other's sketches (hipMemcpyPeerAsync -- the all-gather without
+ * RCCL and without a process per device), each builds the index of all n sketches and joins its own block of rows,
+ * which goes straight into the caller's matrix.  Range: s <= 65535, n < 2^31.  SketchSize < 2: the status of
+ * polyhip_mash_sketch_batch (the reference panics in Sketch); SketchSize 0 with a matrix asked for: POLYHIP_ERR_PANIC
+ * (mash.go:117).
+ */
+int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs,
+                                        const uint64_t *offsets, uint64_t n,
+                                        uint32_t k, uint32_t s,
+                                        uint32_t *sketches, uint16_t *counts,
+                                        double *dist);
 
 /* ---- K3: search/align SmithWaterman  (search/align/align.go:171-232) ---- */
 /*

@@ -111,4 +111,8 @@ struct PackedSlot {
 
 constexpr uint64_t HOST_CHUNK_BYTES = 64ull << 20;
 
+// mash_distance.hip: row blocks of the shared-count / distance matrix from device-resident sketches to host buffers
+int k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const uint32_t *dY, uint64_t ny, uint32_t sy,
+                    uint16_t *counts, double *dist);
+
 } // namespace polyhip

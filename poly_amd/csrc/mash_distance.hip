@@ -1635,17 +1635,16 @@ int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts, uint64_t nx,
     return POLYHIP_OK;
 }
 
-static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,
-                               uint16_t *counts, double *dist)
+} // extern "C"
+
+// Row blocks of the matrix from DEVICE-resident sketches to HOST buffers (the calling thread's current device): what
+// crosses PCIe is the matrix (2 and/or 8 bytes per pair), so row blocks of ~64 MB alternate between two device slots;
+// block b is joined on the calling thread's first stream while block b-1 travels back on the second (the joins
+// themselves share the workspace's X side and stay in order on one stream).  One index for all blocks.  Everything the
+// caller enqueued on the thread's first stream before (uploads, a sketching pass) is ordered in front.
+int polyhip::k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const uint32_t *dY, uint64_t ny, uint32_t sy,
+                             uint16_t *counts, double *dist)
 {
-    if (sx == 0 || sy == 0)
-        return polyhip_mash_shared_counts_dev(nullptr, nx, sx, nullptr, ny, sy, nullptr, 0, nullptr, 0, nullptr);
-    if (nx == 0 || ny == 0)
-        return POLYHIP_OK;
-    PH_REQUIRE(X && Y && (counts || dist), "polyhip_mash_distance_matrix: null pointer");
-    // The matrix is what crosses PCIe (2 and/or 8 bytes per pair): row blocks of ~64 MB alternate between two device
-    // slots; block b is joined on the calling thread's first stream while block b-1 travels back on the second (the
-    // joins themselves share the workspace's X side and stay in order on one stream).  One index for all blocks.
     HostStreams &hs = host_streams();
     PH_HIP(hs.init());
     hipStream_t sc = hs.s[0], sd = hs.s[1];
@@ -1653,7 +1652,7 @@ static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, cons
     const uint64_t rows = std::max<uint64_t>(1, std::min<uint64_t>(nx, HOST_CHUNK_BYTES / std::max<uint64_t>(1, ny * per_pair)));
     const uint64_t nblocks = (nx + rows - 1) / rows;
     const bool one_index = stripe_sketches(ny, sy) >= ny; // else every block builds its stripes' indexes itself
-    DevBuf dX, dY, dW;
+    DevBuf dW;
     struct Slot {
         DevBuf dC, dD;
         hipEvent_t computed = nullptr, downloaded = nullptr;
@@ -1665,8 +1664,6 @@ static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, cons
                 (void)hipEventDestroy(downloaded);
         }
     } slot[2];
-    PH_HIP(dX.alloc(nx * (size_t)sx * 4));
-    PH_HIP(dY.alloc(ny * (size_t)sy * 4));
     const size_t wb = polyhip_mash_shared_counts_workspace_bytes(rows, sx, ny, sy);
     PH_HIP(dW.alloc(wb));
     for (uint64_t q = 0; q < std::min<uint64_t>(2, nblocks); ++q) {
@@ -1676,19 +1673,17 @@ static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, cons
         PH_HIP(hipEventCreateWithFlags(&slot[q].computed, hipEventDisableTiming));
         PH_HIP(hipEventCreateWithFlags(&slot[q].downloaded, hipEventDisableTiming));
     }
-    PH_HIP(hipMemcpyAsync(dY.p, Y, ny * (size_t)sy * 4, hipMemcpyHostToDevice, sc));
-    PH_HIP(hipMemcpyAsync(dX.p, X, nx * (size_t)sx * 4, hipMemcpyHostToDevice, sc));
     int rc = POLYHIP_OK;
     if (one_index)
-        rc = polyhip_mash_index_build_dev(dY.as<uint32_t>(), ny, sy, dW.p, wb, sc);
+        rc = polyhip_mash_index_build_dev(dY, ny, sy, dW.p, wb, sc);
     for (uint64_t b = 0; b < nblocks && rc == POLYHIP_OK; ++b) {
         Slot &S = slot[b & 1];
         const uint64_t r0 = b * rows, m = std::min<uint64_t>(rows, nx - r0);
         if (b >= 2)
             PH_HIP(hipStreamWaitEvent(sc, S.downloaded, 0)); // block b-2 has left this slot
-        const uint32_t *dx = dX.as<uint32_t>() + r0 * (uint64_t)sx;
-        rc = one_index ? polyhip_mash_shared_counts_reuse_dev(dx, m, sx, dY.as<uint32_t>(), ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc)
-                       : polyhip_mash_shared_counts_dev(dx, m, sx, dY.as<uint32_t>(), ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc);
+        const uint32_t *dx = dX + r0 * (uint64_t)sx;
+        rc = one_index ? polyhip_mash_shared_counts_reuse_dev(dx, m, sx, dY, ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc)
+                       : polyhip_mash_shared_counts_dev(dx, m, sx, dY, ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc);
         if (rc == POLYHIP_OK && dist)
             rc = polyhip_mash_distance_from_counts_dev(S.dC.as<uint16_t>(), m, ny, ny, sx, sy, S.dD.as<double>(), ny, sc);
         if (rc != POLYHIP_OK)
@@ -1706,6 +1701,29 @@ static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, cons
         return rc;
     PH_HIP(e);
     return POLYHIP_OK;
+}
+
+extern "C" {
+
+static int distance_matrix_one(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,
+                               uint16_t *counts, double *dist)
+{
+    if (sx == 0 || sy == 0)
+        return polyhip_mash_shared_counts_dev(nullptr, nx, sx, nullptr, ny, sy, nullptr, 0, nullptr, 0, nullptr);
+    if (nx == 0 || ny == 0)
+        return POLYHIP_OK;
+    PH_REQUIRE(X && Y && (counts || dist), "polyhip_mash_distance_matrix: null pointer");
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    DevBuf dX, dY;
+    PH_HIP(dX.alloc(nx * (size_t)sx * 4));
+    PH_HIP(dY.alloc(ny * (size_t)sy * 4));
+    PH_HIP(hipMemcpyAsync(dY.p, Y, ny * (size_t)sy * 4, hipMemcpyHostToDevice, hs.s[0]));
+    PH_HIP(hipMemcpyAsync(dX.p, X, nx * (size_t)sx * 4, hipMemcpyHostToDevice, hs.s[0]));
+    const int rc = k2_rows_to_host(dX.as<uint32_t>(), nx, sx, dY.as<uint32_t>(), ny, sy, counts, dist);
+    if (rc != POLYHIP_OK)
+        (void)hs.sync_both(); // the uploads read the caller's memory
+    return rc;
 }
 
 int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, const uint32_t *Y, uint64_t ny, uint32_t sy,

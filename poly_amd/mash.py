@@ -132,6 +132,32 @@ def DistanceMatrix(sketches: list[Mash]) -> np.ndarray:
     return distance_matrix_packed(S, S, False, True)[1]
 
 
+def sketch_distance_matrix_packed(seqs: np.ndarray, offsets: np.ndarray, k: int, s: int, want_sketches: bool = True,
+                                  want_counts: bool = True, want_dist: bool = True, prior: np.ndarray | None = None):
+    """Host-pointer entry point (polyhip_mash_sketch_distance_matrix): reads -> (sketches | None, counts | None,
+    dist | None) without the sketches leaving HBM in between; on a device list the reads shard, the devices exchange
+    their sketches by peer copies and each joins its block of rows."""
+    n = len(offsets) - 1
+    seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    sk = None
+    if want_sketches or prior is not None:
+        sk = np.zeros((n, s), dtype=np.uint32) if prior is None else np.ascontiguousarray(prior, dtype=np.uint32)
+        assert sk.shape == (n, s)
+    counts = np.zeros((n, n), dtype=np.uint16) if want_counts else None
+    dist = np.zeros((n, n), dtype=np.float64) if want_dist else None
+    _lib.check(_lib.lib().polyhip_mash_sketch_distance_matrix(
+        seqs.ctypes.data, offsets.ctypes.data, n, k, s, sk.ctypes.data if sk is not None else None,
+        counts.ctypes.data if counts is not None else None, dist.ctypes.data if dist is not None else None))
+    return sk, counts, dist
+
+
+def SketchDistanceMatrix(seqs, k: int, s: int) -> np.ndarray:
+    """Additive batch API (BASELINE configs[2]): dist[i][j] = Sketch(seqs[i]).Distance(Sketch(seqs[j]))."""
+    buf, offs = _pack(seqs)
+    return sketch_distance_matrix_packed(buf, offs, k, s, False, False, True)[2]
+
+
 def shared_counts_workspace_bytes(nx: int, sx: int, ny: int, sy: int) -> int:
     return int(_lib.lib().polyhip_mash_shared_counts_workspace_bytes(nx, sx, ny, sy))
 

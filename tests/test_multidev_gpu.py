@@ -160,6 +160,57 @@ def test_distance_matrix_rows_over_devices(ids):
     assert (few_c == one_c[:2]).all()
 
 
+@pytest.mark.parametrize("ids", [[], [0, 0, 0], [0] * 5])
+def test_reads_to_distance_matrix_in_one_call(ids):
+    """BASELINE configs[2] as one host call: reads -> sketches -> (peer exchange) -> row blocks.  Families of mutated
+    genomes give non-trivial counts; a read shorter than k + s leaves a positional, stale-padded sketch (mash.go:81-84)
+    whose pairs go through the reference's own merge; one read is most of the batch (empty shards)."""
+    from poly_amd import devices, mash
+    rng = np.random.default_rng(12)
+    k, s = 21, 150
+    genomes = [_dna(rng, 3000) for _ in range(6)]
+    reads = []
+    for i in range(90):
+        g = bytearray(genomes[i % 6])
+        for j in rng.integers(0, len(g), 25):
+            g[int(j)] = int(rng.choice(list(b"ACGT")))
+        reads.append(bytes(g))
+    reads[10] = _dna(rng, 100)      # fewer than s windows
+    reads[11] = b""
+    reads[40] = genomes[0] * 40     # 120 kb: a shard of its own
+    buf, offs = _pack(reads)
+    prior = rng.integers(0, 1 << 32, (len(reads), s), dtype=np.uint32)
+    want_sk = orc.mash_sketch_batch(buf, offs, k, s, out=prior.copy())
+    want_c, want_d = mash.distance_matrix_packed(want_sk, want_sk)  # the two-call path, checked against the oracle below
+    with devices.devices(ids):
+        sk, c, d = mash.sketch_distance_matrix_packed(buf, offs, k, s, prior=prior.copy())
+        sk0, c0, _ = mash.sketch_distance_matrix_packed(buf, offs, k, s, want_sketches=False, want_dist=False)
+    assert (sk == want_sk).all() and (c == want_c).all() and (d == want_d).all()
+    zero_prior = orc.mash_sketch_batch(buf, offs, k, s)
+    assert sk0 is None and (c0 == mash.distance_matrix_packed(zero_prior, zero_prior, True, False)[0]).all()
+    for i in range(0, 90, 7):
+        for j in (0, 6, 10, 11, 40, 89):
+            a, b = orc.Mash(k, s), orc.Mash(k, s)
+            a.Sketches, b.Sketches = want_sk[i].copy(), want_sk[j].copy()
+            assert d[i, j] == a.Distance(b)
+    assert c.max() > 50  # the families do share hashes
+
+
+def test_reads_to_distance_matrix_panics_like_the_reference():
+    from poly_amd import _lib, devices, mash
+    rng = np.random.default_rng(13)
+    reads = [_dna(rng, 300) for _ in range(20)]
+    buf, offs = _pack(reads)
+    for ids in ([], [0, 0]):
+        devices.set_devices(ids)
+        with pytest.raises(_lib.GoPanic) as e:  # SketchSize 0 and a matrix: mash.go:117
+            mash.sketch_distance_matrix_packed(buf, offs, 21, 0)
+        assert "mash.go:117" in str(e.value)
+        with pytest.raises(_lib.GoPanic) as e:  # SketchSize 0, sketches only: Sketch itself panics on the first read with a window
+            mash.sketch_distance_matrix_packed(buf, offs, 21, 0, want_counts=False, want_dist=False)
+        assert "on sequence 0 " in str(e.value)
+
+
 # ---- K3 SmithWaterman / NeedlemanWunsch ----------------------------------------------------------------------------
 
 def _nuc4(gap=-2):
