@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=400, help="reads per core in the CPU-baseline sample")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
+    ap.add_argument("--host-devices", type=int, default=0,
+                    help="N > 0: the PCIe-inclusive host-pointer legs (extra.e2e_host_pointers) run on the library's device list "
+                         "0..N-1 (polyhip_set_devices: ONE host call fanned out over N GPUs; ids wrap around the visible devices)")
     return ap.parse_args()
 
 
@@ -220,6 +223,42 @@ def cpu_baseline_extra():
     e["kind"] = "port (interpreted Python: not comparable with compiled Go)"
     out["fastq_feeder"] = e
     return out
+
+
+def oracle_spot_checks(extra: dict) -> dict:
+    """AFTER the timing: what the secondary legs computed against the CPU oracle (this file is the only place outside tests/
+    that imports it; poly_amd/bench_extra.py only hands over the samples).  SW: 8 pairs of the configs[3] batch -- score, end
+    cell, both aligned strings (align.go:171-232); K2: 8 x 8 cells of the configs[2] row block incl. far columns
+    (mash.go:107-135); K4: 64 windows of the configs[4] genome, Tm / dH / dS bit for bit (primers.go:70-105)."""
+    import numpy as np
+    import oracle as orc
+    res = {}
+    sw = extra.get("smith_waterman") if isinstance(extra, dict) else None
+    for name in ("smith_waterman", "smith_waterman_250bp", "smith_waterman_1kb"):
+        leg = extra.get(name) if isinstance(extra, dict) else None
+        spot = leg.pop("_spot", None) if isinstance(leg, dict) else None
+        if spot is None:
+            continue
+        om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+        ok = True
+        for q in spot["pairs"]:
+            sc, a, b, ea, eb = orc.smith_waterman(q["read"], spot["ref"], om, spot["gap"])
+            ok &= (sc, ea, eb, a.encode("latin-1"), b.encode("latin-1")) == (q["score"], q["endA"], q["endB"], q["alnA"], q["alnB"])
+        res[name] = bool(ok)
+    leg = extra.get("mash_distance") if isinstance(extra, dict) else None
+    spot = leg.pop("_spot", None) if isinstance(leg, dict) else None
+    if spot is not None:
+        sk = spot["sketches"]
+        res["mash_distance"] = bool(all(orc.mash_shared(sk[i], sk[j]) == c for i, j, c in spot["cells"]))
+        res["mash_distance_far_columns_checked"] = sum(1 for i, j, c in spot["cells"] if j >= 12_500)
+    leg = extra.get("santalucia_scan") if isinstance(extra, dict) else None
+    spot = leg.pop("_spot", None) if isinstance(leg, dict) else None
+    if spot is not None:
+        res["santalucia_scan"] = bool(all(orc.santalucia(w["window"], 500e-9, 50e-3, 0.0) == (w["tm"], w["dH"], w["dS"]) for w in spot))
+    for leg in (extra.values() if isinstance(extra, dict) else ()):  # nothing unserialisable may reach the JSON line
+        if isinstance(leg, dict):
+            leg.pop("_spot", None)
+    return res
 
 
 def valu_issue_ceiling(kmers_per_s: float) -> dict:
@@ -639,16 +678,54 @@ def main() -> int:
         if not args.no_extra:
             try:
                 from poly_amd import bench_extra
-                line["extra"] = bench_extra.run(dev)
+                hd = None
+                if args.host_devices > 0:
+                    hd = [i % torch.cuda.device_count() for i in range(args.host_devices)]
+                line["extra"] = bench_extra.run(dev, hd)
             except ImportError:
                 pass
+            if isinstance(line.get("extra"), dict):
+                checks = {"mash_sketch": parity}
+                try:
+                    checks.update(oracle_spot_checks(line["extra"]))
+                except Exception as e:  # reported, never fatal for the measured numbers
+                    checks["error"] = f"{type(e).__name__}: {e}"
+                    for leg in line["extra"].values():
+                        if isinstance(leg, dict):
+                            leg.pop("_spot", None)
+                line["parity_spot_check"] = checks
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_reads)
             if isinstance(line.get("extra"), dict):
                 for name, base in cpu_baseline_extra().items():
                     if isinstance(line["extra"].get(name), dict):
                         line["extra"][name]["cpu_baseline"] = base
+        # BASELINE's metric has two halves: k-mers/s (value) AND SW cell updates/s.  The second half goes where a reader
+        # of the line's head (roofline.*: flat scalars) and of its TAIL (the last object of the line) both find it.
+        swx = line.get("extra", {}).get("smith_waterman") if isinstance(line.get("extra"), dict) else None
+        if isinstance(swx, dict) and "cell_updates_per_s" in swx:
+            rf = swx.get("roofline", {})
+            sec = {"metric": "align.SmithWaterman cell updates/s (score pass, BASELINE configs[3]: 1M x 150 bp vs 5 kb, one GPU)",
+                   "value": swx["cell_updates_per_s"], "unit": "cell updates/s", "ms_per_step": swx["score_pass_ms"],
+                   "value_with_strings": swx.get("cell_updates_per_s_align_one_call"), "ms_per_step_with_strings": swx.get("align_one_call_ms"),
+                   "roofline": {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel")},
+                   "cpu_baseline": swx.get("cpu_baseline")}
+            line["roofline"].update({"secondary_metric": "SW cell updates/s", "secondary_value": sec["value"],
+                                     "secondary_ms_per_step": sec["ms_per_step"], "secondary_bound": rf.get("bound"),
+                                     "secondary_frac": rf.get("frac"), "secondary_peak_T_cell_updates_per_s": rf.get("peak")})
+            if isinstance(line.get("cpu_baseline"), dict) and isinstance(sec["cpu_baseline"], dict):
+                line["cpu_baseline"]["secondary_value"] = sec["cpu_baseline"].get("value")
+                line["cpu_baseline"]["secondary_unit"] = "SW cell updates/s, 1 core"
+            line["secondary"] = sec
     if rank == 0:
+        # the line ends with what a reader of its last two kilobytes needs: both halves of the metric and the checks
+        for key in ("secondary", "parity_spot_check"):
+            if key in line:
+                line[key] = line.pop(key)
+        line["summary"] = {"kmers_per_s": line["value"], "hbm_frac": line["roofline"]["frac"],
+                           "sw_cell_updates_per_s": (line.get("secondary") or {}).get("value"),
+                           "sw_valu_frac": ((line.get("secondary") or {}).get("roofline") or {}).get("frac"),
+                           "parity_spot_check": line.get("parity_spot_check")}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:

@@ -11,20 +11,54 @@ HBM_PEAK_GBS = 8000.0
 
 
 def _time(fn, reps: int = 10, warm: int = 5) -> float:
-    """median of `reps` (>= 10) separately event-timed launches after `warm` (>= 5) untimed ones
-    (>= 5 warm-ups, median of >= 10), in ms; events on the launch stream"""
+    """ms per launch, events on the launch stream, after `warm` (>= 5) untimed launches.  A launch of a
+    millisecond or more: median of `reps` (>= 10) separately timed launches.  Below that an event pair around ONE launch
+    measures the event machinery as much as the kernel (round 3: 0.33 / 0.36 / 0.46 ms for the same K4 kernel on three
+    boxes), so 20 back-to-back launches sit inside one event pair and the figure is the median of >= 10 such groups / 20."""
     reps, warm = max(reps, 10), max(warm, 5)
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    p0.record()
+    fn()
+    p1.record()
+    torch.cuda.synchronize()
+    inner = 20 if p0.elapsed_time(p1) < 1.0 else 1
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for e0, e1 in evs:
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
     torch.cuda.synchronize()
-    ts = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    ts = sorted(e0.elapsed_time(e1) / inner for e0, e1 in evs)
+    _time.last_inner = inner
     return 0.5 * (ts[(reps - 1) // 2] + ts[reps // 2])
+
+
+def _traffic(name: str):
+    """HBM bytes per launch of the named leg from the round's PMC passes (profiles/traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of scripts/collect_profiles_r04.sh, corrected per MI355X_MICROARCH.md) -- counters cannot
+    be read from inside this process, so the number is the profile's, not this run's; None when there is no entry."""
+    import json
+    import os
+    try:
+        t = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")))
+        return t.get(name, {}).get("hbm_bytes_per_launch"), t.get(name, {}).get("source")
+    except Exception:
+        return None, None
+
+
+def _hbm_roofline(name: str, alg_bytes: float, ms: float, kernel: str, bound_note: str | None = None) -> dict:
+    gbs = alg_bytes / ms * 1e3 / 1e9
+    traffic, src = _traffic(name)
+    r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_launch": int(alg_bytes), "traffic": traffic, "traffic_source": src, "kernel": kernel,
+         "launches_per_timed_group": getattr(_time, "last_inner", 1)}
+    if bound_note:
+        r["bound_note"] = bound_note
+    return r
 
 
 def _wall(fn, reps: int = 5, warm: int = 2) -> float:
@@ -101,6 +135,15 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
     ms_fused = _time(lambda: align.sw_align_dev(sc, A, offA, LA, B, None, LB, score, ea, eb, er, alnA, alnB, ln, work, tbw), 2)
     cells = n * LA * LB
     alg = n * (LA + 8 + 8)  # read + score + end position per pair
+    # what bench.py compares with the oracle after the timing (it owns the oracle import; this package never touches it):
+    # 8 pairs spread over the batch -- read, score, end cell, both aligned strings of the LAST call above (score + strings
+    # in one call)
+    idx = [int(i) for i in torch.linspace(0, n - 1, 8).long().tolist()]
+    lens = ln[idx].tolist()
+    spot = {"ref": bytes(B.cpu().numpy()), "gap": -2, "pairs": [
+        {"pair": p, "read": bytes(A[p * LA:(p + 1) * LA].cpu().numpy()), "score": int(score[p]), "endA": int(ea[p]), "endB": int(eb[p]),
+         "alnA": bytes(alnA[p, stride - l:].cpu().numpy()), "alnB": bytes(alnB[p, stride - l:].cpu().numpy())}
+        for p, l in zip(idx, lens)]}
     if (n, LA, LB) != (1_000_000, 150, 5000):  # other read lengths: the plain figures (which kernels ran is the library's choice)
         return {
             "workload": f"{n} x {LA} bp reads vs one {LB} bp reference, NUC_4, gap -2",
@@ -108,7 +151,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
             "cell_updates_per_s_with_traceback": cells / (ms_score + ms_tb) * 1e3, "traceback_ms": ms_tb,
             "align_one_call_ms": ms_fused, "cell_updates_per_s_align_one_call": cells / ms_fused * 1e3,
             "score_path": align.last_path(), "traceback_path": align.sw_traceback_last_path(),
-            "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
+            "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()), "_spot": spot,
         }
     return {
         "workload": f"{n} x {LA} bp reads vs one {LB} bp reference, NUC_4, gap -2 (BASELINE configs[3])",
@@ -124,7 +167,9 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / ceiling,
         "roofline": {"bound": "valu", "achieved": cells / ms_score * 1e3 / 1e12, "peak": ceiling / 1e12,
                      "unit": "T cell updates/s", "frac": cells / ms_score * 1e3 / ceiling,
-                     "kernel": f"polyhip::k3p::sw_pk_kernel<152,false,{'true' if half else 'false'}> (+ locate + tie wave, all inside score_pass_ms)",
+                     "kernel": ("polyhip::k3p::sw_pk1_kernel<152,false> (half-float cells) + k3p::sw_locate16_kernel<76> + k3w::sw_wave_kernel<3> "
+                                "for the ties, all inside score_pass_ms" if half else
+                                "polyhip::k3p::sw_pk_kernel<152,false,false> (int16 cells) + locate + tie wave, all inside score_pass_ms"),
                      "derivation": f"packed {'half-float' if half else 'int16'} recurrence: {per_blk} VALU instructions = "
                                    f"{4 * per_blk:.1f} issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x "
                                    f"{clock / 1e9:.3f} GHz (the clock the kernel sustains); HBM is not the bound (166 B per 750,000 cells)",
@@ -133,7 +178,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
                                "ceiling_T_cell_updates_per_s": ceiling_floor / 1e12,
                                "frac": cells / ms_score * 1e3 / ceiling_floor},
                      "hbm_achieved_GBs": alg / ms_score * 1e3 / 1e9},
-        "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()),
+        "mean_score": float(score.double().mean()), "mean_alignment_len": float(ln.double().mean()), "_spot": spot,
     }
 
 
@@ -146,8 +191,21 @@ def tm_scan(dev, n: int = 5_000_000, Lmin: int = 18, Lmax: int = 30):
     ms = _time(lambda: primers.santalucia_scan_dev(g, n, 0, ns, Lmin, Lmax, 500e-9, 50e-3, 0.0, *out, ns), 10)
     win = sum(n - L + 1 for L in range(Lmin, Lmax + 1))
     gbs = (win * 24 + n) / ms * 1e3 / 1e9
+    # 64 windows for bench.py's oracle comparison: (start, length) spread over the genome and the lengths
+    gen = torch.Generator().manual_seed(5)
+    starts = torch.randint(0, n - Lmax, (64,), generator=gen).tolist()
+    spot = []
+    for q, a in enumerate(starts):
+        L = Lmin + q % nl
+        spot.append({"start": a, "L": L, "window": bytes(g[a:a + L].cpu().numpy()),
+                     "tm": float(out[0][(L - Lmin) * ns + a]), "dH": float(out[1][(L - Lmin) * ns + a]),
+                     "dS": float(out[2][(L - Lmin) * ns + a])})
     return {"workload": f"SantaLucia Tm/dH/dS of all {Lmin}..{Lmax}-mers of a {n} B genome (BASELINE configs[4])",
-            "windows_per_s": win / ms * 1e3, "ms": ms, "algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS}
+            "windows_per_s": win / ms * 1e3, "ms": ms, "algorithmic_GBs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS,
+            # 24 B out per window + the genome once; this one IS bound by the HBM write stream
+            "roofline": _hbm_roofline("santalucia_scan", win * 24 + n, ms, "polyhip::k4::scan_kernel<18,30>",
+                                      "HBM write stream: ~6.3 TB/s is what a pure streaming kernel reaches on this part (MI355X_MICROARCH.md)"),
+            "_spot": spot}
 
 
 def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
@@ -167,6 +225,18 @@ def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
     mode = mash.shared_counts_mode(work)
     nonzero = int((counts != 0).sum())
     pairs = nrows * N
+    # 8 x 8 cells for bench.py's oracle comparison: 8 rows of the block, each against 4 columns of its own family (hundreds
+    # of shared hashes) and 4 FAR columns (other ranks' sketches, beyond the block's own rows)
+    gen = torch.Generator().manual_seed(3)
+    rows_ = torch.randint(0, nrows, (8,), generator=gen).tolist()
+    cells, need = [], set()
+    for i in rows_:
+        cols = [(i // copies) * copies + int(c) for c in torch.randint(0, copies, (4,), generator=gen)]
+        cols += [int(c) for c in torch.randint(nrows, N, (4,), generator=gen)]
+        for j in cols:
+            cells.append((i, j, int(counts[i, j]) & 0xFFFF))
+            need.update((i, j))
+    spot = {"s": s, "cells": cells, "sketches": {q: sk[q].cpu().numpy().view("uint32").copy() for q in sorted(need)}}
     out = {"workload": f"{nrows} x {N} sketch pairs (row block 1/{rows_div} of the all-vs-all over {N} sketches of s={s}; "
                        f"{nfam} families x {copies} copies at 1 % substitution) (BASELINE configs[2], one rank)",
            "pairs_per_s_counts": pairs / ms * 1e3, "counts_ms": ms, "index_build_ms": ms_index, "join_only_ms": ms_join,
@@ -178,7 +248,7 @@ def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
                         "frac": pairs * 2 / ms * 1e3 / 1e9 / HBM_PEAK_GBS,
                         "frac_join_only": pairs * 2 / ms_join * 1e3 / 1e9 / HBM_PEAK_GBS,
                         "kernel": "polyhip::k2::rowjoin_dense_kernel<10> (+ the index build in counts_ms)"},
-           "join_mode": mode[0], "nonzero_pairs": nonzero}
+           "join_mode": mode[0], "nonzero_pairs": nonzero, "_spot": spot}
     # the path's collective through the C ABI on a 1-rank communicator (libpolyhip's own RCCL calls; at N ranks
     # bench.py --gpus N times the real exchange) and the index built as 8 parts, as 8 ranks would
     try:
@@ -214,7 +284,10 @@ def rotation(dev, n: int = 100_000, L: int = 5000):
     out = torch.zeros_like(seqs)
     ms = _time(lambda: seqhash.least_rotation_batch_dev(seqs, offs, L, rot, out), 5)
     return {"workload": f"RotateSequence of {n} circular sequences of {L} bp", "bases_per_s": n * L / ms * 1e3, "ms": ms,
-            "algorithmic_GBs": (2 * n * L + 8 * n) / ms * 1e3 / 1e9}
+            "algorithmic_GBs": (2 * n * L + 8 * n) / ms * 1e3 / 1e9,
+            # sequence in, rotated sequence + index out
+            "roofline": _hbm_roofline("least_rotation", 2 * n * L + 8 * n, ms, "polyhip::k5::least_rotation_wave_kernel",
+                                      "the candidate search compares bytes in LDS: issue-bound well below the HBM line (DESIGN.md K5)")}
 
 
 def hashing(dev, n: int = 100_000, L: int = 5000):
@@ -227,7 +300,11 @@ def hashing(dev, n: int = 100_000, L: int = 5000):
     work = torch.empty(seqhash.seqhash_workspace_bytes(n, n * L, True, True), dtype=torch.uint8, device=dev)
     ms = _time(lambda: seqhash.seqhash_batch_dev(seqs, offs, n * L, L, 0, True, True, out, err, work), 3)
     return {"workload": f"seqhash.Hash(DNA, circular, double-stranded) of {n} sequences of {L} bp",
-            "sequences_per_s": n / ms * 1e3, "bases_per_s": n * L / ms * 1e3, "ms": ms}
+            "sequences_per_s": n / ms * 1e3, "bases_per_s": n * L / ms * 1e3, "ms": ms,
+            # algorithmic: the sequence in, 72 + 4 bytes out; everything between (normalised copy, reverse complement, two
+            # rotations) is the implementation's own traffic
+            "roofline": _hbm_roofline("seqhash", n * L + 76 * n, ms, "polyhip::s2::prepare / k5 wave x2 / select / chunk / hash",
+                                      "BLAKE3 compression is ALU work: see DESIGN.md S2 for the instruction-issue bound")}
 
 
 def fastq_feeder(dev, n: int = 200_000, L: int = 1000):
@@ -245,7 +322,9 @@ def fastq_feeder(dev, n: int = 200_000, L: int = 1000):
     ms = _time(lambda: fastq.pack_dev(img, seqs, offs, None, res, work), 5)
     r = [int(x) for x in res.cpu()]
     return {"workload": f"FASTQ image of {n} records x {L} bp ({nb} B) -> packed read batch on the device",
-            "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
+            "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1],
+            # the file in, the sequences + one offset per record out
+            "roofline": _hbm_roofline("fastq_feeder", nb + r[3] + 8 * (r[0] + 1), ms, "polyhip::fq::* (count, ranked write, validate, scan, gather)")}
 
 
 def sw_pairs(dev, n: int = 200_000, L: int = 150):
@@ -318,12 +397,32 @@ def fasta_feeder(dev, n: int = 100_000, L: int = 4000, width: int = 80):
     ms = _time(lambda: fasta.pack_dev(img, seqs, offs, None, res, work), 5)
     r = [int(x) for x in res.cpu()]
     return {"workload": f"FASTA image of {n} records x {L} bp in {width}-column lines ({nb} B) -> packed batch on the device",
-            "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1]}
+            "file_GBs": nb / ms * 1e3 / 1e9, "records_per_s": n / ms * 1e3, "ms": ms, "records": r[0], "error_code": r[1],
+            "roofline": _hbm_roofline("fasta_feeder", nb + r[2] + 8 * (r[0] + 1), ms, "polyhip::fq::* (count, ranked write, classify, scans, gather)")}
 
 
-def e2e(dev) -> dict:
+def e2e(dev, host_devices=None) -> dict:
     """PCIe-inclusive rates of the host-pointer flavours (what a cgo caller with Go-heap buffers gets):
-    pageable numpy memory in, pageable numpy memory out, synchronous calls.  Never the headline value."""
+    pageable numpy memory in, pageable numpy memory out, synchronous calls.  Never the headline value.
+    `host_devices`: the library's device list for these calls (polyhip_set_devices; bench.py --host-devices N) -- one
+    host call fanned out over N GPUs, each shard over its own PCIe link; None = the one-device call."""
+    import numpy as np
+    from . import devices as _devices
+    out = {}
+    if host_devices:
+        _devices.set_devices(host_devices)
+    try:
+        out = _e2e_body(dev)
+    finally:
+        if host_devices:
+            _devices.set_devices([])
+    for v in out.values():
+        if isinstance(v, dict):
+            v["devices"] = list(host_devices) if host_devices else "calling thread's current device (no list)"
+    return out
+
+
+def _e2e_body(dev) -> dict:
     import numpy as np
     out = {}
     # K1: 200k reads x 10 kb (2 GB in, 0.8 GB out)
@@ -458,12 +557,33 @@ def e2e(dev) -> dict:
     return out
 
 
-def run(dev) -> dict:
+def e2e_fanout_check(dev) -> dict:
+    """The fan-out's own cost on this box: the K1 host call of e2e() once on the plain one-device path and once on the
+    device list [0, 0] (two workers sharing the GPU and its one PCIe link -- nothing to gain here, so the difference is
+    what splitting, the worker hand-off and the second pipeline cost).  On a multi-GPU node: bench.py --host-devices N."""
+    import numpy as np
+    from . import devices as _devices
+    n, L, k, s = 100_000, 10_000, 21, 1000
+    d = torch.empty(n * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xC2, d)
+    host = d.cpu().numpy()
+    del d
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    sk1, sk2 = np.zeros((n, s), dtype=np.uint32), np.zeros((n, s), dtype=np.uint32)
+    ms1 = _wall(lambda: mash.sketch_batch_packed(host, offs, k, s, out=sk1), 5, 1)
+    with _devices.devices([dev.index or 0] * 2):
+        ms2 = _wall(lambda: mash.sketch_batch_packed(host, offs, k, s, out=sk2), 5, 1)
+    return {"workload": f"polyhip_mash_sketch_batch, {n} reads x {L} B from pageable host memory",
+            "ms_one_device": ms1, "ms_device_list_0_0": ms2, "same_sketches": bool((sk1 == sk2).all())}
+
+
+def run(dev, host_devices=None) -> dict:
     out = {}
     for name, fn in (("smith_waterman", sw), ("smith_waterman_250bp", lambda d: sw(d, 400_000, 250)),
                      ("smith_waterman_1kb", lambda d: sw(d, 20_000, 1000)), ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder),
-                     ("fasta_feeder", fasta_feeder), ("e2e_host_pointers", e2e)):
+                     ("fasta_feeder", fasta_feeder), ("e2e_host_pointers", lambda d: e2e(d, host_devices)),
+                     ("e2e_fanout_check", e2e_fanout_check)):
         try:
             out[name] = fn(dev)
         except Exception as e:  # a secondary number must never take the headline down

@@ -54,6 +54,24 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// hipMallocAsync'd scratch of a _dev entry point: freed on the stream when the entry point is through with it
+// (release()), or on whichever early return comes first
+struct StreamFree {
+    void *p;
+    hipStream_t st;
+    hipError_t release()
+    {
+        void *q = p;
+        p = nullptr;
+        return q ? hipFreeAsync(q, st) : hipSuccess;
+    }
+    ~StreamFree()
+    {
+        if (p)
+            (void)hipFreeAsync(p, st);
+    }
+};
+
 // Testing aids: NAME=0 (or =1) in the environment, read per call, switches one kernel variant off (or on) so that
 // the parity tests can cross-check the variants; never needed in production.
 inline bool env_is(const char *name, char value)
@@ -137,10 +155,25 @@ struct AuxStream {
         return e;
     }
 };
-inline AuxStream &aux_stream()
+// one per (calling thread, caller stream): the two slots of a host-pointer pipeline run on two streams of one thread,
+// and a single aux stream for both would make each slot's join wait for the other slot's forked work as well (round-3
+// advice).  Four entries per thread, recycled round robin (a recycled stream simply keeps its order: fork() waits).
+inline AuxStream &aux_stream(hipStream_t caller)
 {
-    static thread_local AuxStream a;
-    return a;
+    struct Entry {
+        hipStream_t key = nullptr;
+        bool used = false;
+        AuxStream a;
+    };
+    static thread_local Entry e[4];
+    static thread_local unsigned next = 0;
+    for (Entry &x : e)
+        if (x.used && x.key == caller)
+            return x.a;
+    Entry &x = e[next++ & 3];
+    x.used = true;
+    x.key = caller;
+    return x.a;
 }
 
 // value of the lane below (lane 0 gets 0): one DPP move (wave_shr:1, a GFX9 control gfx950 still has) instead of

@@ -1364,13 +1364,19 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     // database of one sketch size); built together with a join it takes that join's geometry.  If a later join does not
     // fit what the build assumed (another counter width, more than one stripe), the index is rebuilt with 8-byte items
     // first -- correct, at the price of a build.
+    // Compact items are ALWAYS made for gY -- a function of (ny, sy) alone, which every later reuse call has to repeat --,
+    // never for the geometry of the join that happened to come with the build: a workspace then holds either 8-byte items
+    // or gY's compact ones (the device says which, H_FMT), whoever built it, and a reuse call can tell from its own
+    // arguments whether it can read them (round-3 advice: a fused call with min(sx, sy) <= 1023 < sy used to leave items
+    // for 10-bit counters that a later reuse with sx >= 1024 decoded as 16-bit ones).
     const DenseGeom gJ = dense_geom(join ? sx : sy, sy, ny), gY = dense_geom(sy, sy, ny);
-    bool allow_compact = (join && build) ? gJ.compact_ok : gY.compact_ok;
-    if (join && !build && gY.compact_ok && !(gJ.compact_ok && gJ.bits == gY.bits)) {
-        build = true;
+    const bool fits_Y = gJ.compact_ok && gJ.bits == gY.bits; // the join at hand reads items made for gY
+    bool allow_compact = gY.compact_ok && (!join || fits_Y);
+    if (join && !build && gY.compact_ok && !fits_Y) {
+        build = true; // the index in the workspace may be compact and this join cannot read that
         allow_compact = false;
     }
-    const DenseGeom &gB = (join && (what & 1)) ? gJ : gY; // the geometry compact items are made for
+    const DenseGeom &gB = gY; // the geometry compact items are made for
 
     if (build) {
         // header, Y flags and the histogram start at zero

@@ -1354,12 +1354,13 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
         // rare path synchronises the stream
         unsigned long long *d_first = nullptr, h_first = ~0ull;
         PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&d_first), sizeof h_first, st));
+        StreamFree guard{d_first, st}; // an early return below must not leak the stream-ordered allocation
         PH_HIP(hipMemsetAsync(d_first, 0xFF, sizeof h_first, st));
         hipLaunchKernelGGL(k1::sketch_tiny_kernel, dim3((unsigned)std::min<uint64_t>(n, 4096)), dim3(k1::THREADS), 0, st, d_seqs,
                            d_offsets, n, k, s, d_out, d_first);
         PH_HIP(hipGetLastError());
         PH_HIP(hipMemcpyAsync(&h_first, d_first, sizeof h_first, hipMemcpyDeviceToHost, st));
-        PH_HIP(hipFreeAsync(d_first, st));
+        PH_HIP(guard.release());
         PH_HIP(hipStreamSynchronize(st));
         if (h_first != ~0ull)
             return set_error(POLYHIP_ERR_PANIC,
@@ -1372,13 +1373,18 @@ int polyhip_mash_sketch_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offse
         // beyond the LDS layouts: the wide kernel, candidates in a stream-ordered global scratch
         const uint32_t s4 = (s + 3u) & ~3u;
         const uint32_t cap = 2 * s4 + 2 * k1::WIDE_ROUND;
-        const unsigned grid = (unsigned)std::min<uint64_t>(n, s > 16384 ? 256 : 1024);
+        // two candidate buffers of `cap` hashes per workgroup: the grid shrinks so that the scratch stays within 4 GiB
+        // (s = 2^24 is 268 MB per workgroup: 16 of them; s = 10,000 keeps its 1024)
+        const uint64_t per_wg = 2ull * cap * sizeof(uint32_t), budget = 4ull << 30;
+        const unsigned grid = (unsigned)std::max<uint64_t>(
+            1, std::min<uint64_t>(std::min<uint64_t>(n, s > 16384 ? 256 : 1024), budget / per_wg));
         uint32_t *scratch = nullptr;
-        PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), (size_t)grid * 2 * cap * sizeof(uint32_t), st));
+        PH_HIP(hipMallocAsync(reinterpret_cast<void **>(&scratch), (size_t)grid * per_wg, st));
+        StreamFree guard{scratch, st};
         hipLaunchKernelGGL(k1::sketch_wide_kernel, dim3(grid), dim3(k1::THREADS), 0, st, d_seqs, d_offsets, n, k, s, d_out, scratch,
                            cap);
         PH_HIP(hipGetLastError());
-        PH_HIP(hipFreeAsync(scratch, st));
+        PH_HIP(guard.release());
         return POLYHIP_OK;
     }
     const uint64_t CHUNK = 1ull << 30;

@@ -1945,7 +1945,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
         PH_HIP(hipGetLastError());
     }
     const hipStream_t caller_st = st;
-    AuxStream &aux = aux_stream();
+    AuxStream &aux = aux_stream(st);
     // whatever way this function is left after the fork, the caller's stream waits for the library's
     struct Joiner {
         AuxStream &a;

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""profiles/traffic.json from the round's FETCH_SIZE / WRITE_SIZE passes of scripts/quick_legs.py (rocpd_summary tables):
+
+    python scripts/traffic_json.py r04 profiles > profiles/traffic.json
+
+Per leg: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 summed over the leg's kernels / CALLS -- the
+gfx950 corrections of MI355X_MICROARCH.md's HBM section (FETCH_SIZE counts half of what a streaming read moves on this
+part: calibrated in profiles/r01_calib_fetch.md; WRITE_SIZE x 1: profiles/r01_calib_write.md)."""
+import json
+import re
+import sys
+
+CALLS = 4
+LEGS = {  # leg -> (group, kernel-name prefixes)
+    "santalucia_scan": ("A", ("polyhip::k4::",)),
+    "least_rotation": ("A", ("polyhip::k5::",)),
+    "fastq_feeder": ("A", ("polyhip::fq::",)),
+    "seqhash": ("B", ("polyhip::s2::", "polyhip::k5::")),
+    "fasta_feeder": ("B", ("polyhip::fq::",)),
+}
+
+
+def counter_sums(path, counter):
+    out = {}
+    for line in open(path):
+        m = re.match(r"\| `(.*)` \| (\w+) \| (\d+) \| ([0-9.e+]+) \| ([0-9.e+]+) \|", line)
+        if m and m.group(2) == counter:
+            out[m.group(1)] = out.get(m.group(1), 0.0) + float(m.group(4))
+    return out
+
+
+def main():
+    rnd, d = sys.argv[1], sys.argv[2]
+    res = {}
+    for leg, (grp, prefixes) in LEGS.items():
+        f = counter_sums(f"{d}/{rnd}_legs{grp}_fetch.md", "FETCH_SIZE")
+        w = counter_sums(f"{d}/{rnd}_legs{grp}_write.md", "WRITE_SIZE")
+        pick = lambda t: sum(v for k, v in t.items() if any(p in k for p in prefixes))
+        rd, wr = 2 * pick(f) * 1024 / CALLS, pick(w) * 1024 / CALLS
+        res[leg] = {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr,
+                    "kernels": sorted(k for k in f if any(p in k for p in prefixes)),
+                    "source": f"profiles/{rnd}_legs{grp}_fetch.md + profiles/{rnd}_legs{grp}_write.md (rocprofv3 --pmc passes of "
+                              f"scripts/quick_legs.py {grp}: {CALLS} launches; FETCH_SIZE x 2 and WRITE_SIZE x 1 KB per MI355X_MICROARCH.md); "
+                              "NOT measured by the bench run"}
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

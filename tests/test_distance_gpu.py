@@ -234,6 +234,42 @@ def test_column_stripes_beyond_one_index(mash, monkeypatch):
     assert work.numel() == small    # the workspace is sized for a stripe, not for the whole set
 
 
+def test_reuse_after_a_fused_call_with_another_sketch_size(mash, join_kind):
+    """round-3 advice: polyhip_mash_shared_counts_dev(X of 500 hashes, Y of 1100) used to leave compact items made for
+    10-bit counters (min(sx, sy) <= 1023) that a later polyhip_mash_shared_counts_reuse_dev with sx = 1100 decoded as
+    16-bit ones, and with Y sets of two stripes the reuse launched no matching kernel at all.  Reuse after a fused call
+    is documented usage (include/polyhip.h): every order of the three calls must give the reference's merge counts."""
+    import torch
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(35)
+    Y = _small_valued_families(rng, 6, 6, 1100)
+    X5 = np.sort(np.concatenate([Y[:12, :350], rng.integers(0, 1 << 19, (12, 150), dtype=np.uint32)], axis=1), axis=1)
+    Yt = torch.from_numpy(Y.view(np.int32)).to(dev)
+    X5t = torch.from_numpy(X5.view(np.int32).copy()).to(dev)
+    want5, wantY = _oracle_counts(X5, Y), _oracle_counts(Y, Y)
+    for order in (("fused5", "reuse5", "reuseY"), ("fused5", "reuseY", "reuse5"), ("fusedY", "reuse5", "reuseY"),
+                  ("build", "reuse5", "reuseY", "reuse5")):
+        work = torch.zeros(mash.shared_counts_workspace_bytes(len(Y), 1100, len(Y), 1100), dtype=torch.uint8, device=dev)
+        for step in order:
+            c5 = torch.full((len(X5), len(Y)), -1, dtype=torch.int16, device=dev)
+            cY = torch.full((len(Y), len(Y)), -1, dtype=torch.int16, device=dev)
+            if step == "build":
+                mash.index_build_dev(Yt, work)
+            elif step == "fused5":
+                mash.shared_counts_dev(X5t, Yt, c5, work)
+            elif step == "fusedY":
+                mash.shared_counts_dev(Yt, Yt, cY, work)
+            elif step == "reuse5":
+                mash.shared_counts_reuse_dev(X5t, Yt, c5, work)
+            else:
+                mash.shared_counts_reuse_dev(Yt, Yt, cY, work)
+            torch.cuda.synchronize()
+            if step.endswith("5"):
+                assert (c5.cpu().numpy().view(np.uint16) == want5).all(), (order, step)
+            elif step != "build":
+                assert (cY.cpu().numpy().view(np.uint16) == wantY).all(), (order, step)
+
+
 def _small_valued_families(rng, nfam, copies, s, bits=19, sub=0.1):
     """related ascending sketches whose hashes stay below 2^bits: a few thousand of them already have fine buckets (the
     value's bits below its bucket are few), which is what lets a SMALL test reach the compact item format"""
@@ -337,8 +373,8 @@ def test_full_size_config3_row_block_properties(mash):
     """BASELINE configs[2] at FULL size for one rank of 8: a 12,500 x 100,000 row block of the all-vs-all over
     100,000 sketches of s = 1000 (1000 families x 100 copies at 1 % substitution, sketched by K1).  Properties of
     the whole block: the diagonal shares all s hashes; the block is symmetric where it overlaps its own rows;
-    counts never exceed s; 300 sampled cells (in-family and out) equal the reference's merge; distances are
-    exactly 1 - count/s in fp64."""
+    counts never exceed s; 2,400 sampled cells over ALL 100,000 columns (in-family, in-block, and >= 500 in the far
+    columns) and 64 full rows equal the reference's merge (mash.go:107-135); distances are exactly 1 - count/s in fp64."""
     import torch
     from poly_amd import bench_extra
     dev = torch.device("cuda:0")
@@ -355,11 +391,37 @@ def test_full_size_config3_row_block_properties(mash):
     assert bool((c >= 0).all()) and bool((c <= s).all())
     assert torch.equal(c[:, :nrows], c[:, :nrows].T)
     rng = np.random.default_rng(9)
-    sk_h = sk[: nrows].cpu().numpy().view(np.uint32)
-    for _ in range(300):
+    sk_h = sk.cpu().numpy().view(np.uint32)  # ALL 100,000 sketches: the sampled columns span the whole block
+    c_h = c.cpu().numpy()
+    cells = []
+    for _ in range(2400):
         i = int(rng.integers(0, nrows))
-        j = int(rng.integers(0, nrows)) if rng.random() < 0.5 else (i // 100) * 100 + int(rng.integers(0, 100))
-        assert int(c[i, j]) == orc.mash_shared(sk_h[i], sk_h[j]), (i, j)
+        u = rng.random()
+        if u < 0.35:
+            j = (i // 100) * 100 + int(rng.integers(0, 100))  # in the row's own family: hundreds of shared hashes
+        elif u < 0.55:
+            j = int(rng.integers(0, nrows))                   # the part of the block that overlaps its own rows
+        else:
+            j = int(rng.integers(nrows, N))                   # far columns: other ranks' sketches
+        cells.append((i, j))
+    cells += [(0, N - 1), (nrows - 1, N - 1), (nrows - 1, nrows), (0, nrows)]
+    assert sum(1 for _, j in cells if j >= nrows) >= 500
+    for i, j in cells:
+        assert int(c_h[i, j]) == orc.mash_shared(sk_h[i], sk_h[j]), (i, j)
+    # 64 FULL rows against the reference's merge over all 100,000 columns (the oracle's C loop on every host core:
+    # ctypes releases the GIL): every count, and with it the rows' number of nonzero cells -- a stray count anywhere
+    # in a far column cannot hide
+    import concurrent.futures as cf
+    import os
+    rows64 = np.sort(rng.choice(nrows, 64, replace=False))
+    groups = np.array_split(rows64, max(1, min(len(rows64), os.cpu_count() or 1)))
+    with cf.ThreadPoolExecutor(len(groups)) as ex:
+        parts = list(ex.map(lambda g: orc.mash_distance_matrix(sk_h[g], sk_h), groups))
+    want_d = np.concatenate(parts, axis=0)
+    want_c = np.rint((1.0 - want_d) * s).astype(np.int64)       # exact: Distance = 1 - same/s with same an integer <= s
+    assert (1.0 - want_c / np.float64(s) == want_d).all()        # ... and the rounding did not invent a count
+    assert (c_h[rows64].astype(np.int64) == want_c).all()
+    assert int((c_h[rows64] != 0).sum()) == int((want_c != 0).sum())
     dist = torch.empty((nrows, N), dtype=torch.float64, device=dev)
     mash.distance_from_counts_dev(counts, s, s, dist)
     # exactly mash.go:134,139 -- 1 - float64(same)/float64(size), IEEE division (numpy; torch's scalar divide on the
