@@ -58,6 +58,77 @@ func call(f func() C.int) error {
 	return check(f())
 }
 
+// ---- one host call over the node's GPUs (include/polyhip.h: polyhip_set_devices) ----
+//
+// The Go API of the drop-in has ONE call per batch (mash.SketchBatch, align.SmithWatermanBatch, primers.SantaLuciaScan,
+// seqhash.HashBatch ...), so the node's GPUs are reached from inside that call: with a device list every host-pointer
+// entry point below shards its batch over the list (one worker thread per entry, each on its own device and PCIe
+// link) and writes the results straight into the Go slices it was handed.  Nothing else in this package changes:
+// no device pointers, no allocator, no process per GPU.
+
+// SetDevices installs the process-wide device list; an empty list returns to the calling thread's current device.
+// An id may repeat ([]int{0, 0, 0}: the shards share that GPU -- the fan-out's test mode on a one-GPU box).
+func SetDevices(ids []int) error {
+	cids := make([]C.int, len(ids)+1)
+	for i, d := range ids {
+		cids[i] = C.int(d)
+	}
+	return call(func() C.int { return C.polyhip_set_devices((*C.int)(unsafe.Pointer(&cids[0])), C.int(len(ids))) })
+}
+
+// Devices returns the current device list (the POLYHIP_DEVICES environment variable seeds it).
+func Devices() []int {
+	var cids [64]C.int
+	n := int(C.polyhip_get_devices((*C.int)(unsafe.Pointer(&cids[0])), C.int(64)))
+	if n > 64 {
+		n = 64
+	}
+	out := make([]int, n)
+	for i := range out {
+		out[i] = int(cids[i])
+	}
+	return out
+}
+
+// Init is polyhip_init: devices 0..n-1 (n <= 0: every visible device).  Shutdown clears the list.
+func Init(nDevices int) error { return call(func() C.int { return C.polyhip_init(C.int(nDevices)) }) }
+func Shutdown() error         { return call(func() C.int { return C.polyhip_shutdown() }) }
+
+// IsASCII reports whether every byte is below 0x80.  The C ABI refuses other input wherever the reference would
+// case-fold or map it through string(byte) (Go treats such bytes as UTF-8 there: strings.ToUpper turns an invalid byte
+// into the three bytes of U+FFFD, primers.go:71,109); the overlays route such sequences to the reference's own bodies
+// (kept in the fork as *CPU functions) instead, so the drop-in returns exactly what the reference returns for them.
+func IsASCII(s string) bool {
+	for i := 0; i < len(s); i++ {
+		if s[i] >= 0x80 {
+			return false
+		}
+	}
+	return true
+}
+
+// MashSketchDistanceMatrix: BASELINE configs[2] in one call -- reads in, sketches (n*s, in/out like MashSketchBatch; nil:
+// not wanted) and the all-vs-all matrix out (counts n*n and/or dist n*n; either may be nil).  On a device list the
+// reads shard, the devices exchange their sketches by peer copies and each joins its block of rows.
+func MashSketchDistanceMatrix(seqs []byte, offs []uint64, k, s int, sketches []uint32, counts []uint16, dist []float64) error {
+	var ps *C.uint32_t
+	var pc *C.uint16_t
+	var pd *C.double
+	if sketches != nil {
+		ps = (*C.uint32_t)(unsafe.Pointer(&sketches[0]))
+	}
+	if counts != nil {
+		pc = (*C.uint16_t)(unsafe.Pointer(&counts[0]))
+	}
+	if dist != nil {
+		pd = (*C.double)(unsafe.Pointer(&dist[0]))
+	}
+	return call(func() C.int {
+		return C.polyhip_mash_sketch_distance_matrix((*C.uint8_t)(unsafe.Pointer(&seqs[0])), (*C.uint64_t)(unsafe.Pointer(&offs[0])),
+			C.uint64_t(len(offs)-1), C.uint32_t(k), C.uint32_t(s), ps, pc, pd)
+	})
+}
+
 // MashSketchBatch: out is n*s uint32, in/out (prior Sketches), see polyhip_mash_sketch_batch.
 func MashSketchBatch(seqs []byte, offs []uint64, k, s int, out []uint32) error {
 	return call(func() C.int {

@@ -6,7 +6,11 @@
 // body (polyhip.MinTmCalls), the batch / scan entry points below are what uses the device.  UNCOMPILED here.
 package primers
 
-import "github.com/bebop/poly/internal/polyhip"
+import (
+	"math"
+
+	"github.com/bebop/poly/internal/polyhip"
+)
 
 // SantaLucia is primers.go:70-105.  Bit-identical results (same fp64 operation order, Go's math.Log algorithm).
 func SantaLucia(sequence string, primerConcentration, saltConcentration, magnesiumConcentration float64) (meltingTemp, dH, dS float64) {
@@ -36,10 +40,26 @@ func MarmurDoty(sequence string) float64 {
 
 // SantaLuciaBatch scores many primers in one device call (bit-identical to SantaLucia of each).
 func SantaLuciaBatch(sequences []string, primerConcentration, saltConcentration, magnesiumConcentration float64) (meltingTemp, dH, dS []float64) {
-	buf, offs := polyhip.Pack(sequences)
+	// a sequence with a byte >= 0x80 is upper-cased as UTF-8 by the reference (primers.go:71: an invalid byte becomes
+	// the three bytes of U+FFFD, so even the length changes): those go through the reference's own body, the device
+	// gets a one-letter stand-in whose results are overwritten
+	packed, odd := sequences, []int(nil)
+	for i, q := range sequences {
+		if !polyhip.IsASCII(q) {
+			if odd == nil {
+				packed = append([]string(nil), sequences...)
+			}
+			packed[i] = "A"
+			odd = append(odd, i)
+		}
+	}
+	buf, offs := polyhip.Pack(packed)
 	tm, h, s, err := polyhip.SantaLuciaBatch(buf, offs, primerConcentration, saltConcentration, magnesiumConcentration)
 	if err != nil {
 		panic(err)
+	}
+	for _, i := range odd {
+		tm[i], h[i], s[i] = santaLuciaCPU(sequences[i], primerConcentration, saltConcentration, magnesiumConcentration)
 	}
 	return tm, h, s
 }
@@ -53,6 +73,24 @@ type TmTable struct {
 // SantaLuciaScan evaluates every window of every length minLen..maxLen of genome in one device call; the
 // grow-until-Tm loops of primers/pcr (pcr.go:47-53, 94-101) become lookups into this table.
 func SantaLuciaScan(genome string, minLen, maxLen int, primerConcentration, saltConcentration, magnesiumConcentration float64) TmTable {
+	if !polyhip.IsASCII(genome) && minLen >= 1 && minLen <= maxLen && len(genome) >= minLen {
+		// bytes >= 0x80 (see SantaLuciaBatch): every window through the reference's own body -- slow, and what the
+		// reference returns
+		ld := len(genome) - minLen + 1
+		t := TmTable{MinLen: minLen, MaxLen: maxLen, Stride: ld, Tm: make([]float64, ld*(maxLen-minLen+1)),
+			DH: make([]float64, ld*(maxLen-minLen+1)), DS: make([]float64, ld*(maxLen-minLen+1))}
+		for l := minLen; l <= maxLen; l++ {
+			for i := 0; i < ld; i++ {
+				at := (l-minLen)*ld + i
+				if i+l > len(genome) {
+					t.Tm[at], t.DH[at], t.DS[at] = math.NaN(), math.NaN(), math.NaN()
+					continue
+				}
+				t.Tm[at], t.DH[at], t.DS[at] = santaLuciaCPU(genome[i:i+l], primerConcentration, saltConcentration, magnesiumConcentration)
+			}
+		}
+		return t
+	}
 	tm, h, s, ld, err := polyhip.SantaLuciaScan([]byte(genome), minLen, maxLen, primerConcentration, saltConcentration, magnesiumConcentration)
 	if err != nil {
 		panic(err)

@@ -64,3 +64,25 @@ func DistanceMatrix(ms []*Mash) []float64 {
 	}
 	return dist
 }
+
+// SketchDistanceMatrix is BASELINE configs[2] in one call: New(kmerSize, sketchSize).Sketch(seq) for every sequence
+// (mash.go:59-104) and dist[i*n+j] = ms[i].Distance(ms[j]) (mash.go:107-140) without the sketches leaving HBM in between.
+// With polyhip.SetDevices / POLYHIP_DEVICES the reads shard over the node's GPUs, which exchange their sketches over
+// xGMI and join one block of rows each.
+func SketchDistanceMatrix(seqs []string, kmerSize, sketchSize int) ([]*Mash, []float64) {
+	n := len(seqs)
+	if n == 0 {
+		return nil, nil
+	}
+	buf, offs := polyhip.Pack(seqs)
+	sk := make([]uint32, n*sketchSize+1)
+	dist := make([]float64, n*n)
+	if err := polyhip.MashSketchDistanceMatrix(buf, offs, kmerSize, sketchSize, sk, nil, dist); err != nil {
+		panic(err)
+	}
+	ms := make([]*Mash, n)
+	for i := range ms {
+		ms[i] = &Mash{KmerSize: kmerSize, SketchSize: sketchSize, Sketches: sk[i*sketchSize : (i+1)*sketchSize : (i+1)*sketchSize]}
+	}
+	return ms, dist
+}

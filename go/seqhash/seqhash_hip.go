@@ -33,13 +33,32 @@ func HashBatch(sequences []string, sequenceType SequenceType, circular bool, dou
 		return out, errs
 	}
 	ds := doubleStranded && sequenceType != PROTEIN
-	buf, offs := polyhip.Pack(sequences)
+	// a byte >= 0x80 is not an error of the BATCH: the reference returns an ordinary per-sequence error for it
+	// ("Only letters ... Got letter: ...", seqhash.go:157,169, after upper-casing it as UTF-8), and clone.CircularLigate
+	// drops that error on purpose.  Those sequences run the reference's own body; the device gets a stand-in.
+	packed, odd := sequences, []int(nil)
+	for i, q := range sequences {
+		if !polyhip.IsASCII(q) {
+			if odd == nil {
+				packed = append([]string(nil), sequences...)
+			}
+			packed[i] = "A"
+			odd = append(odd, i)
+		}
+	}
+	buf, offs := polyhip.Pack(packed)
 	hashes, codes, err := polyhip.SeqhashBatch(buf, offs, c, circular, ds)
 	if err != nil {
-		panic(err)
+		panic(err) // a device failure: the reference's signature has nowhere to put it
+	}
+	isOdd := make(map[int]bool, len(odd))
+	for _, i := range odd {
+		isOdd[i] = true
+		out[i], errs[i] = hashCPU(sequences[i], sequenceType, circular, doubleStranded)
 	}
 	for i := range sequences {
 		switch {
+		case isOdd[i]:
 		case codes[i]>>8 == 2: // seqhash.go:157
 			errs[i] = errors.New("Only letters ATUGCYRSWKMBDHVNZ are allowed for DNA/RNA. Got letter: " + string(rune(codes[i]&0xFF)))
 		case codes[i]>>8 == 3: // seqhash.go:169
