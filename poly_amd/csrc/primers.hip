@@ -138,8 +138,40 @@ __device__ __forceinline__ double melting(double dH, double dS, double rlog)
 // ---- scan ---------------------------------------------------------------------
 // LMIN_CT > 0: lengths LMIN_CT..LMAX_CT known at compile time (everything unrolls,
 // no predicated adds); LMIN_CT == 0: runtime Lmin, nl <= NL_MAX lengths.
+//
+// Round 4: who writes which 128-byte line.  The scan is bound by its write stream (24 B per window), and what that
+// stream sustains depends on ONE thing (scripts/ubench/write_bw.hip, profiles/r04_write_bw.md): whether a line is written
+// by one workgroup or by two.  Workgroups land on the eight XCDs in turn, each XCD has its own L2, so a line whose two
+// parts come from neighbouring workgroups never merges on the chip: both parts go to memory as partial writes.  39 planes
+// written in blocks that start wherever 256 * blockIdx falls reach 3.5 TB/s; the same bytes in blocks that own whole lines
+// reach 5.4 TB/s -- 8 or 16 bytes per lane makes no difference, and lines shared by the waves of ONE workgroup (one CU, one
+// L2) cost nothing.  The round-3 kernel's time was EXACTLY the time of its store pattern alone.
+// So a workgroup computes 256 consecutive starts but OWNS, plane by plane, the 240 of them (15 lines) that begin at that
+// plane's own line boundary (ld, the plane number and the caller's pointer decide the phase); its neighbour computes the
+// other 16 again.  1/16 more arithmetic, and every line of every plane is written by exactly one workgroup (the first
+// and last line of a plane excepted).
+constexpr int SPL = 1;                     // starts per lane
+constexpr int BLOCK_STARTS = THREADS * SPL; // starts a workgroup computes
+constexpr int OWN_STARTS = BLOCK_STARTS - 16; // ... and owns in every plane: whole 128-byte lines of doubles
+
+// cols [lo, hi) of plane `O + plane offset` that workgroup `b` of `nb` writes: from the first line boundary at or after
+// b * OWN_STARTS to the first one at or after (b + 1) * OWN_STARTS (the plane's head and tail go to the first / last one)
+__device__ __forceinline__ void owned_range(const double *plane, uint32_t b, uint32_t nb, uint64_t nstarts, uint64_t &lo, uint64_t &hi)
+{
+    const uint64_t phase = (reinterpret_cast<uintptr_t>(plane) >> 3) & 15u; // doubles past a line boundary at col 0
+    const uint64_t r = (16u - phase) & 15u;                                 // cols = r (mod 16) begin a line
+    const uint64_t T = (uint64_t)b * OWN_STARTS;
+    lo = b == 0 ? 0 : T + r;
+    hi = b + 1 == nb ? nstarts : T + OWN_STARTS + r;
+    if (hi > nstarts)
+        hi = nstarts;
+}
+
+#ifndef PH_K4_WPE
+#define PH_K4_WPE 4
+#endif
 template <int LMIN_CT, int LMAX_CT>
-__global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict__ seq, uint64_t len, uint64_t start0,
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_K4_WPE, 8))) void scan_kernel(const uint8_t *__restrict__ seq, uint64_t len, uint64_t start0,
                                                       uint64_t nstarts, uint32_t Lmin_rt, uint32_t nl_rt, Consts cst,
                                                       double *__restrict__ tm, double *__restrict__ dHo,
                                                       double *__restrict__ dSo, uint64_t ld, double target,
@@ -149,15 +181,16 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict
     const uint32_t Lmin = LMIN_CT > 0 ? (uint32_t)LMIN_CT : Lmin_rt;
     const uint32_t nl = LMIN_CT > 0 ? (uint32_t)(LMAX_CT - LMIN_CT + 1) : nl_rt;
     const uint32_t Lmax = Lmin + nl - 1;
-    const uint32_t span = THREADS + Lmax - 1;       // bytes this block looks at
+    const uint32_t span = BLOCK_STARTS + Lmax - 1;  // bytes this block looks at
     const uint32_t span_pad = (span + 15u) & ~15u;
     double2 *nn = reinterpret_cast<double2 *>(lds);  // 25 entries (400 B, padded to 512)
     uint8_t *up = lds + 512;                         // upper-cased bytes
     uint8_t *cp = up + span_pad;                     // complement of the upper-cased byte
     uint8_t *cd = cp + span_pad;                     // nearest-neighbour code 0..4
+    uint16_t *rad = reinterpret_cast<uint16_t *>(cd + span_pad); // palindromic radius per double-centre (2 * span_pad)
 
     const int tid = threadIdx.x;
-    const uint64_t b0 = start0 + (uint64_t)blockIdx.x * THREADS;
+    const uint64_t b0 = start0 + (uint64_t)blockIdx.x * OWN_STARTS;
     if (tid < 25)
         nn[tid] = c_nn[tid];
     for (uint32_t t = tid; t < span; t += THREADS) {
@@ -168,69 +201,104 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict
         cd[t] = (uint8_t)nt_code(u);
     }
     __syncthreads();
-
-    const uint64_t g = b0 + tid; // my start
-    if (g >= start0 + nstarts)
-        return;
-    const uint64_t col = g - start0;
-
-    double aH[NL_MAX], aS[NL_MAX];
-    bool sym[NL_MAX];
-#pragma unroll
-    for (int l = 0; l < NL_MAX; ++l) {
-        if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
-            break;
-        const uint32_t L = Lmin + l;
-        // seq == ReverseComplement(seq), primers.go:81
-        bool pal = true;
-        for (uint32_t t = 0; t < L && pal; ++t)
-            pal = up[tid + t] == cp[tid + L - 1 - t];
-        sym[l] = pal;
-        double h = 0.0, s = 0.0;
-        h += 0.2; // primers.go:78-79
-        s += -5.7;
-        if (pal) { // :82-83
-            h += 0.0;
-            s += -1.4;
+    // seq == ReverseComplement(seq) (primers.go:81) for the window [a, a + L) compares the pairs (a + t, a + L - 1 - t), all
+    // of which share the DOUBLE-CENTRE 2a + L - 1.  So one radius per double-centre -- how many pairs match, counted from
+    // the innermost outwards, capped at what the longest window needs -- answers every (start, length) with one lookup:
+    // palindrome <=> radius >= ceil(L / 2).  (Round 3 walked every window's pairs: 13 data-dependent loops of dependent
+    // LDS round trips per start; a radius loop ends after 1.3 steps on average and there are two per start.)  A pair
+    // matches when BOTH directions of the reference's comparison hold (the complement table is not an involution on
+    // bytes it does not know).
+    {
+        const uint32_t rmax = (Lmax + 1) / 2;
+        for (uint32_t c = tid; c + 1 < 2 * span; c += THREADS) {
+            int x = (int)(c >> 1), y = (int)((c + 1) >> 1); // innermost pair: x == y (the centre base itself) for even c
+            uint32_t r = 0;
+            while (r < rmax && x >= 0 && y < (int)span && up[x] == cp[y] && up[y] == cp[x]) {
+                ++r;
+                --x;
+                ++y;
+            }
+            rad[c] = (uint16_t)r;
         }
-        const uint32_t last = cd[tid + L - 1];
-        if (last == 0u || last == 3u) { // :89-92, 3' end is A or T
-            h += 2.2;
-            s += 6.9;
-        }
-        s += cst.salt[l]; // :95
-        aH[l] = h;
-        aS[l] = s;
     }
+    __syncthreads();
 
-    // nearest-neighbour terms, left to right (:97-101): one lookup per
-    // dinucleotide, added to every length that still contains it
-    if (LMIN_CT > 0) {
-        uint32_t c0 = cd[tid];
+    const uint64_t end = start0 + nstarts;
+    const uint64_t g0 = b0 + (uint64_t)SPL * tid; // my start
+    const uint64_t col = g0 - start0;
+
+    double aH[SPL][NL_MAX], aS[SPL][NL_MAX];
+    bool sym[SPL][NL_MAX];
+    bool endAT[NL_MAX];
 #pragma unroll
-        for (int j = 0; j + 1 < LMAX_CT; ++j) {
-            const uint32_t c1 = cd[tid + j + 1];
-            const double2 t = nn[c0 * 5u + c1];
-            c0 = c1;
+    for (int q = 0; q < SPL; ++q) {
+        const uint32_t at = SPL * tid + q; // this start's first byte in the staged span
 #pragma unroll
-            for (int l = 0; l < LMAX_CT - LMIN_CT + 1; ++l)
-                if (j + 1 < LMIN_CT + l) {
-                    aH[l] += t.x;
-                    aS[l] += t.y;
-                }
+        for (int l = 0; l < NL_MAX; ++l) {
+            if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
+                break;
+            const uint32_t L = Lmin + l;
+            const bool pal = rad[2 * at + L - 1] >= (L + 1) / 2; // seq == ReverseComplement(seq), primers.go:81
+            sym[q][l] = pal;
+            double h = 0.0, s = 0.0;
+            h += 0.2; // primers.go:78-79
+            s += -5.7;
+            if (pal) { // :82-83
+                h += 0.0;
+                s += -1.4;
+            }
+            const uint32_t last = cd[at + L - 1];
+            const bool at_end = last == 0u || last == 3u;
+            if (at_end) { // :89-92, 3' end is A or T
+                h += 2.2;
+                s += 6.9;
+            }
+            s += cst.salt[l]; // :95
+            aH[q][l] = h;
+            aS[q][l] = s;
+            endAT[l] = at_end;
         }
-    } else {
-        uint32_t c0 = cd[tid];
-        for (uint32_t j = 0; j + 1 < Lmax; ++j) {
-            const uint32_t c1 = cd[tid + j + 1];
-            const double2 t = nn[c0 * 5u + c1];
-            c0 = c1;
+
+        // nearest-neighbour terms, left to right (:97-101): one lookup per
+        // dinucleotide, added to every length that still contains it
+        if (LMIN_CT > 0) {
+            // dH before the nearest-neighbour terms is one of TWO values whatever the length -- 0.2 (+ 0.0 for a
+            // palindrome: the same double) or 0.2 + 2.2 -- and the terms are added left to right, so every length's dH is
+            // a PREFIX of one of two running sums (bit for bit the reference's additions, :97-101): 2 adds per
+            // dinucleotide instead of one per length that contains it (299 -> 58 per start).  dS cannot share: its
+            // start value carries the length's own salt term (:95).
+            double pa = 0.0, pb = 0.0;
+            pa += 0.2;
+            pb += 0.2;
+            pb += 2.2;
+            uint32_t c0 = cd[at];
 #pragma unroll
-            for (int l = 0; l < NL_MAX; ++l) {
-                // x + 0.0 == x for every value an accumulator can hold (never -0.0)
-                const bool in = (uint32_t)l < nl && j + 1 < Lmin + (uint32_t)l;
-                aH[l] += in ? t.x : 0.0;
-                aS[l] += in ? t.y : 0.0;
+            for (int j = 0; j + 1 < LMAX_CT; ++j) {
+                const uint32_t c1 = cd[at + j + 1];
+                const double2 t = nn[c0 * 5u + c1];
+                c0 = c1;
+                pa += t.x;
+                pb += t.x;
+                if (j + 2 >= LMIN_CT) // dinucleotide j is the last one of length j + 2
+                    aH[q][j + 2 - LMIN_CT] = endAT[j + 2 - LMIN_CT] ? pb : pa;
+#pragma unroll
+                for (int l = 0; l < LMAX_CT - LMIN_CT + 1; ++l)
+                    if (j + 1 < LMIN_CT + l)
+                        aS[q][l] += t.y;
+            }
+        } else {
+            uint32_t c0 = cd[at];
+            for (uint32_t j = 0; j + 1 < Lmax; ++j) {
+                const uint32_t c1 = cd[at + j + 1];
+                const double2 t = nn[c0 * 5u + c1];
+                c0 = c1;
+#pragma unroll
+                for (int l = 0; l < NL_MAX; ++l) {
+                    // x + 0.0 == x for every value an accumulator can hold (never -0.0)
+                    const bool in = (uint32_t)l < nl && j + 1 < Lmin + (uint32_t)l;
+                    aH[q][l] += in ? t.x : 0.0;
+                    aS[q][l] += in ? t.y : 0.0;
+                }
             }
         }
     }
@@ -239,43 +307,52 @@ __global__ __launch_bounds__(THREADS) void scan_kernel(const uint8_t *__restrict
         // the grow loop of primers/pcr (pcr.go:47-53: lengthen the primer while MeltingTemp < targetTm) as a reduction:
         // only the first length that is no longer below the target leaves the chip, 2 + 8 bytes per start instead of
         // 24 per window.  Lengths are scanned in ascending order, also across the launches of a long range.
-        if (firstL[col] != 0)
-            return;
-        bool found = false;
 #pragma unroll
-        for (int l = 0; l < NL_MAX; ++l) {
-            if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
-                break;
-            const uint32_t L = Lmin + l;
-            if (!found && (uint32_t)l < nl && g + L <= len) {
-                const double t = melting(aH[l], aS[l], sym[l] ? cst.rlog_sym : cst.rlog_non);
-                if (!(t < target)) {
-                    found = true;
-                    firstL[col] = (uint16_t)L;
-                    if (firstTm)
-                        firstTm[col] = t;
+        for (int q = 0; q < SPL; ++q) {
+            const uint64_t g = g0 + q;
+            if (g >= end || SPL * tid + q >= OWN_STARTS || firstL[col + q] != 0) // the last 16 starts are the next workgroup's
+                continue;
+            bool found = false;
+#pragma unroll
+            for (int l = 0; l < NL_MAX; ++l) {
+                if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
+                    break;
+                const uint32_t L = Lmin + l;
+                if (!found && (uint32_t)l < nl && g + L <= len) {
+                    const double t = melting(aH[q][l], aS[q][l], sym[q][l] ? cst.rlog_sym : cst.rlog_non);
+                    if (!(t < target)) {
+                        found = true;
+                        firstL[col + q] = (uint16_t)L;
+                        if (firstTm)
+                            firstTm[col + q] = t;
+                    }
                 }
             }
         }
         return;
     }
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
 #pragma unroll
     for (int l = 0; l < NL_MAX; ++l) {
         if (LMIN_CT > 0 && l >= LMAX_CT - LMIN_CT + 1)
             break;
         if ((uint32_t)l < nl) {
             const uint32_t L = Lmin + l;
-            const uint64_t o = (uint64_t)l * ld + col;
-            if (g + L <= len) {
-                tm[o] = melting(aH[l], aS[l], sym[l] ? cst.rlog_sym : cst.rlog_non);
-                dHo[o] = aH[l];
-                dSo[o] = aS[l];
-            } else { // window runs off the end of the sequence
-                const double qnan = __longlong_as_double(0x7FF8000000000000ll);
-                tm[o] = qnan;
-                dHo[o] = qnan;
-                dSo[o] = qnan;
-            }
+            const uint64_t po = (uint64_t)l * ld;
+            const bool fits = g0 + L <= len; // else the window runs off the end of the sequence
+            const double t = fits ? melting(aH[0][l], aS[0][l], sym[0][l] ? cst.rlog_sym : cst.rlog_non) : qnan;
+            const double h = fits ? aH[0][l] : qnan;
+            const double e = fits ? aS[0][l] : qnan;
+            uint64_t lo, hi;
+            owned_range(tm + po, blockIdx.x, gridDim.x, nstarts, lo, hi);
+            if (col >= lo && col < hi)
+                tm[po + col] = t;
+            owned_range(dHo + po, blockIdx.x, gridDim.x, nstarts, lo, hi);
+            if (col >= lo && col < hi)
+                dHo[po + col] = h;
+            owned_range(dSo + po, blockIdx.x, gridDim.x, nstarts, lo, hi);
+            if (col >= lo && col < hi)
+                dSo[po + col] = e;
         }
     }
 }
@@ -353,8 +430,8 @@ __global__ __launch_bounds__(THREADS) void marmur_doty_kernel(const uint8_t *__r
 
 static size_t scan_smem(uint32_t Lmax)
 {
-    const uint32_t span_pad = (THREADS + Lmax - 1 + 15u) & ~15u;
-    return 512 + 3 * (size_t)span_pad;
+    const uint32_t span_pad = (BLOCK_STARTS + Lmax - 1 + 15u) & ~15u;
+    return 512 + 3 * (size_t)span_pad + 4 * (size_t)span_pad; // nn | up, cp, cd | rad (u16 per double-centre)
 }
 
 } // namespace k4
@@ -441,7 +518,7 @@ static int scan_impl(const uint8_t *d_seq, uint64_t len, uint64_t start0, uint64
     PH_REQUIRE(start0 <= len && nstarts <= len - start0 + 0, "polyhip_santalucia_scan: starts [%llu, +%llu) outside the sequence",
                (unsigned long long)start0, (unsigned long long)nstarts);
     hipStream_t st = as_stream(stream);
-    const uint64_t blocks = (nstarts + k4::THREADS - 1) / k4::THREADS;
+    const uint64_t blocks = (nstarts + k4::OWN_STARTS - 1) / k4::OWN_STARTS;
     PH_REQUIRE(blocks < (1ull << 31), "polyhip_santalucia_scan: too many starts for one call");
     if (d_first_len)
         PH_HIP(hipMemsetAsync(d_first_len, 0, nstarts * sizeof(uint16_t), st)); // 0 = no length reaches the target

@@ -88,6 +88,54 @@ def test_scan_matches_oracle_bit_exact(pr, Lmin, Lmax):
         assert (_bits(got[m]) == _bits(w[m])).all(), name
 
 
+def test_scan_palindromes_of_every_length_and_plane_alignment(pr):
+    """The scan decides seq == ReverseComplement(seq) (primers.go:81) from one radius per double-centre and stores two
+    starts per lane, 16 bytes at a time, with a shifted pairing for planes that start on an odd multiple of 8 bytes: every
+    palindromic length 18..30 planted (even ones from ACGT, odd ones around a self-complementary N / S / W centre,
+    transform.go:78-109), near-palindromes broken in their innermost and outermost pair, bytes the complement table does
+    not know (they map to 0: 'Q' against a NUL byte matches in ONE direction only), at genome lengths that make the plane
+    stride odd and even, and through the _dev entry point with start0 / nstarts of either parity."""
+    import torch
+    rng = np.random.default_rng(81)
+    comp = {65: 84, 84: 65, 67: 71, 71: 67}
+
+    def pal(L):
+        half = rng.choice(list(b"ACGT"), L // 2).astype(np.uint8)
+        mid = [int(rng.choice(list(b"NSW")))] if L % 2 else []
+        return bytes(half) + bytes(mid) + bytes(comp[int(b)] for b in half[::-1])
+
+    parts = []
+    for L in range(18, 31):
+        p = pal(L)
+        inner = bytearray(p)
+        inner[L // 2 - 1] = ord("A") if inner[L // 2 - 1] != ord("A") else ord("C")  # innermost pair broken
+        outer = bytearray(p)
+        outer[0] = ord("A") if outer[0] != ord("A") else ord("C")                    # outermost pair broken
+        parts += [bytes(orc.synth_dna(L, 37)), p, bytes(orc.synth_dna(100 + L, 11)), bytes(inner), bytes(outer)]
+    parts += [b"ACGTACGTAQ\x00TACGTACGT", b"\x00" * 20, b"NNNNNNNNNNNNNNNNNNNNNNN", b"acgtacgtaatTACGTACGT"]
+    base = b"".join(parts)
+    for extra in (0, 1):  # plane stride ld = len - 18 + 1 of either parity
+        g = base + b"G" * extra
+        tm, dH, dS = pr.SantaLuciaScan(g, 18, 30, 500e-9, 50e-3, 0.0)
+        want = _scan_oracle(g, 18, 30, 500e-9, 50e-3, 0.0)
+        for got, w in ((tm, want[0]), (dH, want[1]), (dS, want[2])):
+            assert (np.isnan(got) == np.isnan(w)).all()
+            m = ~np.isnan(w)
+            assert (_bits(got[m]) == _bits(w[m])).all()
+    dev = torch.device("cuda:0")
+    gt = torch.from_numpy(np.frombuffer(base, np.uint8).copy()).to(dev)
+    n = len(base)
+    for a, ns in ((0, 701), (1, 700), (3, 333), (512, 513), (1023, 2)):
+        outs = [torch.full((13 * ns + 1,), 7.0, dtype=torch.float64, device=dev) for _ in range(3)]
+        pr.santalucia_scan_dev(gt, n, a, ns, 18, 30, 500e-9, 50e-3, 0.0, *[o[1:] for o in outs], ns)  # planes on odd 8-byte addresses
+        torch.cuda.synchronize()
+        for o, w in zip(outs, want if False else _scan_oracle(base, 18, 30, 500e-9, 50e-3, 0.0)):
+            got = o[1:].view(13, ns).cpu().numpy()
+            ww = w[:, a:a + ns]
+            assert float(o[0]) == 7.0  # nothing written in front of the planes
+            assert (np.isnan(got) == np.isnan(ww)).all() and (_bits(got[~np.isnan(ww)]) == _bits(ww[~np.isnan(ww)])).all(), (a, ns)
+
+
 def test_scan_slices_agree_with_whole(pr):
     """start0/nstarts slicing (the multi-GPU partition) gives the same planes."""
     import torch
