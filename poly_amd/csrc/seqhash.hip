@@ -307,67 +307,151 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const uint8_t *__restri
     }
 }
 
+// Where sequence q's chaining values live: slot cv_base(q) = (bytes in front of it) / 1024 + q of the value buffer.  No
+// scan: consecutive slots are at least ceil(len / 1024) apart (floor((a + len) / 1024) - floor(a / 1024) >= ceil(len / 1024)
+// - 1), and the last one stays below total_bytes / 1024 + n, the buffer's size.  (Round 3 ran a one-workgroup scan of the
+// chunk counts in front of every batch: 0.16 ms of the 1.95 ms a 100k x 5 kb batch took.)
+__device__ __forceinline__ uint64_t cv_base(uint64_t bytes_before, uint64_t q) { return bytes_before / CHUNK + q; }
+
 // chaining values of every chunk of every multi-chunk sequence, ONE THREAD PER CHUNK over the whole batch
-// (a chunk's 16 blocks chain, so the chunk is the unit of parallelism): chunk g belongs to the sequence q
-// with cvoff[q] <= g < cvoff[q + 1] (binary search), its value goes to level A of that sequence's tree.
+// (a chunk's 16 blocks chain, so the chunk is the unit of parallelism): slot g belongs to the sequence q
+// with cv_base(q) <= g < cv_base(q + 1) (binary search), its value goes to level A of that sequence's tree.
 __global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restrict__ cand0,
                                                        const uint8_t *__restrict__ cand1,
-                                                       const uint64_t *__restrict__ offs, uint64_t n,
-                                                       const uint64_t *__restrict__ cvoff, uint64_t max_chunks,
+                                                       const uint64_t *__restrict__ offs, uint64_t n, uint64_t max_chunks,
                                                        const uint32_t *__restrict__ sel, const uint32_t *__restrict__ err,
                                                        uint32_t *__restrict__ cvbuf)
 {
     const uint64_t g = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (g >= max_chunks)
         return;
-    uint64_t lo = 0, hi = n; // last q with cvoff[q] <= g
+    const uint64_t first = offs[0];
+    uint64_t lo = 0, hi = n; // last q with cv_base(q) <= g
     while (hi - lo > 1) {
         const uint64_t mid = (lo + hi) >> 1;
-        if (cvoff[mid] <= g)
+        if (cv_base(offs[mid] - first, mid) <= g)
             lo = mid;
         else
             hi = mid;
     }
     const uint64_t q = lo, o0 = offs[q], len = offs[q + 1] - o0;
     const uint64_t nchunks = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
-    const uint64_t c = g - cvoff[q];
+    const uint64_t qbase = cv_base(o0 - first, q);
+    const uint64_t c = g - qbase;
     if (c >= nchunks || nchunks == 1 || err[q] != 0u)
         return; // behind the batch's last chunk; single-chunk sequences are the root compression's business
     const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
     uint32_t cv[8];
     chunk_cv(data, len, c, false, cv);
-    uint32_t *A = cvbuf + cvoff[q] * 16;
+    uint32_t *A = cvbuf + qbase * 16;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         A[c * 8 + i] = cv[i];
 }
 
-// choose the bytewise smaller candidate (sort.Strings), BLAKE3 it, format the seqhash
+// "v1_" + flags + "_" + hex(root), seqhash.go:221-222
+__device__ __forceinline__ void format_hash(const uint32_t (&root)[8], uint32_t prefix_letters, char *__restrict__ o)
+{
+    o[0] = 'v';
+    o[1] = '1';
+    o[2] = '_';
+    o[3] = (char)(prefix_letters & 0xFF);
+    o[4] = (char)((prefix_letters >> 8) & 0xFF);
+    o[5] = (char)((prefix_letters >> 16) & 0xFF);
+    o[6] = '_';
+    const char *hex = "0123456789abcdef";
+    for (int i = 0; i < 8; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t byte = (root[i] >> (8 * j)) & 0xFF; // little-endian words
+            o[7 + (4 * i + j) * 2] = hex[byte >> 4];
+            o[7 + (4 * i + j) * 2 + 1] = hex[byte & 15];
+        }
+    o[71] = 0;
+}
+
+// The tree above the chunks for sequences of up to SMALL_CHUNKS chunks (64 kB), ONE THREAD PER SEQUENCE: a 5 kb plasmid
+// has five chunk values and four parent compressions, one after the other -- a workgroup per sequence (round 3) kept one
+// or two of its 64 lanes busy through three barriers and cost 0.44 ms per 100k sequences, the lanes of this kernel are all
+// busy and it costs a twentieth of that.  Level-by-level pairing with the odd value promoted (= BLAKE3's left-full tree),
+// ping-pong between the two halves of the sequence's slot range.
+constexpr uint64_t SMALL_CHUNKS = 64;
+__global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__restrict__ cand0, const uint8_t *__restrict__ cand1,
+                                                            const uint64_t *__restrict__ offs, uint64_t n,
+                                                            uint32_t *__restrict__ cvbuf, const uint32_t *__restrict__ sel,
+                                                            const uint32_t *__restrict__ err, uint32_t prefix_letters,
+                                                            char *__restrict__ out)
+{
+    const uint64_t q = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
+    if (q >= n)
+        return;
+    char *o = out + q * 72;
+    if (err[q] != 0u) {
+        o[0] = 0;
+        return;
+    }
+    const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
+    const uint64_t nchunks = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
+    if (nchunks > SMALL_CHUNKS)
+        return; // hash_kernel's
+    uint32_t root[8];
+    if (nchunks == 1) {
+        const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
+        chunk_cv(data, len, 0, true, root);
+    } else {
+        uint32_t *A = cvbuf + cv_base(o0 - offs[0], q) * 16, *B = A + nchunks * 8; // level A was filled by chunk_kernel
+        uint64_t m = nchunks;
+        uint32_t *src = A, *dst = B;
+        uint32_t iv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            iv[i] = c_iv[i];
+        while (m > 2) {
+            const uint64_t pairs = m / 2;
+            for (uint64_t p = 0; p < pairs; ++p) {
+                uint32_t blk[16], cv[8];
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    blk[i] = src[p * 16 + i];
+                compress(iv, blk, 0, 64, PARENT, cv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    dst[p * 8 + i] = cv[i];
+            }
+            if (m & 1) // the odd one is promoted unchanged
+                for (int i = 0; i < 8; ++i)
+                    dst[pairs * 8 + i] = src[(m - 1) * 8 + i];
+            m = pairs + (m & 1);
+            uint32_t *t = src;
+            src = dst;
+            dst = t;
+        }
+        uint32_t blk[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            blk[i] = src[i];
+        compress(iv, blk, 0, 64, PARENT | ROOT, root);
+    }
+    format_hash(root, prefix_letters, o);
+}
+
+// the same for sequences of MORE than SMALL_CHUNKS chunks: a workgroup per sequence, a level's pairs side by side
 __global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restrict__ cand0,
                                                        const uint8_t *__restrict__ cand1,
                                                        const uint64_t *__restrict__ offs, uint64_t n,
-                                                       const uint64_t *__restrict__ cvoff, uint32_t *__restrict__ cvbuf,
-                                                       const uint32_t *__restrict__ sel,
+                                                       uint32_t *__restrict__ cvbuf, const uint32_t *__restrict__ sel,
                                                        const uint32_t *__restrict__ err, uint32_t prefix_letters,
                                                        char *__restrict__ out)
 {
     const int tid = threadIdx.x;
     for (uint64_t q = blockIdx.x; q < n; q += gridDim.x) {
         char *o = out + q * 72;
-        if (err[q] != 0u) {
-            if (tid == 0)
-                o[0] = 0;
-            continue;
-        }
         const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
-        const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
         const uint64_t nchunks = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
-        uint32_t *A = cvbuf + cvoff[q] * 16, *B = A + nchunks * 8; // two levels of chaining values
+        if (nchunks <= SMALL_CHUNKS || err[q] != 0u)
+            continue; // hash_small_kernel's
+        uint32_t *A = cvbuf + cv_base(o0 - offs[0], q) * 16, *B = A + nchunks * 8; // two levels of chaining values
         uint32_t root[8];
-        if (nchunks == 1) {
-            if (tid == 0)
-                chunk_cv(data, len, 0, true, root);
-        } else {
+        {
             // level A was filled by chunk_kernel
             uint64_t m = nchunks;
             uint32_t *src = A, *dst = B;
@@ -409,62 +493,8 @@ __global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restric
                 compress(iv, blk, 0, 64, PARENT | ROOT, root);
             }
         }
-        if (tid == 0) {
-            o[0] = 'v';
-            o[1] = '1';
-            o[2] = '_';
-            o[3] = (char)(prefix_letters & 0xFF);
-            o[4] = (char)((prefix_letters >> 8) & 0xFF);
-            o[5] = (char)((prefix_letters >> 16) & 0xFF);
-            o[6] = '_';
-            const char *hex = "0123456789abcdef";
-            for (int i = 0; i < 8; ++i)
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t byte = (root[i] >> (8 * j)) & 0xFF; // little-endian words
-                    o[7 + (4 * i + j) * 2] = hex[byte >> 4];
-                    o[7 + (4 * i + j) * 2 + 1] = hex[byte & 15];
-                }
-            o[71] = 0;
-        }
-    }
-}
-
-// cvoff[q] = number of chunks of the sequences before q (exclusive scan; single block is plenty here)
-__global__ __launch_bounds__(1024) void chunk_scan_kernel(const uint64_t *__restrict__ offs, uint64_t n,
-                                                         uint64_t *__restrict__ cvoff)
-{
-    __shared__ uint64_t wsum[16];
-    __shared__ uint64_t carry;
-    const int tid = threadIdx.x;
-    if (tid == 0)
-        carry = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + tid;
-        uint64_t v = 0;
-        if (i < n) {
-            const uint64_t len = offs[i + 1] - offs[i];
-            v = len == 0 ? 1 : (len + CHUNK - 1) / CHUNK;
-        }
-        uint64_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint64_t t = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d)
-                incl += t;
-        }
-        if ((tid & 63) == 63)
-            wsum[tid >> 6] = incl;
-        __syncthreads();
-        uint64_t pre = carry;
-        for (int w = 0; w < (tid >> 6); ++w)
-            pre += wsum[w];
-        if (i < n)
-            cvoff[i] = pre + incl - v;
-        __syncthreads();
-        if (tid == 1023)
-            carry = pre + incl;
-        __syncthreads();
+        if (tid == 0)
+            format_hash(root, prefix_letters, o);
     }
 }
 
@@ -523,7 +553,6 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     uint8_t *norm = w + L.off_norm, *rc = double_stranded ? w + L.off_rc : nullptr;
     uint8_t *rot0 = w + L.off_rot0, *rot1 = w + L.off_rot1;
     uint64_t *rotidx = reinterpret_cast<uint64_t *>(w + L.off_rotidx);
-    uint64_t *cvoff = reinterpret_cast<uint64_t *>(w + L.off_cvoff);
     uint32_t *cvbuf = reinterpret_cast<uint32_t *>(w + L.off_cv);
     uint32_t *sel = reinterpret_cast<uint32_t *>(w + L.off_sel);
 
@@ -544,7 +573,6 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
             c1 = rot1;
         }
     }
-    hipLaunchKernelGGL(s2::chunk_scan_kernel, dim3(1), dim3(1024), 0, st, d_offsets, n, cvoff);
     const uint32_t letters = (uint32_t)(seq_type == 0 ? 'D' : seq_type == 1 ? 'R' : 'P') |
                              ((uint32_t)(circular ? 'C' : 'L') << 8) | ((uint32_t)(double_stranded ? 'D' : 'S') << 16);
     if (c1) {
@@ -554,10 +582,13 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     {
         const uint64_t max_chunks = total_bytes / s2::CHUNK + n + 1; // >= the batch's chunk count
         hipLaunchKernelGGL(s2::chunk_kernel, dim3((unsigned)((max_chunks + s2::THREADS - 1) / s2::THREADS)),
-                           dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, cvoff, max_chunks, sel, d_err, cvbuf);
+                           dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, max_chunks, sel, d_err, cvbuf);
     }
-    hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvoff, cvbuf, sel,
-                       d_err, letters, d_out);
+    hipLaunchKernelGGL(s2::hash_small_kernel, dim3((unsigned)((n + s2::THREADS - 1) / s2::THREADS)), dim3(s2::THREADS), 0, st, c0, c1,
+                       d_offsets, n, cvbuf, sel, d_err, letters, d_out);
+    if (max_len > s2::SMALL_CHUNKS * s2::CHUNK) // some sequence has more chunks than one thread should merge
+        hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvbuf, sel, d_err,
+                           letters, d_out);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }

@@ -153,7 +153,8 @@ def test_hash_batch_matches_oracle(sh, stype, circular, ds):
         alpha = b"ACGTacgtUuNRYSWKMBDHVZ"
     seqs = [b"", b"A", b"AT", b"TA", b"GAATTC", b"ACGU", b"acgu", b"ZZZ", b"AAAA"]
     # lengths around the 64-byte block and 1024-byte chunk edges, and multi-level trees
-    for L in (63, 64, 65, 127, 128, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 4097, 5000, 7 * 1024, 8 * 1024 + 1, 20_000):
+    for L in (63, 64, 65, 127, 128, 1023, 1024, 1025, 2047, 2048, 2049, 3072, 4097, 5000, 7 * 1024, 8 * 1024 + 1, 20_000,
+              64 * 1024 - 1, 64 * 1024, 64 * 1024 + 1, 65 * 1024 + 7, 200_000):  # one thread merges up to 64 chunk values, a workgroup more
         seqs.append(bytes(rng.choice(list(alpha), L).astype(np.uint8)))
     for _ in range(60):
         seqs.append(bytes(rng.choice(list(alpha[:4] if stype != "PROTEIN" else alpha), int(rng.integers(1, 3000))).astype(np.uint8)))
