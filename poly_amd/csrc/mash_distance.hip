@@ -1206,14 +1206,42 @@ __global__ __launch_bounds__(THREADS) void generic_kernel(const uint32_t *__rest
 }
 
 // mash.go:134,139: 1 - float64(same)/float64(smaller.SketchSize)
+// Distance = 1 - float64(same) / float64(size) (mash.go:134,139) for a whole count matrix.  A count is one of size + 1
+// integers, so the IEEE division happens once per VALUE -- a table of the size + 1 results in LDS, filled by every
+// workgroup for itself -- and a pair costs one table read: the kernel is the stream of its 2 + 8 bytes per pair (round 3
+// divided twice per pair: a 64-bit index division and the fp64 one).  A workgroup takes tiles of 2048 consecutive pairs
+// of one row; a wave's load is 256 contiguous bytes (two counts per lane) and its store 1 KB (two distances per lane),
+// whole 128-byte lines where the rows allow.
+constexpr uint32_t DIST_TAB_MAX = 8192; // table entries (64 KB of LDS); larger sketch sizes divide per pair
+constexpr uint32_t DIST_TILE = THREADS * 8;
 __global__ __launch_bounds__(THREADS) void distance_kernel(const uint16_t *__restrict__ counts, uint64_t nx,
-                                                          uint64_t ny, uint64_t ldc, double smaller,
+                                                          uint64_t ny, uint64_t ldc, double smaller, uint32_t ntab,
                                                           double *__restrict__ dist, uint64_t ldd)
 {
-    const uint64_t total = nx * ny;
-    for (uint64_t p = (uint64_t)blockIdx.x * THREADS + threadIdx.x; p < total; p += (uint64_t)gridDim.x * THREADS) {
-        const uint64_t i = p / ny, j = p - i * ny;
-        dist[i * ldd + j] = 1 - (double)counts[i * ldc + j] / smaller;
+    extern __shared__ __attribute__((aligned(16))) double dtab[];
+    for (uint32_t c = threadIdx.x; c < ntab; c += THREADS)
+        dtab[c] = 1 - (double)c / smaller;
+    __syncthreads();
+    auto value = [&](uint32_t c) { return c < ntab ? dtab[c] : 1 - (double)c / smaller; };
+    const uint64_t tpr = (ny + DIST_TILE - 1) / DIST_TILE, ntiles = nx * tpr;
+    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint64_t i = t / tpr, j0 = (t - i * tpr) * DIST_TILE; // wave-uniform division
+        const uint16_t *cp = counts + i * ldc + j0;
+        double *dp = dist + i * ldd + j0;
+        const uint64_t left = ny - j0;
+        const bool fast = left >= DIST_TILE && ((reinterpret_cast<uintptr_t>(cp) & 3u) | (reinterpret_cast<uintptr_t>(dp) & 15u)) == 0;
+        if (fast) {
+            uint32_t w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = reinterpret_cast<const uint32_t *>(cp)[q * THREADS + threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                reinterpret_cast<double2 *>(dp)[q * THREADS + threadIdx.x] = make_double2(value(w[q] & 0xFFFFu), value(w[q] >> 16));
+        } else {
+            for (uint64_t e = threadIdx.x; e < left && e < DIST_TILE; e += THREADS)
+                dp[e] = value(cp[e]);
+        }
     }
 }
 
@@ -1633,10 +1661,12 @@ int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts, uint64_t nx,
         return POLYHIP_OK;
     PH_REQUIRE(d_counts && d_dist, "polyhip_mash_distance_from_counts: null pointer");
     PH_REQUIRE(ld_counts >= ny && ld_dist >= ny, "polyhip_mash_distance_from_counts: row stride < ny");
-    const uint64_t pairs = nx * ny;
-    const unsigned blocks = (unsigned)std::min<uint64_t>((pairs + k2::THREADS - 1) / k2::THREADS, 256ull * 32ull);
-    hipLaunchKernelGGL(k2::distance_kernel, dim3(blocks), dim3(k2::THREADS), 0, as_stream(stream), d_counts, nx, ny,
-                       ld_counts, (double)std::min(sx, sy), d_dist, ld_dist);
+    const uint32_t smaller = std::min(sx, sy);
+    const uint32_t ntab = smaller + 1 <= k2::DIST_TAB_MAX ? smaller + 1 : 0u;
+    const uint64_t tiles = nx * ((ny + k2::DIST_TILE - 1) / k2::DIST_TILE);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(tiles, 256ull * 32ull);
+    hipLaunchKernelGGL(k2::distance_kernel, dim3(blocks), dim3(k2::THREADS), (size_t)ntab * sizeof(double), as_stream(stream),
+                       d_counts, nx, ny, ld_counts, (double)smaller, ntab, d_dist, ld_dist);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
