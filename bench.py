@@ -265,10 +265,10 @@ def valu_issue_ceiling(kmers_per_s: float) -> dict:
     """K1's VALU-issue ceiling: instructions per k-mer from the SQ_INSTS_VALU counter (profiles/k1_issue.json), times the
     average issue cost of the kernel's own instruction mix -- its disassembly histogram priced with the two measured issue
     classes, 2 cycles for plain add/sub/and/or/xor/lshr, 4 for everything else (scripts/valu_mix.py ->
-    profiles/r03_valu_mix.json) -- at the clock the kernel actually sustains (SQ_BUSY_CYCLES / duration of the same counter
+    profiles/valu_mix.json) -- at the clock the kernel actually sustains (SQ_BUSY_CYCLES / duration of the same counter
     pass: a VALU-dense kernel does not hold the 2.4 GHz peak clock).  None of it is measured by this run; `source` says so."""
     try:
-        mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json")))
+        mix = json.load(open(os.path.join(ROOT, "profiles", "valu_mix.json")))
         cyc = mix["kernels"]["K1 polyhip::k1::sketch_slab_kernel<21>"]["cycles_per_valu_instruction"]
         ki = json.load(open(os.path.join(ROOT, "profiles", "k1_issue.json")))
         ipk, clock = ki["valu_instructions_per_kmer"], ki["clock_GHz"] * 1e9
@@ -278,7 +278,7 @@ def valu_issue_ceiling(kmers_per_s: float) -> dict:
     return {"instructions_per_kmer": ipk, "cycles_per_instruction": cyc, "clock_GHz": clock / 1e9, "simds": 1024,
             "ceiling_kmers_per_s": ceiling, "frac": kmers_per_s / ceiling,
             "ceiling_at_peak_clock_kmers_per_s": 1024 * 2.4e9 * 64 / (ipk * cyc),
-            "source": f"{ki.get('source')}; instruction mix: profiles/r03_valu_mix.json (scripts/valu_mix.py: "
+            "source": f"{ki.get('source')}; instruction mix: profiles/valu_mix.json (scripts/valu_mix.py: "
                       f"{mix['kernels']['K1 polyhip::k1::sketch_slab_kernel<21>']['valu_full_rate']} full-rate + "
                       f"{mix['kernels']['K1 polyhip::k1::sketch_slab_kernel<21>']['valu_half_rate']} half-rate VALU instructions in the "
                       "kernel's per-read loop); NOT measured by this run"}

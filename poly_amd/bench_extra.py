@@ -114,7 +114,7 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
     half = align.last_packed_half()  # gfx950's half-float cell (scores < 2048): 17 instructions per row and block, else 22
     # VALU-issue ceiling: the kernel's own instruction count per row and 4-column block (counter-measured for the
     # half-float cell, profiles/k3_issue.json; every instruction of the packed recurrence is a 4-cycle one,
-    # profiles/r03_valu_mix.json) at the clock the kernel sustains; beside it the ceiling of the 14-instruction recurrence
+    # profiles/valu_mix.json) at the clock the kernel sustains; beside it the ceiling of the 14-instruction recurrence
     # floor, which says how far the stream is from the algorithm, not from its own issue rate
     import json as _json
     import os as _os

@@ -90,8 +90,10 @@ __device__ void compress(const uint32_t cv[8], const uint32_t block[16], uint64_
     out[7] = s7 ^ s15;
 }
 
-// chaining value of chunk `idx` of data[0..len); root = this chunk is the whole input
-__device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_t idx, bool root, uint32_t cv[8])
+// chaining value of chunk `idx` of the string data[rot..len) + data[0..rot) -- the rotation `rot` of data[0..len), never
+// materialised (round 3 wrote both strands' rotated copies out, 1 GB per 100k x 5 kb, only to read them back here) --;
+// root = this chunk is the whole input
+__device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_t rot, uint64_t idx, bool root, uint32_t cv[8])
 {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -102,11 +104,12 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
     for (uint32_t b = 0; b < nblocks; ++b) {
         const uint64_t off = base + (uint64_t)b * 64;
         const uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
+        const uint64_t src = off + rot >= len ? off + rot - len : off + rot; // where the block starts in data[] (rot < len, off < len)
         uint32_t w[16];
-        if (blen == 64) {
-            // a full block: aligned dwords funnelled to the data's own alignment (the 17th dword is only
-            // touched when it holds bytes of this block)
-            const uintptr_t addr = reinterpret_cast<uintptr_t>(data + off);
+        // 64 bytes from an arbitrary address: aligned dwords funnelled to the data's own alignment (the 17th dword is only
+        // touched when it holds bytes of the block)
+        auto load16 = [](const uint8_t *p, uint32_t (&o)[16]) {
+            const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
             const uint32_t sh = (uint32_t)(addr & 3u);
             const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
             uint32_t d[17];
@@ -116,7 +119,29 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
             d[16] = sh ? gd[16] : 0u;
 #pragma unroll
             for (int i = 0; i < 16; ++i)
-                w[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+                o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+        };
+        if (blen == 64) {
+            load16(data + src, w); // (past the end of data[] these are the next sequence's bytes or the workspace's padding)
+            if (src + 64 > len) {
+                // the one block per rotated sequence that runs over the end of data[]: its first m bytes are the string's
+                // last ones, the rest its first ones -- a second funnelled load, placed so that byte i of the block is byte
+                // i of both, and a select per dword (a byte-by-byte path here stalled the whole wave behind the one lane
+                // in sixty-four that needed it: 0.20 -> 0.45 ms for the chunk kernel)
+                const uint32_t m = (uint32_t)(len - src); // 1 .. 63
+                uint32_t v[16];
+                load16(data - m, v); // >= 63 bytes in front of data[]: the previous sequence or the workspace's front padding
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint32_t lo = 4u * (uint32_t)i;
+                    if (lo >= m)
+                        w[i] = v[i];
+                    else if (lo + 4u > m) {
+                        const uint32_t keep = (1u << (8u * (m - lo))) - 1u;
+                        w[i] = (w[i] & keep) | (v[i] & ~keep);
+                    }
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -125,7 +150,7 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t p = 4 * i + j;
                     if (p < blen)
-                        x |= (uint32_t)data[off + p] << (8 * j);
+                        x |= (uint32_t)data[src + p >= len ? src + p - len : src + p] << (8 * j); // the string's last, short block
                 }
                 w[i] = x;
             }
@@ -285,16 +310,19 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
 __global__ __launch_bounds__(THREADS) void select_kernel(const uint8_t *__restrict__ cand0,
                                                         const uint8_t *__restrict__ cand1,
                                                         const uint64_t *__restrict__ offs, uint64_t n,
+                                                        const uint64_t *__restrict__ rot0, const uint64_t *__restrict__ rot1,
                                                         uint32_t *__restrict__ sel)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t nw = (uint64_t)gridDim.x * (THREADS / 64);
     for (uint64_t q = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); q < n; q += nw) {
         const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
+        const uint64_t r0 = rot0 ? rot0[q] : 0, r1 = rot1 ? rot1[q] : 0; // the candidates are rotations of the two strands
         uint32_t pick = 0;
         for (uint64_t t0 = 0; t0 < len; t0 += 64) {
             const uint64_t t = t0 + lane;
-            const uint32_t a = t < len ? cand0[o0 + t] : 0u, b = t < len ? cand1[o0 + t] : 0u;
+            const uint64_t ta = t + r0 >= len ? t + r0 - len : t + r0, tb = t + r1 >= len ? t + r1 - len : t + r1;
+            const uint32_t a = t < len ? cand0[o0 + ta] : 0u, b = t < len ? cand1[o0 + tb] : 0u;
             const uint64_t ne = __ballot(a != b);
             if (ne) {
                 const int f = __builtin_ctzll(ne);
@@ -319,6 +347,7 @@ __device__ __forceinline__ uint64_t cv_base(uint64_t bytes_before, uint64_t q) {
 __global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restrict__ cand0,
                                                        const uint8_t *__restrict__ cand1,
                                                        const uint64_t *__restrict__ offs, uint64_t n, uint64_t max_chunks,
+                                                       const uint64_t *__restrict__ rot0, const uint64_t *__restrict__ rot1,
                                                        const uint32_t *__restrict__ sel, const uint32_t *__restrict__ err,
                                                        uint32_t *__restrict__ cvbuf)
 {
@@ -340,9 +369,11 @@ __global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restric
     const uint64_t c = g - qbase;
     if (c >= nchunks || nchunks == 1 || err[q] != 0u)
         return; // behind the batch's last chunk; single-chunk sequences are the root compression's business
-    const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
+    const bool second = cand1 && sel[q];
+    const uint8_t *data = (second ? cand1 : cand0) + o0;
+    const uint64_t rot = second ? (rot1 ? rot1[q] : 0) : (rot0 ? rot0[q] : 0);
     uint32_t cv[8];
-    chunk_cv(data, len, c, false, cv);
+    chunk_cv(data, len, rot, c, false, cv);
     uint32_t *A = cvbuf + qbase * 16;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -377,6 +408,7 @@ __device__ __forceinline__ void format_hash(const uint32_t (&root)[8], uint32_t 
 constexpr uint64_t SMALL_CHUNKS = 64;
 __global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__restrict__ cand0, const uint8_t *__restrict__ cand1,
                                                             const uint64_t *__restrict__ offs, uint64_t n,
+                                                            const uint64_t *__restrict__ rot0, const uint64_t *__restrict__ rot1,
                                                             uint32_t *__restrict__ cvbuf, const uint32_t *__restrict__ sel,
                                                             const uint32_t *__restrict__ err, uint32_t prefix_letters,
                                                             char *__restrict__ out)
@@ -395,8 +427,9 @@ __global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__re
         return; // hash_kernel's
     uint32_t root[8];
     if (nchunks == 1) {
-        const uint8_t *data = ((cand1 && sel[q]) ? cand1 : cand0) + o0;
-        chunk_cv(data, len, 0, true, root);
+        const bool second = cand1 && sel[q];
+        const uint8_t *data = (second ? cand1 : cand0) + o0;
+        chunk_cv(data, len, len ? (second ? (rot1 ? rot1[q] : 0) : (rot0 ? rot0[q] : 0)) : 0, 0, true, root);
     } else {
         uint32_t *A = cvbuf + cv_base(o0 - offs[0], q) * 16, *B = A + nchunks * 8; // level A was filled by chunk_kernel
         uint64_t m = nchunks;
@@ -507,12 +540,12 @@ static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static Layout layout(uint64_t n, uint64_t total_bytes, int circular, int ds)
 {
     Layout L;
-    size_t o = 0;
+    size_t o = 256; // front padding: a block that wraps around a rotated sequence loads up to 63 bytes in front of it
     L.off_norm = o; o += al(total_bytes + 16);
     L.off_rc = o; o += ds ? al(total_bytes + 16) : 0;
-    L.off_rot0 = o; o += circular ? al(total_bytes + 16) : 0;
-    L.off_rot1 = o; o += (circular && ds) ? al(total_bytes + 16) : 0;
-    L.off_rotidx = o; o += circular ? al(n * 8) : 0;
+    L.off_rot0 = o; // (the rotated copies of round 3 are gone: a rotation is an index, applied where the bytes are read)
+    L.off_rot1 = o;
+    L.off_rotidx = o; o += circular ? al(2 * n * 8) : 0; // least-rotation index of the strand and of its reverse complement
     L.off_cvoff = o; o += al((n + 1) * 8);
     L.off_sel = o; o += al(n * 4);
     // two levels of 8-word chaining values per chunk; chunks <= total_bytes / 1024 + n
@@ -551,8 +584,8 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     hipStream_t st = as_stream(stream);
     uint8_t *w = static_cast<uint8_t *>(d_work);
     uint8_t *norm = w + L.off_norm, *rc = double_stranded ? w + L.off_rc : nullptr;
-    uint8_t *rot0 = w + L.off_rot0, *rot1 = w + L.off_rot1;
     uint64_t *rotidx = reinterpret_cast<uint64_t *>(w + L.off_rotidx);
+    const uint64_t *r0 = nullptr, *r1 = nullptr;
     uint32_t *cvbuf = reinterpret_cast<uint32_t *>(w + L.off_cv);
     uint32_t *sel = reinterpret_cast<uint32_t *>(w + L.off_sel);
 
@@ -561,31 +594,31 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
                        double_stranded ? 1 : 0, norm, rc, d_err);
     PH_HIP(hipGetLastError());
     const uint8_t *c0 = norm, *c1 = rc;
-    if (circular) {
-        int r = polyhip_least_rotation_batch_dev(norm, d_offsets, n, max_len, rotidx, rot0, stream);
+    if (circular) { // the index only: the rotated strings are never written (select / chunk / hash read through the index)
+        int r = polyhip_least_rotation_batch_dev(norm, d_offsets, n, max_len, rotidx, nullptr, stream);
         if (r != POLYHIP_OK)
             return r;
-        c0 = rot0;
+        r0 = rotidx;
         if (double_stranded) {
-            r = polyhip_least_rotation_batch_dev(rc, d_offsets, n, max_len, rotidx, rot1, stream);
+            r = polyhip_least_rotation_batch_dev(rc, d_offsets, n, max_len, rotidx + n, nullptr, stream);
             if (r != POLYHIP_OK)
                 return r;
-            c1 = rot1;
+            r1 = rotidx + n;
         }
     }
     const uint32_t letters = (uint32_t)(seq_type == 0 ? 'D' : seq_type == 1 ? 'R' : 'P') |
                              ((uint32_t)(circular ? 'C' : 'L') << 8) | ((uint32_t)(double_stranded ? 'D' : 'S') << 16);
     if (c1) {
         const unsigned sblocks = (unsigned)std::min<uint64_t>((n + 3) / 4, 256ull * 32ull);
-        hipLaunchKernelGGL(s2::select_kernel, dim3(sblocks), dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, sel);
+        hipLaunchKernelGGL(s2::select_kernel, dim3(sblocks), dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, r0, r1, sel);
     }
     {
         const uint64_t max_chunks = total_bytes / s2::CHUNK + n + 1; // >= the batch's chunk count
         hipLaunchKernelGGL(s2::chunk_kernel, dim3((unsigned)((max_chunks + s2::THREADS - 1) / s2::THREADS)),
-                           dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, max_chunks, sel, d_err, cvbuf);
+                           dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, max_chunks, r0, r1, sel, d_err, cvbuf);
     }
     hipLaunchKernelGGL(s2::hash_small_kernel, dim3((unsigned)((n + s2::THREADS - 1) / s2::THREADS)), dim3(s2::THREADS), 0, st, c0, c1,
-                       d_offsets, n, cvbuf, sel, d_err, letters, d_out);
+                       d_offsets, n, r0, r1, cvbuf, sel, d_err, letters, d_out);
     if (max_len > s2::SMALL_CHUNKS * s2::CHUNK) // some sequence has more chunks than one thread should merge
         hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvbuf, sel, d_err,
                            letters, d_out);

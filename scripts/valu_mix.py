@@ -2,7 +2,7 @@
 """Instruction mix of the hot loops of K1 and K3 from the gfx950 disassembly (no GPU needed), priced with the two issue
 classes measured in profiles/r01_valu_issue_rates.md.
 
-    python scripts/valu_mix.py > profiles/r03_valu_mix.json
+    python scripts/valu_mix.py > profiles/valu_mix.json
 
 For each kernel: the device assembly (hipcc -S --cuda-device-only, poly_amd/build.py's flags), the LARGEST loop body
 that contains the kernel's signature instruction (the murmur3 chain's v_mad_u64_u32 / the packed maximum3), and its VALU
@@ -27,7 +27,7 @@ from poly_amd import build  # noqa: E402
 FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshrrev_b32"}
 KERNELS = [
     ("mash_sketch.hip", r"sketch_slab_kernelILi21E", "v_mad_u64_u32", "K1 polyhip::k1::sketch_slab_kernel<21>"),
-    ("sw_packed.hip", r"sw_pk_kernelILi152ELb0ELb1E", "v_pk_maximum3_f16", "K3 polyhip::k3p::sw_pk_kernel<152,false,true>"),
+    ("sw_packed.hip", r"sw_pk1_kernelILi152ELb0E", "v_pk_maximum3_f16", "K3 polyhip::k3p::sw_pk1_kernel<152,false>"),
 ]
 
 
