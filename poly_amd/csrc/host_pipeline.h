@@ -44,6 +44,22 @@ struct HostStreams {
             dev = cur;
         return e;
     }
+    // a fan-out worker that ends (its device list was replaced) gives its streams back; the calling threads of a host
+    // program keep theirs for the life of the process
+    void destroy()
+    {
+        for (int q = 0; q < 2; ++q)
+            if (s[q]) {
+                (void)hipStreamSynchronize(s[q]);
+                (void)hipStreamDestroy(s[q]);
+                s[q] = nullptr;
+            }
+        if (ev) {
+            (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
+        dev = -1;
+    }
     hipError_t sync_both()
     {
         hipError_t e = hipStreamSynchronize(s[0]);

@@ -1,5 +1,6 @@
 // multi_device.hip -- the process-wide device list and its worker threads (see multi_device.h).
 #include "multi_device.h"
+#include "host_pipeline.h"
 
 #include <condition_variable>
 #include <cstring>
@@ -42,8 +43,10 @@ struct Worker {
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return stop || !q.empty(); });
-                if (q.empty())
-                    return; // stop, and nothing left to do
+                if (q.empty()) { // stop, and nothing left to do
+                    host_streams().destroy();
+                    return;
+                }
                 t = q.front();
                 q.pop_front();
             }
