@@ -125,7 +125,17 @@ struct PackedSlot {
     }
 };
 
-constexpr uint64_t HOST_CHUNK_BYTES = 64ull << 20;
+// chunk size of the two-slot host pipelines; POLYHIP_HOST_CHUNK_MB=<n> overrides it (testing / tuning aid)
+inline uint64_t host_chunk_bytes()
+{
+    if (const char *e = getenv("POLYHIP_HOST_CHUNK_MB")) {
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v >= 1 && v <= 65536)
+            return v << 20;
+    }
+    return 64ull << 20;
+}
+#define HOST_CHUNK_BYTES (::polyhip::host_chunk_bytes())
 
 // mash_distance.hip: row blocks of the shared-count / distance matrix from device-resident sketches to host buffers
 int k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const uint32_t *dY, uint64_t ny, uint32_t sy,
