@@ -939,7 +939,11 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             // buckets at a time: the first 128 items of each are loaded back to back (a family's copies of one hash are
             // one bucket), then consumed.
             constexpr uint32_t NW = DENSE_THREADS / 64;
+#ifdef PH_K2_NOWALK // ablation probe (wrong counts): how long is a row without its bucket walk?
+            for (uint32_t jb = 0; false && wave + NW * jb < nd; jb += 64) {
+#else
             for (uint32_t jb = 0; wave + NW * jb < nd; jb += 64) {
+#endif
                 const uint32_t mine = wave + NW * (jb + lane);
                 uint32_t mval = 0, mlim = 0, mbeg = 0, mend = 0; // beyond nd: an empty bucket
                 if (mine < nd) {
@@ -1023,7 +1027,11 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                 // counter dwords once, clears them, and sends each of their PER fields to its own run of eight columns
                 // (field k = columns [k * ndw, (k + 1) * ndw), k * ndw a multiple of 8: all stores 16-byte aligned)
                 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+#ifdef PH_K2_NOFLUSH // ablation probe (nothing written): how long is a row without its flush?
+                for (uint32_t t = tid * 8; false && t < ndw; t += DENSE_THREADS * 8) {
+#else
                 for (uint32_t t = tid * 8; t < ndw; t += DENSE_THREADS * 8) {
+#endif
                     const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
                     const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
                     *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
