@@ -64,3 +64,33 @@ def test_no_cpu_fallback():
     with pytest.raises(_lib.PolyhipError) as ei:
         mash.New(21, 10).Sketch("ACGT" * 20)
     assert ei.value.status == _lib.ERR_HIP
+
+
+def test_device_list_without_gpu():
+    """polyhip_set_devices / polyhip_init (include/polyhip.h, "one host call over several GPUs"): without a usable device a
+    non-empty list is refused with POLYHIP_ERR_HIP or _INVALID (never installed), the empty list is always fine, and a
+    POLYHIP_DEVICES value that cannot be honoured is ignored at start-up -- the fan-out is no CPU fallback either."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from poly_amd import _lib, devices
+    assert devices.get_devices() == []
+    devices.set_devices([])
+    for call in (lambda: devices.set_devices([0]), lambda: devices.set_devices([0, 0, 0]), lambda: devices.init(2)):
+        with pytest.raises(_lib.PolyhipError) as ei:
+            call()
+        assert ei.value.status in (_lib.ERR_HIP, _lib.ERR_INVALID)
+        assert devices.get_devices() == []
+    with pytest.raises(_lib.PolyhipError):
+        _lib.check(_lib.lib().polyhip_set_devices(None, 3))  # ids missing
+    with pytest.raises(_lib.PolyhipError):
+        _lib.check(_lib.lib().polyhip_set_devices(None, 65))  # more than the 64 a list holds
+    code = ("from poly_amd import _lib, devices, mash\n"
+            "print('list', devices.get_devices())\n"
+            "try:\n    mash.New(21, 10).Sketch('ACGT' * 20)\nexcept _lib.PolyhipError as e:\n    print('status', e.status)\n")
+    env = dict(os.environ, POLYHIP_DEVICES="0,0,0", PYTHONPATH=ROOT)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "list []" in res.stdout and f"status {_lib.ERR_HIP}" in res.stdout, res.stdout + res.stderr
