@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -222,9 +223,11 @@ __device__ __forceinline__ uint32_t load4(const uint8_t *p)
 __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restrict__ seqs,
                                                          const uint64_t *__restrict__ offs, uint64_t n, int seq_type,
                                                          int want_rc, uint8_t *__restrict__ norm,
-                                                         uint8_t *__restrict__ rc, uint32_t *__restrict__ err)
+                                                         uint8_t *__restrict__ rc, uint32_t *__restrict__ err,
+                                                         unsigned long long *__restrict__ first_non_ascii)
 {
     __shared__ unsigned long long first_bad; // (position << 8) | letter
+    __shared__ unsigned long long first_hi;  // position of the sequence's first byte >= 0x80 (the host flavour refuses those)
     __shared__ uint8_t upL[256], cmpL[256], okL[256];
     {
         const uint32_t b = threadIdx.x; // THREADS == 256
@@ -239,13 +242,20 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
         const uint64_t o0 = offs[q], len = offs[q + 1] - o0;
         const uint8_t *src = seqs + o0;
         __syncthreads();
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             first_bad = ~0ull;
+            first_hi = ~0ull;
+        }
         __syncthreads();
+        auto flag = [&](uint64_t t, uint32_t b) { // a letter outside the alphabet (rare: off the fast path)
+            atomicMin(&first_bad, ((unsigned long long)t << 8) | upL[b]);
+            if (b & 0x80u)
+                atomicMin(&first_hi, (unsigned long long)t);
+        };
         auto one = [&](uint64_t t) { // byte t of the sequence -> norm[t], rc[len-1-t]
             const uint32_t b = src[t], c = upL[b];
             if (!okL[b])
-                atomicMin(&first_bad, ((unsigned long long)t << 8) | c);
+                flag(t, b);
             norm[o0 + t] = (uint8_t)c;
             if (want_rc)
                 rc[o0 + (len - 1 - t)] = cmpL[b];
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
                     const uint64_t t = threadIdx.x < 4 ? threadIdx.x : tail0 + (threadIdx.x - 4);
                     const uint32_t b = src[t];
                     if (!okL[b])
-                        atomicMin(&first_bad, ((unsigned long long)t << 8) | upL[b]);
+                        flag(t, b);
                     dst[t] = upL[b];
                 }
                 uint32_t *od = reinterpret_cast<uint32_t *>(dst + head);
@@ -275,7 +285,7 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
                     for (int k = 0; k < 4; ++k) {
                         const uint32_t b = (w >> (8 * k)) & 0xFFu;
                         if (!okL[b])
-                            atomicMin(&first_bad, ((unsigned long long)(t + k) << 8) | upL[b]);
+                            flag(t + k, b);
                         o |= (uint32_t)upL[b] << (8 * k);
                     }
                     od[d] = o;
@@ -300,8 +310,11 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
             err[q] = first_bad == ~0ull ? 0u : (((seq_type == 2 ? 3u : 2u) << 8) | (uint32_t)(first_bad & 0xFF));
+            if (first_hi != ~0ull) // byte offset inside the batch: the host flavour names it and refuses the call
+                atomicMin(first_non_ascii, (unsigned long long)(o0 - offs[0]) + first_hi);
+        }
     }
 }
 
@@ -590,8 +603,12 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     uint32_t *sel = reinterpret_cast<uint32_t *>(w + L.off_sel);
 
     const unsigned blocks = (unsigned)std::min<uint64_t>(n, 256ull * 32ull);
+    // the workspace's first word: batch offset of the first byte >= 0x80, all ones if there is none (what the reference
+    // would treat as UTF-8; polyhip_seqhash_batch reads it back and refuses the call, a device-pointer caller may)
+    unsigned long long *non_ascii = reinterpret_cast<unsigned long long *>(w);
+    PH_HIP(hipMemsetAsync(non_ascii, 0xFF, 8, st));
     hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type,
-                       double_stranded ? 1 : 0, norm, rc, d_err);
+                       double_stranded ? 1 : 0, norm, rc, d_err, non_ascii);
     PH_HIP(hipGetLastError());
     const uint8_t *c0 = norm, *c1 = rc;
     if (circular) { // the index only: the rotated strings are never written (select / chunk / hash read through the index)
@@ -641,14 +658,13 @@ static int seqhash_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint6
                    (unsigned long long)(i + md::base().item));
         max_len = std::max(max_len, offsets[i + 1] - offsets[i]);
     }
-    const uint64_t b0 = offsets[0], nbytes = offsets[n] - b0;
-    {
-        const uint64_t i = first_non_ascii(seqs + b0, nbytes);
-        PH_REQUIRE(i == nbytes, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)", seqs[b0 + i],
-                   (unsigned long long)(i + md::base().byte));
-    }
-    // chunks of ~64 MB through two slots on the calling thread's two streams: chunk c is uploaded and hashed while the
-    // seqhashes of chunk c-1 travel back
+    (void)max_len;
+    // Bytes >= 0x80 (refused: Go would treat them as UTF-8) are found by the DEVICE's normalising pass, which reads every
+    // byte anyway, and reported through the first word of the workspace -- the host scan of round 3 was 11 of the 27 ms
+    // a 100k x 5 kb batch took from host memory.
+    // Chunks of ~64 MB through two slots on the calling thread's two streams: chunk c is uploaded and hashed while the
+    // seqhashes of chunk c-1 travel back (its download is issued AFTER chunk c's kernels: a download into pageable memory
+    // holds the host until the data is there).
     HostStreams &hs = host_streams();
     PH_HIP(hs.init());
     const Chunks ch = cut_packed(offsets, n, 76, HOST_CHUNK_BYTES);
@@ -663,6 +679,17 @@ static int seqhash_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint6
         PH_HIP(slot[q].derr.alloc(ch.max_items * 4));
         PH_HIP(slot[q].dwork.alloc(wb));
     }
+    std::vector<unsigned long long> hi(ch.count(), ~0ull); // per chunk: offset of its first byte >= 0x80
+    auto download = [&](size_t c) -> hipError_t {
+        Slot &S = slot[c & 1];
+        const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0;
+        hipError_t e = hipMemcpyAsync(out + i0 * 72, S.dout.p, m * 72, hipMemcpyDeviceToHost, S.in.st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(err + i0, S.derr.p, m * 4, hipMemcpyDeviceToHost, S.in.st);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(&hi[c], S.dwork.p, 8, hipMemcpyDeviceToHost, S.in.st);
+        return e;
+    };
     for (size_t c = 0; c < ch.count(); ++c) {
         Slot &S = slot[c & 1];
         const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0, cb = offsets[i0 + m] - offsets[i0];
@@ -677,10 +704,17 @@ static int seqhash_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint6
             (void)hs.sync_both();
             return rc;
         }
-        PH_HIP(hipMemcpyAsync(out + i0 * 72, S.dout.p, m * 72, hipMemcpyDeviceToHost, S.in.st));
-        PH_HIP(hipMemcpyAsync(err + i0, S.derr.p, m * 4, hipMemcpyDeviceToHost, S.in.st));
+        if (c > 0)
+            PH_HIP(download(c - 1));
     }
+    PH_HIP(download(ch.count() - 1));
     PH_HIP(hs.sync_both());
+    for (size_t c = 0; c < ch.count(); ++c)
+        if (hi[c] != ~0ull) {
+            const uint64_t at = offsets[ch.cut[c]] - offsets[0] + hi[c];
+            return set_error(POLYHIP_ERR_INVALID, "polyhip_seqhash_batch: byte 0x%02x at %llu is not ASCII (Go would case-fold it as UTF-8)",
+                             seqs[offsets[0] + at], (unsigned long long)(at + md::base().byte));
+        }
     return POLYHIP_OK;
 }
 

@@ -206,3 +206,34 @@ def test_clone_example_golden():
     assert sh.RotateSequence(gg) == gg
     rots = [gg[r:] + gg[:r] for r in range(0, len(gg), 11)]
     assert set(sh.RotateBatch(rots) if hasattr(sh, "RotateBatch") else [sh.RotateSequence(x) for x in rots]) == {gg}
+
+
+def test_bytes_above_0x7f_are_refused_with_their_position():
+    """seqhash.go:143 upper-cases the sequence as UTF-8: a byte >= 0x80 is (part of) a rune the alphabet check then names --
+    the C ABI refuses such a batch (POLYHIP_ERR_INVALID with the byte and its offset; the Go overlay routes those sequences
+    to the reference's own body).  Since round 4 the byte is found by the device's normalising pass, chunk by chunk, not by a
+    host scan: first offending byte of the batch, also behind an earlier ASCII letter that is merely outside the alphabet,
+    also on a device list, also in a later chunk of the host pipeline."""
+    import os
+    from poly_amd import _lib, devices, seqhash
+    rng = np.random.default_rng(91)
+    seqs = [bytes(rng.choice(list(b"ACGT"), int(L)).astype(np.uint8)) for L in rng.integers(50, 4000, 300)]
+    seqs[20] = b"ACGTXACGT"                      # an alphabet error (per-sequence code), not a refusal
+    buf, offs = __import__("poly_amd.mash", fromlist=["_pack"])._pack(seqs)
+    hs, err = seqhash.seqhash_batch_packed(buf, offs, 0, True, True)
+    assert err[20] == ((2 << 8) | ord("X")) and hs[19] == orc.seqhash(seqs[19], "DNA", True, True)
+    bad = buf.copy()
+    at = int(offs[200]) + 7
+    bad[at] = 0xC3
+    bad[int(offs[250]) + 1] = 0xFF               # a later one: the first is named
+    for ids, chunk_mb in (([], None), ([0, 0, 0], None), ([], "1")):
+        devices.set_devices(ids)
+        if chunk_mb:
+            os.environ["POLYHIP_HOST_CHUNK_MB"] = chunk_mb  # ~1 MB chunks: the byte sits in a later chunk
+        try:
+            with pytest.raises(_lib.PolyhipError) as e:
+                seqhash.seqhash_batch_packed(bad, offs, 0, True, True)
+        finally:
+            os.environ.pop("POLYHIP_HOST_CHUNK_MB", None)
+            devices.set_devices([])
+        assert e.value.status == _lib.ERR_INVALID and f"byte 0xc3 at {at} is not ASCII" in e.value.message, e.value.message
