@@ -5,6 +5,11 @@
 #pragma once
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -123,6 +128,141 @@ struct PackedSlot {
             e = hipMemcpyAsync(dseq.p, seqs + b0, offsets[i0 + m] - b0, hipMemcpyHostToDevice, st);
         return e;
     }
+};
+
+// A helper thread per host call that runs the call's DOWNLOADS.  A copy between the device and pageable host memory holds
+// the calling thread until the bytes are across, so one thread alone takes uploads and downloads in turns and uses half of
+// the duplex link; with the downloads of finished chunks on this thread, chunk c + 1 goes up while chunk c comes down
+// (a Go slice is pageable memory: this is the case that matters for cgo callers).  Jobs run in the order they were pushed.
+class Downloader {
+  public:
+    explicit Downloader(int device) : dev_(device), th_([this] { loop(); }) {}
+    ~Downloader()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+    void push(std::function<hipError_t()> job)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            q_.push_back(std::move(job));
+        }
+        cv_.notify_all();
+    }
+    // until `count` jobs have finished; the first error any job returned
+    hipError_t wait(size_t count)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [&] { return done_ >= count; });
+        return err_;
+    }
+
+  private:
+    void loop()
+    {
+        (void)hipSetDevice(dev_);
+        for (;;) {
+            std::function<hipError_t()> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || next_ < q_.size(); });
+                if (next_ >= q_.size())
+                    return;
+                job = std::move(q_[next_++]);
+            }
+            const hipError_t e = job();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (e != hipSuccess && err_ == hipSuccess)
+                    err_ = e;
+                ++done_;
+            }
+            cv_.notify_all();
+        }
+    }
+    int dev_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<std::function<hipError_t()>> q_;
+    size_t next_ = 0, done_ = 0;
+    hipError_t err_ = hipSuccess;
+    bool stop_ = false;
+    std::thread th_; // last: the thread starts when everything above exists
+};
+
+// The two-slot pipelines' download side: chunk c's results travel back on a helper thread and a stream of their own while
+// the calling thread uploads chunk c + 1 (both directions of the link at once).  With a single chunk there is nothing to
+// overlap and no thread is started: the copies run on the slot's own stream.
+//     Duplex dx;  dx.init(nchunks);
+//     for c:  dx.slot_free(c);  upload + launch on st;  dx.download(c, st, [=](hipStream_t s) { return hipMemcpyAsync(.., s); });
+//     dx.finish();
+class Duplex {
+  public:
+    ~Duplex()
+    {
+        dl_.reset(); // drains the queue and joins
+        for (hipEvent_t e : ev_)
+            if (e)
+                (void)hipEventDestroy(e);
+        if (ds_) {
+            (void)hipStreamSynchronize(ds_);
+            (void)hipStreamDestroy(ds_);
+        }
+    }
+    hipError_t init(size_t nchunks)
+    {
+        if (nchunks < 2)
+            return hipSuccess;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        for (int q = 0; q < 2 && e == hipSuccess; ++q)
+            e = hipEventCreateWithFlags(&ev_[q], hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipStreamCreateWithFlags(&ds_, hipStreamNonBlocking);
+        if (e == hipSuccess)
+            dl_.reset(new Downloader(dev));
+        return e;
+    }
+    // the slot of chunk c is free again: chunk c - 2's download (and so its kernels and uploads) is through
+    hipError_t slot_free(size_t c, hipStream_t slot_stream)
+    {
+        if (!dl_)
+            return hipStreamSynchronize(slot_stream);
+        return c >= 2 ? dl_->wait(c - 1) : hipSuccess;
+    }
+    // everything enqueued on `slot_stream` so far produces chunk c's results; `copies(stream)` enqueues their downloads
+    hipError_t download(size_t c, hipStream_t slot_stream, std::function<hipError_t(hipStream_t)> copies)
+    {
+        if (!dl_)
+            return copies(slot_stream);
+        hipEvent_t ev = ev_[c & 1];
+        const hipError_t e = hipEventRecord(ev, slot_stream);
+        if (e != hipSuccess)
+            return e;
+        hipStream_t ds = ds_;
+        dl_->push([=]() -> hipError_t {
+            hipError_t x = hipStreamWaitEvent(ds, ev, 0);
+            if (x == hipSuccess)
+                x = copies(ds);
+            if (x == hipSuccess)
+                x = hipStreamSynchronize(ds);
+            return x;
+        });
+        ++pushed_;
+        return hipSuccess;
+    }
+    hipError_t finish() { return dl_ ? dl_->wait(pushed_) : hipSuccess; }
+
+  private:
+    std::unique_ptr<Downloader> dl_;
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    hipStream_t ds_ = nullptr;
+    size_t pushed_ = 0;
 };
 
 // chunk size of the two-slot host pipelines; POLYHIP_HOST_CHUNK_MB=<n> overrides it (testing / tuning aid)

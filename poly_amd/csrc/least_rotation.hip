@@ -795,10 +795,16 @@ static int least_rotation_batch_one(const uint8_t *seqs, const uint64_t *offsets
         if (rotated)
             PH_HIP(slot[q].dout.alloc(ch.max_bytes + 16));
     }
+    // the rotated sequences are as many bytes as went up: their download runs on the pipeline's helper thread, beside the
+    // next chunk's upload.  (100k x 5 kb: 19.7 -> 18.5 ms only: with two slots chunk c + 2's upload waits for chunk c's
+    // download, and this runtime's pageable copies slow each other down when both directions run -- 64 MB down takes 2.7 ms
+    // beside an upload against 1.2 ms alone; K1, whose uploads are 2.5x its downloads, gains 1.3x from the same helper.)
+    Duplex dx;
+    PH_HIP(dx.init(ch.count()));
     for (size_t c = 0; c < ch.count(); ++c) {
         Slot &S = slot[c & 1];
         const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0, cb = offsets[i0 + m] - offsets[i0];
-        PH_HIP(hipStreamSynchronize(S.in.st)); // chunk c-2 has left this slot
+        PH_HIP(dx.slot_free(c, S.in.st)); // chunk c-2 has left this slot
         PH_HIP(S.in.upload(seqs, offsets, i0, m));
         uint64_t ml = 0;
         for (uint64_t i = 0; i < m; ++i)
@@ -806,13 +812,21 @@ static int least_rotation_batch_one(const uint8_t *seqs, const uint64_t *offsets
         const int rc = polyhip_least_rotation_batch_dev(S.in.dseq.as<uint8_t>(), S.in.doff.as<uint64_t>(), m, ml, S.drot.as<uint64_t>(),
                                                         rotated ? S.dout.as<uint8_t>() : nullptr, S.in.st);
         if (rc != POLYHIP_OK) {
+            (void)dx.finish();
             (void)hs.sync_both();
             return rc;
         }
-        PH_HIP(hipMemcpyAsync(rot_index + i0, S.drot.p, m * 8, hipMemcpyDeviceToHost, S.in.st));
-        if (rotated && cb)
-            PH_HIP(hipMemcpyAsync(rotated + offsets[i0], S.dout.p, cb, hipMemcpyDeviceToHost, S.in.st));
+        uint64_t *dst_rot = rot_index + i0;
+        uint8_t *dst_seq = rotated && cb ? rotated + offsets[i0] : nullptr;
+        const void *src_rot = S.drot.p, *src_seq = S.dout.p;
+        PH_HIP(dx.download(c, S.in.st, [=](hipStream_t st) -> hipError_t {
+            hipError_t e = hipMemcpyAsync(dst_rot, src_rot, m * 8, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess && dst_seq)
+                e = hipMemcpyAsync(dst_seq, src_seq, cb, hipMemcpyDeviceToHost, st);
+            return e;
+        }));
     }
+    PH_HIP(dx.finish());
     PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }

@@ -479,22 +479,38 @@ static int run_batch_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t
         for (int o = 0; o < NOUT; ++o)
             PH_HIP(slot[q].d[o].alloc(ch.max_items * 8));
     }
+    Duplex dx; // the planes travel back on the pipeline's helper thread while the next chunk goes up
+    PH_HIP(dx.init(ch.count()));
     for (size_t c = 0; c < ch.count(); ++c) {
         Slot &S = slot[c & 1];
         const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0;
-        PH_HIP(hipStreamSynchronize(S.in.st)); // chunk c-2 has left this slot
+        PH_HIP(dx.slot_free(c, S.in.st)); // chunk c-2 has left this slot
         PH_HIP(S.in.upload(seqs, offsets, i0, m));
         double *dd[NOUT];
         for (int o = 0; o < NOUT; ++o)
             dd[o] = S.d[o].template as<double>();
         const int rc = launch(S.in.dseq.template as<uint8_t>(), S.in.doff.template as<uint64_t>(), m, dd, S.in.st);
         if (rc != POLYHIP_OK) {
+            (void)dx.finish();
             (void)hs.sync_both();
             return rc;
         }
-        for (int o = 0; o < NOUT; ++o)
-            PH_HIP(hipMemcpyAsync(outs[o] + i0, dd[o], m * 8, hipMemcpyDeviceToHost, S.in.st));
+        struct Planes {
+            double *dst[NOUT];
+            const double *src[NOUT];
+        } pl;
+        for (int o = 0; o < NOUT; ++o) {
+            pl.dst[o] = outs[o] + i0;
+            pl.src[o] = dd[o];
+        }
+        PH_HIP(dx.download(c, S.in.st, [=](hipStream_t st) -> hipError_t {
+            hipError_t e = hipSuccess;
+            for (int o = 0; o < NOUT && e == hipSuccess; ++o)
+                e = hipMemcpyAsync(pl.dst[o], pl.src[o], m * 8, hipMemcpyDeviceToHost, st);
+            return e;
+        }));
     }
+    PH_HIP(dx.finish());
     PH_HIP(hs.sync_both());
     return POLYHIP_OK;
 }
