@@ -442,23 +442,39 @@ __device__ __forceinline__ uint32_t newline_mask16(const uint8_t *__restrict__ a
 // newlines per 4096-byte window
 // (also leaves every 16-byte chunk's masks -- 2 (FASTQ) or 4 (FASTA) bytes per 16 of file -- so that the ranked write below
 // does not read the file a second time: 51 MB instead of 408 MB for the bench's image)
+constexpr int COUNT_SUB = 4; // 4 KB windows per workgroup of the count pass
 template <bool SPEC, class MaskT>
 __global__ __launch_bounds__(THREADS) void count_newlines_kernel(const uint8_t *__restrict__ abase, uint32_t mis,
-                                                                uint64_t nbytes, uint32_t *__restrict__ counts,
+                                                                uint64_t nbytes, uint64_t nblocks, uint32_t *__restrict__ counts,
                                                                 MaskT *__restrict__ masks)
 {
-    __shared__ uint32_t ws[THREADS / 64];
-    const uint32_t mk = newline_mask16<SPEC>(abase, (uint64_t)blockIdx.x * THREADS + threadIdx.x, mis, nbytes);
-    masks[(uint64_t)blockIdx.x * THREADS + threadIdx.x] = (MaskT)mk;
-    uint32_t c = (uint32_t)__popc(mk & 0xFFFFu);
+    // COUNT_SUB windows of 4 KB per workgroup, their four 16-byte loads per lane in flight together (one window per
+    // workgroup was 100k workgroups of one load each for a 400 MB image: 3.5 TB/s); a count per 4 KB window as before
+    __shared__ uint32_t ws[COUNT_SUB][THREADS / 64];
+    uint32_t mk[COUNT_SUB];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        c += (uint32_t)__shfl_xor((int)c, d, 64);
-    if ((threadIdx.x & 63) == 0)
-        ws[threadIdx.x >> 6] = c;
+    for (int q = 0; q < COUNT_SUB; ++q) {
+        const uint64_t blk = (uint64_t)blockIdx.x * COUNT_SUB + q;
+        mk[q] = blk < nblocks ? newline_mask16<SPEC>(abase, blk * THREADS + threadIdx.x, mis, nbytes) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < COUNT_SUB; ++q) {
+        const uint64_t blk = (uint64_t)blockIdx.x * COUNT_SUB + q;
+        if (blk < nblocks)
+            masks[blk * THREADS + threadIdx.x] = (MaskT)mk[q];
+        uint32_t c = (uint32_t)__popc(mk[q] & 0xFFFFu);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            c += (uint32_t)__shfl_xor((int)c, d, 64);
+        if ((threadIdx.x & 63) == 0)
+            ws[q][threadIdx.x >> 6] = c;
+    }
     __syncthreads();
-    if (threadIdx.x == 0)
-        counts[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+    if (threadIdx.x < COUNT_SUB) {
+        const uint64_t blk = (uint64_t)blockIdx.x * COUNT_SUB + threadIdx.x;
+        if (blk < nblocks)
+            counts[blk] = ws[threadIdx.x][0] + ws[threadIdx.x][1] + ws[threadIdx.x][2] + ws[threadIdx.x][3];
+    }
 }
 
 // line_end[k] = file-relative position of the k-th '\n'.  A wave per 4096-byte window (the unit the counts were scanned in), four
@@ -1050,8 +1066,8 @@ int polyhip_fastq_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(res + fq::R_FIRSTBAD, 0xFF, 8, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
     const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
-    hipLaunchKernelGGL((fq::count_newlines_kernel<false, uint16_t>), dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis,
-                       nbytes, counts, reinterpret_cast<uint16_t *>(w + L.off_masks));
+    hipLaunchKernelGGL((fq::count_newlines_kernel<false, uint16_t>), dim3((unsigned)((L.nblocks + fq::COUNT_SUB - 1) / fq::COUNT_SUB)), dim3(fq::THREADS), 0, st, abase, mis,
+                       nbytes, (uint64_t)L.nblocks, counts, reinterpret_cast<uint16_t *>(w + L.off_masks));
     if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
     hipLaunchKernelGGL((fq::write_newlines_kernel<false, uint16_t>), dim3((unsigned)((L.nblocks + 3) / 4)), dim3(fq::THREADS), 0, st,
@@ -1143,8 +1159,8 @@ int polyhip_fasta_pack_dev(const uint8_t *d_file, uint64_t nbytes, uint8_t *d_se
     PH_HIP(hipMemsetAsync(dst, 0, 16, st));
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(d_file) & 15u);
     const uint8_t *abase = d_file - mis; // 16-byte aligned; bytes in front of the file are masked out
-    hipLaunchKernelGGL((fq::count_newlines_kernel<true, uint32_t>), dim3((unsigned)L.nblocks), dim3(fq::THREADS), 0, st, abase, mis,
-                       nbytes, counts, reinterpret_cast<uint32_t *>(w + L.off_masks));
+    hipLaunchKernelGGL((fq::count_newlines_kernel<true, uint32_t>), dim3((unsigned)((L.nblocks + fq::COUNT_SUB - 1) / fq::COUNT_SUB)), dim3(fq::THREADS), 0, st, abase, mis,
+                       nbytes, (uint64_t)L.nblocks, counts, reinterpret_cast<uint32_t *>(w + L.off_masks));
     if (int rc = scan_u32(counts, L.nblocks, nullptr, 1, L.nblocks, blockoff, scanpart, st))
         return rc;
     hipLaunchKernelGGL((fq::write_newlines_kernel<true, uint32_t>), dim3((unsigned)((L.nblocks + 3) / 4)), dim3(fq::THREADS), 0, st,
