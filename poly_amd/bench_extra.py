@@ -578,9 +578,11 @@ def e2e_fanout_check(dev) -> dict:
 
 
 def run(dev, host_devices=None) -> dict:
+    # (the 1 kb leg: 80k pairs fill the chip at 8 lanes per pair -- 6.1e12 cell updates/s; 20k pairs leave it a third full: 4.3e12)
     out = {}
     for name, fn in (("smith_waterman", sw), ("smith_waterman_250bp", lambda d: sw(d, 400_000, 250)),
-                     ("smith_waterman_1kb", lambda d: sw(d, 80_000, 1000)),  # 80k pairs fill the chip (8 lanes per pair); 20k measure 4.3e12, 80k 6.1e12 ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
+                     ("smith_waterman_1kb", lambda d: sw(d, 80_000, 1000)),
+                     ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder),
                      ("fasta_feeder", fasta_feeder), ("e2e_host_pointers", lambda d: e2e(d, host_devices)),
                      ("e2e_fanout_check", e2e_fanout_check)):
