@@ -795,12 +795,13 @@ static int least_rotation_batch_one(const uint8_t *seqs, const uint64_t *offsets
         if (rotated)
             PH_HIP(slot[q].dout.alloc(ch.max_bytes + 16));
     }
-    // the rotated sequences are as many bytes as went up: their download runs on the pipeline's helper thread, beside the
-    // next chunk's upload.  (100k x 5 kb: 19.7 -> 18.5 ms only: with two slots chunk c + 2's upload waits for chunk c's
-    // download, and this runtime's pageable copies slow each other down when both directions run -- 64 MB down takes 2.7 ms
-    // beside an upload against 1.2 ms alone; K1, whose uploads are 2.5x its downloads, gains 1.3x from the same helper.)
+    // The rotated sequences are as many bytes as went up.  Their download on the pipeline's helper thread (Duplex) beside
+    // the next chunk's upload does NOT pay here: with two slots chunk c + 2's upload waits for chunk c's download, and this
+    // runtime's pageable copies slow each other down when both directions run (64 MB down takes 2.7 ms beside an upload
+    // against 1.2 ms alone) -- 19.7 -> 18.5 ms on one box, 19.4 -> 22.6 on another.  K1, whose uploads are 2.5x its
+    // downloads, gains 1.3x from the same helper; this call keeps the copies on the slot's own stream (init(0)).
     Duplex dx;
-    PH_HIP(dx.init(ch.count()));
+    PH_HIP(dx.init(0));
     for (size_t c = 0; c < ch.count(); ++c) {
         Slot &S = slot[c & 1];
         const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0, cb = offsets[i0 + m] - offsets[i0];

@@ -479,8 +479,8 @@ static int run_batch_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t
         for (int o = 0; o < NOUT; ++o)
             PH_HIP(slot[q].d[o].alloc(ch.max_items * 8));
     }
-    Duplex dx; // the planes travel back on the pipeline's helper thread while the next chunk goes up
-    PH_HIP(dx.init(ch.count()));
+    Duplex dx; // (as many bytes come back as go up: no helper thread, see least_rotation.hip)
+    PH_HIP(dx.init(0));
     for (size_t c = 0; c < ch.count(); ++c) {
         Slot &S = slot[c & 1];
         const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0;
