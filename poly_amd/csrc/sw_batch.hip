@@ -682,6 +682,18 @@ size_t polyhip_sw_workspace_bytes(const polyhip_scoring *sc, uint64_t npairs, ui
     return k3::plan(sc, npairs, max_lenA, lenB, shared_B != 0).work_bytes;
 }
 
+} // extern "C"
+void polyhip::k3::score_choice(int *path, int *half, bool set)
+{
+    if (set) {
+        g_last_path = *path;
+        g_last_half = *half;
+    } else {
+        *path = g_last_path;
+        *half = g_last_half;
+    }
+}
+extern "C" {
 int polyhip_sw_last_path(void) { return k3::g_last_path; }
 int polyhip_sw_last_packed_half(void) { return k3::g_last_half; }
 
@@ -915,11 +927,20 @@ int polyhip_sw_batch(const polyhip_scoring *sc, const uint8_t *A, const uint64_t
     // pairs are independent -- the reads split by bytes, the shared reference goes to every device
     PH_REQUIRE(offA && score && endA && endB && err, "polyhip_sw_batch: null pointer");
     const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 24);
-    return md::run(*P, [&](size_t q) {
+    size_t first = 0;
+    while (first + 1 < md::size(*P) && cut[first + 1] == cut[first])
+        ++first;
+    KernelChoice kc;
+    const int rc = md::run(*P, [&](size_t q) {
         const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
         md::BaseScope pos(i0, 0);
-        return sw_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0, err + i0);
+        const int r = sw_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0, err + i0);
+        if (q == first)
+            kc = kernel_choice_get();
+        return r;
     });
+    kernel_choice_set(kc);
+    return rc;
 }
 
 } // extern "C"

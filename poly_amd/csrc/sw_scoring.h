@@ -62,6 +62,16 @@ struct polyhip_scoring {
 namespace polyhip {
 // the handle (or its copy) whose tables live on the calling thread's current device; null + polyhip_last_error() on failure
 const polyhip_scoring *scoring_here(const polyhip_scoring *sc);
+// polyhip_sw_last_path & friends are per-thread; a fan-out runs the kernels on worker threads, so the wrapper carries
+// the first non-empty shard's answers back to the caller's thread (sw_batch.hip / sw_traceback.hip own the variables)
+struct KernelChoice {
+    int sw_path = 0, sw_half = 0, tb_path = 0, tb_half = 0, nw_path = 0;
+};
+KernelChoice kernel_choice_get();            // this thread's
+void kernel_choice_set(const KernelChoice &); // ... becomes this
+namespace k3 {
+void score_choice(int *path, int *half, bool set); // sw_batch.hip's two variables
+}
 } // namespace polyhip
 
 // ---- packed score pass (sw_packed.hip), driven from polyhip_sw_batch_dev (sw_batch.hip) ----------------

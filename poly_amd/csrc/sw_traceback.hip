@@ -1845,6 +1845,25 @@ using namespace polyhip;
 
 extern "C" {
 
+} // extern "C"
+polyhip::KernelChoice polyhip::kernel_choice_get()
+{
+    KernelChoice c;
+    k3::score_choice(&c.sw_path, &c.sw_half, false);
+    c.tb_path = k3t::g_tb_last_path;
+    c.tb_half = k3t::g_tb_last_half;
+    c.nw_path = k3t::g_nw_last_path;
+    return c;
+}
+void polyhip::kernel_choice_set(const KernelChoice &c)
+{
+    int p = c.sw_path, h = c.sw_half;
+    k3::score_choice(&p, &h, true);
+    k3t::g_tb_last_path = c.tb_path;
+    k3t::g_tb_last_half = c.tb_half;
+    k3t::g_nw_last_path = c.nw_path;
+}
+extern "C" {
 int polyhip_sw_traceback_last_path(void) { return k3t::g_tb_last_path; }
 int polyhip_sw_traceback_last_half(void) { return k3t::g_tb_last_half; }
 
@@ -2228,13 +2247,22 @@ int polyhip_sw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
     // pairs are independent; a shard's strings land in its own run of the caller's fixed-stride slots
     PH_REQUIRE(offA && score && endA && endB && err && alnA && alnB && alnLen, "polyhip_sw_align_batch: null pointer");
     const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 24 + 2ull * aln_stride);
-    return md::run(*P, [&](size_t q) {
+    size_t first = 0;
+    while (first + 1 < md::size(*P) && cut[first + 1] == cut[first])
+        ++first;
+    KernelChoice kc;
+    const int rc = md::run(*P, [&](size_t q) {
         const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
         md::BaseScope pos(i0, 0);
-        return sw_align_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0,
-                                  err + i0, alnA + i0 * (size_t)aln_stride, alnB + i0 * (size_t)aln_stride, alnLen + i0,
-                                  aln_stride);
+        const int r = sw_align_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0,
+                                         err + i0, alnA + i0 * (size_t)aln_stride, alnB + i0 * (size_t)aln_stride, alnLen + i0,
+                                         aln_stride);
+        if (q == first)
+            kc = kernel_choice_get();
+        return r;
     });
+    kernel_choice_set(kc); // polyhip_sw_last_path & co. on the caller's thread: what the first shard's kernels were
+    return rc;
 }
 
 // The same with PACKED strings: a pair's strings are a few hundred bytes of its aln_stride-byte slots (151 of 525 at
@@ -2482,14 +2510,22 @@ int polyhip_sw_align_batch_packed(const polyhip_scoring *sc, const uint8_t *A, c
     const size_t nsh = md::size(*P);
     const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 24 + 8 + 2 * 160);
     std::vector<PackedShard> sh(nsh);
+    size_t first = 0;
+    while (first + 1 < nsh && cut[first + 1] == cut[first])
+        ++first;
+    KernelChoice kc;
     int rc = md::run(*P, [&](size_t q) {
         sh[q].i0 = cut[q];
         sh[q].m = cut[q + 1] - cut[q];
         const uint64_t i0 = sh[q].i0;
         md::BaseScope pos(i0, 0);
-        return packed_shard_align(sc, A, offA + i0, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0, err + i0,
-                                  sh[q]);
+        const int r = packed_shard_align(sc, A, offA + i0, B, offB ? offB + i0 : nullptr, lenB, score + i0, endA + i0, endB + i0,
+                                         err + i0, sh[q]);
+        if (q == first)
+            kc = kernel_choice_get();
+        return r;
     });
+    kernel_choice_set(kc);
     if (rc != POLYHIP_OK)
         return rc; // the shards' device buffers go with `sh`
     std::vector<uint64_t> base(nsh + 1, 0);
@@ -2678,12 +2714,21 @@ int polyhip_nw_align_batch(const polyhip_scoring *sc, const uint8_t *A, const ui
         return nw_align_batch_one(sc, A, offA, npairs, B, offB, lenB, score, err, alnA, alnB, alnLen, aln_stride);
     PH_REQUIRE(offA && score && err && alnA && alnB && alnLen, "polyhip_nw_align_batch: null pointer");
     const std::vector<uint64_t> cut = split_pairs(*P, offA, offB, npairs, 16 + 2ull * aln_stride);
-    return md::run(*P, [&](size_t q) {
+    size_t first = 0;
+    while (first + 1 < md::size(*P) && cut[first + 1] == cut[first])
+        ++first;
+    KernelChoice kc;
+    const int rc = md::run(*P, [&](size_t q) {
         const uint64_t i0 = cut[q], m = cut[q + 1] - i0;
         md::BaseScope pos(i0, 0);
-        return nw_align_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, err + i0,
-                                  alnA + i0 * (size_t)aln_stride, alnB + i0 * (size_t)aln_stride, alnLen + i0, aln_stride);
+        const int r = nw_align_batch_one(sc, A, offA + i0, m, B, offB ? offB + i0 : nullptr, lenB, score + i0, err + i0,
+                                         alnA + i0 * (size_t)aln_stride, alnB + i0 * (size_t)aln_stride, alnLen + i0, aln_stride);
+        if (q == first)
+            kc = kernel_choice_get();
+        return r;
     });
+    kernel_choice_set(kc);
+    return rc;
 }
 
 } // extern "C"

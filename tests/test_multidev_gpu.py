@@ -38,6 +38,7 @@ def _single_device_afterwards():
 
 def test_device_list_roundtrip():
     from poly_amd import _lib, devices
+    devices.set_devices([])  # (the suite itself may run under POLYHIP_DEVICES: see the module's last test)
     assert devices.get_devices() == []
     devices.set_devices([0, 0, 0])
     assert devices.get_devices() == [0, 0, 0]
@@ -432,3 +433,20 @@ def test_two_caller_threads_on_two_aliased_devices():
     assert res.returncode == 0, res.stdout + res.stderr
     assert "abi_threads ok: 2 threads" in res.stdout
     assert "device list: 2" in res.stdout
+
+
+def test_other_suites_under_a_device_list():
+    """The parity suites of the other modules -- every host-pointer call they make, their error cases, their
+    polyhip_*_last_path assertions (the fan-out hands the first shard's kernel choice back to the caller's thread) -- once
+    more in a process whose device list is 0,0,0 from the start.  (The whole `-m gpu` suite passes that way; this keeps
+    the part of it that finishes in under a minute in the suite itself.)"""
+    if os.environ.get("POLYHIP_DEVICES"):
+        pytest.skip("already running under a device list")
+    env = dict(os.environ, POLYHIP_DEVICES="0,0,0", PYTHONPATH=ROOT)
+    suites = ["tests/test_align_gpu.py", "tests/test_primers_gpu.py", "tests/test_seqhash_gpu.py", "tests/test_stress_gpu.py",
+              "tests/test_pcr_gpu.py", "tests/test_clone_gpu.py"]
+    res = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu"] + suites, env=env, capture_output=True, text=True,
+                         timeout=1500, cwd=ROOT)
+    tail = (res.stdout + res.stderr)[-2000:]
+    assert res.returncode == 0, tail
+    assert " passed" in res.stdout and "failed" not in res.stdout, tail
