@@ -81,7 +81,7 @@ int polyhip_device_arch(char *buf, size_t buflen);
  * failing shard's, i.e. the first failure in batch order; positions in messages are positions of the whole batch).
  * An id may appear more than once ("0,0,0"): the shards then share that GPU (testing on a one-GPU box).  The _dev
  * entry points, the feeders and polyhip_scoring_create are not affected (a scoring handle is copied to the other
- * devices of the list on first use).  polyhip_sw_last_path and friends describe calls on the calling thread only.
+ * devices of the list on first use).  polyhip_sw_last_path and friends then describe the first non-empty shard's kernels.
  *   polyhip_set_devices(ids, n)  n = 0 clears the list.  Calls in flight finish on the list they started with.
  *   polyhip_get_devices          -> the list's length (ids filled up to `capacity`).
  *   polyhip_init(n)              = polyhip_set_devices({0 .. n-1}); n <= 0: every visible device.
