@@ -651,6 +651,21 @@ def main() -> int:
             tm_extra = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
             line["extra"] = {"smith_waterman": sw_extra, "santalucia_scan": tm_extra}
+            if "cell_updates_per_s" in sw_extra:
+                # the metric's second half at N ranks: every rank's own 1M config-4 reads, the slowest rank sets the time
+                rf1 = (r or {}).get("roofline", {}) if isinstance(r, dict) else {}
+                peak = rf1.get("peak")
+                sec = {"metric": f"align.SmithWaterman cell updates/s (score pass, BASELINE configs[3] per GPU, {world} GPUs, reads sharded, no collective)",
+                       "value": sw_extra["cell_updates_per_s"], "unit": "cell updates/s", "ms_per_step": sw_extra["score_pass_ms"],
+                       "value_with_strings": sw_extra.get("cell_updates_per_s_with_traceback"),
+                       "roofline": {"bound": rf1.get("bound"), "achieved": sw_extra["cell_updates_per_s"] / 1e12,
+                                    "peak": peak * world if peak else None, "unit": "T cell updates/s",
+                                    "frac": sw_extra["cell_updates_per_s"] / 1e12 / (peak * world) if peak else None,
+                                    "kernel": rf1.get("kernel")}}
+                line["roofline"].update({"secondary_metric": "SW cell updates/s", "secondary_value": sec["value"],
+                                         "secondary_ms_per_step": sec["ms_per_step"], "secondary_bound": rf1.get("bound"),
+                                         "secondary_frac": sec["roofline"]["frac"]})
+                line["secondary"] = sec
         # BASELINE configs[2], LAST and under a watchdog: per-rank sketches -> the product's RCCL all-gather -> this
         # rank's row block (the one collective on the path).  It drives a second communicator (libpolyhip's
         # own); if a rank fails inside a step the others would wait in a collective for ever -- the watchdog then
