@@ -450,3 +450,74 @@ def test_other_suites_under_a_device_list():
     tail = (res.stdout + res.stderr)[-2000:]
     assert res.returncode == 0, tail
     assert " passed" in res.stdout and "failed" not in res.stdout, tail
+
+
+def test_full_size_config4_over_a_device_list():
+    """BASELINE configs[3] at full size through ONE host call on the list 0,0,0: all 1,000,000 reads of the contract's
+    generator (windows of the 5 kb reference, 5 % substitutions + 1 % indels) against the shared reference, score + end +
+    packed aligned strings.  Equal to the one-device call array by array (three shards of ~333k pairs, each more than one
+    262,144-pair chunk: the strings' running total crosses chunks AND shards), 400 pairs against the oracle
+    (align.go:171-232), and the size-independent properties on all of them: offsets ascending and consistent with the
+    strings' total, both strings of a pair of one length, a score of 0 exactly where the strings are empty."""
+    import torch
+    from poly_amd import align, devices, workloads
+    sc, omat, gap = _nuc4()
+    n, LA, LB = 1_000_000, 150, 5000
+    B_t, A_t = workloads.config4_reads(n, LA, LB, device=torch.device("cuda:0"))
+    A = A_t.reshape(-1).cpu().numpy()
+    B = B_t.cpu().numpy()
+    del A_t, B_t
+    offA = np.arange(0, (n + 1) * LA, LA, dtype=np.uint64)
+
+    def call():
+        score = np.zeros(n, np.int64)
+        endA, endB, err = (np.zeros(n, np.uint32) for _ in range(3))
+        off = np.zeros(n + 1, np.uint64)
+        cap = n * 170
+        alnA, alnB = np.zeros(cap, np.uint8), np.zeros(cap, np.uint8)
+        from poly_amd import _lib
+        _lib.check(_lib.lib().polyhip_sw_align_batch_packed(
+            sc.handle(), A.ctypes.data, offA.ctypes.data, n, B.ctypes.data, None, LB, score.ctypes.data, endA.ctypes.data,
+            endB.ctypes.data, err.ctypes.data, alnA.ctypes.data, alnB.ctypes.data, off.ctypes.data, cap))
+        return score, endA, endB, err, off, alnA, alnB
+
+    one = call()
+    with devices.devices([0, 0, 0]):
+        got = call()
+    total = int(one[4][n])
+    for q in range(5):
+        assert (got[q] == one[q]).all(), q
+    assert (got[5][:total] == one[5][:total]).all() and (got[6][:total] == one[6][:total]).all()
+    off = got[4].astype(np.int64)
+    lens = np.diff(off)
+    assert off[0] == 0 and (lens >= 0).all() and total == int(lens.sum()) and not got[3].any()
+    assert ((lens == 0) == (got[0] == 0)).all() and lens.max() <= LA + LB
+    rng = np.random.default_rng(4)
+    ref = bytes(B)
+    for p in rng.integers(0, n, 400):
+        w = orc.smith_waterman(bytes(A[p * LA:(p + 1) * LA]), ref, omat, gap)
+        assert (int(got[0][p]), got[5][off[p]:off[p + 1]].tobytes().decode(), got[6][off[p]:off[p + 1]].tobytes().decode(),
+                int(got[1][p]), int(got[2][p])) == w, int(p)
+
+
+def test_full_read_length_sketches_over_a_device_list():
+    """BASELINE configs[1]'s read shape (10 kb, k = 21, s = 1000) through the host call on a device list: 60,000 reads
+    (600 MB: three shards, each several 256 MB chunks of its own pipeline + the download helper), equal to the one-device
+    call, 300 reads against the oracle (mash.go:68-104), every row ascending with no marker left behind."""
+    import torch
+    from poly_amd import devices, mash
+    n, L, k, s = 60_000, 10_000, 21, 1000
+    d = torch.empty(n * L, dtype=torch.uint8, device=torch.device("cuda:0"))
+    mash.synth_dna_dev(0xC2, d)
+    host = d.cpu().numpy()
+    del d
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    one = mash.sketch_batch_packed(host, offs, k, s)
+    with devices.devices([0, 0, 0]):
+        got = mash.sketch_batch_packed(host, offs, k, s)
+    assert (got == one).all()
+    assert (np.diff(got.astype(np.int64), axis=1) >= 0).all()
+    rng = np.random.default_rng(6)
+    for i in rng.integers(0, n, 300):
+        want = orc.mash_sketch_batch(host[i * L:(i + 1) * L], offs[:2], k, s)[0]
+        assert (got[i] == want).all(), int(i)
