@@ -36,6 +36,7 @@
 #include "common.h"
 #include "host_pipeline.h"
 #include "multi_device.h"
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -1482,13 +1483,14 @@ static int sketch_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64
     PH_HIP(hipGetDevice(&dev));
     int rc_loop = POLYHIP_OK;
     {
-        Downloader dl(dev); // joined at the end of this block, before the slots go
+        // (a single chunk -- a single sequence from mash.Sketch -- has nothing to overlap: no helper thread, the copy runs here)
+        std::unique_ptr<Downloader> dlp(nchunks >= 2 ? new Downloader(dev) : nullptr); // joined at the end of this block
         size_t pushed = 0;
         for (size_t c = 0; c < nchunks; ++c) {
             Slot &S = slot[c & 1];
             const uint64_t i0 = cut[c], m = cut[c + 1] - i0, b0 = offsets[i0];
             if (c >= 2) { // chunk c-2 has left this slot: its download is through (and with it its kernels and uploads)
-                const hipError_t e = dl.wait(c - 1);
+                const hipError_t e = dlp->wait(c - 1);
                 if (e != hipSuccess) {
                     rc_loop = set_error(POLYHIP_ERR_HIP, "polyhip_mash_sketch_batch: download: %s", hipGetErrorString(e));
                     break;
@@ -1528,17 +1530,23 @@ static int sketch_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint64
             hipEvent_t ev = S.computed;
             hipStream_t ds = dls.s;
             const size_t bytes = m * row;
-            dl.push([=]() -> hipError_t {
+            auto job = [=]() -> hipError_t {
                 hipError_t x = hipStreamWaitEvent(ds, ev, 0);
                 if (x == hipSuccess)
                     x = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ds);
                 if (x == hipSuccess)
                     x = hipStreamSynchronize(ds);
                 return x;
-            });
-            ++pushed;
+            };
+            if (dlp) {
+                dlp->push(job);
+                ++pushed;
+            } else if ((e = job()) != hipSuccess) {
+                rc_loop = set_error(POLYHIP_ERR_HIP, "polyhip_mash_sketch_batch: download: %s", hipGetErrorString(e));
+                break;
+            }
         }
-        const hipError_t e = dl.wait(pushed);
+        const hipError_t e = dlp ? dlp->wait(pushed) : hipSuccess;
         if (e != hipSuccess && rc_loop == POLYHIP_OK)
             rc_loop = set_error(POLYHIP_ERR_HIP, "polyhip_mash_sketch_batch: download: %s", hipGetErrorString(e));
     }
