@@ -427,7 +427,9 @@ int polyhip_sw_last_path(void);
 int polyhip_sw_last_packed_half(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
- * kernel for reads of 257..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off). */
+ * kernel for reads of 153..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off), 5 = the half-float byte-profile
+ * kernel with TWO LANES per pair (four bands of 64 rows) for reads of 153..256 symbols against one reference under the
+ * half-float condition below (POLYHIP_TB_HALF2=0 or POLYHIP_TB_F16=0: path 4 instead; testing aids). */
 int polyhip_sw_traceback_last_path(void);
 /* 1 when that call's byte-profile kernel (path 1) ran in its half-float form (gfx950: packed halves, two bands of rows
  * per lane, nine instructions per cell pair instead of eighteen) -- taken under the packed score pass's condition

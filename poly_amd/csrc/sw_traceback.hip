@@ -86,8 +86,13 @@ __device__ __forceinline__ uint32_t pair_window(uint32_t wcols, uint32_t eA, int
     const uint64_t g = (uint64_t)(-gap), top = (uint64_t)smax * eA;
     const uint64_t span = eA + (top > (uint64_t)M ? (top - (uint64_t)M) / g : 0);
     const uint64_t over = top + (uint64_t)smax > (uint64_t)M ? (top + (uint64_t)smax - (uint64_t)M) / g + 1 : 0;
-    const uint64_t cand = eA + (wide ? top / g : std::min<uint64_t>(over, top / g));
-    const uint64_t need = span + cand + 2;
+    // Round 4: the two bounds are not independent.  A walk cell in row i sits at column j >= eB - (eA - i) - lw (it is
+    // eA - i rows and at most lw = (smax*eA - M)/|gap| left moves away from the end cell), and a path into one of its
+    // candidates climbs at most i rows: it begins at column >= j - 1 - i - over >= eB - eA - lw - over - 1, wherever on
+    // the walk the cell is.  So the DP needs span + over columns, not span + eA + over: the eA columns "to the left of the
+    // walk" were counted as if the walk could be at its leftmost column while still in its bottom row.  (`wide` keeps the
+    // old sum with every cell of the rows <= eA exact; the tests compare the two on every pair.)
+    const uint64_t need = (wide ? span + eA + top / g : span + std::min<uint64_t>(over, top / g)) + 2;
     return need < wcols ? (uint32_t)need : wcols;
 }
 
@@ -898,6 +903,285 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
     }
     alnLen[pair] = (active && rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
 }
+
+// ---- 153..256 rows on packed halves: TWO LANES per pair, four bands of RB rows ---------------------------------------
+// One lane cannot hold more than two bands of 76 rows at two waves per SIMD (tb_prof16_kernel<128> spills 357 registers
+// into its sweep), and one wave per pair (tb_wave_kernel<4>) pays a lane shift per cell.  So a pair takes the lanes 2p
+// and 2p + 1 of its wave: rows [0, RB) / [RB, 2 RB) in the low / high halves of lane 2p, rows [2 RB, 3 RB) / [3 RB, 4 RB)
+// in those of lane 2p + 1, band b one 4-column block behind band b - 1 -- the same skew as between the two bands of one
+// lane, continued across the lane boundary: what band 1 leaves behind (last row: four values, their gap-decayed copies,
+// one diagonal value) moves from the high halves of lane 2p to the low halves of lane 2p + 1 by one DPP row_shr:1 per
+// register and block (27 instructions against the ~2750 of a block's 64 row pairs).  A lane runs nblk + 3 iterations.
+// Row macros, direction-word layout (per lane) and the walk's arithmetic are tb_prof16_kernel's; the walk is the even
+// lane's, which reads its partner's words too.  A deferred end cell is searched in the wave's last four iterations (band b
+// sweeps the pair's last block in iteration nmax - 1 + b; the even lane's rows come first in row-major order).
+template <int RB>
+__global__ __launch_bounds__(THREADS, 2) void tb_prof16x2_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ B, uint32_t lenB_pad, const uint2 *__restrict__ prof16,
+    const uint8_t *__restrict__ codeA, int ncodes, int gap, uint32_t *__restrict__ endA,
+    uint32_t *__restrict__ endB, uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
+    uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
+    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    static_assert(RB % 16 == 0 && RB <= 64, "RB");
+    constexpr int RL = 2 * RB; // rows per lane
+    constexpr int RA = 4 * RB; // rows per pair
+    constexpr int NG = RB / 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tbf[];
+    const int ncp = ncodes + 1;
+    const uint32_t nqB = lenB_pad / 4; // real blocks; block nqB is the all-pad one
+    const uint32_t pstride = (uint32_t)ncp * 8u;
+    uint2 *P = reinterpret_cast<uint2 *>(lds_tbf);
+    uint8_t *codeL = lds_tbf + (size_t)(nqB + 1) * pstride;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t hl = (uint32_t)lane & 1u; // which half of the pair's rows this lane holds
+    for (uint32_t v = tid; v < (nqB + 1) * (uint32_t)ncp; v += THREADS)
+        P[v] = prof16[v];
+    codeL[tid] = codeA[tid];
+    __syncthreads();
+
+    const uint64_t pair = pair0 + (((uint64_t)blockIdx.x * THREADS + tid) >> 1);
+    const bool active = pair < pair1;
+    uint32_t lenA = 0, eA = 0, eB = 0;
+    int64_t M = 0;
+    const uint8_t *ap = A;
+    uint64_t oA = 0;
+    if (active) {
+        const uint64_t o0 = offA[pair];
+        oA = o0;
+        lenA = (uint32_t)(offA[pair + 1] - o0);
+        ap = A + o0;
+        if (err[pair] == 0u) {
+            eA = endA[pair];
+            eB = endB[pair];
+            M = score[pair];
+        }
+    }
+    // everything below is the same in both lanes of a pair (its rows apart)
+    const bool locate = active && (wide & 2) && eA == k3p::SW_END_DEFERRED; // as tb_prof_kernel
+    const uint32_t rowsA = locate ? lenA : eA;
+    const bool work = active && rowsA > 0 && rowsA <= lenA && eB > 0 && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide & 1) + (locate ? 4u : 0u)) : 0u;
+    const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u;
+    const uint32_t jb0 = (c_s - 1u) & ~3u;
+    const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u; // <= nblk_alloc - 3
+
+    // byte offsets (code * 8) of my RL rows inside a profile block, four rows per register and band (as tb_prof16_kernel)
+    uint32_t apk0[RB / 4], apk1[RB / 4];
+    const uint32_t row0 = hl * RL;
+    const uint64_t totalA = offA[pair1];
+    if (totalA < 0xFFFFFFF0ull) {
+        const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(A) & 3u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(A) - misA, 0,
+                                                                            (int)(((uint32_t)totalA + misA + 3u) & ~3u), 0x00020000);
+        const uint32_t b0 = (uint32_t)oA + misA + row0; // beyond the batch's last byte a buffer load returns 0: masked below
+        uint32_t dd[RL / 4];
+        {
+            uint32_t aw[RL / 4 + 1];
+#pragma unroll
+            for (int w = 0; w <= RL / 4; ++w)
+                aw[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b0 & ~3u) + 4u * w), 0, 0);
+#pragma unroll
+            for (int w = 0; w < RL / 4; ++w)
+                dd[w] = __builtin_amdgcn_alignbyte(aw[w + 1], aw[w], b0 & 3u);
+        }
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t i0 = row0 + 4 * w + b, i1 = row0 + RB + 4 * w + b;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+                if (work && i0 < lenA) {
+                    const uint32_t c = codeL[(dd[w] >> (8 * b)) & 0xFFu];
+                    c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                if (work && i1 < lenA) {
+                    const uint32_t c = codeL[(dd[RB / 4 + w] >> (8 * b)) & 0xFFu];
+                    c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                k0 |= (c0 * 8u) << (8 * b);
+                k1 |= (c1 * 8u) << (8 * b);
+            }
+            apk0[w] = k0;
+            apk1[w] = k1;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t i0 = row0 + 4 * w + b, i1 = row0 + RB + 4 * w + b;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+                if (work && i0 < lenA) {
+                    const uint32_t c = codeL[ap[i0]];
+                    c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                if (work && i1 < lenA) {
+                    const uint32_t c = codeL[ap[i1]];
+                    c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                k0 |= (c0 * 8u) << (8 * b);
+                k1 |= (c1 * 8u) << (8 * b);
+            }
+            apk0[w] = k0;
+            apk1[w] = k1;
+        }
+    }
+
+    uint32_t H[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        H[i] = 0;
+
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
+    const uint32_t pad_base = lds_base + nqB * pstride;
+
+    // end-aligned lanes as in tb_prof_kernel; a lane runs nblk + 3 iterations (band b finishes b blocks later)
+    uint32_t nmax = nblk;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    const uint32_t lag = nmax - nblk;
+    const uint32_t gh = tbf_half_bits(gap); // gap < 0
+    const uint32_t gap2 = gh | (gh << 16), one2 = 0x00010001u, two2 = 0x00020002u;
+    const uint32_t Mh_pair = tbf_half_bits((int)M);
+    uint32_t key = 0xFFFFFFFFu;
+    const uint32_t oddmask = hl ? 0xFFFFFFFFu : 0u;
+    // what the band above my first band left behind for the block it finished one iteration ago, and my first band's own
+    // last row already in the high halves: what my two bands find above their first rows
+    uint32_t hh0 = 0, hh1 = 0, hh2 = 0, hh3 = 0, hg0 = 0, hg1 = 0, hg2 = 0, hg3 = 0, hd = 0;
+    // find_tag: 0, 1 = search my first band's cells for the deferred end cell, 2 = my second band's; Mh = the maximum as a
+    // half, or a pattern no H has (0xFFFF) in the lanes whose turn it is not
+    auto sweep = [&](uint32_t tt, auto find_tag, const uint32_t Mh) __attribute__((always_inline)) {
+        constexpr int FIND = decltype(find_tag)::value;
+        const uint32_t bt = tt - lag - 2u * hl;         // my first band's block (as an unsigned number: "negative" = none yet)
+        const uint32_t base0 = bt < nblk ? lds_base + ((jb0 >> 2) + bt) * pstride : pad_base;
+        const uint32_t base1 = bt - 1u < nblk ? lds_base + ((jb0 >> 2) + bt - 1u) * pstride : pad_base;
+        uint32_t pr0 = hh0, pr1 = hh1, pr2 = hh2, pr3 = hh3, pg0 = hg0, pg1 = hg1, pg2 = hg2, pg3 = hg3, pdiag = hd;
+        uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
+        tbf_u32x2 xa[4], ya[4], xb[4], yb[4];
+        PH_TBF_ISSUE(apk0[0], apk1[0], xa, ya);
+#pragma unroll
+        for (int g = 0; g < RB / 4; ++g) {
+            if (g + 1 < RB / 4) {
+                PH_TBF_ISSUE(apk0[g + 1], apk1[g + 1], xb, yb);
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            }
+            PH_TBF_ROW(4 * g + 0, xa[0].x, xa[0].y, ya[0].x, ya[0].y);
+            PH_TBF_ROW(4 * g + 1, xa[1].x, xa[1].y, ya[1].x, ya[1].y);
+            PH_TBF_ROW(4 * g + 2, xa[2].x, xa[2].y, ya[2].x, ya[2].y);
+            PH_TBF_ROW(4 * g + 3, xa[3].x, xa[3].y, ya[3].x, ya[3].y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xa[q] = xb[q];
+                ya[q] = yb[q];
+            }
+        }
+        // My first band's last row (low halves) becomes my second band's row above (high halves) of the next iteration; the
+        // low halves of an odd lane take what the even lane's second band (its high halves) has just finished -- the row
+        // above this lane's first band in the next iteration.  Even lanes: zeros (row 0 has H = 0 above it).
+        auto pass = [&](uint32_t mine) {
+            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mine, 0x111 /* row_shr:1 */, 0xF, 0xF, true) & oddmask;
+            return __builtin_amdgcn_alignbit(mine, up, 16); // low half = the partner's high half, high half = my low half
+        };
+        hd = hh3;
+        hh0 = pass(pr0);
+        hh1 = pass(pr1);
+        hh2 = pass(pr2);
+        hh3 = pass(pr3);
+        hg0 = pass(pg0);
+        hg1 = pass(pg1);
+        hg2 = pass(pg2);
+        hg3 = pass(pg3);
+    };
+    const bool any_locate = __any(locate) != 0; // wave-uniform
+    const uint32_t Mh_even = hl ? 0xFFFFu : Mh_pair, Mh_odd = hl ? Mh_pair : 0xFFFFu;
+    // iterations 0 .. nmax + 2 (nblk is the same in both lanes of a pair, so a lane and the partner it reads are in step);
+    // with a deferred end cell in the wave the last four carry the search: band b sweeps the pair's last block in
+    // iteration nmax - 1 + b
+    for (uint32_t t = 0; t <= nmax + 2u; ++t) {
+        if (nblk == 0u || t < lag)
+            continue;
+        // (one call site per instantiation: with two, hipcc stops inlining the lambda and every array it captures -- H, the
+        // row codes -- moves to scratch: 99 ms instead of 17 for 400k reads of 250 bp)
+        if (any_locate && (t + 1u == nmax || t == nmax + 1u))
+            sweep(t, std::integral_constant<int, 1>{}, t + 1u == nmax ? Mh_even : Mh_odd);
+        else if (any_locate && (t == nmax || t == nmax + 2u))
+            sweep(t, std::integral_constant<int, 2>{}, t == nmax ? Mh_even : Mh_odd);
+        else
+            sweep(t, std::integral_constant<int, 0>{}, 0xFFFFu);
+    }
+    // row-major order: the even lane's rows come first
+    const uint32_t key_odd = (uint32_t)__shfl_down((int)key, 1, 64);
+    if (key == 0xFFFFFFFFu && key_odd != 0xFFFFFFFFu)
+        key = key_odd + ((uint32_t)RL << 2);
+
+    if (!active || hl != 0u)
+        return;
+    uint32_t len = 0;
+    bool lost = false;
+    if (work && locate) {
+        lost = key == 0xFFFFFFFFu; // cannot happen: the packed pass saw M in this block
+        eA = lost ? 0u : (key >> 2) + 1u;
+        eB = lost ? 0u : eB - 3u + (key & 3u);
+        endA[pair] = eA;
+        endB[pair] = eB;
+        if (lost)
+            err[pair] = 0xFFFFFFFEu;
+    } else if (locate) {
+        endA[pair] = 0u;
+        endB[pair] = 0u;
+    }
+    if (work && !lost) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this wave's own stores (my partner's included), read back by me
+        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
+        const uint16_t *P16 = reinterpret_cast<const uint16_t *>(P);
+        uint32_t i = eA, j = eB;
+        int h = (int)M;
+        while (h > 0 && i > 0 && j > jb0 && len < stride) {
+            const uint32_t jj = j - 1u, r = i - 1u, band = r / (uint32_t)RB, rr = r - band * RB, g = rr >> 4;
+            const uint32_t bit = 15u - (rr & 15u) + 16u * (band & 1u);
+            const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
+            const uint32_t *wp = dirw + (band >> 1) + (((size_t)tt * TBU + (jj & 3u)) * NG + g) * 2 * 64;
+            const uint32_t wg = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wl = __hip_atomic_load(wp + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint8_t sa = ap[r], sb = B[jj];
+            uint8_t ca, cb;
+            if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
+                h -= tbf_half_score(P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
+                ca = sa;
+                cb = sb;
+                --i;
+                --j;
+            } else if (((wl >> bit) & 1u) == 0u) { // :220-223
+                h -= gap;
+                ca = sa;
+                cb = '-';
+                --i;
+            } else { // :224-227
+                h -= gap;
+                ca = '-';
+                cb = sb;
+                --j;
+            }
+            outA[stride - 1 - len] = ca;
+            outB[stride - 1 - len] = cb;
+            ++len;
+        }
+    }
+    alnLen[pair] = (rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
+}
 #undef PH_TBF_ISSUE
 #undef PH_TBF_ADDR
 #undef PH_TBF_ROW
@@ -1631,6 +1915,10 @@ struct Plan {
     // its half-float two-band form (tb_prof16_kernel): every H < 2048, the table of halves fits twice into a CU's LDS
     bool half_ok;
     size_t half_smem;
+    // 153..256 rows, two lanes per pair (tb_prof16x2_kernel): the same table, four bands of 64 rows
+    bool half2_ok;
+    uint32_t nblk_alloc2;
+    size_t half2_per_pair;
     // one wave per pair for 256 < lenA <= 4096 (score known): tb_wave_kernel
     int wave_r;            // 0 = not applicable
     size_t wave_per_pair;
@@ -1680,10 +1968,17 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
         p.half_smem = half_tab + 256;
         p.half_ok = (p.ra == 64 || p.ra == 152) && p.half_smem <= 79 * 1024 &&
                     (uint64_t)sc->smax * std::min<uint64_t>(max_lenA, lenB) <= 2047ull && (int64_t)sc->smax - sc->gap <= 2048;
-        if (p.half_ok)
+        p.half2_ok = p.ra == 256 && p.half_smem <= 79 * 1024 &&
+                     (uint64_t)sc->smax * std::min<uint64_t>(max_lenA, lenB) <= 2047ull && (int64_t)sc->smax - sc->gap <= 2048;
+        p.nblk_alloc2 = p.nblk_alloc + 2; // bands 2 and 3 finish two iterations after band 1
+        if (p.half_ok || p.half2_ok)
             p.prof_bytes = std::max(p.prof_bytes, align_up(half_tab, 256));
         const size_t per = (size_t)p.nblk_alloc * TBU * ((p.ra + 31) / 32) * 2 * 4;
         p.per_pair = std::max(p.per_pair, per);
+        // two lanes per pair, each with the words of its two bands (4 groups of 16 rows, G and L)
+        p.half2_per_pair = (size_t)p.nblk_alloc2 * TBU * 4 * 2 * 4 * 2;
+        if (p.half2_ok)
+            p.per_pair = std::max(p.per_pair, p.half2_per_pair);
     }
     return p;
 }
@@ -1897,6 +2192,8 @@ static bool traceback_uses_prof(const polyhip_scoring *sc, uint32_t max_lenA, ui
 {
     const k3t::Plan p = k3t::plan(sc, max_lenA, lenB);
     const bool wave_ok = p.wave_r != 0 && !env_is("POLYHIP_TB_WAVE", '0');
+    if (p.prof_ok && p.half2_ok && !env_is("POLYHIP_TB_PROF", '0') && !env_is("POLYHIP_TB_F16", '0') && !env_is("POLYHIP_TB_HALF2", '0'))
+        return true; // its two-lanes-per-pair form (153..256 rows)
     return p.prof_ok && !(p.ra == 256 && wave_ok) && !env_is("POLYHIP_TB_PROF", '0');
 }
 
@@ -1920,40 +2217,50 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     // byte-profile kernel's 44.0 at one wave per SIMD); they remain for tables too large for the wave kernel's LDS
     const bool wave_ok = p.wave_r != 0 && d_score != nullptr && d_B != nullptr &&
                          !env_is("POLYHIP_TB_WAVE", '0'); // testing aid: no one-wave-per-pair traceback
-    const bool use_prof = p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr && !(p.ra == 256 && wave_ok) &&
+    // 153..256 rows against one reference on packed halves, two lanes per pair (path 5; POLYHIP_TB_HALF2=0 or
+    // POLYHIP_TB_F16=0: the one-wave-per-pair kernel as before, testing aids): 400k x 250 bp vs 5 kb 34.5 ms -> see DESIGN.md
+    const bool use_half2 = p.prof_ok && p.half2_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr &&
+                           !env_is("POLYHIP_TB_PROF", '0') && !env_is("POLYHIP_TB_F16", '0') && !env_is("POLYHIP_TB_HALF2", '0');
+    const bool use_prof = !use_half2 && p.prof_ok && d_offB == nullptr && d_score != nullptr && d_B != nullptr &&
+                          !(p.ra == 256 && wave_ok) &&
                           !env_is("POLYHIP_TB_PROF", '0'); // testing aid: the table kernel for a shared reference
-    const bool use_wave = !use_prof && (p.ra == 0 || p.ra == 256) && wave_ok;
-    k3t::g_tb_last_path = use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
+    const bool use_wave = !use_half2 && !use_prof && (p.ra == 0 || p.ra == 256) && wave_ok;
+    k3t::g_tb_last_path = use_half2 ? 5 : use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
     // only the byte-profile kernels know a deferred end cell: the fused entry point decided with traceback_uses_prof();
     // should the two conditions ever drift apart, fail here instead of walking from row 4e9
-    PH_REQUIRE(!deferred || use_prof, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
+    PH_REQUIRE(!deferred || use_prof || use_half2, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
     // bit 0: the conservative per-pair window (POLYHIP_TB_WIDE=1, testing aid); bit 1: deferred end cells allowed
     const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0);
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
-    uint64_t chunk = usable / p.per_pair / k3t::THREADS * k3t::THREADS;
+    // (the two-lane kernel's direction words take a quarter of the one-wave-per-pair kernel's, which sizes the workspace of
+    // its row class: its chunks are cut by its own figure, or they would fill a third of the chip)
+    const size_t per_pair = use_half2 ? p.half2_per_pair : p.per_pair;
+    uint64_t chunk = usable / per_pair / k3t::THREADS * k3t::THREADS;
     // A batch that needs several chunks of the direction workspace: the byte-profile and the one-wave-per-pair kernels take them through the two
     // HALVES of the workspace on two streams (the caller's and one of the library's), so that the end of one chunk --
     // waves finish at different times, and the walk that closes a wave's work waits on memory, not on issue -- overlaps
     // the sweeps of the next (one chunk after the other: the waves of a chunk were resident 67 % of its time,
     // profiles/r02_tbh_pmc_a.md).  POLYHIP_TB_OVERLAP=0: one chunk after the other (testing aid).
     const size_t half_bytes = (usable / 2) & ~(size_t)255; // where the upper half starts
-    const uint64_t half_chunk = half_bytes / p.per_pair / k3t::THREADS * k3t::THREADS;
-    const bool overlap = (use_prof || use_wave) && npairs > chunk && half_chunk >= 16384 && !env_is("POLYHIP_TB_OVERLAP", '0');
+    const uint64_t half_chunk = half_bytes / per_pair / k3t::THREADS * k3t::THREADS;
+    const bool overlap = (use_prof || use_wave || use_half2) && npairs > chunk && half_chunk >= 16384 && !env_is("POLYHIP_TB_OVERLAP", '0');
     if (overlap)
         chunk = half_chunk;
     else if (use_prof && chunk >= 131072)
         chunk = chunk / 131072 * 131072; // whole rounds of 256 CUs x 2 workgroups x 256 pairs
+    else if (use_half2 && chunk >= 65536)
+        chunk = chunk / 65536 * 65536; // the same with 128 pairs per workgroup
     PH_REQUIRE(chunk >= (uint64_t)k3t::THREADS, "polyhip_sw_traceback: workspace too small (%zu B; %zu B per pair, >= %d pairs)",
-               work_bytes, p.per_pair, k3t::THREADS);
+               work_bytes, per_pair, k3t::THREADS);
     hipStream_t st = as_stream(stream);
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     int8_t *prof = static_cast<int8_t *>(d_work);
     void *d_dir = static_cast<uint8_t *>(d_work) + p.prof_bytes;
     // half-float two-band form of the byte-profile kernel (POLYHIP_TB_F16=0: the 32-bit one, testing aid)
     const bool use_half = use_prof && p.half_ok && !env_is("POLYHIP_TB_F16", '0');
-    k3t::g_tb_last_half = use_half ? 1 : 0;
-    if (use_half) {
+    k3t::g_tb_last_half = (use_half || use_half2) ? 1 : 0;
+    if (use_half || use_half2) {
         const uint32_t n16 = (p.lenB_pad / 4 + 1) * (uint32_t)(sc->ncodes + 1);
         hipLaunchKernelGGL(k3t::tb_profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, (uint32_t)lenB, p.lenB_pad,
                            sc->d_lutc, sc->ncodes, sc->ncodes + 1, reinterpret_cast<uint2 *>(prof));
@@ -2016,6 +2323,18 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
             else
                 PH_TBW_LAUNCH(64);
 #undef PH_TBW_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
+        }
+        if (use_half2) {
+            const unsigned blocks2 = (unsigned)((p1 - p0 + k3t::THREADS / 2 - 1) / (k3t::THREADS / 2));
+            auto kern = k3t::tb_prof16x2_kernel<64>;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)p.half_smem));
+            hipLaunchKernelGGL(kern, dim3(blocks2), dim3(k3t::THREADS), p.half_smem, st, d_A, d_offA, p0, p1, d_B, p.lenB_pad,
+                               reinterpret_cast<const uint2 *>(prof), sc->d_codeA, sc->ncodes, (int)sc->gap, d_endA, d_endB, d_err,
+                               d_score, (int)sc->smax, p.win.wcols, wide, p.nblk_alloc2, dirbuf, d_alnA, d_alnB, d_alnLen,
+                               aln_stride);
             PH_HIP(hipGetLastError());
             continue;
         }

@@ -327,7 +327,7 @@ def test_device_resident_chunked_workspace(al):
 
 
 @pytest.mark.parametrize("gap,LB,L", [(-2, 5000, 150), (-7, 5000, 150), (-2, 15000, 150), (-2, 5000, 250), (-7, 5000, 250)])
-def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB, L):
+def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, tb_cell, gap, LB, L):
     """(gap -2: even unrelated reads score > 300, the linear phase of local alignment; gap -7: scores fall
     to the noise floor, so the per-pair windows range from the tightest to the batch-wide bound.)  200k reads at 0..90 % substitutions + 0..12 % indels (scores from 750 down to the noise floor)
     against one 5 kb reference.  The byte-profile kernel (score given), the table kernel (no score: the
@@ -378,7 +378,13 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, gap, LB, L)
     a1, b1, l1, path1 = run(score, False)
     a2, b2, l2, path2 = run(None, False)
     a3, b3, l3, path3 = run(score, True)
-    assert (path1, path2, path3) == ((1, 2, 1) if L <= 152 else (4, 2, 4))  # 153..256 rows: one wave per pair
+    # 153..256 rows: two lanes per pair on packed halves (5); the 32-bit form of the fixture: one wave per pair (4)
+    assert (path1, path2, path3) == ((1, 2, 1) if L <= 152 else (5, 2, 5) if tb_cell == "half" else (4, 2, 4))
+    if L > 152 and tb_cell == "half":  # ... and the one-wave-per-pair kernel on the same input, every pair
+        monkeypatch.setenv("POLYHIP_TB_HALF2", "0")
+        a4, b4, l4, path4 = run(score, False)
+        monkeypatch.delenv("POLYHIP_TB_HALF2", raising=False)
+        assert path4 == 4 and torch.equal(l1, l4) and torch.equal(a1, a4) and torch.equal(b1, b4)
     assert int(score.min()) < (100 if gap == -7 else 400) * L // 150 and int(score.max()) == 5 * L
     for a, b, ln in ((a2, b2, l2), (a3, b3, l3)):
         assert torch.equal(l1, ln) and torch.equal(a1, a) and torch.equal(b1, b)
@@ -579,8 +585,9 @@ def test_config4_full_size_mutated_batch(al, monkeypatch, tb_cell):
     del chk
 
 
+@pytest.mark.parametrize("L", [150, 250])
 @pytest.mark.parametrize("kind", ["random", "repeats", "ragged_bad"])
-def test_fused_align_equals_two_passes(al, monkeypatch, kind):
+def test_fused_align_equals_two_passes(al, monkeypatch, tb_cell, kind, L):
     """polyhip_sw_align_batch_dev (deferred end cell, found by the traceback kernel in its last block) against
     POLYHIP_SW_FUSE=0 (locate in the score pass, then the traceback) on 100k reads at 0..60 % mutations: a tandem-repeat
     reference (maxima in several blocks: the tie list), ragged lengths incl. empty reads, bad symbols; a sample vs the oracle"""
@@ -588,7 +595,7 @@ def test_fused_align_equals_two_passes(al, monkeypatch, kind):
     align = al[0]
     dev = torch.device("cuda:0")
     rng = np.random.default_rng({"random": 1, "repeats": 2, "ragged_bad": 3}[kind])
-    LB, n, L = 4000, 100_000, 150
+    LB, n = 4000, 100_000 if L == 150 else 60_000  # L = 250: two lanes per pair in both passes (tb path 5; 32-bit fixture: 4)
     ref = orc.synth_dna(0xC4, LB).copy()
     if kind == "repeats":
         ref = np.tile(ref[:250], 16)
@@ -623,7 +630,7 @@ def test_fused_align_equals_two_passes(al, monkeypatch, kind):
         tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
         align.sw_align_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, alnA, alnB, ln, work, tbw)
         torch.cuda.synchronize()
-        assert align.last_path() == 3 and align.sw_traceback_last_path() == 1
+        assert align.last_path() == 3 and align.sw_traceback_last_path() == (1 if L == 150 else 5 if tb_cell == "half" else 4)
         outs[fuse] = (score, ea, eb, er, ln, alnA, alnB)
     monkeypatch.delenv("POLYHIP_SW_FUSE", raising=False)
     for x, y in zip(outs[True][:5], outs[False][:5]):
