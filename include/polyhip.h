@@ -239,9 +239,14 @@ int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx,
  *             (= mash.New), nothing out.
  *   counts    n * n sameHashes (u16), and/or  dist  n * n float64 Distance; either may be NULL (both NULL: sketch only).
  * On a device list (polyhip_set_devices) this is SURVEY 8e's flow inside one process: the reads shard by bytes, every
- * device sketches its shard, the devices pull each other's sketches (hipMemcpyPeerAsync -- the all-gather without
- * RCCL and without a process per device), each builds the index of all n sketches and joins its own block of rows,
- * which goes straight into the caller's matrix.  Range: s <= 65535, n < 2^31.  SketchSize < 2: the status of
+ * device sketches its shard, and the devices build ONE index of all n sketches together without gathering the sketches
+ * (round 4): each runs the index's first level on its own rows, the 8-byte items travel by value range
+ * (hipMemcpyPeerAsync -- no RCCL, no process per device), the second level runs on 1/N of the range per device, the
+ * finished parts are exchanged; each device then joins the rows it sketched, which go straight into the caller's
+ * matrix.  A set with an irregular sketch (a read with fewer than s windows: its pairs take the reference's merge,
+ * which reads raw sketches), a matrix too wide for the dense join, or POLYHIP_K2_EXCHANGE=0 take the gather instead:
+ * the devices pull each other's sketches and each builds the whole index.  polyhip_mash_sketch_distance_matrix_last_path
+ * says which ran.  Range: s <= 65535, n < 2^31.  SketchSize < 2: the status of
  * polyhip_mash_sketch_batch (the reference panics in Sketch); SketchSize 0 with a matrix asked for: POLYHIP_ERR_PANIC
  * (mash.go:117).
  */
@@ -250,6 +255,9 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs,
                                         uint32_t k, uint32_t s,
                                         uint32_t *sketches, uint16_t *counts,
                                         double *dist);
+/* the calling thread's last polyhip_mash_sketch_distance_matrix: 0 = one device, 1 = a device list with the item exchange,
+ * 2 = a device list with the sketch gather (tests) */
+int polyhip_mash_sketch_distance_matrix_last_path(void);
 
 /* ---- K3: search/align SmithWaterman  (search/align/align.go:171-232) ---- */
 /*

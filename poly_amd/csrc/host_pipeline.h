@@ -278,7 +278,30 @@ inline uint64_t host_chunk_bytes()
 #define HOST_CHUNK_BYTES (::polyhip::host_chunk_bytes())
 
 // mash_distance.hip: row blocks of the shared-count / distance matrix from device-resident sketches to host buffers
+// (index_work: a workspace that already holds the index of Y -- sized with k2_rows_per_block's rows on its X side --, or
+// null: the call builds the index in a workspace of its own)
 int k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const uint32_t *dY, uint64_t ny, uint32_t sy,
-                    uint16_t *counts, double *dist);
+                    uint16_t *counts, double *dist, void *index_work = nullptr, size_t index_work_bytes = 0);
+uint64_t k2_rows_per_block(uint64_t nx, uint64_t ny, bool counts, bool dist);
+
+// mash_distance.hip: the index of a sketch set that is SPREAD over the devices of a list, built without gathering the
+// sketches (every device runs level 1 on its own rows, the 8-byte items travel by value range,
+// level 2 runs on 1/N of the range, the finished parts are exchanged).  Shard q lives on worker q of the pool: `sk` is
+// that device's n x s array of which rows [i0, i1) are valid.  On return *built says whether every device's `work` holds
+// the whole index (false: the set has an irregular sketch, the geometry is not the dense join's, or the input is so
+// dense that the merge would take it -- the caller gathers the sketches instead).
+struct K2XShard {
+    int dev = -1;
+    uint64_t i0 = 0, i1 = 0;
+    const uint32_t *sk = nullptr;
+    DevBuf work;
+    size_t work_bytes = 0;
+    // (scratch of the exchange)
+    std::vector<uint32_t> h_gcount, h_cstart;
+    uint32_t h_maxval = 0, h_maxmult = 0, h_fmt = 0;
+    uint64_t h_nirr = 0, h_est = 0;
+    DevBuf segtab, segptr;
+};
+int k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t n, uint32_t s, uint64_t rows_blk, bool *built);
 
 } // namespace polyhip

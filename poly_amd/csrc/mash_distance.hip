@@ -343,7 +343,8 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
                                                                 const uint32_t *__restrict__ hdr, uint32_t cshift_extra,
                                                                 uint32_t nc, uint32_t per_batch, uint32_t id_bits,
                                                                 uint32_t c0, uint32_t c1,
-                                                                uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
+                                                                uint32_t *__restrict__ gcur, uint2 *__restrict__ citems,
+                                                                uint32_t id_base)
 {
     extern __shared__ uint32_t lh[]; // count[nc] then base[nc]
     uint32_t *lbase = lh + nc;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
                 ++occ;
             const uint32_t c = v >> cshift;
             if (c - c0 < c1 - c0)
-                citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (uint32_t)q | (occ << id_bits));
+                citems[lbase[c] + atomicAdd(&lh[c], 1u)] = make_uint2(v, (id_base + (uint32_t)q) | (occ << id_bits));
         }
     }
 }
@@ -414,8 +415,9 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
    
     const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags,
     const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t nc, uint32_t per_batch, uint32_t id_bits,
-    uint32_t c0, uint32_t c1, uint32_t *__restrict__ gcur, uint2 *__restrict__ citems)
+    uint32_t c0, uint32_t c1, uint32_t *__restrict__ gcur, uint2 *__restrict__ citems, uint32_t id_base)
 {
+    // id_base: the number of the first sketch of `sk` in the whole set (a device that indexes its own shard of it)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_stage[];
     uint2 *stage = reinterpret_cast<uint2 *>(lds_stage);      // STAGE_ITEMS
     uint32_t *cnt = lds_stage + 2 * (size_t)STAGE_ITEMS;        // nc: count, then cursor
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
                     while (occ < e && base[i - occ - 1] == v[u])
                         ++occ;
                 }
-                stage[stage_swz(lstart[v[u] >> cshift] + rk[u])] = make_uint2(v[u], (uint32_t)(q0 + qi) | (occ << id_bits));
+                stage[stage_swz(lstart[v[u] >> cshift] + rk[u])] = make_uint2(v[u], (id_base + (uint32_t)(q0 + qi)) | (occ << id_bits));
             }
         __syncthreads();
         for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
@@ -521,11 +523,17 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
 #define PH_K2_FINE_THREADS 512
 #endif
 constexpr int FINE_THREADS = PH_K2_FINE_THREADS; // a coarse bucket is a chain of memory round trips: 8 waves per SIMD hide more of them
+// SEG (the item exchange of a device list, round 4): a coarse bucket arrives as `nseg` pieces, one per device that ran
+// level 1 on its own sketches -- piece g of bucket c = segbase[g][seglo[g * segld + (c - cfirst)] ..
+// seglo[g * segld + (c - cfirst) + 1]) -- and leaves at cstart[c] of the WHOLE set's coarse offsets, as ever.
+template <bool SEG>
 __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__restrict__ citems,
                                                            const uint32_t *__restrict__ cstart, uint32_t cfirst, uint32_t nc,
                                                            uint32_t fpc_log2, uint32_t *__restrict__ hdr,
                                                            uint32_t *__restrict__ start, uint2 *__restrict__ items,
-                                                           uint32_t id_bits, uint32_t ndw, uint32_t field_bits)
+                                                           uint32_t id_bits, uint32_t ndw, uint32_t field_bits,
+                                                           const uint2 *const *__restrict__ segbase,
+                                                           const uint32_t *__restrict__ seglo, uint32_t nseg, uint32_t segld)
 {
     constexpr int T = FINE_THREADS;
     __shared__ uint32_t cnt[FPC_MAX];
@@ -538,22 +546,28 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
     const int tid = threadIdx.x;
     unsigned long long sq = 0;
     for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) { // coarse buckets [cfirst, nc)
-        const uint32_t lo = cstart[c], hi = cstart[c + 1];
+        const uint32_t lo = cstart[c];
+        const uint32_t npieces = SEG ? nseg : 1u;
         __syncthreads();
         for (uint32_t f = tid; f < fpc; f += T)
             cnt[f] = 0;
         __syncthreads();
         // eight loads in flight per thread: the loop is a chain of memory round trips otherwise (96 % of the wave
         // cycles were s_waitcnt, profiles/r02_k2_pmc_sq.md)
-        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * T) {
-            uint32_t x[8];
+        for (uint32_t g = 0; g < npieces; ++g) {
+            const uint2 *__restrict__ src = SEG ? segbase[g] : citems;
+            const uint32_t plo = SEG ? seglo[(size_t)g * segld + (c - cfirst)] : lo;
+            const uint32_t phi = SEG ? seglo[(size_t)g * segld + (c - cfirst) + 1u] : cstart[c + 1];
+            for (uint32_t t0 = plo + tid; t0 < phi; t0 += 8 * T) {
+                uint32_t x[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                x[u] = t0 + u * T < hi ? citems[t0 + u * T].x : 0u;
+                for (int u = 0; u < 8; ++u)
+                    x[u] = t0 + u * T < phi ? src[t0 + u * T].x : 0u;
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (t0 + u * T < hi)
-                    atomicAdd(&cnt[(x[u] >> shift) & (fpc - 1u)], 1u);
+                for (int u = 0; u < 8; ++u)
+                    if (t0 + u * T < phi)
+                        atomicAdd(&cnt[(x[u] >> shift) & (fpc - 1u)], 1u);
+            }
         }
         __syncthreads();
         // exclusive scan of cnt[0..fpc): PER consecutive entries per thread
@@ -590,12 +604,16 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
             run += v[i];
         }
         __syncthreads();
-        for (uint32_t t0 = lo + tid; t0 < hi; t0 += 8 * T) {
+        for (uint32_t g = 0; g < npieces; ++g) {
+        const uint2 *__restrict__ src = SEG ? segbase[g] : citems;
+        const uint32_t plo = SEG ? seglo[(size_t)g * segld + (c - cfirst)] : lo;
+        const uint32_t hi = SEG ? seglo[(size_t)g * segld + (c - cfirst) + 1u] : cstart[c + 1];
+        for (uint32_t t0 = plo + tid; t0 < hi; t0 += 8 * T) {
             uint2 it[8];
             uint32_t at[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u)
-                it[u] = t0 + u * T < hi ? citems[t0 + u * T] : make_uint2(0u, 0u);
+                it[u] = t0 + u * T < hi ? src[t0 + u * T] : make_uint2(0u, 0u);
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 at[u] = t0 + u * T < hi ? atomicAdd(&cnt[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
@@ -614,6 +632,7 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
                         items[at[u]] = it[u];
                     }
                 }
+        }
         }
     }
 #pragma unroll
@@ -783,7 +802,14 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int BITS, bool COMPACT>
+// REG (round 4; rows of at most DENSE_THREADS hashes): no LDS staging of the row at all.  Thread t keeps element t of the
+// row -- its value, the values on either side, its bucket's bounds, all loaded a row ahead -- and IS the descriptor of that
+// element: "first copy of its value in the row" is a compare with the element in front, the multiplicity is 1 unless the
+// next element is equal (then a short scan of the row in global memory), and a wave walks the buckets of ITS OWN 64
+// consecutive elements by v_readlane (an element that is not a first copy, or whose bucket is empty, is an empty bucket).
+// What goes: the row's copy in LDS, the LDS atomic per distinct value, four descriptor arrays and the three barriers
+// around them -- 5.5 of a row's 24 us at config 3 (profiles/r04_write_bw.md).  POLYHIP_K2_REGROW=0: the staged form.
+template <int BITS, bool COMPACT, bool REG = false>
 __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint32_t *__restrict__ X, uint64_t nx, uint32_t sx,
                                                                const uint8_t *__restrict__ flagsX,
                                                                const uint32_t *__restrict__ start,
@@ -827,17 +853,25 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
         uint32_t skip;   // irregular row (flagsX): the merge's
         uint32_t v;      // my hash of it
         uint32_t bs, be; // its bucket
+        uint32_t pv, nv; // REG: the hashes in front of and behind mine
     };
     auto load_row = [&](uint64_t k, Pre &q) {
         const uint64_t r = k * G + off;
         q.i = -1;
         q.skip = 0;
         q.v = 0;
+        q.pv = q.nv = 0;
         if (r < nrows) {
             q.i = (int64_t)(rows ? rows[r] : r);
             q.skip = rows ? 0u : flagsX[q.i];
-            if (ahead && (uint32_t)tid < sx)
-                q.v = X[(uint64_t)q.i * sx + tid];
+            if (ahead && (uint32_t)tid < sx) {
+                const uint32_t *xp = X + (uint64_t)q.i * sx;
+                q.v = xp[tid];
+                if constexpr (REG) { // (the same cache lines)
+                    q.pv = tid ? xp[tid - 1] : 0u;
+                    q.nv = (uint32_t)tid + 1u < sx ? xp[tid + 1] : 0u;
+                }
+            }
         }
     };
     auto load_bounds = [&](Pre &q) {
@@ -853,6 +887,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
     // the counters start at zero and every flush leaves them so (a thread clears the dwords it has just written out)
     for (uint32_t t = tid * 4; t < stripe_dwords; t += DENSE_THREADS * 4) // stripe_dwords is a multiple of 8
         *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
+    if constexpr (REG)
+        lds_barrier();
     Pre cur, nxt;
     load_row(0, cur);
     load_bounds(cur);
@@ -860,7 +896,28 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
     for (uint64_t k = 0; cur.i >= 0; ++k) {
         const uint64_t i = (uint64_t)cur.i;
         const bool work = !cur.skip; // wave-uniform (irregular rows belong to the merge)
-        if (work) {
+        uint32_t rval = 0, rlim = 0, rbeg = 0, rend = 0; // REG: my element as a bucket descriptor (empty unless it is a first copy)
+        if constexpr (REG) {
+            const bool first = work && (uint32_t)tid < sx && (tid == 0 || cur.pv != cur.v);
+            if (first && cur.be > cur.bs) { // (bounds of a bucket beyond nbk were never loaded: 0, 0)
+                uint32_t a = 1;
+                if ((uint32_t)tid + 1u < sx && cur.nv == cur.v) { // a value the row repeats (rare)
+                    const uint32_t *xp = X + i * sx;
+                    while ((uint32_t)tid + a < sx && xp[tid + a] == cur.v)
+                        ++a;
+                }
+                if (COMPACT) {
+                    rval = (shift ? (cur.v & low_mask) << (32u - shift) : 0u) + (1u << CK_LOW);
+                    rlim = min(a, occ_cap) << CK_LOW;
+                } else {
+                    rval = cur.v;
+                    rlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
+                }
+                rbeg = cur.bs;
+                rend = cur.be;
+            }
+        }
+        if (work && !REG) {
             lds_barrier();
             if (tid == 0)
                 ndist = 0;
@@ -902,7 +959,8 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
         nxt = nn;
         if (!work)
             continue;
-        const uint32_t nd = ndist;
+        const uint32_t nd = REG ? 0u : ndist;
+        (void)nd;
         for (uint64_t c0 = 0; c0 < ny; c0 += stripe_cols) {
             const uint32_t ncols = (uint32_t)min((uint64_t)stripe_cols, ny - c0);
             // column c of the stripe = field c / ndw of dword c % ndw: neighbouring columns (a bucket is a family's
@@ -939,28 +997,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             // buckets at a time: the first 128 items of each are loaded back to back (a family's copies of one hash are
             // one bucket), then consumed.
             constexpr uint32_t NW = DENSE_THREADS / 64;
-#ifdef PH_K2_NOWALK // ablation probe (wrong counts): how long is a row without its bucket walk?
-            for (uint32_t jb = 0; false && wave + NW * jb < nd; jb += 64) {
-#else
-            for (uint32_t jb = 0; wave + NW * jb < nd; jb += 64) {
-#endif
-                const uint32_t mine = wave + NW * (jb + lane);
-                uint32_t mval = 0, mlim = 0, mbeg = 0, mend = 0; // beyond nd: an empty bucket
-                if (mine < nd) {
-                    const uint32_t a = dmul[mine];
-                    mval = dval[mine];
-                    if (COMPACT) {
-                        // key = the value's low bits in the item's top field, + 1 in the occurrence field (items store
-                        // occurrence + 1); multiplicity capped at what the field numbers
-                        mval = (shift ? (mval & low_mask) << (32u - shift) : 0u) + (1u << CK_LOW);
-                        mlim = min(a, occ_cap) << CK_LOW;
-                    } else {
-                        mlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
-                    }
-                    mbeg = dbeg[mine];
-                    mend = dend[mine];
-                }
-                const uint32_t cnt = min(64u, (nd - wave - NW * jb + NW - 1) / NW); // my buckets in this chunk
+            // up to 64 buckets whose descriptors sit in the wave's lanes
+            auto walk_chunk = [&](const uint32_t mval, const uint32_t mlim, const uint32_t mbeg, const uint32_t mend,
+                                  const uint32_t cnt) __attribute__((always_inline)) {
                 if constexpr (COMPACT) {
                     // Buffer loads: a bucket is its own little buffer (base and size are scalars built on the scalar
                     // unit), every lane reads at the constant offset 4 * lane, and a lane beyond the bucket's end gets 0 =
@@ -1016,6 +1055,38 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                             }
                         }
                     }
+                }
+            };
+            if constexpr (REG) {
+                // my wave's 64 consecutive elements of the row (the last wave of a 1000-hash row: 40)
+                const uint32_t w0 = (uint32_t)wave * 64u;
+#ifndef PH_K2_NOWALK
+                if (w0 < sx)
+                    walk_chunk(rval, rlim, rbeg, rend, min(64u, sx - w0));
+#endif
+            } else {
+#ifdef PH_K2_NOWALK // ablation probe (wrong counts): how long is a row without its bucket walk?
+                for (uint32_t jb = 0; false && wave + NW * jb < nd; jb += 64) {
+#else
+                for (uint32_t jb = 0; wave + NW * jb < nd; jb += 64) {
+#endif
+                    const uint32_t mine = wave + NW * (jb + lane);
+                    uint32_t mval = 0, mlim = 0, mbeg = 0, mend = 0; // beyond nd: an empty bucket
+                    if (mine < nd) {
+                        const uint32_t a = dmul[mine];
+                        mval = dval[mine];
+                        if (COMPACT) {
+                            // key = the value's low bits in the item's top field, + 1 in the occurrence field (items store
+                            // occurrence + 1); multiplicity capped at what the field numbers
+                            mval = (shift ? (mval & low_mask) << (32u - shift) : 0u) + (1u << CK_LOW);
+                            mlim = min(a, occ_cap) << CK_LOW;
+                        } else {
+                            mlim = a > (0xFFFFFFFFu >> id_bits) ? 0xFFFFFFFFu : a << id_bits;
+                        }
+                        mbeg = dbeg[mine];
+                        mend = dend[mine];
+                    }
+                    walk_chunk(mval, mlim, mbeg, mend, min(64u, (nd - wave - NW * jb + NW - 1) / NW)); // my buckets in this chunk
                 }
             }
             lds_barrier();
@@ -1446,14 +1517,15 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(k2::coarse_scatter_staged_kernel, dim3((unsigned)std::min<uint64_t>((ny + pb - 1) / pb, PH_K2_STAGE_GRID)), dim3(k2::STAGE_THREADS),
-                               smem, st, d_Y, ny, sy, flagsY, hdr, L.fpc_log2, L.nc, pb, id_bits, c0, c1, gcur, citems);
+                               smem, st, d_Y, ny, sy, flagsY, hdr, L.fpc_log2, L.nc, pb, id_bits, c0, c1, gcur, citems, 0u);
         } else {
             hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
-                               flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems);
+                               flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems, 0u);
         }
         if (c1 > c0)
-            hipLaunchKernelGGL(k2::fine_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st, citems,
-                               cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
+            hipLaunchKernelGGL(k2::fine_kernel<false>, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st, citems,
+                               cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits,
+                               (const uint2 *const *)nullptr, (const uint32_t *)nullptr, 0u, 0u);
         PH_HIP(hipGetLastError());
     }
     if (!join)
@@ -1481,9 +1553,11 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     auto launch_dense = [&](const uint32_t *rows, unsigned blocks) -> int {
         const uint32_t sdw = (uint32_t)std::min<uint64_t>(stripe_dwords, (((ny + per - 1) / per) + 7) & ~7ull);
         const size_t smem = row_bytes + (size_t)sdw * 4;
+        // rows of at most 1024 hashes: a thread per element, no staging of the row (REG; POLYHIP_K2_REGROW=0: the staged form)
+        const bool regrow = sx <= (uint32_t)k2::DENSE_THREADS && !env_is("POLYHIP_K2_REGROW", '0');
 #define PH_K2_DENSE_LAUNCH(BITS_, COMPACT_)                                                                                   \
     do {                                                                                                                      \
-        auto kern = k2::rowjoin_dense_kernel<BITS_, COMPACT_>;                                                                \
+        auto kern = regrow ? k2::rowjoin_dense_kernel<BITS_, COMPACT_, true> : k2::rowjoin_dense_kernel<BITS_, COMPACT_, false>; \
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX, start,                 \
                            static_cast<const void *>(items), L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);               \
@@ -1686,14 +1760,19 @@ int polyhip_mash_distance_from_counts_dev(const uint16_t *d_counts, uint64_t nx,
 // block b is joined on the calling thread's first stream while block b-1 travels back on the second (the joins
 // themselves share the workspace's X side and stay in order on one stream).  One index for all blocks.  Everything the
 // caller enqueued on the thread's first stream before (uploads, a sketching pass) is ordered in front.
+uint64_t polyhip::k2_rows_per_block(uint64_t nx, uint64_t ny, bool counts, bool dist)
+{
+    const uint64_t per_pair = (counts ? 2 : 0) + (dist ? 8 : 0);
+    return std::max<uint64_t>(1, std::min<uint64_t>(nx, HOST_CHUNK_BYTES / std::max<uint64_t>(1, ny * per_pair)));
+}
+
 int polyhip::k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const uint32_t *dY, uint64_t ny, uint32_t sy,
-                             uint16_t *counts, double *dist)
+                             uint16_t *counts, double *dist, void *index_work, size_t index_work_bytes)
 {
     HostStreams &hs = host_streams();
     PH_HIP(hs.init());
     hipStream_t sc = hs.s[0], sd = hs.s[1];
-    const uint64_t per_pair = (counts ? 2 : 0) + (dist ? 8 : 0);
-    const uint64_t rows = std::max<uint64_t>(1, std::min<uint64_t>(nx, HOST_CHUNK_BYTES / std::max<uint64_t>(1, ny * per_pair)));
+    const uint64_t rows = k2_rows_per_block(nx, ny, counts != nullptr, dist != nullptr);
     const uint64_t nblocks = (nx + rows - 1) / rows;
     const bool one_index = stripe_sketches(ny, sy) >= ny; // else every block builds its stripes' indexes itself
     DevBuf dW;
@@ -1708,8 +1787,16 @@ int polyhip::k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const
                 (void)hipEventDestroy(downloaded);
         }
     } slot[2];
-    const size_t wb = polyhip_mash_shared_counts_workspace_bytes(rows, sx, ny, sy);
-    PH_HIP(dW.alloc(wb));
+    size_t wb = polyhip_mash_shared_counts_workspace_bytes(rows, sx, ny, sy);
+    void *wp = index_work;
+    if (index_work) {
+        PH_REQUIRE(one_index && index_work_bytes >= wb, "k2_rows_to_host: the prebuilt index's workspace is too small (%zu < %zu)",
+                   index_work_bytes, wb);
+        wb = index_work_bytes;
+    } else {
+        PH_HIP(dW.alloc(wb));
+        wp = dW.p;
+    }
     for (uint64_t q = 0; q < std::min<uint64_t>(2, nblocks); ++q) {
         PH_HIP(slot[q].dC.alloc(rows * ny * 2 + 16));
         if (dist)
@@ -1718,16 +1805,16 @@ int polyhip::k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const
         PH_HIP(hipEventCreateWithFlags(&slot[q].downloaded, hipEventDisableTiming));
     }
     int rc = POLYHIP_OK;
-    if (one_index)
-        rc = polyhip_mash_index_build_dev(dY, ny, sy, dW.p, wb, sc);
+    if (one_index && !index_work)
+        rc = polyhip_mash_index_build_dev(dY, ny, sy, wp, wb, sc);
     for (uint64_t b = 0; b < nblocks && rc == POLYHIP_OK; ++b) {
         Slot &S = slot[b & 1];
         const uint64_t r0 = b * rows, m = std::min<uint64_t>(rows, nx - r0);
         if (b >= 2)
             PH_HIP(hipStreamWaitEvent(sc, S.downloaded, 0)); // block b-2 has left this slot
         const uint32_t *dx = dX + r0 * (uint64_t)sx;
-        rc = one_index ? polyhip_mash_shared_counts_reuse_dev(dx, m, sx, dY, ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc)
-                       : polyhip_mash_shared_counts_dev(dx, m, sx, dY, ny, sy, S.dC.as<uint16_t>(), ny, dW.p, wb, sc);
+        rc = one_index ? polyhip_mash_shared_counts_reuse_dev(dx, m, sx, dY, ny, sy, S.dC.as<uint16_t>(), ny, wp, wb, sc)
+                       : polyhip_mash_shared_counts_dev(dx, m, sx, dY, ny, sy, S.dC.as<uint16_t>(), ny, wp, wb, sc);
         if (rc == POLYHIP_OK && dist)
             rc = polyhip_mash_distance_from_counts_dev(S.dC.as<uint16_t>(), m, ny, ny, sx, sy, S.dD.as<double>(), ny, sc);
         if (rc != POLYHIP_OK)
@@ -1791,3 +1878,266 @@ int polyhip_mash_distance_matrix(const uint32_t *X, uint64_t nx, uint32_t sx, co
 }
 
 } // extern "C"
+
+// ---- the index of a sketch set that is spread over a device list, without gathering the sketches (round 4) --------------
+// DESIGN.md section 4.  Device q holds rows [i0, i1) of the n sketches (it has just made them).  Gathering the set (400 MB
+// into every device at config 3) only to turn it into index items N times over is what bounds the step at ~2.8x on 8 GPUs;
+// here every device
+//   A  takes the largest last element of ITS rows                                  -> host: the set's maximum (bucket shift)
+//   B  checks its rows and counts their items per coarse bucket                    -> host: the set's histogram, the part
+//                                                                                     bounds (equal numbers of items)
+//   C  runs level 1 on its rows (1/N of the scatter; sketch ids are the set's)     -> its items, grouped by coarse bucket
+//   D  pulls, from every device, the items of ITS part of the value range (one peer copy per device: a device's items of
+//      a range of coarse buckets are contiguous) and runs level 2 on them -- a coarse bucket is N pieces (fine_kernel<true>)
+//   E  pulls the other parts' finished items and bucket starts (the same ragged exchange as the N-rank build's,
+//      polyhip_mash_index_allgather_dev, by peer copies) and takes the self-join size of the whole index
+// -- 1/N of level 1 and level 2 each, and what travels is 7/8 x (8-byte items of 1/N of the set + the 4-byte index) instead
+// of 7/8 x (the sketches + nothing).  Rounds are md::run calls (each a barrier between the devices' threads); the host
+// reduces a few kilobytes between them.  Falls back (*built = false, nothing lost but the rounds so far) when a sketch is
+// irregular (the merge reads raw sketches of both sides), the join would not be the dense one, or the self-join size says
+// "merge everything": the caller then gathers the sketches as before.
+int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t n, uint32_t s, uint64_t rows_blk, bool *built)
+{
+    *built = false;
+    const size_t N = sh.size();
+    if (N < 2 || n == 0 || s == 0 || stripe_sketches(n, s) < n || n >= (1ull << 31))
+        return POLYHIP_OK;
+    const k2::Layout L = k2::layout(rows_blk, s, n, s);
+    const DenseGeom gY = dense_geom(s, s, n);
+    if (gY.force || !gY.dense_all)
+        return POLYHIP_OK;
+    const bool allow_compact = gY.compact_ok;
+    uint32_t id_bits = 1;
+    while ((1ull << id_bits) < n && id_bits < k2::ID_BITS_MAX)
+        ++id_bits;
+    const uint32_t max_occ = (1u << (32 - id_bits)) - 2u;
+    const bool staged = s <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0');
+    struct View { // one device's workspace
+        uint8_t *w;
+        uint32_t *hdr, *start, *gcount, *cstart, *gcur, *irrY;
+        uint8_t *flagsY;
+        uint2 *citems, *items;
+    };
+    auto view = [&](K2XShard &x) {
+        View v;
+        v.w = x.work.as<uint8_t>();
+        v.hdr = reinterpret_cast<uint32_t *>(v.w);
+        v.flagsY = v.w + L.off_flagsY;
+        v.irrY = reinterpret_cast<uint32_t *>(v.w + L.off_irrY);
+        v.start = reinterpret_cast<uint32_t *>(v.w + L.off_start);
+        v.gcount = reinterpret_cast<uint32_t *>(v.w + L.off_gcount);
+        v.cstart = reinterpret_cast<uint32_t *>(v.w + L.off_cstart);
+        v.gcur = reinterpret_cast<uint32_t *>(v.w + L.off_gcur);
+        v.citems = reinterpret_cast<uint2 *>(v.w + L.off_citems);
+        v.items = reinterpret_cast<uint2 *>(v.w + L.off_items);
+        return v;
+    };
+    // ---- A: workspace, the largest last element of my rows
+    int rc = md::run(P, [&](size_t q) {
+        K2XShard &x = sh[q];
+        HostStreams &hs = host_streams();
+        PH_HIP(hs.init());
+        hipStream_t st = hs.s[0];
+        x.work_bytes = L.total;
+        PH_HIP(x.work.alloc(x.work_bytes));
+        const View v = view(x);
+        PH_HIP(hipMemsetAsync(v.w, 0, L.off_irrY, st));
+        PH_HIP(hipMemsetAsync(v.gcount, 0, (size_t)L.nc * 4, st));
+        const uint64_t m = x.i1 - x.i0;
+        if (m)
+            hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((m + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
+                               x.sk + x.i0 * (uint64_t)s, m, s, v.hdr);
+        PH_HIP(hipGetLastError());
+        PH_HIP(hipMemcpyAsync(&x.h_maxval, v.hdr + k2::H_MAXVAL, 4, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipStreamSynchronize(st));
+        return (int)POLYHIP_OK;
+    });
+    if (rc != POLYHIP_OK)
+        return rc;
+    uint32_t maxval = 0;
+    for (const K2XShard &x : sh)
+        maxval = std::max(maxval, x.h_maxval);
+    // ---- B: check my rows, count their items per coarse bucket
+    rc = md::run(P, [&](size_t q) {
+        K2XShard &x = sh[q];
+        hipStream_t st = host_streams().s[0];
+        const View v = view(x);
+        const uint64_t m = x.i1 - x.i0;
+        PH_HIP(hipMemcpyAsync(v.hdr + k2::H_MAXVAL, &maxval, 4, hipMemcpyHostToDevice, st));
+        if (m)
+            hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(m)), dim3(k2::THREADS), (size_t)L.nc * 4, st,
+                               x.sk + x.i0 * (uint64_t)s, m, s, v.flagsY + x.i0, v.hdr, 0, max_occ, L.nbk_log2, L.fpc_log2, L.nc,
+                               v.gcount);
+        PH_HIP(hipGetLastError());
+        x.h_gcount.assign(L.nc, 0);
+        std::vector<uint8_t> fl(m);
+        PH_HIP(hipMemcpyAsync(x.h_gcount.data(), v.gcount, (size_t)L.nc * 4, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipMemcpyAsync(&x.h_maxmult, v.hdr + k2::H_MAXMULT, 4, hipMemcpyDeviceToHost, st));
+        if (m)
+            PH_HIP(hipMemcpyAsync(fl.data(), v.flagsY + x.i0, m, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipStreamSynchronize(st));
+        x.h_nirr = 0;
+        for (uint8_t f : fl)
+            x.h_nirr += f ? 1 : 0;
+        return (int)POLYHIP_OK;
+    });
+    if (rc != POLYHIP_OK)
+        return rc;
+    uint64_t nirr = 0;
+    uint32_t maxmult = 0;
+    std::vector<uint32_t> gstart(L.nc + 1, 0); // the SET's coarse offsets
+    for (const K2XShard &x : sh) {
+        nirr += x.h_nirr;
+        maxmult = std::max(maxmult, x.h_maxmult);
+    }
+    if (nirr)
+        return POLYHIP_OK; // an irregular sketch: its pairs go through the merge, which reads raw sketches
+    {
+        uint64_t run = 0;
+        for (uint32_t c = 0; c < L.nc; ++c) {
+            gstart[c] = (uint32_t)run;
+            for (const K2XShard &x : sh)
+                run += x.h_gcount[c];
+        }
+        gstart[L.nc] = (uint32_t)run;
+    }
+    std::vector<uint32_t> bnd(N + 1);
+    k2::part_bounds(gstart.data(), L.nc, (uint32_t)N, bnd.data());
+    // ---- C: level 1 on my rows
+    rc = md::run(P, [&](size_t q) {
+        K2XShard &x = sh[q];
+        hipStream_t st = host_streams().s[0];
+        const View v = view(x);
+        const uint64_t m = x.i1 - x.i0;
+        PH_HIP(hipMemcpyAsync(v.hdr + k2::H_MAXMULT, &maxmult, 4, hipMemcpyHostToDevice, st));
+        // shift and item format: the same inputs on every device, the same answer (no irregular sketch: the lists stay empty)
+        hipLaunchKernelGGL(k2::lists_kernel, dim3(1), dim3(k2::THREADS), 0, st, v.flagsY, (uint64_t)0, v.flagsY, (uint64_t)0,
+                           v.irrY, v.irrY, v.irrY, v.hdr, L.nbk_log2, allow_compact ? 1 : 0);
+        hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, v.gcount, L.nc, v.cstart, v.gcur, v.start, L.nbk);
+        if (m) {
+            const uint32_t *sk = x.sk + x.i0 * (uint64_t)s;
+            if (staged) {
+                const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / s);
+                const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
+                PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                hipLaunchKernelGGL(k2::coarse_scatter_staged_kernel, dim3((unsigned)std::min<uint64_t>((m + pb - 1) / pb, PH_K2_STAGE_GRID)),
+                                   dim3(k2::STAGE_THREADS), smem, st, sk, m, s, v.flagsY + x.i0, v.hdr, L.fpc_log2, L.nc, pb, id_bits,
+                                   0u, L.nc, v.gcur, v.citems, (uint32_t)x.i0);
+            } else {
+                const uint32_t per_batch = std::max<uint32_t>(1u, k2::BATCH_ITEMS / s);
+                hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3((unsigned)((m + per_batch - 1) / per_batch)), dim3(k2::THREADS),
+                                   (size_t)L.nc * 8, st, sk, m, s, v.flagsY + x.i0, v.hdr, L.fpc_log2, L.nc, per_batch, id_bits, 0u,
+                                   L.nc, v.gcur, v.citems, (uint32_t)x.i0);
+            }
+        }
+        PH_HIP(hipGetLastError());
+        x.h_cstart.assign(L.nc + 1, 0);
+        PH_HIP(hipMemcpyAsync(x.h_cstart.data(), v.cstart, (size_t)(L.nc + 1) * 4, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipMemcpyAsync(&x.h_fmt, v.hdr + k2::H_FMT, 4, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipStreamSynchronize(st));
+        return (int)POLYHIP_OK;
+    });
+    if (rc != POLYHIP_OK)
+        return rc;
+    const uint64_t item_bytes = sh[0].h_fmt ? 4 : 8;
+    auto enable_peer = [](int me, int other) -> int {
+        if (me == other)
+            return POLYHIP_OK;
+        int can = 0;
+        PH_HIP(hipDeviceCanAccessPeer(&can, me, other));
+        if (can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(other, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                PH_HIP(e);
+            (void)hipGetLastError(); // "already enabled" is sticky otherwise
+        } // without peer access the runtime stages the copy through the host: slower, still correct
+        return POLYHIP_OK;
+    };
+    // ---- D: the items of my part of the value range from everybody, level 2 on them
+    rc = md::run(P, [&](size_t q) {
+        K2XShard &x = sh[q];
+        hipStream_t st = host_streams().s[0];
+        const View v = view(x);
+        const uint32_t c0 = bnd[q], c1 = bnd[q + 1], ncp = c1 - c0 + 1;
+        // the set's coarse offsets replace mine (every device's own offsets are on the host by now)
+        PH_HIP(hipMemcpyAsync(v.cstart, gstart.data(), (size_t)(L.nc + 1) * 4, hipMemcpyHostToDevice, st));
+        PH_HIP(hipMemcpyAsync(v.start + L.nbk, &gstart[L.nc], 4, hipMemcpyHostToDevice, st));
+        PH_HIP(hipMemsetAsync(v.hdr + k2::H_EST_LO, 0, 8, st));
+        if (c1 > c0) {
+            std::vector<const uint2 *> base(N);
+            std::vector<uint32_t> lo((size_t)N * ncp);
+            uint64_t goff = x.h_cstart[L.nc]; // pulled pieces go behind my own items
+            for (size_t p = 0; p < N; ++p) {
+                const K2XShard &o = sh[p];
+                const uint32_t a = o.h_cstart[c0], len = o.h_cstart[c1] - a;
+                for (uint32_t c = c0; c <= c1; ++c)
+                    lo[p * ncp + (c - c0)] = o.h_cstart[c] - a;
+                if (p == q) {
+                    base[p] = v.citems + a;
+                    continue;
+                }
+                base[p] = v.citems + goff;
+                if (len) {
+                    if (int e = enable_peer(x.dev, o.dev))
+                        return e;
+                    PH_HIP(hipMemcpyPeerAsync(v.citems + goff, x.dev, view(const_cast<K2XShard &>(o)).citems + a, o.dev, (size_t)len * 8, st));
+                }
+                goff += len;
+            }
+            PH_REQUIRE(goff <= n * (uint64_t)s, "k2_exchange_index: pieces beyond the item region");
+            PH_HIP(x.segptr.alloc(N * sizeof(const uint2 *)));
+            PH_HIP(x.segtab.alloc(lo.size() * 4));
+            PH_HIP(hipMemcpyAsync(x.segptr.p, base.data(), N * sizeof(const uint2 *), hipMemcpyHostToDevice, st));
+            PH_HIP(hipMemcpyAsync(x.segtab.p, lo.data(), lo.size() * 4, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k2::fine_kernel<true>, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st,
+                               v.citems, v.cstart, c0, c1, L.fpc_log2, v.hdr, v.start, v.items, id_bits, gY.ndw ? gY.ndw : 8u,
+                               (uint32_t)gY.bits, x.segptr.as<const uint2 *>(), x.segtab.as<uint32_t>(), (uint32_t)N, ncp);
+            PH_HIP(hipGetLastError());
+            PH_HIP(hipStreamSynchronize(st)); // (the tables are host vectors of this scope)
+        } else {
+            PH_HIP(hipStreamSynchronize(st));
+        }
+        return (int)POLYHIP_OK;
+    });
+    if (rc != POLYHIP_OK)
+        return rc;
+    // ---- E: the other parts, finished; the self-join size of the whole index
+    rc = md::run(P, [&](size_t q) {
+        K2XShard &x = sh[q];
+        hipStream_t st = host_streams().s[0];
+        const View v = view(x);
+        for (size_t p = 0; p < N; ++p) {
+            if (p == q || bnd[p + 1] == bnd[p])
+                continue;
+            const K2XShard &o = sh[p];
+            const View ov = view(const_cast<K2XShard &>(o));
+            if (int e = enable_peer(x.dev, o.dev))
+                return e;
+            const uint64_t ia = (uint64_t)gstart[bnd[p]] * item_bytes, ib = (uint64_t)gstart[bnd[p + 1]] * item_bytes;
+            if (ib > ia)
+                PH_HIP(hipMemcpyPeerAsync(reinterpret_cast<uint8_t *>(v.items) + ia, x.dev, reinterpret_cast<const uint8_t *>(ov.items) + ia,
+                                          o.dev, ib - ia, st));
+            const uint64_t sa = (uint64_t)bnd[p] << L.fpc_log2, sb = (uint64_t)bnd[p + 1] << L.fpc_log2;
+            PH_HIP(hipMemcpyPeerAsync(v.start + sa, x.dev, ov.start + sa, o.dev, (sb - sa) * 4, st));
+        }
+        if (int e = polyhip_mash_index_finalize_dev(n, s, v.w, x.work_bytes, st))
+            return e;
+        uint32_t est[2] = {0, 0};
+        PH_HIP(hipMemcpyAsync(est, v.hdr + k2::H_EST_LO, 8, hipMemcpyDeviceToHost, st));
+        PH_HIP(hipStreamSynchronize(st));
+        x.h_est = (uint64_t)est[0] | ((uint64_t)est[1] << 32);
+        return (int)POLYHIP_OK;
+    });
+    if (rc != POLYHIP_OK)
+        return rc;
+    // the join's own decision (decide_kernel), taken here for the largest X a device will bring: if the merge would take
+    // the input, it needs every raw sketch -- gather them after all
+    {
+        const double generic_cost = (double)n * (double)n * (double)(2 * s) * 4.0; // est_scale = nx / n: both sides scale with nx
+        if ((double)sh[0].h_est > generic_cost)
+            return POLYHIP_OK;
+    }
+    *built = true;
+    return POLYHIP_OK;
+}

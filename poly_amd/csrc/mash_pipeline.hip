@@ -23,6 +23,8 @@ using namespace polyhip;
 
 namespace {
 
+thread_local int g_last_path = 0;
+
 // one device's part: its copy of the sketch array, the reads it sketched
 struct SketchShard {
     uint64_t i0 = 0, i1 = 0; // reads [i0, i1)
@@ -141,6 +143,7 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs, const uint64_t *off
         return polyhip_mash_shared_counts_dev(nullptr, n, 0, nullptr, n, 0, nullptr, 0, nullptr, 0, nullptr);
     std::shared_ptr<md::Pool> P = md::pool();
     const size_t nsh = P ? md::size(*P) : 1;
+    g_last_path = P ? 2 : 0;
     const uint64_t row = (uint64_t)s * 4;
     const std::vector<uint64_t> cut = md::split(n, nsh, [&](uint64_t i) { return offsets[i] - offsets[0] + i * row; });
     std::vector<SketchShard> sh(nsh);
@@ -161,9 +164,41 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs, const uint64_t *off
     for (size_t q = 0; q < nsh; ++q) // SketchSize 1: the reference panics in Sketch, before any distance is asked for
         if (sh[q].panic != POLYHIP_OK)
             return set_error(sh[q].panic, "%s", sh[q].panic_text.c_str());
+    // Round B without gathering the sketches (round 4; POLYHIP_K2_EXCHANGE=0: the gather, testing aid and the way back):
+    // the devices build ONE index together -- level 1 on their own rows, items exchanged by value range, level 2 on 1/N of the
+    // range, finished parts exchanged (k2_exchange_index, mash_distance.hip) -- and every device joins the rows it sketched.
+    if (P && nsh >= 2 && (counts || dist) && !env_is("POLYHIP_K2_EXCHANGE", '0')) {
+        std::vector<K2XShard> xs(nsh);
+        uint64_t rows_blk = 1;
+        for (size_t q = 0; q < nsh; ++q) {
+            xs[q].dev = sh[q].dev;
+            xs[q].i0 = sh[q].i0;
+            xs[q].i1 = sh[q].i1;
+            xs[q].sk = sh[q].dSk.as<uint32_t>();
+            rows_blk = std::max(rows_blk, k2_rows_per_block(sh[q].i1 - sh[q].i0, n, counts != nullptr, dist != nullptr));
+        }
+        bool built = false;
+        rc = k2_exchange_index(*P, xs, n, s, rows_blk, &built);
+        if (rc != POLYHIP_OK)
+            return rc;
+        if (built)
+            g_last_path = 1;
+        if (built)
+            return md::run(*P, [&](size_t q) {
+                const uint64_t i0 = sh[q].i0, m = sh[q].i1 - i0;
+                if (m == 0)
+                    return (int)POLYHIP_OK;
+                const uint32_t *sk = sh[q].dSk.as<uint32_t>();
+                return k2_rows_to_host(sk + i0 * (uint64_t)s, m, s, sk, n, s, counts ? counts + i0 * n : nullptr,
+                                       dist ? dist + i0 * n : nullptr, xs[q].work.p, xs[q].work_bytes);
+            });
+        // (an irregular sketch, a join that is not the dense one, or an input the merge would take: gather after all)
+    }
     rc = P ? md::run(*P, round_b) : round_b(0);
     // the sketch arrays are freed by whoever drops `sh` (hipFree takes a pointer of any device)
     return rc;
 }
+
+int polyhip_mash_sketch_distance_matrix_last_path(void) { return g_last_path; }
 
 } // extern "C"

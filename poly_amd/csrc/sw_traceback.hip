@@ -619,12 +619,13 @@ __global__ __launch_bounds__(256) void tb_profile16_kernel(const uint8_t *__rest
         pg3 = g3;                                                           \
         H[r_] = h3;                                                         \
         if ((r_ & 15) == 15 || r_ == RB - 1) {                              \
-            uint32_t *o_ = dirw + ((size_t)tt * TBU * NG + (r_ >> 4)) * 2 * 64; \
-            _Pragma("unroll") for (int c_ = 0; c_ < TBU; ++c_)              \
-            {                                                               \
-                o_[((size_t)c_ * NG * 2 + 0) * 64] = wG[c_];                \
-                o_[((size_t)c_ * NG * 2 + 1) * 64] = wL[c_];                \
-            }                                                               \
+            /* a lane's eight words of (iteration, row group) are ONE 32-byte piece, (G, L) of a column side by side: the \
+               walk, which visits a block's four columns one after the other, then fetches one piece per block and row  \
+               group instead of two words in two different lines per step (19 GB of 64-byte fetches for 1M reads)        \
+             */                                                             \
+            uint4 *o_ = reinterpret_cast<uint4 *>(dirw + ((size_t)tt * NG + (r_ >> 4)) * (64 * 8)); \
+            o_[0] = make_uint4(wG[0], wL[0], wG[1], wL[1]);                 \
+            o_[1] = make_uint4(wG[2], wL[2], wG[3], wL[3]);                 \
         }                                                                   \
     } while (0)
 // the profile entries of four row pairs (one packed register of code offsets per band): eight ds_read_b64
@@ -775,7 +776,8 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
         H[i] = 0;
 
     const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
-    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane;
+    static_assert(TBU == 4, "a lane's piece of direction words is (G, L) x four columns");
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane * 8;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
     const uint32_t pad_base = lds_base + nqB * pstride;
 
@@ -869,14 +871,16 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
         const uint16_t *P16 = reinterpret_cast<const uint16_t *>(P);
         uint32_t i = eA, j = eB;
         int h = (int)M;
+        if (wide & 4) // POLYHIP_TB_NOWALK=1: ablation probe (empty strings) -- what does the sweep cost on its own?
+            h = 0;
         while (h > 0 && i > 0 && j > jb0 && len < stride) {
             const uint32_t jj = j - 1u, r = i - 1u, band = r >= (uint32_t)RB ? 1u : 0u, rr = r - band * RB, g = rr >> 4;
             const uint32_t rows = min(16u, (uint32_t)RB - 16u * g);
             const uint32_t bit = rows - 1u - (rr & 15u) + 16u * band;
             const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
-            const uint32_t *wp = dirw + (((size_t)tt * TBU + (jj & 3u)) * NG + g) * 2 * 64;
-            const uint32_t wg = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t wl = __hip_atomic_load(wp + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t *wp = reinterpret_cast<const uint64_t *>(dirw + ((size_t)tt * NG + g) * (64 * 8) + (jj & 3u) * 2u);
+            const uint64_t w2 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wg = (uint32_t)w2, wl = (uint32_t)(w2 >> 32);
             const uint8_t sa = ap[r], sb = B[jj];
             uint8_t ca, cb;
             if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
@@ -1037,7 +1041,7 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16x2_kernel(
         H[i] = 0;
 
     const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
-    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane;
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane * 8;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(P));
     const uint32_t pad_base = lds_base + nqB * pstride;
 
@@ -1149,13 +1153,16 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16x2_kernel(
         const uint16_t *P16 = reinterpret_cast<const uint16_t *>(P);
         uint32_t i = eA, j = eB;
         int h = (int)M;
+        if (wide & 4) // POLYHIP_TB_NOWALK=1: ablation probe
+            h = 0;
         while (h > 0 && i > 0 && j > jb0 && len < stride) {
             const uint32_t jj = j - 1u, r = i - 1u, band = r / (uint32_t)RB, rr = r - band * RB, g = rr >> 4;
             const uint32_t bit = 15u - (rr & 15u) + 16u * (band & 1u);
             const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
-            const uint32_t *wp = dirw + (band >> 1) + (((size_t)tt * TBU + (jj & 3u)) * NG + g) * 2 * 64;
-            const uint32_t wg = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t wl = __hip_atomic_load(wp + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint64_t *wp =
+                reinterpret_cast<const uint64_t *>(dirw + (band >> 1) * 8u + ((size_t)tt * NG + g) * (64 * 8) + (jj & 3u) * 2u);
+            const uint64_t w2 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t wg = (uint32_t)w2, wl = (uint32_t)(w2 >> 32);
             const uint8_t sa = ap[r], sb = B[jj];
             uint8_t ca, cb;
             if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
@@ -2230,7 +2237,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     // should the two conditions ever drift apart, fail here instead of walking from row 4e9
     PH_REQUIRE(!deferred || use_prof || use_half2, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
     // bit 0: the conservative per-pair window (POLYHIP_TB_WIDE=1, testing aid); bit 1: deferred end cells allowed
-    const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0);
+    const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0) | (env_is("POLYHIP_TB_NOWALK", '1') ? 4 : 0);
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     // (the two-lane kernel's direction words take a quarter of the one-wave-per-pair kernel's, which sizes the workspace of

@@ -152,6 +152,11 @@ def sketch_distance_matrix_packed(seqs: np.ndarray, offsets: np.ndarray, k: int,
     return sk, counts, dist
 
 
+def sketch_distance_matrix_last_path() -> int:
+    """0 = one device, 1 = a device list with the item exchange, 2 = a device list with the sketch gather (tests)"""
+    return int(_lib.lib().polyhip_mash_sketch_distance_matrix_last_path())
+
+
 def SketchDistanceMatrix(seqs, k: int, s: int) -> np.ndarray:
     """Additive batch API (BASELINE configs[2]): dist[i][j] = Sketch(seqs[i]).Distance(Sketch(seqs[j]))."""
     buf, offs = _pack(seqs)

@@ -197,6 +197,99 @@ def test_reads_to_distance_matrix_in_one_call(ids):
     assert c.max() > 50  # the families do share hashes
 
 
+def _family_reads(rng, nfam, copies, L, nsub):
+    genomes = [_dna(rng, L) for _ in range(nfam)]
+    reads = []
+    for i in range(nfam * copies):
+        g = bytearray(genomes[i % nfam])
+        for j in rng.integers(0, len(g), nsub):
+            g[int(j)] = int(rng.choice(list(b"ACGT")))
+        reads.append(bytes(g))
+    return reads
+
+
+@pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0], [0] * 5, [0] * 8])
+def test_reads_to_distance_matrix_by_item_exchange(ids, monkeypatch):
+    """The device list's ONE index without gathering the sketches (level 1 on a device's own rows, items exchanged by
+    value range, level 2 on 1/N of the range, finished parts exchanged): every read has its s windows, so the exchange
+    runs (last_path 1) -- equal to the gather (POLYHIP_K2_EXCHANGE=0, last_path 2), to the one-device call and to the
+    two-call path on the oracle's sketches (mash.go:68-140).  Reads of very different sizes (ragged, empty shards), a
+    tandem repeat (a hash many times in ONE sketch: occurrence numbers cross the exchange), both level-1 scatters."""
+    from poly_amd import devices, mash
+    rng = np.random.default_rng(len(ids))
+    k, s = 21, 150
+    reads = _family_reads(rng, 7, 30, 3000, 30)
+    reads[3] = _dna(rng, 200) * 30            # period 200: every hash of the sketch 30 times over
+    reads[50] = reads[3][:4000]
+    reads[100] = _family_reads(rng, 1, 1, 150_000, 0)[0]  # most of the batch's bytes: shards without a read
+    buf, offs = _pack(reads)
+    want_sk = orc.mash_sketch_batch(buf, offs, k, s)
+    want_c, want_d = mash.distance_matrix_packed(want_sk, want_sk)
+    for stage in ("1", "0"):
+        monkeypatch.setenv("POLYHIP_K2_STAGE", stage)
+        with devices.devices(ids):
+            monkeypatch.delenv("POLYHIP_K2_EXCHANGE", raising=False)
+            sk, c, d = mash.sketch_distance_matrix_packed(buf, offs, k, s)
+            assert mash.sketch_distance_matrix_last_path() == 1
+            monkeypatch.setenv("POLYHIP_K2_EXCHANGE", "0")
+            sk2, c2, d2 = mash.sketch_distance_matrix_packed(buf, offs, k, s)
+            assert mash.sketch_distance_matrix_last_path() == 2
+        monkeypatch.delenv("POLYHIP_K2_EXCHANGE", raising=False)
+        assert (sk == want_sk).all() and (c == want_c).all() and (d == want_d).all()
+        assert (sk2 == want_sk).all() and (c2 == want_c).all() and (d2 == want_d).all()
+    for i in range(0, len(reads), 11):
+        for j in (0, 3, 50, 100, 7, 209):
+            assert int(c[i, j]) == orc.mash_shared(want_sk[i], want_sk[j])
+    assert c[3, 50] >= 90 and c.max() == s
+
+
+def test_item_exchange_falls_back_where_the_merge_needs_raw_sketches():
+    """one read with fewer than s windows (a positional sketch, mash.go:81-84): its pairs are the merge's, which reads both
+    raw sketches -- the devices gather the sketches as before (last_path 2) and the matrix is the one-device call's"""
+    from poly_amd import devices, mash
+    rng = np.random.default_rng(77)
+    k, s = 21, 150
+    reads = _family_reads(rng, 4, 10, 2500, 20)
+    reads[17] = _dna(rng, 120)
+    buf, offs = _pack(reads)
+    one = mash.sketch_distance_matrix_packed(buf, offs, k, s)
+    assert mash.sketch_distance_matrix_last_path() == 0
+    with devices.devices([0, 0, 0]):
+        got = mash.sketch_distance_matrix_packed(buf, offs, k, s)
+        assert mash.sketch_distance_matrix_last_path() == 2
+    for a, b in zip(one, got):
+        assert (a == b).all()
+
+
+def test_item_exchange_with_compact_items_at_full_read_length():
+    """12,000 reads of 10 kb (k = 21, s = 1000; 6,000 random ones and a mutated copy of each): 1.2e7 index items -- enough
+    for the compact 4-byte item format (bucket shift 9), which the small tests do not reach -- over five aliased devices:
+    counts equal to the gather's and the one-device call's on all 1.44e8 pairs, sampled pairs equal to the oracle's merge"""
+    import torch
+    from poly_amd import devices, mash
+    n, L, k, s = 12_000, 10_000, 21, 1000
+    d = torch.empty(n // 2 * L, dtype=torch.uint8, device=torch.device("cuda:0"))
+    mash.synth_dna_dev(0xE4, d)
+    half = d.cpu().numpy().reshape(n // 2, L)
+    del d
+    rng = np.random.default_rng(8)
+    twin = half.copy()
+    hit = rng.random(twin.shape) < 0.004
+    twin[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    host = np.concatenate([half, twin]).reshape(-1)
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    sk1, c1, _ = mash.sketch_distance_matrix_packed(host, offs, k, s, want_dist=False)
+    with devices.devices([0] * 5):
+        sk5, c5, _ = mash.sketch_distance_matrix_packed(host, offs, k, s, want_dist=False)
+        assert mash.sketch_distance_matrix_last_path() == 1
+    assert (sk5 == sk1).all() and (c5 == c1).all()
+    assert (np.diagonal(c5) == s).all() and int((c5 != 0).sum()) >= 2 * n
+    for i in rng.integers(0, n // 2, 40):
+        for j in (int(i), int(i) + n // 2, int(rng.integers(0, n))):
+            assert int(c5[i, j]) == orc.mash_shared(sk5[i], sk5[j]) and c5[i, j] == c5[j, i]
+    assert c5[0, n // 2] > 300
+
+
 def test_reads_to_distance_matrix_panics_like_the_reference():
     from poly_amd import _lib, devices, mash
     rng = np.random.default_rng(13)
