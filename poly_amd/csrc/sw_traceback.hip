@@ -656,6 +656,124 @@ __global__ __launch_bounds__(256) void tb_profile16_kernel(const uint8_t *__rest
 
 typedef uint32_t tbf_u32x2 __attribute__((ext_vector_type(2)));
 
+// The walk over the half-float kernels' direction words (tb_prof16_kernel: LP = 1 lane per pair, two bands; tb_prof16x2_kernel:
+// LP = 2, four bands): `dirw` = the pair's (first) lane's piece inside its wave's buffer, jb0 / lag = where the pair's
+// window began and how many iterations its wave started ahead of it.  COHERENT: the words were stored by this very wave a
+// moment ago (agent-scope loads); else by a kernel that has finished (plain loads: a block's four columns are one 32-byte
+// piece, the second to fourth step of a diagonal hit L1).  P16 / codeL may live in LDS or in global memory.
+template <int RB, int LP, bool COHERENT>
+__device__ __forceinline__ uint32_t tbf_walk(const uint32_t *__restrict__ dirw, uint32_t jb0, uint32_t lag, uint32_t eA, uint32_t eB,
+                                             int M, int gap, int ncp, const uint16_t *P16, const uint8_t *codeL,
+                                             const uint8_t *__restrict__ ap, const uint8_t *__restrict__ B,
+                                             uint8_t *__restrict__ outA, uint8_t *__restrict__ outB, uint32_t stride)
+{
+    // A step used to be a chain of its own: two byte loads, the direction words' load, two byte stores per cell -- 150
+    // dependent round trips per read.  Now the lane keeps (i) the 32-byte piece of direction words it is in (a block's four
+    // columns x (G, L) of one row group: a diagonal stays in it for up to four steps), (ii) the aligned dword of the read
+    // that holds the current row's symbol, (iii) eight finished characters of either string (one unaligned 8-byte store
+    // per eight steps: strings are filled from the back, so the newest character is the lowest byte).
+    constexpr int NG = (RB + 15) / 16;
+    uint32_t i = eA, j = eB, len = 0;
+    int h = M;
+    uint64_t pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0; // the piece: (G, L) of columns 0..3
+    uint32_t pkey = 0xFFFFFFFFu;
+    const uint32_t a0 = (uint32_t)(reinterpret_cast<uintptr_t>(ap) & 3u);
+    const uint32_t *apw = reinterpret_cast<const uint32_t *>(ap - a0); // aligned dwords over the read (the same words its bytes live in)
+    uint32_t aw = 0, akey = 0xFFFFFFFFu;
+    uint64_t accA = 0, accB = 0;
+    while (h > 0 && i > 0 && j > jb0 && len < stride) {
+        const uint32_t jj = j - 1u, r = i - 1u, band = r / (uint32_t)RB, rr = r - band * RB, g = rr >> 4;
+        const uint32_t rows = min(16u, (uint32_t)RB - 16u * g);
+        const uint32_t bit = rows - 1u - (rr & 15u) + 16u * (band & 1u);
+        const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
+        const uint32_t key = (tt * NG + g) * 2u + (LP == 2 ? (band >> 1) : 0u);
+        if (key != pkey) {
+            const uint32_t *pp = dirw + (LP == 2 ? (band >> 1) * 8u : 0u) + ((size_t)tt * NG + g) * (64 * 8);
+            if (COHERENT) { // stored by this very wave a moment ago
+                const uint64_t *p8 = reinterpret_cast<const uint64_t *>(pp);
+                pc0 = __hip_atomic_load(p8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pc1 = __hip_atomic_load(p8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pc2 = __hip_atomic_load(p8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pc3 = __hip_atomic_load(p8 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const uint4 q0 = reinterpret_cast<const uint4 *>(pp)[0], q1 = reinterpret_cast<const uint4 *>(pp)[1];
+                pc0 = (uint64_t)q0.x | ((uint64_t)q0.y << 32);
+                pc1 = (uint64_t)q0.z | ((uint64_t)q0.w << 32);
+                pc2 = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
+                pc3 = (uint64_t)q1.z | ((uint64_t)q1.w << 32);
+            }
+            pkey = key;
+        }
+        const uint32_t ar = a0 + r;
+        if ((ar >> 2) != akey) {
+            akey = ar >> 2;
+            aw = apw[akey];
+        }
+        const uint32_t c = jj & 3u;
+        const uint64_t w2 = c == 0u ? pc0 : c == 1u ? pc1 : c == 2u ? pc2 : pc3;
+        const uint32_t wg = (uint32_t)w2, wl = (uint32_t)(w2 >> 32);
+        const uint8_t sa = (uint8_t)(aw >> (8u * (ar & 3u))), sb = B[jj];
+        uint8_t ca, cb;
+        if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
+            h -= tbf_half_score(P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
+            ca = sa;
+            cb = sb;
+            --i;
+            --j;
+        } else if (((wl >> bit) & 1u) == 0u) { // :220-223
+            h -= gap;
+            ca = sa;
+            cb = '-';
+            --i;
+        } else { // :224-227
+            h -= gap;
+            ca = '-';
+            cb = sb;
+            --j;
+        }
+        accA = (accA << 8) | ca;
+        accB = (accB << 8) | cb;
+        ++len;
+        if ((len & 7u) == 0u) { // characters stride - len .. stride - len + 7
+            __builtin_memcpy(outA + (stride - len), &accA, 8);
+            __builtin_memcpy(outB + (stride - len), &accB, 8);
+        }
+    }
+    for (uint32_t k = 0, n = len & 7u; k < n; ++k) { // the last, partly filled group: its newest character is the lowest byte
+        outA[stride - len + k] = (uint8_t)(accA >> (8u * k));
+        outB[stride - len + k] = (uint8_t)(accB >> (8u * k));
+    }
+    return len;
+}
+
+// The walk as a kernel of its own (round 4; POLYHIP_TB_SPLITWALK=1 -- it lost, see traceback_impl): a thread per pair, no
+// LDS, under 30 registers, eight waves per SIMD.  The sweep kernel leaves (jb0, lag) per pair in `walkinfo` ((0 | 1, ~0):
+// nothing to walk, alnLen = 0 | ~0).
+template <int RB, int LP>
+__global__ __launch_bounds__(256) void tb_walk16_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0,
+                                                       uint64_t pair1, const uint8_t *__restrict__ B,
+                                                       const uint16_t *__restrict__ prof16, const uint8_t *__restrict__ codeA, int ncodes,
+                                                       int gap, const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB,
+                                                       const int64_t *__restrict__ score, uint32_t nblk_alloc,
+                                                       const uint32_t *__restrict__ dirbuf, const uint2 *__restrict__ walkinfo,
+                                                       uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB,
+                                                       uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    constexpr int NG = (RB + 15) / 16;
+    constexpr uint32_t PPW = 64 / LP; // pairs of one sweep wave
+    const uint64_t pl = (uint64_t)blockIdx.x * 256 + threadIdx.x, pair = pair0 + pl;
+    if (pair >= pair1)
+        return;
+    const uint2 info = walkinfo[pl];
+    if (info.y == 0xFFFFFFFFu) {
+        alnLen[pair] = info.x ? 0xFFFFFFFFu : 0u;
+        return;
+    }
+    const uint32_t *dirw = dirbuf + (pl / PPW) * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + (uint32_t)(pl % PPW) * (LP * 8u);
+    alnLen[pair] = tbf_walk<RB, LP, false>(dirw, info.x, info.y, endA[pair], endB[pair], (int)score[pair], gap, ncodes + 1, prof16, codeA,
+                                           A + offA[pair], B, alnA + pair * stride, alnB + pair * stride, stride);
+}
+
 template <int RB>
 __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
@@ -663,7 +781,7 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
     const uint8_t *__restrict__ codeA, int ncodes, int gap, uint32_t *__restrict__ endA,
     uint32_t *__restrict__ endB, uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
     uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
-    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride, uint2 *__restrict__ walkinfo)
 {
     static_assert(RB % 4 == 0 && RB <= 76, "RB");
     constexpr int RA = 2 * RB;
@@ -865,45 +983,14 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
         endA[pair] = 0u;
         endB[pair] = 0u;
     }
-    if (work && !lost) {
+    if (walkinfo) { // the walk is a kernel of its own (tb_walk16_kernel)
+        walkinfo[pair - pair0] = (work && !lost) ? make_uint2(jb0, lag) : make_uint2((rowsA > 0 && lenA > RA) ? 1u : 0u, 0xFFFFFFFFu);
+        return;
+    }
+    if (work && !lost && !(wide & 4)) { // (wide & 4: POLYHIP_TB_NOWALK=1, ablation probe -- what does the sweep cost on its own?)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
-        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
-        const uint16_t *P16 = reinterpret_cast<const uint16_t *>(P);
-        uint32_t i = eA, j = eB;
-        int h = (int)M;
-        if (wide & 4) // POLYHIP_TB_NOWALK=1: ablation probe (empty strings) -- what does the sweep cost on its own?
-            h = 0;
-        while (h > 0 && i > 0 && j > jb0 && len < stride) {
-            const uint32_t jj = j - 1u, r = i - 1u, band = r >= (uint32_t)RB ? 1u : 0u, rr = r - band * RB, g = rr >> 4;
-            const uint32_t rows = min(16u, (uint32_t)RB - 16u * g);
-            const uint32_t bit = rows - 1u - (rr & 15u) + 16u * band;
-            const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
-            const uint64_t *wp = reinterpret_cast<const uint64_t *>(dirw + ((size_t)tt * NG + g) * (64 * 8) + (jj & 3u) * 2u);
-            const uint64_t w2 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t wg = (uint32_t)w2, wl = (uint32_t)(w2 >> 32);
-            const uint8_t sa = ap[r], sb = B[jj];
-            uint8_t ca, cb;
-            if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
-                h -= tbf_half_score(P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
-                ca = sa;
-                cb = sb;
-                --i;
-                --j;
-            } else if (((wl >> bit) & 1u) == 0u) { // :220-223
-                h -= gap;
-                ca = sa;
-                cb = '-';
-                --i;
-            } else { // :224-227
-                h -= gap;
-                ca = '-';
-                cb = sb;
-                --j;
-            }
-            outA[stride - 1 - len] = ca;
-            outB[stride - 1 - len] = cb;
-            ++len;
-        }
+        len = tbf_walk<RB, 1, true>(dirw, jb0, lag, eA, eB, (int)M, gap, ncp, reinterpret_cast<const uint16_t *>(P), codeL, ap, B,
+                                    alnA + pair * stride, alnB + pair * stride, stride);
     }
     alnLen[pair] = (active && rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
 }
@@ -926,7 +1013,7 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16x2_kernel(
     const uint8_t *__restrict__ codeA, int ncodes, int gap, uint32_t *__restrict__ endA,
     uint32_t *__restrict__ endB, uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
     uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
-    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride, uint2 *__restrict__ walkinfo)
 {
     static_assert(RB % 16 == 0 && RB <= 64, "RB");
     constexpr int RL = 2 * RB; // rows per lane
@@ -1147,45 +1234,14 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16x2_kernel(
         endA[pair] = 0u;
         endB[pair] = 0u;
     }
-    if (work && !lost) {
+    if (walkinfo) { // the walk is a kernel of its own (tb_walk16_kernel)
+        walkinfo[pair - pair0] = (work && !lost) ? make_uint2(jb0, lag) : make_uint2((rowsA > 0 && lenA > RA) ? 1u : 0u, 0xFFFFFFFFu);
+        return;
+    }
+    if (work && !lost && !(wide & 4)) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // this wave's own stores (my partner's included), read back by me
-        uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
-        const uint16_t *P16 = reinterpret_cast<const uint16_t *>(P);
-        uint32_t i = eA, j = eB;
-        int h = (int)M;
-        if (wide & 4) // POLYHIP_TB_NOWALK=1: ablation probe
-            h = 0;
-        while (h > 0 && i > 0 && j > jb0 && len < stride) {
-            const uint32_t jj = j - 1u, r = i - 1u, band = r / (uint32_t)RB, rr = r - band * RB, g = rr >> 4;
-            const uint32_t bit = 15u - (rr & 15u) + 16u * (band & 1u);
-            const uint32_t tt = ((jj - jb0) >> 2) + lag + band; // the wave iteration that swept this cell
-            const uint64_t *wp =
-                reinterpret_cast<const uint64_t *>(dirw + (band >> 1) * 8u + ((size_t)tt * NG + g) * (64 * 8) + (jj & 3u) * 2u);
-            const uint64_t w2 = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t wg = (uint32_t)w2, wl = (uint32_t)(w2 >> 32);
-            const uint8_t sa = ap[r], sb = B[jj];
-            uint8_t ca, cb;
-            if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
-                h -= tbf_half_score(P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
-                ca = sa;
-                cb = sb;
-                --i;
-                --j;
-            } else if (((wl >> bit) & 1u) == 0u) { // :220-223
-                h -= gap;
-                ca = sa;
-                cb = '-';
-                --i;
-            } else { // :224-227
-                h -= gap;
-                ca = '-';
-                cb = sb;
-                --j;
-            }
-            outA[stride - 1 - len] = ca;
-            outB[stride - 1 - len] = cb;
-            ++len;
-        }
+        len = tbf_walk<RB, 2, true>(dirw, jb0, lag, eA, eB, (int)M, gap, ncp, reinterpret_cast<const uint16_t *>(P), codeL, ap, B,
+                                    alnA + pair * stride, alnB + pair * stride, stride);
     }
     alnLen[pair] = (rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
 }
@@ -2184,8 +2240,8 @@ size_t polyhip_sw_traceback_workspace_bytes(const polyhip_scoring *sc, uint64_t 
     // enough for every pair in one launch, capped at 8 GiB (the entry point loops over chunks);
     // never less than one workgroup's worth
     const uint64_t padded = (npairs + k3t::THREADS - 1) / k3t::THREADS * k3t::THREADS;
-    uint64_t want = padded * p.per_pair;
-    const uint64_t cap = 8ull << 30, floor_ = (uint64_t)k3t::THREADS * p.per_pair;
+    uint64_t want = padded * (p.per_pair + 8); // (+ 8: what the half-float kernels hand to their walk kernel per pair)
+    const uint64_t cap = 8ull << 30, floor_ = (uint64_t)k3t::THREADS * (p.per_pair + 8);
     if (want > cap)
         want = cap / floor_ * floor_;
     if (want < floor_)
@@ -2242,7 +2298,14 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     // (the two-lane kernel's direction words take a quarter of the one-wave-per-pair kernel's, which sizes the workspace of
     // its row class: its chunks are cut by its own figure, or they would fill a third of the chip)
-    const size_t per_pair = use_half2 ? p.half2_per_pair : p.per_pair;
+    // POLYHIP_TB_SPLITWALK=1 (a measured alternative, kept as a cross-check): the half-float kernels' walk as a kernel of its
+    // own behind each sweep (tb_walk16_kernel; 8 bytes per pair behind a chunk's direction words carry (window start, wave
+    // lag) over).  With a thread per pair and eight waves per SIMD every pair of a chunk walks at once -- and a million
+    // half-written output lines are in flight against 32 MB of L2: 9.4 ms per 1M config-4 reads against 8.5 ms with the
+    // walk at the end of the sweep kernel (profiles/r04_tb_walk.log).
+    const bool half_any = use_half2 || (use_prof && p.half_ok && !env_is("POLYHIP_TB_F16", '0'));
+    const bool split_walk = half_any && env_is("POLYHIP_TB_SPLITWALK", '1');
+    const size_t per_pair = (use_half2 ? p.half2_per_pair : p.per_pair) + (split_walk ? 8 : 0);
     uint64_t chunk = usable / per_pair / k3t::THREADS * k3t::THREADS;
     // A batch that needs several chunks of the direction workspace: the byte-profile and the one-wave-per-pair kernels take them through the two
     // HALVES of the workspace on two streams (the caller's and one of the library's), so that the end of one chunk --
@@ -2333,6 +2396,10 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
             PH_HIP(hipGetLastError());
             continue;
         }
+        // (chunk = the pairs a (half) workspace holds: its direction words first, then the walk's 8 bytes per pair)
+        uint2 *walkinfo = split_walk ? reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(dirbuf) + chunk * (per_pair - 8)) : nullptr;
+        const unsigned wblocks16 = (unsigned)((p1 - p0 + 255) / 256);
+        const bool walk_now = split_walk && !(wide & 4);
         if (use_half2) {
             const unsigned blocks2 = (unsigned)((p1 - p0 + k3t::THREADS / 2 - 1) / (k3t::THREADS / 2));
             auto kern = k3t::tb_prof16x2_kernel<64>;
@@ -2341,7 +2408,11 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
             hipLaunchKernelGGL(kern, dim3(blocks2), dim3(k3t::THREADS), p.half_smem, st, d_A, d_offA, p0, p1, d_B, p.lenB_pad,
                                reinterpret_cast<const uint2 *>(prof), sc->d_codeA, sc->ncodes, (int)sc->gap, d_endA, d_endB, d_err,
                                d_score, (int)sc->smax, p.win.wcols, wide, p.nblk_alloc2, dirbuf, d_alnA, d_alnB, d_alnLen,
-                               aln_stride);
+                               aln_stride, walkinfo);
+            if (walk_now)
+                hipLaunchKernelGGL((k3t::tb_walk16_kernel<64, 2>), dim3(wblocks16), dim3(256), 0, st, d_A, d_offA, p0, p1, d_B,
+                                   reinterpret_cast<const uint16_t *>(prof), sc->d_codeA, sc->ncodes, (int)sc->gap, d_endA, d_endB,
+                                   d_score, p.nblk_alloc2, dirbuf, walkinfo, d_alnA, d_alnB, d_alnLen, aln_stride);
             PH_HIP(hipGetLastError());
             continue;
         }
@@ -2354,7 +2425,11 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.half_smem, st, d_A, d_offA, p0, p1, d_B,          \
                            p.lenB_pad, reinterpret_cast<const uint2 *>(prof), sc->d_codeA, sc->ncodes, (int)sc->gap,   \
                            d_endA, d_endB, d_err, d_score, (int)sc->smax, p.win.wcols, wide, p.nblk_alloc, dirbuf,     \
-                           d_alnA, d_alnB, d_alnLen, aln_stride);                                                      \
+                           d_alnA, d_alnB, d_alnLen, aln_stride, walkinfo);                                            \
+        if (walk_now)                                                                                                  \
+            hipLaunchKernelGGL((k3t::tb_walk16_kernel<RB_, 1>), dim3(wblocks16), dim3(256), 0, st, d_A, d_offA, p0, p1, d_B, \
+                               reinterpret_cast<const uint16_t *>(prof), sc->d_codeA, sc->ncodes, (int)sc->gap, d_endA,  \
+                               d_endB, d_score, p.nblk_alloc, dirbuf, walkinfo, d_alnA, d_alnB, d_alnLen, aln_stride);   \
     } while (0)
             if (p.ra == 64)
                 PH_TBH_LAUNCH(32);

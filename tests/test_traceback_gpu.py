@@ -380,6 +380,11 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, tb_cell, ga
     a3, b3, l3, path3 = run(score, True)
     # 153..256 rows: two lanes per pair on packed halves (5); the 32-bit form of the fixture: one wave per pair (4)
     assert (path1, path2, path3) == ((1, 2, 1) if L <= 152 else (5, 2, 5) if tb_cell == "half" else (4, 2, 4))
+    if tb_cell == "half":  # the half-float kernels' walk as a kernel of its own behind the sweep (the default: inside it)
+        monkeypatch.setenv("POLYHIP_TB_SPLITWALK", "1")
+        a5, b5, l5, path5 = run(score, False)
+        monkeypatch.delenv("POLYHIP_TB_SPLITWALK", raising=False)
+        assert path5 == path1 and torch.equal(l1, l5) and torch.equal(a1, a5) and torch.equal(b1, b5)
     if L > 152 and tb_cell == "half":  # ... and the one-wave-per-pair kernel on the same input, every pair
         monkeypatch.setenv("POLYHIP_TB_HALF2", "0")
         a4, b4, l4, path4 = run(score, False)
