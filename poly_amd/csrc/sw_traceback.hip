@@ -661,7 +661,7 @@ typedef uint32_t tbf_u32x2 __attribute__((ext_vector_type(2)));
 // window began and how many iterations its wave started ahead of it.  COHERENT: the words were stored by this very wave a
 // moment ago (agent-scope loads); else by a kernel that has finished (plain loads: a block's four columns are one 32-byte
 // piece, the second to fourth step of a diagonal hit L1).  P16 / codeL may live in LDS or in global memory.
-template <int RB, int LP, bool COHERENT>
+template <int RB, int LP, bool COHERENT, bool BYTAB = false> // BYTAB: P16 = halves [code of a][byte of b] (every pair its own B)
 __device__ __forceinline__ uint32_t tbf_walk(const uint32_t *__restrict__ dirw, uint32_t jb0, uint32_t lag, uint32_t eA, uint32_t eB,
                                              int M, int gap, int ncp, const uint16_t *P16, const uint8_t *codeL,
                                              const uint8_t *__restrict__ ap, const uint8_t *__restrict__ B,
@@ -715,7 +715,7 @@ __device__ __forceinline__ uint32_t tbf_walk(const uint32_t *__restrict__ dirw, 
         const uint8_t sa = (uint8_t)(aw >> (8u * (ar & 3u))), sb = B[jj];
         uint8_t ca, cb;
         if (((wg >> bit) & 1u) == 0u) { // align.go:215-219
-            h -= tbf_half_score(P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
+            h -= tbf_half_score(BYTAB ? P16[(size_t)codeL[sa] * 256 + sb] : P16[((size_t)(jj >> 2) * ncp + codeL[sa]) * 4 + (jj & 3u)]);
             ca = sa;
             cb = sb;
             --i;
@@ -991,6 +991,274 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
         len = tbf_walk<RB, 1, true>(dirw, jb0, lag, eA, eB, (int)M, gap, ncp, reinterpret_cast<const uint16_t *>(P), codeL, ap, B,
                                     alnA + pair * stride, alnB + pair * stride, stride);
+    }
+    alnLen[pair] = (active && rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
+}
+
+// ---- every pair with its own B (reads against reads) on packed halves ---------------------------------------------------
+// tb_prof16_kernel's sweep, rows and walk; what changes is where a row finds its scores.  There is no table of the one
+// reference's blocks: a lane builds the profile entries of ITS block -- for every symbol code c the four halves
+// S(c, b_j .. b_j+3) -- from its own four B symbols when the block starts (24 lookups in a table of halves [code][byte] in
+// LDS, six 8-byte stores into the lane's slot: ~60 of the block's ~3300 instructions) and keeps two slots: band 0 works on
+// the new block, band 1 on the one before.  Slots are 56 bytes per lane (up to seven codes), so a wave's reads spread over
+// the banks two lanes at a time.  The next block's four B symbols are loaded an iteration ahead.
+template <int RB>
+__global__ __launch_bounds__(THREADS, 2) void tb_pair16_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
+    const uint8_t *__restrict__ Ball, const uint64_t *__restrict__ offB, const int8_t *__restrict__ lutc,
+    const uint8_t *__restrict__ codeA, int ncodes, int gap, uint32_t *__restrict__ endA,
+    uint32_t *__restrict__ endB, uint32_t *__restrict__ err, const int64_t *__restrict__ score, int smax,
+    uint32_t wcols, int wide, uint32_t nblk_alloc, uint32_t *__restrict__ dirbuf, uint8_t *__restrict__ alnA,
+    uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
+{
+    static_assert(RB % 4 == 0 && RB <= 76, "RB");
+    constexpr uint32_t SLOT = 56; // bytes per lane and slot: seven codes (ncodes + the pad code <= 7)
+    uint2 *const walkinfo = nullptr;
+    constexpr int RA = 2 * RB;
+    constexpr int NG = (RB + 15) / 16;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_tbf[];
+    const int ncp = ncodes + 1;
+    // LDS: two slots per lane, the table of halves H16[code][byte] (the pad code's row: -128 everywhere), the A codes
+    uint8_t *slots = lds_tbf;
+    uint16_t *H16 = reinterpret_cast<uint16_t *>(lds_tbf + 2 * (size_t)THREADS * SLOT);
+    uint8_t *codeL = reinterpret_cast<uint8_t *>(H16 + (size_t)ncp * 256);
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (uint32_t v = tid; v < (uint32_t)ncp * 256u; v += THREADS)
+        H16[v] = (uint16_t)tbf_half_bits(v < (uint32_t)ncodes * 256u ? (int)lutc[v] : -128);
+    codeL[tid] = codeA[tid];
+    {
+        const uint32_t padh = tbf_half_bits(-128), pad2 = padh | (padh << 16);
+        for (int q = 0; q < 2; ++q)
+            for (int c = 0; c < 7; ++c)
+                *reinterpret_cast<uint2 *>(slots + ((size_t)q * THREADS + tid) * SLOT + c * 8) = make_uint2(pad2, pad2);
+    }
+    __syncthreads();
+
+    const uint64_t pair = pair0 + (uint64_t)blockIdx.x * THREADS + tid;
+    const bool active = pair < pair1;
+    uint32_t lenA = 0, eA = 0, eB = 0;
+    int64_t M = 0;
+    const uint8_t *ap = A, *B = Ball;
+    uint64_t oA = 0;
+    uint32_t lenB = 0;
+    if (active) {
+        const uint64_t o0 = offA[pair];
+        oA = o0;
+        lenA = (uint32_t)(offA[pair + 1] - o0);
+        ap = A + o0;
+        const uint64_t ob = offB[pair];
+        B = Ball + ob;
+        lenB = (uint32_t)(offB[pair + 1] - ob);
+        if (err[pair] == 0u) {
+            eA = endA[pair];
+            eB = endB[pair];
+            M = score[pair];
+        }
+    }
+    const bool locate = active && (wide & 2) && eA == k3p::SW_END_DEFERRED; // as tb_prof_kernel
+    const uint32_t rowsA = locate ? lenA : eA;
+    const bool work = active && rowsA > 0 && rowsA <= lenA && eB > 0 && eB <= lenB && M > 0 && lenA <= RA;
+    const uint32_t mycols = work ? min(wcols + 4u, pair_window(wcols, rowsA, M, smax, gap, wide & 1) + (locate ? 4u : 0u)) : 0u;
+    const uint32_t c_s = (work && eB > mycols) ? eB - mycols + 1u : 1u;
+    const uint32_t jb0 = (c_s - 1u) & ~3u;
+    const uint32_t nblk = work ? (eB - jb0 + TBU - 1) / TBU : 0u; // <= nblk_alloc - 1
+
+    // byte offsets (code * 8) of my rows inside a profile block, four rows per register and band.  The read's bytes come as
+    // RA / 4 + 1 aligned dwords, all in flight at once, through a buffer resource over this launch's reads (as
+    // sw_pk1_kernel does; a byte at a time the prologue was RA dependent round trips); 4 GB and more keep the byte loads.
+    uint32_t apk0[RB / 4], apk1[RB / 4];
+    const uint64_t totalA = offA[pair1];
+    if (totalA < 0xFFFFFFF0ull) {
+        const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(A) & 3u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(A) - misA, 0,
+                                                                            (int)(((uint32_t)totalA + misA + 3u) & ~3u), 0x00020000);
+        const uint32_t b0 = (uint32_t)oA + misA;
+        uint32_t dd[RA / 4];
+        {
+            uint32_t aw[RA / 4 + 1];
+#pragma unroll
+            for (int w = 0; w <= RA / 4; ++w)
+                aw[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b0 & ~3u) + 4u * w), 0, 0);
+#pragma unroll
+            for (int w = 0; w < RA / 4; ++w)
+                dd[w] = __builtin_amdgcn_alignbyte(aw[w + 1], aw[w], b0 & 3u);
+        }
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i0 = 4 * w + b, i1 = RB + 4 * w + b;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+                if (work && (uint32_t)i0 < lenA) {
+                    const uint32_t c = codeL[(dd[w] >> (8 * b)) & 0xFFu];
+                    c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                if (work && (uint32_t)i1 < lenA) {
+                    const uint32_t c = codeL[(dd[RB / 4 + w] >> (8 * b)) & 0xFFu];
+                    c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                k0 |= (c0 * 8u) << (8 * b);
+                k1 |= (c1 * 8u) << (8 * b);
+            }
+            apk0[w] = k0;
+            apk1[w] = k1;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t k0 = 0, k1 = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i0 = 4 * w + b, i1 = RB + 4 * w + b;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes;
+                if (work && (uint32_t)i0 < lenA) {
+                    const uint32_t c = codeL[ap[i0]];
+                    c0 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                if (work && (uint32_t)i1 < lenA) {
+                    const uint32_t c = codeL[ap[i1]];
+                    c1 = c == 0xFFu ? (uint32_t)ncodes : c;
+                }
+                k0 |= (c0 * 8u) << (8 * b);
+                k1 |= (c1 * 8u) << (8 * b);
+            }
+            apk0[w] = k0;
+            apk1[w] = k1;
+        }
+    }
+
+    uint32_t H[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        H[i] = 0;
+
+    const uint64_t wave_global = ((uint64_t)blockIdx.x * THREADS + tid) >> 6;
+    static_assert(TBU == 4, "a lane's piece of direction words is (G, L) x four columns");
+    uint32_t *dirw = dirbuf + wave_global * ((size_t)nblk_alloc * TBU * NG * 2 * 64) + lane * 8;
+    const uint32_t slot_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(slots)) + (uint32_t)tid * SLOT;
+    // the four B symbols of a block, as the bytes of one register (0xFF = past the end of B: the pad score); block 0 now,
+    // the others an iteration ahead
+    auto block_syms = [&](uint32_t bt) -> uint32_t {
+        uint32_t w = 0xFFFFFFFFu;
+        if (bt < nblk) {
+            const uint32_t j = jb0 + 4u * bt;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (j + u < lenB)
+                    w = (w & ~(0xFFu << (8 * u))) | ((uint32_t)B[j + u] << (8 * u));
+        }
+        return w;
+    };
+    uint32_t bnext = block_syms(0);
+
+    // end-aligned lanes as in tb_prof_kernel; a lane runs nblk + 1 iterations (band 1 finishes one block later)
+    uint32_t nmax = nblk;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, d, 64));
+    const uint32_t lag = nmax - nblk;
+    const uint32_t gh = tbf_half_bits(gap); // gap < 0
+    const uint32_t gap2 = gh | (gh << 16), one2 = 0x00010001u, two2 = 0x00020002u;
+    const uint32_t Mh = tbf_half_bits((int)M);
+    uint32_t key = 0xFFFFFFFFu;
+    // band 0's last row of the block before, already in the high halves: what band 1 finds above its first row
+    uint32_t hh0 = 0, hh1 = 0, hh2 = 0, hh3 = 0, hg0 = 0, hg1 = 0, hg2 = 0, hg3 = 0, hd = 0;
+    auto sweep = [&](uint32_t tt, auto find_tag) {
+        constexpr int FIND = decltype(find_tag)::value; // 0, 1 = search band 0's cells, 2 = band 1's
+        const uint32_t bt = tt - lag;                   // band 0's block; band 1 works on bt - 1
+        // my slot of this iteration takes block bt's entries; the other one still holds block bt - 1's (pad entries before
+        // the first block: the slots start that way)
+        const uint32_t base0 = slot_base + (tt & 1u) * (THREADS * SLOT), base1 = slot_base + ((tt & 1u) ^ 1u) * (THREADS * SLOT);
+        {
+            const uint32_t bw = bnext;
+            bnext = block_syms(bt + 1u);
+            const uint32_t s0 = bw & 0xFFu, s1 = (bw >> 8) & 0xFFu, s2 = (bw >> 16) & 0xFFu, s3 = bw >> 24;
+            const uint32_t padh = tbf_half_bits(-128);
+            for (int c = 0; c < ncp; ++c) {
+                const uint16_t *row = H16 + c * 256;
+                const uint32_t h0 = s0 != 0xFFu ? row[s0] : padh, h1 = s1 != 0xFFu ? row[s1] : padh;
+                const uint32_t h2 = s2 != 0xFFu ? row[s2] : padh, h3 = s3 != 0xFFu ? row[s3] : padh;
+                const uint64_t e64 = (uint64_t)(h0 | (h1 << 16)) | ((uint64_t)(h2 | (h3 << 16)) << 32);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(base0 + (uint32_t)c * 8u), "v"(e64) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        uint32_t pr0 = hh0, pr1 = hh1, pr2 = hh2, pr3 = hh3, pg0 = hg0, pg1 = hg1, pg2 = hg2, pg3 = hg3, pdiag = hd;
+        uint32_t wG[TBU] = {0u, 0u, 0u, 0u}, wL[TBU] = {0u, 0u, 0u, 0u};
+        tbf_u32x2 xa[4], ya[4], xb[4], yb[4];
+        PH_TBF_ISSUE(apk0[0], apk1[0], xa, ya);
+#pragma unroll
+        for (int g = 0; g < RB / 4; ++g) {
+            if (g + 1 < RB / 4) {
+                PH_TBF_ISSUE(apk0[g + 1], apk1[g + 1], xb, yb);
+                asm volatile("s_waitcnt lgkmcnt(8)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
+                               "+v"(ya[3]));
+            }
+            PH_TBF_ROW(4 * g + 0, xa[0].x, xa[0].y, ya[0].x, ya[0].y);
+            PH_TBF_ROW(4 * g + 1, xa[1].x, xa[1].y, ya[1].x, ya[1].y);
+            PH_TBF_ROW(4 * g + 2, xa[2].x, xa[2].y, ya[2].x, ya[2].y);
+            PH_TBF_ROW(4 * g + 3, xa[3].x, xa[3].y, ya[3].x, ya[3].y);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                xa[q] = xb[q];
+                ya[q] = yb[q];
+            }
+        }
+        // band 0's last row (low halves) becomes band 1's row above (high halves) of the next iteration
+        hd = hh3;
+        hh0 = pr0 << 16;
+        hh1 = pr1 << 16;
+        hh2 = pr2 << 16;
+        hh3 = pr3 << 16;
+        hg0 = pg0 << 16;
+        hg1 = pg1 << 16;
+        hg2 = pg2 << 16;
+        hg3 = pg3 << 16;
+    };
+    const bool any_locate = __any(locate) != 0; // wave-uniform
+    // iterations 0 .. nmax; with a deferred end cell in the wave the last two carry the search (band 0's last block,
+    // then band 1's)
+    for (uint32_t t = 0; t <= nmax; ++t) {
+        if (nblk == 0u || t < lag)
+            continue;
+        if (any_locate && t + 1u == nmax)
+            sweep(t, std::integral_constant<int, 1>{});
+        else if (any_locate && t == nmax)
+            sweep(t, std::integral_constant<int, 2>{});
+        else
+            sweep(t, std::integral_constant<int, 0>{});
+    }
+
+    if (!active)
+        return;
+    uint32_t len = 0;
+    bool lost = false;
+    if (work && locate) {
+        lost = key == 0xFFFFFFFFu; // cannot happen: the packed pass saw M in this block
+        eA = lost ? 0u : (key >> 2) + 1u;
+        eB = lost ? 0u : eB - 3u + (key & 3u);
+        endA[pair] = eA;
+        endB[pair] = eB;
+        if (lost)
+            err[pair] = 0xFFFFFFFEu;
+    } else if (locate) {
+        endA[pair] = 0u;
+        endB[pair] = 0u;
+    }
+    if (walkinfo) { // the walk is a kernel of its own (tb_walk16_kernel)
+        walkinfo[pair - pair0] = (work && !lost) ? make_uint2(jb0, lag) : make_uint2((rowsA > 0 && lenA > RA) ? 1u : 0u, 0xFFFFFFFFu);
+        return;
+    }
+    if (work && !lost && !(wide & 4)) { // (wide & 4: POLYHIP_TB_NOWALK=1, ablation probe -- what does the sweep cost on its own?)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // my own stores, read back by me
+        len = tbf_walk<RB, 1, true, true>(dirw, jb0, lag, eA, eB, (int)M, gap, ncp, H16, codeL, ap, B, alnA + pair * stride,
+                                          alnB + pair * stride, stride);
     }
     alnLen[pair] = (active && rowsA > 0 && lenA > RA) ? 0xFFFFFFFFu : len;
 }
@@ -1982,6 +2250,10 @@ struct Plan {
     bool half2_ok;
     uint32_t nblk_alloc2;
     size_t half2_per_pair;
+    // every pair its own B on packed halves (tb_pair16_kernel): rows <= 152, at most six symbol codes
+    bool pair16_ok;
+    uint32_t pair16_nblk_alloc;
+    size_t pair16_smem;
     // one wave per pair for 256 < lenA <= 4096 (score known): tb_wave_kernel
     int wave_r;            // 0 = not applicable
     size_t wave_per_pair;
@@ -2016,6 +2288,13 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
         const size_t nwl = p.wave_r <= 16 ? 1 : 2 * ((p.wave_r + 31) / 32);
         p.wave_per_pair = ((size_t)p.win.wcols + 63) * 64 * nwl * 4;
         p.per_pair = std::max(p.per_pair, p.wave_per_pair);
+    }
+    p.pair16_ok = reg && (p.ra == 64 || p.ra == 152) && sc->ncodes <= 6 && sc->int8_ok && sc->gap <= -1 && sc->smax > 0 && lenB > 0 &&
+                  (uint64_t)sc->smax * std::min<uint64_t>(max_lenA, lenB) <= 2047ull && (int64_t)sc->smax - sc->gap <= 2048;
+    if (p.pair16_ok) {
+        p.pair16_nblk_alloc = (p.win.wcols + 2 * (TBU - 1)) / TBU + 3;
+        p.pair16_smem = 2 * (size_t)THREADS * 56 + (size_t)(sc->ncodes + 1) * 512 + 256;
+        p.per_pair = std::max(p.per_pair, (size_t)p.pair16_nblk_alloc * TBU * ((p.ra + 31) / 32) * 2 * 4);
     }
     p.cp = sc->cp <= 8 ? 8 : 32;
     p.lenB_pad = (uint32_t)align_up((size_t)std::min<uint64_t>(lenB, 1u << 30), TBU);
@@ -2288,7 +2567,10 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
                           !(p.ra == 256 && wave_ok) &&
                           !env_is("POLYHIP_TB_PROF", '0'); // testing aid: the table kernel for a shared reference
     const bool use_wave = !use_half2 && !use_prof && (p.ra == 0 || p.ra == 256) && wave_ok;
-    k3t::g_tb_last_path = use_half2 ? 5 : use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
+    // every pair its own B, rows <= 152, on packed halves (path 6; POLYHIP_TB_PAIR16=0 or POLYHIP_TB_F16=0: the table kernel)
+    const bool use_pair16 = p.pair16_ok && d_offB != nullptr && d_score != nullptr && d_B != nullptr && !use_wave &&
+                            !env_is("POLYHIP_TB_F16", '0') && !env_is("POLYHIP_TB_PAIR16", '0');
+    k3t::g_tb_last_path = use_pair16 ? 6 : use_half2 ? 5 : use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
     // only the byte-profile kernels know a deferred end cell: the fused entry point decided with traceback_uses_prof();
     // should the two conditions ever drift apart, fail here instead of walking from row 4e9
     PH_REQUIRE(!deferred || use_prof || use_half2, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
@@ -2329,7 +2611,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     void *d_dir = static_cast<uint8_t *>(d_work) + p.prof_bytes;
     // half-float two-band form of the byte-profile kernel (POLYHIP_TB_F16=0: the 32-bit one, testing aid)
     const bool use_half = use_prof && p.half_ok && !env_is("POLYHIP_TB_F16", '0');
-    k3t::g_tb_last_half = (use_half || use_half2) ? 1 : 0;
+    k3t::g_tb_last_half = (use_half || use_half2 || use_pair16) ? 1 : 0;
     if (use_half || use_half2) {
         const uint32_t n16 = (p.lenB_pad / 4 + 1) * (uint32_t)(sc->ncodes + 1);
         hipLaunchKernelGGL(k3t::tb_profile16_kernel, dim3((n16 + 255) / 256), dim3(256), 0, st, d_B, (uint32_t)lenB, p.lenB_pad,
@@ -2366,6 +2648,25 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
             st = (chunk_no & 1) ? aux.s : caller_st;
             if (chunk_no & 1)
                 dirbuf = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_dir) + half_bytes);
+        }
+        if (use_pair16) {
+#define PH_TBQ_LAUNCH(RB_)                                                                                             \
+    do {                                                                                                               \
+        auto kern = k3t::tb_pair16_kernel<RB_>;                                                                        \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                   (int)p.pair16_smem));                                                               \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(k3t::THREADS), p.pair16_smem, st, d_A, d_offA, p0, p1, d_B, d_offB, \
+                           sc->d_lutc, sc->d_codeA, sc->ncodes, (int)sc->gap, d_endA, d_endB, d_err, d_score,          \
+                           (int)sc->smax, p.win.wcols, wide, p.pair16_nblk_alloc, dirbuf, d_alnA, d_alnB, d_alnLen,    \
+                           aln_stride);                                                                                \
+    } while (0)
+            if (p.ra == 64)
+                PH_TBQ_LAUNCH(32);
+            else
+                PH_TBQ_LAUNCH(76);
+#undef PH_TBQ_LAUNCH
+            PH_HIP(hipGetLastError());
+            continue;
         }
         if (use_wave) {
             const unsigned wblocks = (unsigned)((p1 - p0 + k3t::THREADS / 64 - 1) / (k3t::THREADS / 64));

@@ -204,6 +204,71 @@ def test_ragged(al, maxlen, reflen):
     _check(al, _scoring(al, "-ACGT", pm, -1), orc.SubstitutionMatrix("-ACGT", "-ACGT", pm), -1, reads, ref=ref)
 
 
+@pytest.mark.parametrize("maxA,maxB", [(150, 150), (64, 90), (152, 40), (100, 600)])
+def test_every_pair_its_own_reference_on_packed_halves(al, monkeypatch, tb_cell, maxA, maxB):
+    """reads against reads (offB given): the half-float kernel whose profile is built per lane (path 6; the 32-bit fixture and
+    POLYHIP_TB_PAIR16=0: the table kernel, path 2) -- 30k pairs of ragged lengths (B of 1 .. maxB symbols, some shorter than
+    a block of four; empty reads; related and unrelated pairs; a pair of tandem repeats: ties), every pair equal to the table
+    kernel, a sample equal to the oracle"""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(maxA * 1000 + maxB)
+    n = 30_000
+    la = rng.integers(0, maxA + 1, n)
+    lb = rng.integers(1, maxB + 1, n)
+    la[:50] = maxA
+    lb[:50] = maxB
+    lb[50:60] = rng.integers(1, 4, 10)
+    src = orc.synth_dna(77, 4 * (maxA + maxB) + 64)
+    As, Bs = [], []
+    for p in range(n):
+        o = int(rng.integers(0, len(src) - max(la[p], lb[p]) - 1))
+        b = src[o:o + lb[p]].copy()
+        if p % 3 == 0:      # unrelated
+            a = src[(o * 7 + 13) % (len(src) - maxA - 1):][:la[p]].copy()
+        else:               # a (mutated) piece of b, or b of it
+            a = np.resize(b, la[p]).copy() if la[p] else b[:0].copy()
+            hit = rng.random(len(a)) < 0.08
+            a[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+        As.append(a.tobytes())
+        Bs.append(b.tobytes())
+    As[60], Bs[60] = (b"ACGT" * 40)[:maxA], (b"ACGT" * 200)[:maxB]
+    A, offA = _pack(As)
+    Bf, offB = _pack(Bs)
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    At, oAt = torch.from_numpy(A).to(dev), torch.from_numpy(offA.astype(np.int64)).to(dev)
+    Bt, oBt = torch.from_numpy(Bf).to(dev), torch.from_numpy(offB.astype(np.int64)).to(dev)
+    score = torch.zeros(n, dtype=torch.int64, device=dev)
+    ea, eb, er = (torch.zeros(n, dtype=torch.int32, device=dev) for _ in range(3))
+    work = torch.empty(align.sw_workspace_bytes(sc, n, maxA, maxB, False), dtype=torch.uint8, device=dev)
+    align.sw_batch_dev(sc, At, oAt, maxA, Bt, oBt, maxB, score, ea, eb, er, work)
+    stride = align.sw_traceback_stride(sc, maxA, maxB)
+    tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, maxA, maxB), dtype=torch.uint8, device=dev)
+    outs = []
+    for mode in ("default", "table"):
+        if mode == "table":
+            monkeypatch.setenv("POLYHIP_TB_PAIR16", "0")
+        a = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        b = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
+        ln = torch.zeros(n, dtype=torch.int32, device=dev)
+        align.sw_traceback_dev(sc, At, oAt, maxA, Bt, oBt, maxB, ea, eb, er, a, b, ln, tbw, score_t=score)
+        torch.cuda.synchronize()
+        outs.append((a, b, ln, align.sw_traceback_last_path()))
+        monkeypatch.delenv("POLYHIP_TB_PAIR16", raising=False)
+    assert (outs[0][3], outs[1][3]) == ((6, 2) if tb_cell == "half" else (2, 2))
+    live = torch.arange(stride, device=dev)[None, :] >= (stride - outs[0][2].long())[:, None]
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert bool(((outs[0][0] == outs[1][0]) | ~live).all()) and bool(((outs[0][1] == outs[1][1]) | ~live).all())
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    a_h, b_h, l_h, s_h = outs[0][0].cpu().numpy(), outs[0][1].cpu().numpy(), outs[0][2].cpu().numpy(), score.cpu().numpy()
+    for p in list(range(0, 70)) + [int(x) for x in rng.integers(0, n, 200)]:
+        ws, wa, wb, _, _ = orc.smith_waterman(As[p], Bs[p], om, -2)
+        wa = wa if isinstance(wa, bytes) else wa.encode()
+        wb = wb if isinstance(wb, bytes) else wb.encode()
+        assert int(s_h[p]) == ws and a_h[p, stride - l_h[p]:].tobytes() == wa and b_h[p, stride - l_h[p]:].tobytes() == wb, p
+
+
 def test_ties_and_repeats(al):
     ref = (b"ACGT" * 300)[:1100]
     reads = [b"ACGT" * k for k in range(1, 30)] + [b"CGTA" * 5, b"TTTT", b"GTAC" * 30, b"A", b"ACGTTGCA" * 8]
