@@ -149,5 +149,27 @@ while time.time() < t_end:
     for q in range(0, npp, 97):
         s_, _, _, oa, ob = orc.smith_waterman(flat[offs[q]:offs[q + 1]].tobytes(), Bp[offb[q]:offb[q + 1]].tobytes(), om2, gap2)
         assert (int(sh[q]), int(ah[q]), int(bh[q])) == (s_, oa, ob), ("pair oracle", it, q, syms, mat, gap2)
-    print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} pp {res[0][1]}/{res[1][1]} gap2 {gap2} paths {p3}/{p1}/{p4} tb {outs[0][3]}/{outs[1][3]} max score {int(score.max())} ok", flush=True)
+    # ... and its traceback: the per-lane-profile half-float kernel (6) where it applies, against the table kernel (2)
+    sco, xa, xb, xe = res[0][0]
+    strp = align.sw_traceback_stride(sc2, L, LBp)
+    tbp = torch.empty(align.sw_traceback_workspace_bytes(sc2, npp, L, LBp), dtype=torch.uint8, device=dev)
+    tbo = []
+    for env in ({}, {"POLYHIP_TB_PAIR16": "0"}):
+        os.environ.update(env)
+        pa = torch.zeros((npp, strp), dtype=torch.uint8, device=dev); pb = torch.zeros((npp, strp), dtype=torch.uint8, device=dev)
+        pl = torch.zeros(npp, dtype=torch.int32, device=dev)
+        align.sw_traceback_dev(sc2, A, offAp, L, Bt, offBt, LBp, xa, xb, xe, pa, pb, pl, tbp, score_t=sco)
+        torch.cuda.synchronize()
+        tbo.append((pa, pb, pl, align.sw_traceback_last_path()))
+        for k in env:
+            os.environ.pop(k, None)
+    livep = torch.arange(strp, device=dev)[None, :] >= (strp - tbo[0][2].long())[:, None]
+    assert torch.equal(tbo[0][2], tbo[1][2]) and bool(((tbo[0][0] == tbo[1][0]) | ~livep).all()) and bool(((tbo[0][1] == tbo[1][1]) | ~livep).all()), \
+        ("pair traceback kernels", it, syms, mat, gap2, LBp, L, tbo[0][3], tbo[1][3])
+    pah, pbh, plh = tbo[0][0].cpu().numpy(), tbo[0][1].cpu().numpy(), tbo[0][2].cpu().numpy()
+    for q in range(0, npp, 197):
+        s_, sa_, sb_, _, _ = orc.smith_waterman(flat[offs[q]:offs[q + 1]].tobytes(), Bp[offb[q]:offb[q + 1]].tobytes(), om2, gap2)
+        sa_ = sa_ if isinstance(sa_, bytes) else sa_.encode(); sb_ = sb_ if isinstance(sb_, bytes) else sb_.encode()
+        assert pah[q, strp - plh[q]:].tobytes() == sa_ and pbh[q, strp - plh[q]:].tobytes() == sb_, ("pair oracle strings", it, q, syms, mat, gap2)
+    print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} pp {res[0][1]}/{res[1][1]} tbp {tbo[0][3]}/{tbo[1][3]} gap2 {gap2} paths {p3}/{p1}/{p4} tb {outs[0][3]}/{outs[1][3]} max score {int(score.max())} ok", flush=True)
 print("fuzz done", it, "iterations")
