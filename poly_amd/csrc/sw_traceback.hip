@@ -59,8 +59,8 @@ static Window window(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB
     uint64_t W = (uint64_t)max_lenA + lenB; // unbounded
     if (sc->gap < 0 && sc->smax > 0)
         W = (uint64_t)max_lenA + ((uint64_t)sc->smax * max_lenA) / (uint64_t)(-sc->gap);
-    if (sc->smax <= 0)
-        W = 0; // every H is 0: nothing to trace
+    if (sc->smax <= 0 && sc->gap <= 0)
+        W = 0; // every H is 0: nothing to trace (with a POSITIVE gap score gap moves alone make positive cells: round-4 sweep)
     w.wcols = (uint32_t)std::min<uint64_t>(full, 2 * W + 2);
     const uint64_t len = std::min<uint64_t>((uint64_t)max_lenA + lenB, W);
     w.stride = (uint32_t)std::max<uint64_t>(len, 1);
@@ -628,6 +628,47 @@ __global__ __launch_bounds__(256) void tb_profile16_kernel(const uint8_t *__rest
             o_[1] = make_uint4(wG[2], wL[2], wG[3], wL[3]);                 \
         }                                                                   \
     } while (0)
+// Two row pairs at a time with their cells interleaved along the anti-diagonal (row r's cell c + 1 and row r + 1's cell c
+// depend on nothing of each other): twice the independent work between two dependent packed instructions.  Only where no
+// end cell is searched (FIND == 0: the search needs row-major order).  -DPH_TBF_WF: a measured variant (scripts/build_variant.sh).
+#define PH_TBF_ROW2(R, XA0, XA1, YA0, YA1, XB0, XB1, YB0, YB1)                 \
+    do {                                                                       \
+        const uint32_t wa0 = __builtin_amdgcn_perm((YA0), (XA0), 0x05040100u); \
+        const uint32_t wa1 = __builtin_amdgcn_perm((YA0), (XA0), 0x07060302u); \
+        const uint32_t wa2 = __builtin_amdgcn_perm((YA1), (XA1), 0x05040100u); \
+        const uint32_t wa3 = __builtin_amdgcn_perm((YA1), (XA1), 0x07060302u); \
+        const uint32_t wb0 = __builtin_amdgcn_perm((YB0), (XB0), 0x05040100u); \
+        const uint32_t wb1 = __builtin_amdgcn_perm((YB0), (XB0), 0x07060302u); \
+        const uint32_t wb2 = __builtin_amdgcn_perm((YB1), (XB1), 0x05040100u); \
+        const uint32_t wb3 = __builtin_amdgcn_perm((YB1), (XB1), 0x07060302u); \
+        const uint32_t lefta = H[(R)], leftb = H[(R) + 1];                     \
+        const uint32_t gla = tbf_addc(lefta, gap2), glb = tbf_addc(leftb, gap2); \
+        uint32_t ha0, ha1, ha2, ha3, ga0, ga1, ga2, ga3, hb0, hb1, hb2, hb3, gb0, gb1, gb2, gb3; \
+        { const int r_ = (R);     PH_TBF_CELL(wa0, pdiag, pg0, gla, ha0, ga0, 0); } \
+        { const int r_ = (R);     PH_TBF_CELL(wa1, pr0, pg1, ga0, ha1, ga1, 1); }   \
+        { const int r_ = (R) + 1; PH_TBF_CELL(wb0, lefta, ga0, glb, hb0, gb0, 0); } \
+        { const int r_ = (R);     PH_TBF_CELL(wa2, pr1, pg2, ga1, ha2, ga2, 2); }   \
+        { const int r_ = (R) + 1; PH_TBF_CELL(wb1, ha0, ga1, gb0, hb1, gb1, 1); }   \
+        { const int r_ = (R);     PH_TBF_CELL(wa3, pr2, pg3, ga2, ha3, ga3, 3); }   \
+        { const int r_ = (R) + 1; PH_TBF_CELL(wb2, ha1, ga2, gb1, hb2, gb2, 2); }   \
+        { const int r_ = (R) + 1; PH_TBF_CELL(wb3, ha2, ga3, gb2, hb3, gb3, 3); }   \
+        pdiag = leftb;                                                         \
+        pr0 = hb0;                                                             \
+        pr1 = hb1;                                                             \
+        pr2 = hb2;                                                             \
+        pr3 = hb3;                                                             \
+        pg0 = gb0;                                                             \
+        pg1 = gb1;                                                             \
+        pg2 = gb2;                                                             \
+        pg3 = gb3;                                                             \
+        H[(R)] = ha3;                                                          \
+        H[(R) + 1] = hb3;                                                      \
+        if ((((R) + 1) & 15) == 15 || (R) + 1 == RB - 1) {                     \
+            uint4 *o_ = reinterpret_cast<uint4 *>(dirw + ((size_t)tt * NG + (((R) + 1) >> 4)) * (64 * 8)); \
+            o_[0] = make_uint4(wG[0], wL[0], wG[1], wL[1]);                    \
+            o_[1] = make_uint4(wG[2], wL[2], wG[3], wL[3]);                    \
+        }                                                                      \
+    } while (0)
 // the profile entries of four row pairs (one packed register of code offsets per band): eight ds_read_b64
 #define PH_TBF_ISSUE(pk0, pk1, X, Y)                                                                       \
     do {                                                                                                   \
@@ -932,10 +973,18 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16_kernel(
                              : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]),
                                "+v"(ya[3]));
             }
+#ifdef PH_TBF_WF
+            if constexpr (FIND == 0) {
+                PH_TBF_ROW2(4 * g + 0, xa[0].x, xa[0].y, ya[0].x, ya[0].y, xa[1].x, xa[1].y, ya[1].x, ya[1].y);
+                PH_TBF_ROW2(4 * g + 2, xa[2].x, xa[2].y, ya[2].x, ya[2].y, xa[3].x, xa[3].y, ya[3].x, ya[3].y);
+            } else
+#endif
+            {
             PH_TBF_ROW(4 * g + 0, xa[0].x, xa[0].y, ya[0].x, ya[0].y);
             PH_TBF_ROW(4 * g + 1, xa[1].x, xa[1].y, ya[1].x, ya[1].y);
             PH_TBF_ROW(4 * g + 2, xa[2].x, xa[2].y, ya[2].x, ya[2].y);
             PH_TBF_ROW(4 * g + 3, xa[3].x, xa[3].y, ya[3].x, ya[3].y);
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 xa[q] = xb[q];
@@ -1516,6 +1565,7 @@ __global__ __launch_bounds__(THREADS, 2) void tb_prof16x2_kernel(
 #undef PH_TBF_ISSUE
 #undef PH_TBF_ADDR
 #undef PH_TBF_ROW
+#undef PH_TBF_ROW2
 #undef PH_TBF_CELL
 
 // ---- reads longer than the 256 rows a lane can hold: ONE WAVE PER PAIR (like sw_wave.hip) ---------------

@@ -170,6 +170,8 @@ while time.time() < t_end:
     for q in range(0, npp, 197):
         s_, sa_, sb_, _, _ = orc.smith_waterman(flat[offs[q]:offs[q + 1]].tobytes(), Bp[offb[q]:offb[q + 1]].tobytes(), om2, gap2)
         sa_ = sa_ if isinstance(sa_, bytes) else sa_.encode(); sb_ = sb_ if isinstance(sb_, bytes) else sb_.encode()
-        assert pah[q, strp - plh[q]:].tobytes() == sa_ and pbh[q, strp - plh[q]:].tobytes() == sb_, ("pair oracle strings", it, q, syms, mat, gap2)
+        assert pah[q, strp - plh[q]:].tobytes() == sa_ and pbh[q, strp - plh[q]:].tobytes() == sb_, \
+            ("pair oracle strings", it, q, syms, mat, gap2, tbo[0][3], pah[q, strp - plh[q]:].tobytes(), pbh[q, strp - plh[q]:].tobytes(), sa_, sb_,
+             flat[offs[q]:offs[q + 1]].tobytes(), Bp[offb[q]:offb[q + 1]].tobytes(), int(sh[q]), int(ah[q]), int(bh[q]), strp)
     print(f"it {it}: syms {syms} gap {gap} LB {LB} L {L} pp {res[0][1]}/{res[1][1]} tbp {tbo[0][3]}/{tbo[1][3]} gap2 {gap2} paths {p3}/{p1}/{p4} tb {outs[0][3]}/{outs[1][3]} max score {int(score.max())} ok", flush=True)
 print("fuzz done", it, "iterations")

@@ -269,6 +269,20 @@ def test_every_pair_its_own_reference_on_packed_halves(al, monkeypatch, tb_cell,
         assert int(s_h[p]) == ws and a_h[p, stride - l_h[p]:].tobytes() == wa and b_h[p, stride - l_h[p]:].tobytes() == wb, p
 
 
+def test_positive_gap_score_with_a_matrix_that_has_no_positive_entry(al):
+    """found by scripts/fuzz_k3.py in round 4: align.Scoring takes any integer as GapPenalty (align.go:73-95); with a positive
+    one every gap move GAINS, so cells are positive although no substitution score is -- the string slots used to be sized
+    for "every H is 0" (one byte).  One reference and every pair its own."""
+    mat = [[0, -8], [-1, -3]]
+    sc = _scoring(al, "AC", mat, 1)
+    om = orc.SubstitutionMatrix("AC", "AC", mat)
+    rng = np.random.default_rng(484)
+    reads = [bytes(rng.choice(list(b"AC"), int(rng.integers(0, 60))).astype(np.uint8)) for _ in range(60)]
+    refs = [bytes(rng.choice(list(b"AC"), int(rng.integers(1, 130))).astype(np.uint8)) for _ in range(60)]
+    _check(al, sc, om, 1, reads, ref=refs[0])
+    _check(al, sc, om, 1, reads, refs=refs)
+
+
 def test_ties_and_repeats(al):
     ref = (b"ACGT" * 300)[:1100]
     reads = [b"ACGT" * k for k in range(1, 30)] + [b"CGTA" * 5, b"TTTT", b"GTAC" * 30, b"A", b"ACGTTGCA" * 8]
