@@ -42,3 +42,13 @@ legs)
   ;;
 esac; done
 for t in $(cd $ROOT/gpurun_out && ls ${R}_*.md 2>/dev/null); do echo "== $t"; grep -E "polyhip" $ROOT/gpurun_out/$t | head -8 | cut -c1-170; done
+# ---- second session of round 4: the final build's evidence (sets: final)
+if echo " $SETS " | grep -q " final "; then
+  R=r04b
+  run ${R}_bench_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_bench_stats -o x -- python bench.py --no-extra --no-cpu-baseline
+  run ${R}_bench_full_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_bench_full_stats -o x -- python bench.py --no-cpu-baseline
+  run ${R}_bench_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_bench_fetch -o x -- python bench.py --no-extra --no-cpu-baseline
+  run ${R}_bench_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_bench_write -o x -- python bench.py --no-extra --no-cpu-baseline
+  run ${R}_k2_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_k2_stats -o x -- python scripts/quick_k2c.py
+  for t in $(cd $ROOT/gpurun_out && ls ${R}_*.md 2>/dev/null); do echo "== $t"; grep -E "polyhip" $ROOT/gpurun_out/$t | head -12 | cut -c1-170; done
+fi
