@@ -577,6 +577,55 @@ def e2e_fanout_check(dev) -> dict:
             "ms_one_device": ms1, "ms_device_list_0_0": ms2, "same_sketches": bool((sk1 == sk2).all())}
 
 
+def e2e_exchange_check(dev) -> dict:
+    """BASELINE configs[2] in ONE host call (polyhip_mash_sketch_distance_matrix: reads -> sketches -> index -> matrix rows) on
+    this box: the one-device call, the device list [0, 0] with the devices building ONE index together (index items
+    exchanged by value range; the sketches are not gathered) and the same list gathering the sketches
+    (POLYHIP_K2_EXCHANGE=0).  Two workers share one GPU here, so the exchange can only cost; the figures say what its
+    five host round trips and the split kernels cost, and that all three give the same matrix."""
+    import os
+    import numpy as np
+    from . import devices as _devices
+    n, L, k, s = 16_000, 10_000, 21, 1000
+    d = torch.empty(n // 2 * L, dtype=torch.uint8, device=dev)
+    mash.synth_dna_dev(0xE5, d)
+    half = d.cpu().numpy().reshape(n // 2, L)
+    del d
+    rng = np.random.default_rng(5)
+    twin = half.copy()
+    hit = rng.random(twin.shape) < 0.004
+    twin[hit] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(hit.sum()))]
+    host = np.concatenate([half, twin]).reshape(-1)
+    del half, twin, hit
+    offs = np.arange(0, (n + 1) * L, L, dtype=np.uint64)
+    res, out = {}, {"workload": f"polyhip_mash_sketch_distance_matrix, {n} reads x {L} B from pageable host memory, k={k}, s={s}, "
+                                f"counts only ({n * n * 2 / 1e6:.0f} MB back)"}
+
+    def call(tag):
+        t = []
+        for _ in range(3):
+            import time
+            t0 = time.perf_counter()
+            _, c, _ = mash.sketch_distance_matrix_packed(host, offs, k, s, want_sketches=False, want_dist=False)
+            t.append((time.perf_counter() - t0) * 1e3)
+        res[tag] = c
+        out["ms_" + tag] = sorted(t)[1]
+        out["path_" + tag] = mash.sketch_distance_matrix_last_path()
+
+    call("one_device")
+    with _devices.devices([dev.index or 0] * 2):
+        call("list_0_0_item_exchange")
+        os.environ["POLYHIP_K2_EXCHANGE"] = "0"
+        try:
+            call("list_0_0_sketch_gather")
+        finally:
+            os.environ.pop("POLYHIP_K2_EXCHANGE", None)
+    out["same_matrix"] = bool((res["one_device"] == res["list_0_0_item_exchange"]).all() and
+                              (res["one_device"] == res["list_0_0_sketch_gather"]).all())
+    out["nonzero_pairs"] = int((res["one_device"] != 0).sum())
+    return out
+
+
 def run(dev, host_devices=None) -> dict:
     # (the 1 kb leg: 80k pairs fill the chip at 8 lanes per pair -- 6.1e12 cell updates/s; 20k pairs leave it a third full: 4.3e12)
     out = {}
@@ -585,7 +634,7 @@ def run(dev, host_devices=None) -> dict:
                      ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder),
                      ("fasta_feeder", fasta_feeder), ("e2e_host_pointers", lambda d: e2e(d, host_devices)),
-                     ("e2e_fanout_check", e2e_fanout_check)):
+                     ("e2e_fanout_check", e2e_fanout_check), ("e2e_exchange_check", e2e_exchange_check)):
         try:
             out[name] = fn(dev)
         except Exception as e:  # a secondary number must never take the headline down
