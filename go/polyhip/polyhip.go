@@ -109,7 +109,9 @@ func IsASCII(s string) bool {
 
 // MashSketchDistanceMatrix: BASELINE configs[2] in one call -- reads in, sketches (n*s, in/out like MashSketchBatch; nil:
 // not wanted) and the all-vs-all matrix out (counts n*n and/or dist n*n; either may be nil).  On a device list the
-// reads shard, the devices exchange their sketches by peer copies and each joins its block of rows.
+// reads shard and the devices build ONE index of all sketches together -- index items exchanged by value range over peer
+// copies, the sketches themselves never gathered -- then each joins the rows it sketched (a set with a read shorter than
+// k + s windows gathers the sketches instead: the reference's merge reads them raw).
 func MashSketchDistanceMatrix(seqs []byte, offs []uint64, k, s int, sketches []uint32, counts []uint16, dist []float64) error {
 	var ps *C.uint32_t
 	var pc *C.uint16_t

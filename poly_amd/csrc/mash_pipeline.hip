@@ -5,10 +5,13 @@
 //
 // The sketches never visit the host between the two steps unless the caller asks for them.  On a device list
 // (multi_device.h) this is SURVEY 8e's configs[2] flow inside one process: the reads shard by bytes, every device
-// sketches its shard into its own copy of the full sketch array, the devices then PULL the other shards' rows from
-// their peers (hipMemcpyPeerAsync over xGMI: the in-process form of the all-gather -- no RCCL, no one-rank-per-device
-// rule, a device may appear twice in the list), build the index of all n sketches and join their own block of rows,
-// which goes straight to the caller's matrix.  The matrix stays sharded by rows all the way: no second collective.
+// sketches its shard into its own copy of the full sketch array; then (round 4) the devices build ONE index together
+// without gathering the sketches -- level 1 on a device's own rows, index items pulled by value range
+// (hipMemcpyPeerAsync over xGMI: no RCCL, no one-rank-per-device rule, a device may appear twice in the list), level 2
+// on 1/N of the range, finished parts pulled (k2_exchange_index, mash_distance.hip) -- and every device joins the rows it
+// sketched, which go straight to the caller's matrix.  Where the merge needs raw sketches (an irregular sketch), or
+// with POLYHIP_K2_EXCHANGE=0, the devices PULL the other shards' rows instead (the in-process all-gather) and each
+// builds the whole index.  The matrix stays sharded by rows all the way: no second collective.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
