@@ -20,7 +20,9 @@
 // reads neighbours one column further, so a DP that starts at endB - 2W - 1 has
 // exact values everywhere the walk looks.  With gap >= 0 (or no positive score)
 // the window is the whole of B.  BASELINE config 4: W = 150 + 5*150/2 = 525, the
-// window is 1052 of the 5000 columns.
+// window was 1052 of the 5000 columns.  (Round 4: the end row need not be counted
+// twice -- see pair_window -- so the batch-wide window is lenA + 2 * smax*lenA/|gap|
+// + 2 = 902 columns, and a read that aligns well takes ~205.)
 //
 // One pair per lane, H column in registers (RA rows) like the score pass; the
 // direction words are written lane-interleaved (a wave stores 256 contiguous
@@ -61,7 +63,12 @@ static Window window(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB
         W = (uint64_t)max_lenA + ((uint64_t)sc->smax * max_lenA) / (uint64_t)(-sc->gap);
     if (sc->smax <= 0 && sc->gap <= 0)
         W = 0; // every H is 0: nothing to trace (with a POSITIVE gap score gap moves alone make positive cells: round-4 sweep)
-    w.wcols = (uint32_t)std::min<uint64_t>(full, 2 * W + 2);
+    // the batch-wide window (no score known: M >= 1): pair_window's bound with lw, over <= smax * lenA / |gap| -- the end row counted
+    // once, as there (round 4: it was 2 W + 2)
+    uint64_t wide = 2 * W + 2;
+    if (sc->gap < 0 && sc->smax > 0)
+        wide = (uint64_t)max_lenA + 2 * (((uint64_t)sc->smax * max_lenA) / (uint64_t)(-sc->gap)) + 2;
+    w.wcols = (uint32_t)std::min<uint64_t>(full, wide);
     const uint64_t len = std::min<uint64_t>((uint64_t)max_lenA + lenB, W);
     w.stride = (uint32_t)std::max<uint64_t>(len, 1);
     return w;

@@ -100,11 +100,20 @@ def test_windowed_walk_equals_the_full_matrix_walk():
     assert checked > 400 and narrowed > 100
 
 
+def test_the_batch_wide_window_covers_every_score():
+    # k3t::window: wcols = lenA + 2 * (smax * lenA / |gap|) + 2 must cover pair_window's need for every end row and score >= 1
+    for smax, gap, lenA in ((5, -2, 150), (5, -7, 150), (11, -1, 64), (1, -9, 256), (3, -3, 37)):
+        wcols = lenA + 2 * ((smax * lenA) // -gap) + 2
+        for eA in range(1, lenA + 1):
+            for M in range(1, smax * eA + 1):
+                assert pair_window(10 ** 9, eA, M, smax, gap, 0) <= wcols, (smax, gap, lenA, eA, M)
+
+
 def test_the_bound_on_a_config4_read():
     # 150 rows, NUC_4 (smax 5), gap -2, a read that aligns with M = 700 of 750: the old sum was 355 columns
-    assert pair_window(1052, 150, 700, 5, -2, 0) == 150 + 25 + 28 + 2
-    assert pair_window(1052, 150, 700, 5, -2, 1) == 150 + 25 + 150 + 375 + 2
+    assert pair_window(902, 150, 700, 5, -2, 0) == 150 + 25 + 28 + 2
+    assert pair_window(10 ** 9, 150, 700, 5, -2, 1) == 150 + 25 + 150 + 375 + 2
     # nothing known about the score: the batch-wide window
-    assert pair_window(1052, 150, 0, 5, -2, 0) == 1052
+    assert pair_window(902, 150, 0, 5, -2, 0) == 902
     # a positive gap score, a matrix without a positive entry: the whole of B
     assert pair_window(300, 40, 17, 0, 1, 0) == 300 and pair_window(300, 40, 17, 5, 0, 0) == 300
