@@ -80,9 +80,20 @@ enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
 struct Layout {
     uint32_t nbk, nbk_log2, nc, nc_log2, fpc_log2;
     size_t off_flagsX, off_flagsY, off_irrX, off_regX, off_irrY, off_ovfX;
-    size_t off_start, off_gcount, off_cstart, off_gcur, off_citems, off_items;
+    size_t off_start, off_gcount, off_cstart, off_gcur, off_pos, off_citems, off_items;
     size_t total;
+    bool sliced; // level 1 by eighths of the value range, level 2 with a coarse bucket in registers (round 4)
 };
+// The SLICED build (round 4).  A sketch is ascending, so its hashes of one eighth of the value range are contiguous in it.
+// A level-1 workgroup takes (eighth r, 64 sketches): 64 slices of ~125 hashes, scattered into the nc / 8 coarse buckets of
+// ITS eighth -- the staged scatter as it was, with nc = 8,192 coarse buckets in all instead of 1,024.  A coarse bucket is
+// then ~12k items: level 2 holds it in its threads' registers and the fine histogram in LDS -- ONE read of the 8-byte
+// items (the two-pass kernel read them twice: 0.85 ms for 1e8 items), the final items written by the bucket's only owner.
+// The slices' bounds (SL_R + 1 positions per sketch) fall out of the check pass, which has the sketch in registers.
+// POLYHIP_K2_SLICED=1 switches it on (default: the round-3 build -- see layout()).
+constexpr uint32_t SL_R = 8, SL_R_LOG2 = 3;
+constexpr uint32_t SL_SLOTS = 128;   // slots per sketch and round of a level-1 stage (8192 / 64 sketches)
+constexpr uint32_t SL_CAP = 16;      // items a level-2 thread keeps (x 1024 threads: a coarse bucket of up to 16,384 items)
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -109,6 +120,11 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     // coarse buckets: few enough that a level-1 workgroup's slice of one is several cache lines long (its 8-byte items
     // are scattered straight to HBM), many enough that level 2 splits a coarse bucket with an LDS histogram (FPC_MAX)
     uint32_t ncl = L.nbk_log2 < (uint32_t)PH_K2_NCLOG ? L.nbk_log2 : (uint32_t)PH_K2_NCLOG;
+    // (measured: correct, and SLOWER -- index 1.94 ms against 1.67 at config 3, profiles/r04b_k2_sliced_stats.md -- so it is
+    // opt-in: POLYHIP_K2_SLICED=1; every K2 test runs it as a fifth way)
+    L.sliced = sy >= 1 && sy <= 1024 && env_is("POLYHIP_K2_SLICED", '1') && !env_is("POLYHIP_K2_STAGE", '0');
+    if (L.sliced)
+        ncl = L.nbk_log2 < 13u ? L.nbk_log2 : 13u; // >= 2^11: at least 256 coarse buckets per eighth
     if (L.nbk_log2 - ncl > 13u)
         ncl = L.nbk_log2 - 13u; // FPC_MAX = 2^13
     L.nc_log2 = ncl;
@@ -123,6 +139,7 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     L.off_gcount = o; o += al((size_t)L.nc * 4);
     L.off_cstart = o; o += al(((size_t)L.nc + 1) * 4);
     L.off_gcur = o; o += al((size_t)L.nc * 4);
+    L.off_pos = o; o += al(ny * (size_t)(SL_R + 1) * 2);
     L.off_citems = o; o += al(ny * (size_t)sy * 8);
     L.off_items = o; o += al(ny * (size_t)sy * 8);
     L.off_flagsX = o; o += al(nx);
@@ -160,21 +177,24 @@ __device__ __forceinline__ uint32_t bucket_shift(uint32_t maxval, uint32_t nbk_l
 // pass counts the regular sketches' items per coarse bucket from those registers: the separate counting pass over Y
 // (0.09 ms) and its read of the flags are gone.
 template <bool YSIDE>
-__global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
-                                                       uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
-                                                       int force_irregular, uint32_t max_occ, uint32_t nbk_log2,
-                                                       uint32_t cshift_extra, uint32_t nc, uint32_t *__restrict__ gcount)
+__global__ __launch_bounds__(1024) void check_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
+                                                    uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
+                                                    int force_irregular, uint32_t max_occ, uint32_t nbk_log2,
+                                                    uint32_t cshift_extra, uint32_t nc, uint32_t *__restrict__ gcount,
+                                                    uint16_t *__restrict__ pos, uint32_t ncl_log2)
 {
+    // (THREADS threads per workgroup, or 1024 for the sliced build's Y side: 8,192 coarse counters per workgroup are flushed
+    // with one global atomic each, so there are 256 workgroups of 16 waves instead of 2,048 of 4)
     extern __shared__ uint32_t lh[]; // YSIDE: nc coarse counters
     uint32_t cshift = 0;
     if (YSIDE) {
-        for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+        for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x)
             lh[c] = 0;
         cshift = bucket_shift(hdr[H_MAXVAL], nbk_log2) + cshift_extra;
         __syncthreads();
     }
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t wave = ((uint64_t)blockIdx.x * THREADS + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (THREADS / 64);
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * (blockDim.x / 64);
     uint32_t multmax = 0; // over this wave's regular sketches
     for (uint64_t q = wave; q < n; q += nwaves) {
         const uint32_t *p = sk + q * s;
@@ -221,6 +241,34 @@ __global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restri
         }
         if (anybad && lane == 0)
             flags[q] = 1;
+        if (YSIDE && pos != nullptr && !anybad && s <= 1024) {
+            // where the sketch crosses from one eighth of the value range into the next: pos[q][r] = its first element of
+            // eighth r (pos[q][SL_R] = s); an eighth without an element of it begins where the next one does
+            const uint32_t rshift = cshift + ncl_log2;
+            uint16_t *pq = pos + q * (SL_R + 1);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t e = (uint32_t)u * 64u + lane;
+                uint32_t nxv = (uint32_t)__shfl_down((int)x[u], 1, 64);
+                const uint32_t first_of_next = u < 15 ? (uint32_t)__shfl((int)x[u < 15 ? u + 1 : 15], 0, 64) : 0u;
+                if (lane == 63u)
+                    nxv = first_of_next;
+                if (e < s) {
+                    const uint32_t ra = min(x[u] >> rshift, SL_R - 1u);
+                    if (e == 0u)
+                        for (uint32_t r = 0; r <= ra; ++r)
+                            pq[r] = 0;
+                    if (e + 1u < s) {
+                        const uint32_t rb = min(nxv >> rshift, SL_R - 1u);
+                        for (uint32_t r = ra + 1u; r <= rb; ++r)
+                            pq[r] = (uint16_t)(e + 1u);
+                    } else {
+                        for (uint32_t r = ra + 1u; r <= SL_R; ++r)
+                            pq[r] = (uint16_t)s;
+                    }
+                }
+            }
+        }
         if (YSIDE && !anybad) {
             multmax = max(multmax, mult);
             if (s <= 1024) {
@@ -239,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void check_kernel(const uint32_t *__restri
         if (lane == 0 && multmax > __hip_atomic_load(&hdr[H_MAXMULT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             atomicMax(&hdr[H_MAXMULT], multmax);
         __syncthreads();
-        for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
+        for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x)
             if (lh[c])
                 atomicAdd(&gcount[c], lh[c]);
     }
@@ -518,6 +566,137 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
     }
 }
 
+// level 1 of the SLICED build: work item (batch of 64 sketches, eighth r of the value range) -- the batch's 64 slices
+// pos[q][r] .. pos[q][r + 1] of their sketches, 128 slots each (a longer slice takes further rounds), scattered into the
+// ncl = nc / 8 coarse buckets of eighth r through the same LDS stage as coarse_scatter_staged_kernel: count with the atomic's
+// return value as the rank, scan, one slice of every bucket from the global cursor, placement, write-out as runs.
+__global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_sliced_kernel(
+    const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags, const uint16_t *__restrict__ pos,
+    const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t ncl, uint32_t id_bits, uint32_t c0, uint32_t c1,
+    uint32_t *__restrict__ gcur, uint2 *__restrict__ citems, uint32_t id_base)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stage[];
+    uint2 *stage = reinterpret_cast<uint2 *>(lds_stage);      // STAGE_ITEMS
+    uint32_t *cnt = lds_stage + 2 * (size_t)STAGE_ITEMS;        // ncl: count, then cursor
+    uint32_t *lstart = cnt + ncl, *gbase = lstart + ncl;        // ncl each
+    __shared__ uint32_t wsum[STAGE_THREADS / 64];
+    __shared__ uint32_t maxlen_s;
+    __shared__ uint32_t spl[64];
+    static_assert(STAGE_ITEMS == 8192 && STAGE_THREADS == 1024, "64 sketches x 128 slots, eight slots per thread");
+    static_assert(STAGE_ITEMS / SL_SLOTS == 64, "the first wave fetches the batch's slices");
+    constexpr int SPT = (int)(STAGE_ITEMS / STAGE_THREADS);
+    constexpr uint32_t NB = STAGE_ITEMS / SL_SLOTS; // sketches per batch
+    const int tid = threadIdx.x;
+    const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
+    const uint64_t nbatches = (n + NB - 1) / NB;
+    for (uint64_t w = blockIdx.x; w < nbatches * SL_R; w += gridDim.x) {
+        const uint64_t q0 = (w / SL_R) * NB;
+        const uint32_t r = (uint32_t)(w % SL_R), cb = r * ncl; // my eighth's first coarse bucket
+        const uint32_t *__restrict__ base = sk + q0 * s;
+        // the batch's 64 slices: start | length << 16 (length 0: no such sketch, or an irregular one -- it has no bounds),
+        // fetched by the first wave, read by everybody (slot i belongs to sketch i / 128)
+        __syncthreads(); // (the previous work item's readers of spl are through)
+        if (tid < (int)NB) {
+            const uint64_t q = q0 + tid;
+            uint32_t plv = 0;
+            if (q < n && !flags[q]) {
+                const uint32_t a = pos[q * (SL_R + 1) + r], b = pos[q * (SL_R + 1) + r + 1];
+                plv = a | ((b - a) << 16);
+            }
+            spl[tid] = plv;
+            uint32_t mymax = plv >> 16;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1)
+                mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, d, 64));
+            if (tid == 0)
+                maxlen_s = mymax;
+        }
+        __syncthreads();
+        const uint32_t maxlen = maxlen_s;
+        for (uint32_t e0 = 0; e0 < maxlen; e0 += SL_SLOTS) { // one round unless a slice is longer than its 128 slots
+            for (uint32_t c = tid; c < ncl; c += STAGE_THREADS)
+                cnt[c] = 0;
+            __syncthreads();
+            uint32_t v[SPT], rk[SPT], in = 0, dup = 0;
+            {
+                uint32_t pv[SPT];
+#pragma unroll
+                for (int u = 0; u < SPT; ++u) {
+                    const uint32_t i = tid + u * STAGE_THREADS, e = (i % SL_SLOTS) + e0;
+                    const uint32_t plv = spl[i / SL_SLOTS];
+                    const bool ok = e < (plv >> 16);
+                    const uint32_t el = (plv & 0xFFFFu) + e, at = (i / SL_SLOTS) * s + el; // (64 sketches of <= 1024 hashes: 32 bits)
+                    v[u] = ok ? base[at] : 0u;
+                    pv[u] = (ok && el > 0u) ? base[at - 1] : ~v[u];
+                    if (!ok)
+                        in |= 0u;
+                    else
+                        in |= 1u << u; // (masked by the part's range below)
+                }
+#pragma unroll
+                for (int u = 0; u < SPT; ++u) {
+                    const uint32_t c = v[u] >> cshift;
+                    const bool mine = (in >> u & 1u) && c - c0 < c1 - c0 && c - cb < ncl;
+                    in = (in & ~(1u << u)) | ((mine ? 1u : 0u) << u);
+                    dup |= (pv[u] == v[u] ? 1u : 0u) << u;
+                    rk[u] = mine ? atomicAdd(&cnt[c - cb], 1u) : 0u;
+                }
+            }
+            __syncthreads();
+            uint32_t carry = 0;
+            for (uint32_t cc = 0; cc < ncl; cc += STAGE_THREADS) {
+                const uint32_t c = cc + tid;
+                const uint32_t vv = c < ncl ? cnt[c] : 0u;
+                const uint32_t slice = vv ? atomicAdd(&gcur[cb + c], vv) : 0u;
+                uint32_t incl = vv;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t t = __shfl_up(incl, d, 64);
+                    if ((tid & 63) >= d)
+                        incl += t;
+                }
+                if ((tid & 63) == 63)
+                    wsum[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t pre = carry, tot = 0;
+                for (int ww = 0; ww < STAGE_THREADS / 64; ++ww) {
+                    if (ww < (tid >> 6))
+                        pre += wsum[ww];
+                    tot += wsum[ww];
+                }
+                if (c < ncl) {
+                    lstart[c] = pre + incl - vv;
+                    gbase[c] = slice - (pre + incl - vv);
+                }
+                carry += tot;
+                __syncthreads();
+            }
+            const uint32_t nitems = carry;
+#pragma unroll
+            for (int u = 0; u < SPT; ++u)
+                if (in >> u & 1u) {
+                    const uint32_t i = tid + u * STAGE_THREADS, e = (i % SL_SLOTS) + e0, el = (spl[i / SL_SLOTS] & 0xFFFFu) + e;
+                    const uint32_t ql = i / SL_SLOTS;
+                    uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
+                    if (dup >> u & 1u) {
+                        const uint32_t at = ql * s + el;
+                        occ = 1;
+                        while (occ < el && base[at - occ - 1] == v[u])
+                            ++occ;
+                    }
+                    stage[stage_swz(lstart[(v[u] >> cshift) - cb] + rk[u])] =
+                        make_uint2(v[u], (id_base + (uint32_t)q0 + ql) | (occ << id_bits));
+                }
+            __syncthreads();
+            for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
+                const uint2 it = stage[stage_swz(t)];
+                citems[gbase[(it.x >> cshift) - cb] + t] = it;
+            }
+            __syncthreads(); // the stage and the counters are rewritten by the next round / work item
+        }
+    }
+}
+
 // level 2: one workgroup per coarse bucket -> fine start[] + final item order (+ self-join size)
 #ifndef PH_K2_FINE_THREADS
 #define PH_K2_FINE_THREADS 512
@@ -533,7 +712,8 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
                                                            uint32_t *__restrict__ start, uint2 *__restrict__ items,
                                                            uint32_t id_bits, uint32_t ndw, uint32_t field_bits,
                                                            const uint2 *const *__restrict__ segbase,
-                                                           const uint32_t *__restrict__ seglo, uint32_t nseg, uint32_t segld)
+                                                           const uint32_t *__restrict__ seglo, uint32_t nseg, uint32_t segld,
+                                                           uint32_t only_above)
 {
     constexpr int T = FINE_THREADS;
     __shared__ uint32_t cnt[FPC_MAX];
@@ -547,6 +727,8 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
     unsigned long long sq = 0;
     for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) { // coarse buckets [cfirst, nc)
         const uint32_t lo = cstart[c];
+        if (!SEG && only_above && cstart[c + 1] - lo <= only_above)
+            continue; // fine_lds_kernel held this bucket in registers; only the (rare) larger ones are left to the two passes
         const uint32_t npieces = SEG ? nseg : 1u;
         __syncthreads();
         for (uint32_t f = tid; f < fpc; f += T)
@@ -634,6 +816,99 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
                 }
         }
         }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        sq += __shfl_xor(sq, d, 64);
+    if ((tid & 63) == 0 && sq)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), sq);
+}
+
+// level 2 of the SLICED build: a coarse bucket of at most SL_CAP x 1024 items sits in its workgroup's registers -- one read of
+// the 8-byte items; the fine histogram (and, as the atomic's return value, every item's rank inside its fine bucket) in
+// LDS; the final items written by the bucket's only owner.  Larger buckets are left to fine_kernel<false> (only_above).
+constexpr int FINE_LDS_THREADS = 1024;
+__global__ __launch_bounds__(FINE_LDS_THREADS) void fine_lds_kernel(const uint2 *__restrict__ citems, const uint32_t *__restrict__ cstart,
+                                                                   uint32_t cfirst, uint32_t nc, uint32_t fpc_log2,
+                                                                   uint32_t *__restrict__ hdr, uint32_t *__restrict__ start,
+                                                                   uint2 *__restrict__ items, uint32_t id_bits, uint32_t ndw,
+                                                                   uint32_t field_bits)
+{
+    constexpr int T = FINE_LDS_THREADS;
+    __shared__ uint32_t hist[FPC_MAX];
+    __shared__ uint32_t ws[T / 64];
+    const uint32_t fpc = 1u << fpc_log2;
+    const uint32_t shift = hdr[H_SHIFT];
+    const bool compact = hdr[H_FMT] != 0u;
+    uint32_t *items32 = reinterpret_cast<uint32_t *>(items);
+    const uint32_t id_mask = (1u << id_bits) - 1u, low_mask = (1u << shift) - 1u, kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
+    const int tid = threadIdx.x;
+    unsigned long long sq = 0;
+    for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) {
+        const uint32_t lo = cstart[c], cntc = cstart[c + 1] - lo;
+        if (cntc > SL_CAP * (uint32_t)T)
+            continue; // fine_kernel<false>'s
+        __syncthreads();
+        for (uint32_t f = tid; f < fpc; f += T)
+            hist[f] = 0;
+        __syncthreads();
+        uint2 it[SL_CAP];
+        uint32_t rk[SL_CAP];
+#pragma unroll
+        for (int u = 0; u < (int)SL_CAP; ++u)
+            it[u] = (uint32_t)(tid + u * T) < cntc ? citems[lo + tid + u * T] : make_uint2(0u, 0u);
+#pragma unroll
+        for (int u = 0; u < (int)SL_CAP; ++u)
+            rk[u] = (uint32_t)(tid + u * T) < cntc ? atomicAdd(&hist[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
+        __syncthreads();
+        // exclusive scan of hist[0..fpc): PER consecutive entries per thread (fpc <= FPC_MAX = 8 x 1024)
+        constexpr int PERMAX = (int)(FPC_MAX / T);
+        const uint32_t per = (fpc + T - 1) / T;
+        uint32_t v[PERMAX], sum = 0;
+#pragma unroll
+        for (int i = 0; i < PERMAX; ++i) {
+            const uint32_t f = tid * per + i;
+            v[i] = ((uint32_t)i < per && f < fpc) ? hist[f] : 0u;
+            sum += v[i];
+            sq += (unsigned long long)v[i] * v[i];
+        }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if ((tid & 63) >= d)
+                incl += t;
+        }
+        if ((tid & 63) == 63)
+            ws[tid >> 6] = incl;
+        __syncthreads();
+        uint32_t run = lo + incl - sum;
+        for (int w = 0; w < (tid >> 6); ++w)
+            run += ws[w];
+#pragma unroll
+        for (int i = 0; i < PERMAX; ++i) {
+            const uint32_t f = tid * per + i;
+            if ((uint32_t)i < per && f < fpc) {
+                start[((size_t)c << fpc_log2) + f] = run;
+                hist[f] = run; // the fine bucket's first position
+            }
+            run += v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < (int)SL_CAP; ++u)
+            if ((uint32_t)(tid + u * T) < cntc) {
+                const uint32_t at = hist[(it[u].x >> shift) & (fpc - 1u)] + rk[u];
+                if (compact) { // as fine_kernel
+                    const uint32_t col = it[u].y & id_mask, occ = it[u].y >> id_bits;
+                    const uint32_t k = __umulhi(col, kmul);
+                    const uint32_t occ1 = (occ + 1u) << CK_LOW;
+                    const uint32_t hi_part = shift ? (((it[u].x & low_mask) << (32u - shift)) | occ1) : occ1;
+                    items32[at] = hi_part | ((col - k * ndw) << 5) | (k * field_bits);
+                } else {
+                    items[at] = it[u];
+                }
+            }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
@@ -1458,6 +1733,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
              *cstart = reinterpret_cast<uint32_t *>(w + L.off_cstart), *gcur = reinterpret_cast<uint32_t *>(w + L.off_gcur);
     uint2 *citems = reinterpret_cast<uint2 *>(w + L.off_citems);
     uint2 *items = reinterpret_cast<uint2 *>(w + L.off_items);
+    uint16_t *pos = reinterpret_cast<uint16_t *>(w + L.off_pos);
 
     // the join packs the Y sketch id into 24 bits and stages an X row in LDS
     const int force = (ny > (1ull << k2::ID_BITS_MAX) || sx > k2::S_MAX) ? 1 : 0;
@@ -1491,8 +1767,13 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         PH_HIP(hipMemsetAsync(gcount, 0, (size_t)L.nc * 4, st));
         hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st, d_Y,
                            ny, sy, hdr);
-        hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(ny)), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy,
-                           flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount);
+        if (L.sliced) // 256 workgroups of 16 waves: 8,192 coarse counters per workgroup are flushed with a global atomic each
+            hipLaunchKernelGGL(k2::check_kernel<true>, dim3((unsigned)std::min<uint64_t>((ny + 15) / 16, 256)), dim3(1024), (size_t)L.nc * 4,
+                               st, d_Y, ny, sy, flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount, pos,
+                               L.nc_log2 - k2::SL_R_LOG2);
+        else
+            hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(ny)), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy,
+                               flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount, (uint16_t *)nullptr, 0u);
         hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                            flagsX, (uint64_t)0, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2, allow_compact ? 1 : 0);
         // ---- inverted index of the Y side: two-level partition by value
@@ -1511,7 +1792,16 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             c1 = b[part + 1];
         }
         // level-1 scatter: through LDS when a sketch fits the stage (POLYHIP_K2_STAGE=0: the direct scatter, testing aid)
-        if (sy <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0')) {
+        if (L.sliced) {
+            const uint32_t ncl = L.nc >> k2::SL_R_LOG2;
+            const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)ncl * 12;
+            const uint64_t witems = ((ny + 63) / 64) * k2::SL_R;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_sliced_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(k2::coarse_scatter_sliced_kernel, dim3((unsigned)std::min<uint64_t>(witems, PH_K2_STAGE_GRID)),
+                               dim3(k2::STAGE_THREADS), smem, st, d_Y, ny, sy, flagsY, pos, hdr, L.fpc_log2, ncl, id_bits, c0, c1, gcur,
+                               citems, 0u);
+        } else if (sy <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0')) {
             const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / sy);
             const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
@@ -1522,10 +1812,14 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
                                flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems, 0u);
         }
-        if (c1 > c0)
+        if (c1 > c0 && L.sliced)
+            hipLaunchKernelGGL(k2::fine_lds_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 2u)), dim3(k2::FINE_LDS_THREADS), 0, st, citems,
+                               cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
+        if (c1 > c0) // (sliced: only the coarse buckets beyond what fine_lds_kernel's registers hold)
             hipLaunchKernelGGL(k2::fine_kernel<false>, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st, citems,
                                cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits,
-                               (const uint2 *const *)nullptr, (const uint32_t *)nullptr, 0u, 0u);
+                               (const uint2 *const *)nullptr, (const uint32_t *)nullptr, 0u, 0u,
+                               L.sliced ? k2::SL_CAP * (uint32_t)k2::FINE_LDS_THREADS : 0u);
         PH_HIP(hipGetLastError());
     }
     if (!join)
@@ -1536,7 +1830,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         hipLaunchKernelGGL(reset_x_kernel, dim3(1), dim3(1), 0, st, hdr);
     PH_HIP(hipMemsetAsync(flagsX, 0, nx, st));
     hipLaunchKernelGGL(k2::check_kernel<false>, dim3(k2::check_grid(nx)), dim3(k2::THREADS), 0, st, d_X, nx, sx, flagsX, hdr, force,
-                       0xFFFFFFFEu, 0u, 0u, 0u, (uint32_t *)nullptr);
+                       0xFFFFFFFEu, 0u, 0u, 0u, (uint32_t *)nullptr, (uint16_t *)nullptr, 0u);
     hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nx + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                        flagsX, nx, flagsY, (uint64_t)0, irrX, regX, irrY, hdr, L.nbk_log2, -1);
     // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
@@ -1917,6 +2211,7 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         uint32_t *hdr, *start, *gcount, *cstart, *gcur, *irrY;
         uint8_t *flagsY;
         uint2 *citems, *items;
+        uint16_t *pos;
     };
     auto view = [&](K2XShard &x) {
         View v;
@@ -1930,6 +2225,7 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         v.gcur = reinterpret_cast<uint32_t *>(v.w + L.off_gcur);
         v.citems = reinterpret_cast<uint2 *>(v.w + L.off_citems);
         v.items = reinterpret_cast<uint2 *>(v.w + L.off_items);
+        v.pos = reinterpret_cast<uint16_t *>(v.w + L.off_pos);
         return v;
     };
     // ---- A: workspace, the largest last element of my rows
@@ -1964,10 +2260,14 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         const View v = view(x);
         const uint64_t m = x.i1 - x.i0;
         PH_HIP(hipMemcpyAsync(v.hdr + k2::H_MAXVAL, &maxval, 4, hipMemcpyHostToDevice, st));
-        if (m)
+        if (m && L.sliced)
+            hipLaunchKernelGGL(k2::check_kernel<true>, dim3((unsigned)std::min<uint64_t>((m + 15) / 16, 256)), dim3(1024), (size_t)L.nc * 4, st,
+                               x.sk + x.i0 * (uint64_t)s, m, s, v.flagsY + x.i0, v.hdr, 0, max_occ, L.nbk_log2, L.fpc_log2, L.nc,
+                               v.gcount, v.pos + x.i0 * (k2::SL_R + 1), L.nc_log2 - k2::SL_R_LOG2);
+        else if (m)
             hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(m)), dim3(k2::THREADS), (size_t)L.nc * 4, st,
                                x.sk + x.i0 * (uint64_t)s, m, s, v.flagsY + x.i0, v.hdr, 0, max_occ, L.nbk_log2, L.fpc_log2, L.nc,
-                               v.gcount);
+                               v.gcount, (uint16_t *)nullptr, 0u);
         PH_HIP(hipGetLastError());
         x.h_gcount.assign(L.nc, 0);
         std::vector<uint8_t> fl(m);
@@ -2016,7 +2316,16 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, v.gcount, L.nc, v.cstart, v.gcur, v.start, L.nbk);
         if (m) {
             const uint32_t *sk = x.sk + x.i0 * (uint64_t)s;
-            if (staged) {
+            if (L.sliced) {
+                const uint32_t ncl = L.nc >> k2::SL_R_LOG2;
+                const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)ncl * 12;
+                PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_sliced_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+                hipLaunchKernelGGL(k2::coarse_scatter_sliced_kernel,
+                                   dim3((unsigned)std::min<uint64_t>(((m + 63) / 64) * k2::SL_R, PH_K2_STAGE_GRID)), dim3(k2::STAGE_THREADS),
+                                   smem, st, sk, m, s, v.flagsY + x.i0, v.pos + x.i0 * (k2::SL_R + 1), v.hdr, L.fpc_log2, ncl, id_bits,
+                                   0u, L.nc, v.gcur, v.citems, (uint32_t)x.i0);
+            } else if (staged) {
                 const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / s);
                 const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
                 PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
@@ -2092,7 +2401,7 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
             PH_HIP(hipMemcpyAsync(x.segtab.p, lo.data(), lo.size() * 4, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k2::fine_kernel<true>, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st,
                                v.citems, v.cstart, c0, c1, L.fpc_log2, v.hdr, v.start, v.items, id_bits, gY.ndw ? gY.ndw : 8u,
-                               (uint32_t)gY.bits, x.segptr.as<const uint2 *>(), x.segtab.as<uint32_t>(), (uint32_t)N, ncp);
+                               (uint32_t)gY.bits, x.segptr.as<const uint2 *>(), x.segtab.as<uint32_t>(), (uint32_t)N, ncp, 0u);
             PH_HIP(hipGetLastError());
             PH_HIP(hipStreamSynchronize(st)); // (the tables are host vectors of this scope)
         } else {

@@ -15,9 +15,9 @@ X = sk[:nrows]
 counts = torch.full((nrows, N), -1, dtype=torch.int16, device=dev)
 work = torch.empty(mash.shared_counts_workspace_bytes(nrows, s, N, s), dtype=torch.uint8, device=dev)
 res = {}
-for tag, env in (("reg", {}), ("staged", {"POLYHIP_K2_REGROW": "0"}), ("reg-wide", {"POLYHIP_K2_COMPACT": "0"}),
-                 ("staged-wide", {"POLYHIP_K2_COMPACT": "0", "POLYHIP_K2_REGROW": "0"})):
-    for k in ("POLYHIP_K2_COMPACT", "POLYHIP_K2_REGROW"):
+for tag, env in (("reg", {}), ("unsliced", {"POLYHIP_K2_SLICED": "0"}), ("staged", {"POLYHIP_K2_REGROW": "0"}), ("reg-wide", {"POLYHIP_K2_COMPACT": "0"}),
+                 ("unsliced-wide", {"POLYHIP_K2_COMPACT": "0", "POLYHIP_K2_SLICED": "0"})):
+    for k in ("POLYHIP_K2_COMPACT", "POLYHIP_K2_REGROW", "POLYHIP_K2_SLICED"):
         os.environ.pop(k, None)
     os.environ.update(env)
     ms_index = _time(lambda: mash.index_build_dev(sk, work), 10)
@@ -29,7 +29,7 @@ for tag, env in (("reg", {}), ("staged", {"POLYHIP_K2_REGROW": "0"}), ("reg-wide
     res[tag] = counts.clone()
     print(f"{tag}: item bytes {fmt}  index {ms_index:.3f} ms  join {ms_join:.3f} ms  one-shot {ms_one:.3f} ms  nonzero {int((counts != 0).sum())}", flush=True)
 print("counts equal:", all(bool(torch.equal(res["reg"], r)) for r in res.values()))
-for k in ("POLYHIP_K2_COMPACT", "POLYHIP_K2_REGROW"):
+for k in ("POLYHIP_K2_COMPACT", "POLYHIP_K2_REGROW", "POLYHIP_K2_SLICED"):
     os.environ.pop(k, None)
 if len(sys.argv) > 1 and sys.argv[1] == "full":
     del res

@@ -225,8 +225,11 @@ def test_reads_to_distance_matrix_by_item_exchange(ids, monkeypatch):
     buf, offs = _pack(reads)
     want_sk = orc.mash_sketch_batch(buf, offs, k, s)
     want_c, want_d = mash.distance_matrix_packed(want_sk, want_sk)
-    for stage in ("1", "0"):
-        monkeypatch.setenv("POLYHIP_K2_STAGE", stage)
+    for mode in ({"POLYHIP_K2_STAGE": "1"}, {"POLYHIP_K2_STAGE": "0"}, {"POLYHIP_K2_SLICED": "1"}):  # the three level-1 scatters
+        monkeypatch.delenv("POLYHIP_K2_STAGE", raising=False)
+        monkeypatch.delenv("POLYHIP_K2_SLICED", raising=False)
+        for k_, v_ in mode.items():
+            monkeypatch.setenv(k_, v_)
         with devices.devices(ids):
             monkeypatch.delenv("POLYHIP_K2_EXCHANGE", raising=False)
             sk, c, d = mash.sketch_distance_matrix_packed(buf, offs, k, s)
