@@ -570,6 +570,13 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
 // pos[q][r] .. pos[q][r + 1] of their sketches, 128 slots each (a longer slice takes further rounds), scattered into the
 // ncl = nc / 8 coarse buckets of eighth r through the same LDS stage as coarse_scatter_staged_kernel: count with the atomic's
 // return value as the rank, scan, one slice of every bucket from the global cursor, placement, write-out as runs.
+// Measured at config 3: 1.18 ms against the staged scatter's 0.64 (profiles/r04b_k2_sliced_stats.md).  Slices average 125
+// hashes, so nearly every batch has one beyond its 128 slots and takes a second, almost empty round -- but laying the slices
+// end to end instead (a thread takes eight consecutive items, found by a search in the slices' prefix sums: one dense round
+// per batch) was built too and is slower still (index 2.13 against 1.94 ms, profiles/r04b_k2_sliced_timing.log): the cost is
+// in the front of a round -- the slice bounds have to arrive before a single hash can be asked for, and the kernel spills at
+// the 64 registers two workgroups per CU allow -- not in the second round.  fine_kernel<false>'s pass over the (no)
+// oversized buckets costs another 0.16 ms; a header flag set by fine_lds_kernel would let it return at once.
 __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_sliced_kernel(
     const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags, const uint16_t *__restrict__ pos,
     const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t ncl, uint32_t id_bits, uint32_t c0, uint32_t c1,
