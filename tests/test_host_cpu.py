@@ -218,3 +218,38 @@ def test_fasta_two_scans_in_one_pass_combination_rule():
             lo = min(n, t * per)
             assert int(seg_start[t]) == int(want[lo]), (n, first, t)
         assert int(seg_start[SEGS]) == int(want[n])
+
+
+def test_slice_bounds_of_the_sliced_index_build():
+    """csrc/mash_distance.hip, check_kernel<true> with `pos`: where an ascending sketch crosses from one eighth of the value
+    range into the next.  The kernel writes pos[r] from the TRANSITIONS it sees (element e in eighth ra, element e + 1 in
+    eighth rb > ra: pos[ra + 1 .. rb] = e + 1; the first element: pos[0 .. its eighth] = 0; the last: pos[its eighth + 1 .. 8]
+    = s) -- restated here and compared with the definition: pos[r] = number of elements below eighth r."""
+    rng = np.random.default_rng(8)
+    R = 8
+    for it in range(300):
+        s = int(rng.integers(1, 1025))
+        rshift = int(rng.integers(0, 29))
+        top = min((R << rshift) - 1, 0xFFFFFFFF)
+        if it % 3 == 0:  # crowded into a few eighths (empty ones in between and at either end)
+            lo = int(rng.integers(0, top + 1))
+            x = np.sort(rng.integers(lo // 2, lo + 1, s, dtype=np.uint64)).astype(np.uint64)
+        else:
+            x = np.sort(rng.integers(0, top + 1, s, dtype=np.uint64)).astype(np.uint64)
+        eighth = np.minimum(x >> np.uint64(rshift), R - 1).astype(np.int64)
+        pos = np.full(R + 1, -1, np.int64)
+        for e in range(s):  # every "lane" on its own, as the kernel
+            ra = eighth[e]
+            if e == 0:
+                pos[0:ra + 1] = 0
+            if e + 1 < s:
+                rb = eighth[e + 1]
+                if rb > ra:
+                    pos[ra + 1:rb + 1] = e + 1
+            else:
+                pos[ra + 1:R + 1] = s
+        want = np.array([int((eighth < r).sum()) for r in range(R + 1)])
+        assert (pos == want).all(), (it, s, rshift)
+        # the slices tile the sketch, and slice r holds exactly the elements of eighth r
+        for r in range(R):
+            assert (eighth[pos[r]:pos[r + 1]] == r).all()
