@@ -108,3 +108,67 @@ def test_limits_of_the_condition():
             assert float(acc) * 2048.0 == smax * k
     # one step beyond is NOT representable: 2049 / 2048 rounds (why the library falls back to the int16 cell there)
     assert float(np.float16(np.float32(2049) / np.float32(2048))) * 2048.0 != 2049.0
+
+
+def _banded_schedule(a, b, mat, gap, RB, nbands):
+    """The half-float traceback kernels' SCHEDULE restated in plain integers (csrc/sw_traceback.hip: tb_prof16_kernel = two
+    bands in one lane, tb_prof16x2_kernel = four bands in two lanes): band k holds rows [k RB, (k + 1) RB) and works on the
+    4-column block tt - k in iteration tt; what it finds above its first row -- four values, their gap-decayed copies, one
+    diagonal value -- is what band k - 1 left behind ONE ITERATION EARLIER (the diagonal value: TWO earlier).  Blocks before
+    the first and behind the last are pad blocks (score -128), rows behind the read pad rows."""
+    la, lb = len(a), len(b)
+    nblk = (lb + 3) // 4
+    PAD = -128
+    out = np.zeros((la + 1, lb + 1), np.int64)
+    Hrow = [[0] * RB for _ in range(nbands)]
+    in_pr = [[0] * 4 for _ in range(nbands)]
+    in_pg = [[0] * 4 for _ in range(nbands)]
+    in_pd = [0] * nbands
+    for tt in range(nblk + nbands - 1):
+        nxt_pr = [row[:] for row in in_pr]
+        nxt_pg = [row[:] for row in in_pg]
+        nxt_pd = in_pd[:]
+        for band in range(nbands):
+            bt = tt - band
+            real_block = 0 <= bt < nblk
+            pr, pg, pdiag = in_pr[band][:], in_pg[band][:], in_pd[band]
+            for r in range(RB):
+                gi = band * RB + r
+                left = Hrow[band][r]
+                gl = max(left + gap, 0)
+                h, g = [0] * 4, [0] * 4
+                for c in range(4):
+                    j = 4 * bt + c
+                    s = mat[a[gi]][b[j]] if (real_block and gi < la and j < lb) else PAD
+                    t = (pdiag if c == 0 else pr[c - 1]) + s
+                    h[c] = max(t, pg[c], gl if c == 0 else g[c - 1])  # v_pk_maximum3_f16 (the clamped operands make it >= 0)
+                    g[c] = max(h[c] + gap, 0)
+                    if real_block and gi < la and j < lb:
+                        out[gi + 1, j + 1] = h[c]
+                pdiag, pr, pg = left, h, g
+                Hrow[band][r] = h[3]
+            if band + 1 < nbands:  # band + 1 finds this above its first row in the NEXT iteration
+                nxt_pr[band + 1], nxt_pg[band + 1] = pr, pg
+                nxt_pd[band + 1] = in_pr[band + 1][3]  # `hd = hh3`: the value that was this iteration's fourth "row above"
+        in_pr, in_pg, in_pd = nxt_pr, nxt_pg, nxt_pd
+    return out
+
+
+@pytest.mark.parametrize("RB,nbands", [(8, 2), (8, 4), (16, 4)])
+def test_the_band_schedule_reproduces_the_recurrence(RB, nbands):
+    rng = np.random.default_rng(RB * 10 + nbands)
+    mat = [[0, 0, 0, 0, 0], [0, 5, -4, -4, -4], [0, -4, 5, -4, -4], [0, -4, -4, 5, -4], [0, -4, -4, -4, 5]]
+    for it in range(25):
+        la = int(rng.integers(1, RB * nbands + 1))
+        lb = int(rng.integers(1, 70))
+        b = rng.integers(1, 5, lb)
+        a = rng.integers(1, 5, la)
+        if it % 2 == 0 and lb >= 4:  # related: long positive paths through every band
+            p = int(rng.integers(0, lb))
+            a = np.resize(np.concatenate([b[p:], b[:p]]), la).copy()
+            hit = rng.random(la) < 0.1
+            a[hit] = rng.integers(1, 5, int(hit.sum()))
+        gap = -int(rng.integers(1, 6))
+        H, _, _ = int_dp(a, b, mat, gap)
+        got = _banded_schedule(a, b, mat, gap, RB, nbands)
+        assert (got == H).all(), (it, la, lb, gap)
