@@ -737,7 +737,14 @@ def main() -> int:
         for key in ("secondary", "parity_spot_check"):
             if key in line:
                 line[key] = line.pop(key)
-        line["summary"] = {"kmers_per_s": line["value"], "hbm_frac": line["roofline"]["frac"],
+        try:
+            from poly_amd.bench_extra import traffic_checks
+            tc = traffic_checks(line)
+        except Exception as e:
+            tc = {"error": f"{type(e).__name__}: {e}"}
+        if tc.get("failed"):
+            sys.stderr.write("bench.py: counter traffic below the algorithmic bytes: " + "; ".join(tc["failed"]) + "\n")
+        line["summary"] = {"kmers_per_s": line["value"], "hbm_frac": line["roofline"]["frac"], "traffic_checks": tc,
                            "sw_cell_updates_per_s": (line.get("secondary") or {}).get("value"),
                            "sw_valu_frac": ((line.get("secondary") or {}).get("roofline") or {}).get("frac"),
                            "parity_spot_check": line.get("parity_spot_check")}

@@ -205,6 +205,15 @@ int polyhip_mash_index_finalize_dev(uint64_t ny, uint32_t sy, void *d_work,
  * a join that does not fit that assumption rebuilds the index with 8-byte items first.  POLYHIP_K2_COMPACT=0 keeps the
  * 8-byte items (testing aid). */
 int polyhip_mash_index_format_dev(const void *d_work, uint32_t *item_bytes);
+/* How the index in d_work was built (synchronous read-back; tests and profiling).  info[0]: 0 = the two-level build on
+ * 8-byte intermediate items, 1 = the sliced build on 4-byte intermediate items (the default where its conditions hold:
+ * compact items, SketchSize <= 1024, <= 131,072 sketches, 2^16 <= largest hash < 2^30, 4 <= bucket shift <= 10; the device
+ * decides the last three), 2 = the sliced build was planned and called off on the device (a sketch repeats a hash more
+ * often than a compact item numbers, or more than 65,536 repeated hashes): the two-level build ran.  For the sliced
+ * build info[1] = coarse buckets (hash >> 16), info[2] = parts of the value range, info[3] = coarse buckets per part,
+ * info[4] = coarse buckets level 2 could not hold in registers (two passes), info[5] = repeated hashes it numbered.
+ * POLYHIP_K2_B4=0 keeps the two-level build (testing aid; the parts API and the in-process item exchange always use it). */
+int polyhip_mash_index_build_info_dev(const void *d_work, uint32_t info[6]);
 int polyhip_mash_index_allgather_dev(struct polyhip_comm *c, uint64_t ny,
                                      uint32_t sy, void *d_work,
                                      size_t work_bytes, polyhip_stream_t stream);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "polyhip_mash_index_part_spans": (C.c_int, [_u64, _u32, _u32, _vp, C.c_size_t, _vp, _vp, _vp]),
     "polyhip_mash_index_finalize_dev": (C.c_int, [_u64, _u32, _vp, C.c_size_t, _vp]),
     "polyhip_mash_index_format_dev": (C.c_int, [_vp, _vp]),
+    "polyhip_mash_index_build_info_dev": (C.c_int, [_vp, _vp]),
     "polyhip_mash_index_allgather_dev": (C.c_int, [_vp, _u64, _u32, _vp, C.c_size_t, _vp]),
     "polyhip_mash_shared_counts_reuse_dev": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _u64, _vp, C.c_size_t, _vp]),
     "polyhip_mash_shared_counts_mode_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -56,9 +56,29 @@ def _hbm_roofline(name: str, alg_bytes: float, ms: float, kernel: str, bound_not
     r = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
          "algorithmic_bytes_per_launch": int(alg_bytes), "traffic": traffic, "traffic_source": src, "kernel": kernel,
          "launches_per_timed_group": getattr(_time, "last_inner", 1)}
+    r["traffic_ratio"] = traffic / alg_bytes if traffic and alg_bytes else None  # counter bytes / algorithmic bytes, >= ~1
     if bound_note:
         r["bound_note"] = bound_note
     return r
+
+
+def traffic_checks(node, path="line", out=None) -> dict:
+    """Every roofline object of the line that carries both `traffic` (HBM bytes from the PMC passes) and
+    `algorithmic_bytes_per_launch`: traffic below 0.98 x the algorithmic bytes is impossible -- a kernel cannot move fewer
+    bytes than the bytes it must read and write -- and means the counter selection dropped kernels (round 4: the feeders'
+    two templated passes).  Returns {"checked": n, "failed": [paths...]}; bench.py puts it in the line's summary."""
+    if out is None:
+        out = {"checked": 0, "failed": []}
+    if isinstance(node, dict):
+        t, a = node.get("traffic"), node.get("algorithmic_bytes_per_launch")
+        if isinstance(t, (int, float)) and isinstance(a, (int, float)) and a > 0:
+            out["checked"] += 1
+            node.setdefault("traffic_ratio", t / a)
+            if t < 0.98 * a:
+                out["failed"].append(f"{path}: traffic {t:.4g} B < 0.98 x algorithmic {a:.4g} B")
+        for k, v in node.items():
+            traffic_checks(v, f"{path}.{k}", out)
+    return out
 
 
 def _wall(fn, reps: int = 5, warm: int = 2) -> float:

@@ -183,4 +183,29 @@ __device__ __forceinline__ int from_lane_below(int v)
     return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true);
 }
 
+// Inclusive sum over the 64 lanes of a wave and the largest value of a wave (in every lane) on DPP moves: no ds_bpermute, and
+// -- what matters in kernels at 64 registers -- no per-step lane-index registers for the compiler to hoist out of loops
+__device__ __forceinline__ uint32_t dpp_incl_scan(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t dpp_wave_max(uint32_t v)
+{
+#define PH_DPP_MAX(ctrl, rows) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false))
+    PH_DPP_MAX(0xb1, 0xf);  // quad_perm [1,0,3,2]
+    PH_DPP_MAX(0x4e, 0xf);  // quad_perm [2,3,0,1]
+    PH_DPP_MAX(0x124, 0xf); // row_ror 4
+    PH_DPP_MAX(0x128, 0xf); // row_ror 8
+    PH_DPP_MAX(0x142, 0xa); // row_bcast15 into rows 1, 3
+    PH_DPP_MAX(0x143, 0xc); // row_bcast31 into rows 2, 3
+#undef PH_DPP_MAX
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 } // namespace polyhip

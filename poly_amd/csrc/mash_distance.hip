@@ -67,7 +67,14 @@ constexpr int JOIN_U = 8;             // buckets a wave keeps in flight
 #define PH_K2_NCLOG 10 // log2 of the most coarse buckets of the index build
 #endif
 
-enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_MAXMULT, H_EST_LO, H_EST_HI, H_FMT, H_WORDS = 16 };
+enum { H_MAXVAL = 0, H_SHIFT, H_MODE, H_NIRRX, H_NIRRY, H_NREGX, H_NOVF, H_MAXMULT, H_EST_LO, H_EST_HI, H_FMT,
+       H_B4, H_B4_NC, H_B4_R, H_B4_CPP, H_B4_MAGIC, H_B4_OVER, H_B4_NDUP, H_WORDS = 32 };
+// H_B4: which index build runs (decided on the device, plan4_kernel / lists_kernel): 0 = the two-level build on 8-byte
+// intermediate items (round 2-3), 1 = the sliced build on 4-byte intermediate items (round 5, below), 2 = the sliced build
+// was planned but the items cannot be compact after all (a sketch repeats a hash too often): the two-level build takes over.
+// H_B4_NC coarse buckets (value >> 16; a power of two), H_B4_R parts of the value range, H_B4_CPP coarse buckets per part,
+// H_B4_MAGIC = ceil(2^32 / CPP), H_B4_OVER = coarse buckets that took level 2's two-pass path (diagnostics), H_B4_NDUP =
+// records in the list of repeated hashes (below).
 // H_FMT: 0 = 8-byte items (value, sketch id | occurrence number << id_bits); 1 = COMPACT 4-byte items, written when the
 // join is known to be the one-stripe dense join and the bits fit (decided on the device, lists_kernel):
 //     [ value's bits below the bucket : shift | occurrence number : 11 - shift | counter dword : 16 | field shift : 5 ]
@@ -80,20 +87,34 @@ enum { MODE_SPARSE = 0, MODE_GENERIC = 1 };
 struct Layout {
     uint32_t nbk, nbk_log2, nc, nc_log2, fpc_log2;
     size_t off_flagsX, off_flagsY, off_irrX, off_regX, off_irrY, off_ovfX;
-    size_t off_start, off_gcount, off_cstart, off_gcur, off_pos, off_citems, off_items;
+    size_t off_start, off_gcount, off_cstart, off_gcur, off_pos, off_g4count, off_dup, off_duplist, off_c4start, off_g4cur, off_citems, off_items;
     size_t total;
-    bool sliced; // level 1 by eighths of the value range, level 2 with a coarse bucket in registers (round 4)
 };
-// The SLICED build (round 4).  A sketch is ascending, so its hashes of one eighth of the value range are contiguous in it.
-// A level-1 workgroup takes (eighth r, 64 sketches): 64 slices of ~125 hashes, scattered into the nc / 8 coarse buckets of
-// ITS eighth -- the staged scatter as it was, with nc = 8,192 coarse buckets in all instead of 1,024.  A coarse bucket is
-// then ~12k items: level 2 holds it in its threads' registers and the fine histogram in LDS -- ONE read of the 8-byte
-// items (the two-pass kernel read them twice: 0.85 ms for 1e8 items), the final items written by the bucket's only owner.
-// The slices' bounds (SL_R + 1 positions per sketch) fall out of the check pass, which has the sketch in registers.
-// POLYHIP_K2_SLICED=1 switches it on (default: the round-3 build -- see layout()).
-constexpr uint32_t SL_R = 8, SL_R_LOG2 = 3;
-constexpr uint32_t SL_SLOTS = 128;   // slots per sketch and round of a level-1 stage (8192 / 64 sketches)
-constexpr uint32_t SL_CAP = 16;      // items a level-2 thread keeps (x 1024 threads: a coarse bucket of up to 16,384 items)
+// The SLICED build on 4-byte intermediate items (round 5; B4 for short).  A sketch is ascending, so its hashes of one part of
+// the value range are CONTIGUOUS in it.  The coarse bucket of a hash is `value >> 16`; an intermediate item is
+//     [ value & 0xFFFF : 16 | sketch id & 0xFFFF : 16 ]
+// -- the coarse bucket is where the item lies, and the sketch id's bit 16 (up to 131,072 sketches: what the one-stripe dense
+// join takes) is WHICH of a coarse bucket's two segments it lies in -- half the bytes of the (value, id) pair the two-level
+// build moves, written once and read once:
+//   plan    geometry from the largest value (device side): NC = 2^(bits - 16) coarse buckets, R parts of CPP coarse buckets
+//   check   a wave per sketch (as before) + the histogram over value >> 16 + where the sketch crosses from part to part
+//   level 1 work item (B sketches, part r): the B slices, up to SLOTS hashes each per round, ordered by coarse bucket in an
+//           LDS stage of 16,384 four-byte items and written out as runs (a quarter wave per run)
+//   level 2 a workgroup per coarse bucket: the bucket in REGISTERS (up to 32 items per thread), the fine histogram in LDS, the
+//           atomic's return value as the item's rank: one read of the intermediate items, the final compact items written by
+//           the bucket's only owner; a coarse bucket beyond the registers takes two passes over its intermediate items.
+// The occurrence number (copies of a value inside ONE sketch) has no room in 32 bits.  Such copies are rare (~1 sketch in
+// 1000 at config 3): the check pass, which walks them anyway, LOGS every copy after the first as (value, id | number << 17) in
+// a list and marks the value's coarse bucket (dupmap); level 2 places all items as "first copy" and then, in a marked bucket,
+// one thread per logged record of that bucket finds the record's slot among the equal items of its fine bucket (the number-th
+// one in slot order) and writes the number in.  More than B4_DUP_MAX records: the two-level build.
+// Conditions (else the two-level build): compact items (so one-stripe dense join: <= 131,072 sketches here), SketchSize <=
+// 1024, the largest value below 2^30 and at least 2^16, 4 <= bucket shift <= 10.  POLYHIP_K2_B4=0 switches it off.
+constexpr uint32_t B4_RMAX = 64;       // parts of the value range at most (pos: R + 1 positions per sketch)
+constexpr uint32_t B4_CPP_MAX = 1024;  // coarse buckets per part at most (level 1's counters in LDS)
+constexpr uint32_t B4_NC_MAX = 16384;  // coarse buckets at most (largest value < 2^30)
+constexpr uint32_t B4_STAGE = 16384;   // items of a level-1 stage (64 KB: two workgroups per CU)
+constexpr uint32_t B4_DUP_MAX = 65536; // records of repeated hashes the build numbers itself; more: the two-level build
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -120,11 +141,6 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     // coarse buckets: few enough that a level-1 workgroup's slice of one is several cache lines long (its 8-byte items
     // are scattered straight to HBM), many enough that level 2 splits a coarse bucket with an LDS histogram (FPC_MAX)
     uint32_t ncl = L.nbk_log2 < (uint32_t)PH_K2_NCLOG ? L.nbk_log2 : (uint32_t)PH_K2_NCLOG;
-    // (measured: correct, and SLOWER -- index 1.94 ms against 1.67 at config 3, profiles/r04b_k2_sliced_stats.md -- so it is
-    // opt-in: POLYHIP_K2_SLICED=1; every K2 test runs it as a fifth way)
-    L.sliced = sy >= 1 && sy <= 1024 && env_is("POLYHIP_K2_SLICED", '1') && !env_is("POLYHIP_K2_STAGE", '0');
-    if (L.sliced)
-        ncl = L.nbk_log2 < 13u ? L.nbk_log2 : 13u; // >= 2^11: at least 256 coarse buckets per eighth
     if (L.nbk_log2 - ncl > 13u)
         ncl = L.nbk_log2 - 13u; // FPC_MAX = 2^13
     L.nc_log2 = ncl;
@@ -139,7 +155,12 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
     L.off_gcount = o; o += al((size_t)L.nc * 4);
     L.off_cstart = o; o += al(((size_t)L.nc + 1) * 4);
     L.off_gcur = o; o += al((size_t)L.nc * 4);
-    L.off_pos = o; o += al(ny * (size_t)(SL_R + 1) * 2);
+    L.off_pos = o; o += al(ny * (size_t)(B4_RMAX + 1) * 2);
+    L.off_g4count = o; o += al((size_t)2 * B4_NC_MAX * 4); // (zeroed together with the dupmap behind it)
+    L.off_dup = o; o += al(B4_NC_MAX / 8);
+    L.off_duplist = o; o += al((size_t)B4_DUP_MAX * 8);
+    L.off_c4start = o; o += al(((size_t)2 * B4_NC_MAX + 1) * 4);
+    L.off_g4cur = o; o += al((size_t)2 * B4_NC_MAX * 4);
     L.off_citems = o; o += al(ny * (size_t)sy * 8);
     L.off_items = o; o += al(ny * (size_t)sy * 8);
     L.off_flagsX = o; o += al(nx);
@@ -181,13 +202,15 @@ __global__ __launch_bounds__(1024) void check_kernel(const uint32_t *__restrict_
                                                     uint8_t *__restrict__ flags, uint32_t *__restrict__ hdr,
                                                     int force_irregular, uint32_t max_occ, uint32_t nbk_log2,
                                                     uint32_t cshift_extra, uint32_t nc, uint32_t *__restrict__ gcount,
-                                                    uint16_t *__restrict__ pos, uint32_t ncl_log2)
+                                                    uint32_t run_if_b4)
 {
-    // (THREADS threads per workgroup, or 1024 for the sliced build's Y side: 8,192 coarse counters per workgroup are flushed
-    // with one global atomic each, so there are 256 workgroups of 16 waves instead of 2,048 of 4)
     extern __shared__ uint32_t lh[]; // YSIDE: nc coarse counters
     uint32_t cshift = 0;
     if (YSIDE) {
+        // the sliced build's own check pass (check4_kernel) has run instead (H_B4 == 1); a second launch (run_if_b4 == 2)
+        // takes over when that build was planned and then called off (lists_kernel)
+        if (hdr[H_B4] != run_if_b4)
+            return;
         for (uint32_t c = threadIdx.x; c < nc; c += blockDim.x)
             lh[c] = 0;
         cshift = bucket_shift(hdr[H_MAXVAL], nbk_log2) + cshift_extra;
@@ -241,34 +264,6 @@ __global__ __launch_bounds__(1024) void check_kernel(const uint32_t *__restrict_
         }
         if (anybad && lane == 0)
             flags[q] = 1;
-        if (YSIDE && pos != nullptr && !anybad && s <= 1024) {
-            // where the sketch crosses from one eighth of the value range into the next: pos[q][r] = its first element of
-            // eighth r (pos[q][SL_R] = s); an eighth without an element of it begins where the next one does
-            const uint32_t rshift = cshift + ncl_log2;
-            uint16_t *pq = pos + q * (SL_R + 1);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const uint32_t e = (uint32_t)u * 64u + lane;
-                uint32_t nxv = (uint32_t)__shfl_down((int)x[u], 1, 64);
-                const uint32_t first_of_next = u < 15 ? (uint32_t)__shfl((int)x[u < 15 ? u + 1 : 15], 0, 64) : 0u;
-                if (lane == 63u)
-                    nxv = first_of_next;
-                if (e < s) {
-                    const uint32_t ra = min(x[u] >> rshift, SL_R - 1u);
-                    if (e == 0u)
-                        for (uint32_t r = 0; r <= ra; ++r)
-                            pq[r] = 0;
-                    if (e + 1u < s) {
-                        const uint32_t rb = min(nxv >> rshift, SL_R - 1u);
-                        for (uint32_t r = ra + 1u; r <= rb; ++r)
-                            pq[r] = (uint16_t)(e + 1u);
-                    } else {
-                        for (uint32_t r = ra + 1u; r <= SL_R; ++r)
-                            pq[r] = (uint16_t)s;
-                    }
-                }
-            }
-        }
         if (YSIDE && !anybad) {
             multmax = max(multmax, mult);
             if (s <= 1024) {
@@ -328,8 +323,12 @@ __global__ __launch_bounds__(THREADS) void lists_kernel(const uint8_t *__restric
         hdr[H_SHIFT] = shift;
         // compact items: the value's low bits and the occurrence number + 1 share 11 bits (the all-zero word is the join's
         // "no item": what a buffer load returns beyond the end of a bucket)
-        if (allow_compact >= 0)
+        if (allow_compact >= 0) {
             hdr[H_FMT] = (allow_compact && shift <= 10u && hdr[H_MAXMULT] <= (1u << (11u - shift)) - 1u) ? 1u : 0u;
+            // the sliced build makes compact items only, and numbers at most B4_DUP_MAX repeated hashes
+            if (hdr[H_B4] == 1u && (hdr[H_FMT] == 0u || hdr[H_B4_NDUP] > B4_DUP_MAX))
+                hdr[H_B4] = 2u;
+        }
     }
 }
 
@@ -396,6 +395,8 @@ __global__ __launch_bounds__(THREADS) void coarse_scatter_kernel(const uint32_t 
 {
     extern __shared__ uint32_t lh[]; // count[nc] then base[nc]
     uint32_t *lbase = lh + nc;
+    if (hdr[H_B4] == 1u)
+        return; // the sliced build's level 1 (scatter4_kernel) runs instead
     const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
     for (uint32_t c = threadIdx.x; c < nc; c += THREADS)
         lh[c] = 0;
@@ -472,6 +473,8 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
     uint32_t *lstart = cnt + nc, *gbase = lstart + nc;          // nc each
     __shared__ uint32_t wsum[STAGE_THREADS / 64];
     const int tid = threadIdx.x;
+    if (hdr[H_B4] == 1u)
+        return; // the sliced build's level 1 (scatter4_kernel) runs instead
     const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
     // persistent workgroups, a batch per turn: 12,500 launches of 1024 threads each cost more than the turns' one barrier
     // (the barrier behind the zeroing also keeps a fast wave out of the stage while a slow one still writes it out)
@@ -566,144 +569,6 @@ __global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_staged_kernel
     }
 }
 
-// level 1 of the SLICED build: work item (batch of 64 sketches, eighth r of the value range) -- the batch's 64 slices
-// pos[q][r] .. pos[q][r + 1] of their sketches, 128 slots each (a longer slice takes further rounds), scattered into the
-// ncl = nc / 8 coarse buckets of eighth r through the same LDS stage as coarse_scatter_staged_kernel: count with the atomic's
-// return value as the rank, scan, one slice of every bucket from the global cursor, placement, write-out as runs.
-// Measured at config 3: 1.18 ms against the staged scatter's 0.64 (profiles/r04b_k2_sliced_stats.md).  Slices average 125
-// hashes, so nearly every batch has one beyond its 128 slots and takes a second, almost empty round -- but laying the slices
-// end to end instead (a thread takes eight consecutive items, found by a search in the slices' prefix sums: one dense round
-// per batch) was built too and is slower still (index 2.13 against 1.94 ms, profiles/r04b_k2_sliced_timing.log): the cost is
-// in the front of a round -- the slice bounds have to arrive before a single hash can be asked for, and the kernel spills at
-// the 64 registers two workgroups per CU allow -- not in the second round.  fine_kernel<false>'s pass over the (no)
-// oversized buckets costs another 0.16 ms; a header flag set by fine_lds_kernel would let it return at once.
-__global__ __launch_bounds__(STAGE_THREADS, 8) void coarse_scatter_sliced_kernel(
-    const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, const uint8_t *__restrict__ flags, const uint16_t *__restrict__ pos,
-    const uint32_t *__restrict__ hdr, uint32_t cshift_extra, uint32_t ncl, uint32_t id_bits, uint32_t c0, uint32_t c1,
-    uint32_t *__restrict__ gcur, uint2 *__restrict__ citems, uint32_t id_base)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds_stage[];
-    uint2 *stage = reinterpret_cast<uint2 *>(lds_stage);      // STAGE_ITEMS
-    uint32_t *cnt = lds_stage + 2 * (size_t)STAGE_ITEMS;        // ncl: count, then cursor
-    uint32_t *lstart = cnt + ncl, *gbase = lstart + ncl;        // ncl each
-    __shared__ uint32_t wsum[STAGE_THREADS / 64];
-    __shared__ uint32_t maxlen_s;
-    __shared__ uint32_t spl[64];
-    static_assert(STAGE_ITEMS == 8192 && STAGE_THREADS == 1024, "64 sketches x 128 slots, eight slots per thread");
-    static_assert(STAGE_ITEMS / SL_SLOTS == 64, "the first wave fetches the batch's slices");
-    constexpr int SPT = (int)(STAGE_ITEMS / STAGE_THREADS);
-    constexpr uint32_t NB = STAGE_ITEMS / SL_SLOTS; // sketches per batch
-    const int tid = threadIdx.x;
-    const uint32_t cshift = hdr[H_SHIFT] + cshift_extra;
-    const uint64_t nbatches = (n + NB - 1) / NB;
-    for (uint64_t w = blockIdx.x; w < nbatches * SL_R; w += gridDim.x) {
-        const uint64_t q0 = (w / SL_R) * NB;
-        const uint32_t r = (uint32_t)(w % SL_R), cb = r * ncl; // my eighth's first coarse bucket
-        const uint32_t *__restrict__ base = sk + q0 * s;
-        // the batch's 64 slices: start | length << 16 (length 0: no such sketch, or an irregular one -- it has no bounds),
-        // fetched by the first wave, read by everybody (slot i belongs to sketch i / 128)
-        __syncthreads(); // (the previous work item's readers of spl are through)
-        if (tid < (int)NB) {
-            const uint64_t q = q0 + tid;
-            uint32_t plv = 0;
-            if (q < n && !flags[q]) {
-                const uint32_t a = pos[q * (SL_R + 1) + r], b = pos[q * (SL_R + 1) + r + 1];
-                plv = a | ((b - a) << 16);
-            }
-            spl[tid] = plv;
-            uint32_t mymax = plv >> 16;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1)
-                mymax = max(mymax, (uint32_t)__shfl_xor((int)mymax, d, 64));
-            if (tid == 0)
-                maxlen_s = mymax;
-        }
-        __syncthreads();
-        const uint32_t maxlen = maxlen_s;
-        for (uint32_t e0 = 0; e0 < maxlen; e0 += SL_SLOTS) { // one round unless a slice is longer than its 128 slots
-            for (uint32_t c = tid; c < ncl; c += STAGE_THREADS)
-                cnt[c] = 0;
-            __syncthreads();
-            uint32_t v[SPT], rk[SPT], in = 0, dup = 0;
-            {
-                uint32_t pv[SPT];
-#pragma unroll
-                for (int u = 0; u < SPT; ++u) {
-                    const uint32_t i = tid + u * STAGE_THREADS, e = (i % SL_SLOTS) + e0;
-                    const uint32_t plv = spl[i / SL_SLOTS];
-                    const bool ok = e < (plv >> 16);
-                    const uint32_t el = (plv & 0xFFFFu) + e, at = (i / SL_SLOTS) * s + el; // (64 sketches of <= 1024 hashes: 32 bits)
-                    v[u] = ok ? base[at] : 0u;
-                    pv[u] = (ok && el > 0u) ? base[at - 1] : ~v[u];
-                    if (!ok)
-                        in |= 0u;
-                    else
-                        in |= 1u << u; // (masked by the part's range below)
-                }
-#pragma unroll
-                for (int u = 0; u < SPT; ++u) {
-                    const uint32_t c = v[u] >> cshift;
-                    const bool mine = (in >> u & 1u) && c - c0 < c1 - c0 && c - cb < ncl;
-                    in = (in & ~(1u << u)) | ((mine ? 1u : 0u) << u);
-                    dup |= (pv[u] == v[u] ? 1u : 0u) << u;
-                    rk[u] = mine ? atomicAdd(&cnt[c - cb], 1u) : 0u;
-                }
-            }
-            __syncthreads();
-            uint32_t carry = 0;
-            for (uint32_t cc = 0; cc < ncl; cc += STAGE_THREADS) {
-                const uint32_t c = cc + tid;
-                const uint32_t vv = c < ncl ? cnt[c] : 0u;
-                const uint32_t slice = vv ? atomicAdd(&gcur[cb + c], vv) : 0u;
-                uint32_t incl = vv;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t t = __shfl_up(incl, d, 64);
-                    if ((tid & 63) >= d)
-                        incl += t;
-                }
-                if ((tid & 63) == 63)
-                    wsum[tid >> 6] = incl;
-                __syncthreads();
-                uint32_t pre = carry, tot = 0;
-                for (int ww = 0; ww < STAGE_THREADS / 64; ++ww) {
-                    if (ww < (tid >> 6))
-                        pre += wsum[ww];
-                    tot += wsum[ww];
-                }
-                if (c < ncl) {
-                    lstart[c] = pre + incl - vv;
-                    gbase[c] = slice - (pre + incl - vv);
-                }
-                carry += tot;
-                __syncthreads();
-            }
-            const uint32_t nitems = carry;
-#pragma unroll
-            for (int u = 0; u < SPT; ++u)
-                if (in >> u & 1u) {
-                    const uint32_t i = tid + u * STAGE_THREADS, e = (i % SL_SLOTS) + e0, el = (spl[i / SL_SLOTS] & 0xFFFFu) + e;
-                    const uint32_t ql = i / SL_SLOTS;
-                    uint32_t occ = 0; // equal values before this one in the same (ascending) sketch
-                    if (dup >> u & 1u) {
-                        const uint32_t at = ql * s + el;
-                        occ = 1;
-                        while (occ < el && base[at - occ - 1] == v[u])
-                            ++occ;
-                    }
-                    stage[stage_swz(lstart[(v[u] >> cshift) - cb] + rk[u])] =
-                        make_uint2(v[u], (id_base + (uint32_t)q0 + ql) | (occ << id_bits));
-                }
-            __syncthreads();
-            for (uint32_t t = tid; t < nitems; t += STAGE_THREADS) {
-                const uint2 it = stage[stage_swz(t)];
-                citems[gbase[(it.x >> cshift) - cb] + t] = it;
-            }
-            __syncthreads(); // the stage and the counters are rewritten by the next round / work item
-        }
-    }
-}
-
 // level 2: one workgroup per coarse bucket -> fine start[] + final item order (+ self-join size)
 #ifndef PH_K2_FINE_THREADS
 #define PH_K2_FINE_THREADS 512
@@ -719,9 +584,10 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
                                                            uint32_t *__restrict__ start, uint2 *__restrict__ items,
                                                            uint32_t id_bits, uint32_t ndw, uint32_t field_bits,
                                                            const uint2 *const *__restrict__ segbase,
-                                                           const uint32_t *__restrict__ seglo, uint32_t nseg, uint32_t segld,
-                                                           uint32_t only_above)
+                                                           const uint32_t *__restrict__ seglo, uint32_t nseg, uint32_t segld)
 {
+    if (hdr[H_B4] == 1u)
+        return; // the sliced build's level 2 (fine4_kernel) makes this index
     constexpr int T = FINE_THREADS;
     __shared__ uint32_t cnt[FPC_MAX];
     __shared__ uint32_t ws[T / 64];
@@ -734,8 +600,6 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
     unsigned long long sq = 0;
     for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) { // coarse buckets [cfirst, nc)
         const uint32_t lo = cstart[c];
-        if (!SEG && only_above && cstart[c + 1] - lo <= only_above)
-            continue; // fine_lds_kernel held this bucket in registers; only the (rare) larger ones are left to the two passes
         const uint32_t npieces = SEG ? nseg : 1u;
         __syncthreads();
         for (uint32_t f = tid; f < fpc; f += T)
@@ -831,97 +695,447 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
         atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), sq);
 }
 
-// level 2 of the SLICED build: a coarse bucket of at most SL_CAP x 1024 items sits in its workgroup's registers -- one read of
-// the 8-byte items; the fine histogram (and, as the atomic's return value, every item's rank inside its fine bucket) in
-// LDS; the final items written by the bucket's only owner.  Larger buckets are left to fine_kernel<false> (only_above).
-constexpr int FINE_LDS_THREADS = 1024;
-__global__ __launch_bounds__(FINE_LDS_THREADS) void fine_lds_kernel(const uint2 *__restrict__ citems, const uint32_t *__restrict__ cstart,
-                                                                   uint32_t cfirst, uint32_t nc, uint32_t fpc_log2,
-                                                                   uint32_t *__restrict__ hdr, uint32_t *__restrict__ start,
-                                                                   uint2 *__restrict__ items, uint32_t id_bits, uint32_t ndw,
-                                                                   uint32_t field_bits)
+// ---- the sliced build on 4-byte intermediate items (B4; the plan is at struct Layout) ---------------------------------------
+// geometry from the largest value: one thread, between maxlast_kernel and the check pass
+__global__ void plan4_kernel(uint32_t *__restrict__ hdr, uint32_t nbk_log2, uint32_t s, uint32_t slice_len)
 {
-    constexpr int T = FINE_LDS_THREADS;
-    __shared__ uint32_t hist[FPC_MAX];
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    const uint32_t maxval = hdr[H_MAXVAL];
+    const uint32_t bits = 32u - (uint32_t)__builtin_clz(maxval | 1u);
+    const uint32_t shift = bucket_shift(maxval, nbk_log2);
+    // a coarse bucket is value >> 16: at most B4_NC_MAX of them, at most 2^12 fine buckets in one (level 2's LDS histogram),
+    // and the shift compact items allow
+    if (bits < 17u || bits > 30u || shift < 4u || shift > 10u)
+        return; // H_B4 stays 0: the two-level build
+    const uint32_t nce = (maxval >> 16) + 1u; // coarse buckets that can hold an item
+    // parts of the value range: a sketch's slice of one part is ~slice_len hashes when the sketch spreads over the whole range
+    uint32_t R = min(max((s + slice_len - 1u) / slice_len, 1u), B4_RMAX);
+    uint32_t cpp = min(max((nce + R - 1u) / R, 2u), B4_CPP_MAX);
+    R = (nce + cpp - 1u) / cpp; // <= 16 when cpp was capped (nce <= 16,384), else <= the first R
+    hdr[H_B4_NC] = 1u << (bits - 16u);
+    hdr[H_B4_R] = R;
+    hdr[H_B4_CPP] = cpp;
+    hdr[H_B4_MAGIC] = (uint32_t)(((1ull << 32) + cpp - 1u) / cpp); // coarse / cpp = umulhi(coarse, magic): exact for coarse < 2^16
+    hdr[H_B4] = 1u;
+}
+
+__device__ __forceinline__ uint32_t b4_part(uint32_t v, uint32_t magic, uint32_t R) { return min(__umulhi(v >> 16, magic), R - 1u); }
+
+// check pass of the sliced build: check_kernel<true>'s wave-per-sketch test (ascending?  a hash repeated more often than an
+// item can number?) + the histogram over value >> 16 (per group of 65,536 sketches: the id bit an intermediate item does not
+// carry) + where the sketch crosses from one part of the value range into the next (pos[q][r] = its first element of part r,
+// pos[q][R] = s; a part without an element of the sketch begins where the next one does) + the list of repeated hashes.
+// A workgroup takes a contiguous run of sketches; its counters (up to 64 KB of LDS) are flushed once per group.
+__global__ __launch_bounds__(1024) void check4_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s, uint8_t *__restrict__ flags,
+                                                     uint32_t *__restrict__ hdr, int force_irregular, uint32_t max_occ, uint32_t G,
+                                                     uint32_t *__restrict__ g4count, uint32_t *__restrict__ dupmap,
+                                                     uint2 *__restrict__ duplist, uint16_t *__restrict__ pos)
+{
+    extern __shared__ uint32_t lh[]; // H_B4_NC counters
+    if (hdr[H_B4] != 1u)
+        return;
+    const uint32_t nc = hdr[H_B4_NC], R = hdr[H_B4_R], magic = hdr[H_B4_MAGIC];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x, qa = (uint64_t)blockIdx.x * per, qb = min(n, qa + per);
+    uint32_t multmax = 0;
+    for (uint32_t g = 0; g < G; ++g) {
+        const uint64_t lo = max(qa, (uint64_t)g << 16), hi = g + 1u < G ? min(qb, (uint64_t)(g + 1u) << 16) : qb;
+        if (lo >= hi)
+            continue;
+        for (uint32_t c = threadIdx.x; c < nc; c += 1024)
+            lh[c] = 0;
+        __syncthreads();
+        for (uint64_t q = lo + wv; q < hi; q += 16) {
+            const uint32_t *p = sk + q * s;
+            uint32_t x[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t e = (uint32_t)u * 64u + lane;
+                x[u] = e < s ? p[e] : 0u;
+            }
+            bool bad = force_irregular != 0, anyeq = false;
+            auto next_of = [&](int u) -> uint32_t { // the element behind x[u]'s (valid while it is not the sketch's last)
+                const uint32_t nv = (uint32_t)__shfl_down((int)x[u], 1, 64);
+                const uint32_t first_of_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)x[u < 15 ? u + 1 : 15]);
+                return lane == 63u ? first_of_next : nv;
+            };
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t e = (uint32_t)u * 64u + lane;
+                const uint32_t nv = next_of(u);
+                const bool has = e + 1u < s;
+                bad = bad || (has && x[u] > nv);
+                anyeq = anyeq || (has && x[u] == nv);
+            }
+            bool anybad = __ballot(bad) != 0ull; // an irregular sketch never enters the index
+            uint32_t mult = 1;
+            if (!anybad && __ballot(anyeq) != 0ull) {
+                // repeated values inside an ascending sketch (rare): the longest run; every copy after the first is logged
+                mult = 0;
+                for (uint32_t e = lane; e < s; e += 64) {
+                    const uint32_t x0 = p[e];
+                    if (e == 0 || p[e - 1] != x0) {
+                        uint32_t a = 1;
+                        while (e + a < s && p[e + a] == x0)
+                            ++a;
+                        mult = max(mult, a);
+                        if (a > 1u) {
+                            atomicOr(&dupmap[x0 >> 21], 1u << ((x0 >> 16) & 31u));
+                            const uint32_t at = atomicAdd(&hdr[H_B4_NDUP], a - 1u);
+                            if (at + (a - 1u) <= B4_DUP_MAX)
+                                for (uint32_t k = 1; k < a; ++k)
+                                    duplist[at + k - 1u] = make_uint2(x0, (uint32_t)q | (k << 17));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+                    mult = max(mult, (uint32_t)__shfl_xor((int)mult, d, 64));
+                if (mult - 1u > max_occ)
+                    anybad = true;
+            }
+            if (anybad) {
+                if (lane == 0)
+                    flags[q] = 1;
+                continue;
+            }
+            multmax = max(multmax, mult);
+            uint16_t *pq = pos + q * (R + 1u);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t e = (uint32_t)u * 64u + lane;
+                const uint32_t nv = next_of(u); // (by every lane: a cross-lane read of a lane that sits out a branch returns 0)
+                if (e < s) {
+                    atomicAdd(&lh[x[u] >> 16], 1u);
+                    const uint32_t ra = b4_part(x[u], magic, R);
+                    if (e == 0u)
+                        for (uint32_t r = 0; r <= ra; ++r)
+                            pq[r] = 0;
+                    if (e + 1u < s) {
+                        const uint32_t rb = b4_part(nv, magic, R);
+                        for (uint32_t r = ra + 1u; r <= rb; ++r)
+                            pq[r] = (uint16_t)(e + 1u);
+                    } else {
+                        for (uint32_t r = ra + 1u; r <= R; ++r)
+                            pq[r] = (uint16_t)s;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < nc; c += 1024)
+            if (lh[c])
+                atomicAdd(&g4count[c * G + g], lh[c]);
+        __syncthreads();
+    }
+    if (lane == 0 && multmax > __hip_atomic_load(&hdr[H_MAXMULT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(&hdr[H_MAXMULT], multmax);
+}
+
+// exclusive scan of g4count[NC * G] -> c4start[NC * G + 1], g4cur = copy; one workgroup, up to 32 consecutive counters per thread
+__global__ __launch_bounds__(1024) void scan4_kernel(const uint32_t *__restrict__ g4count, uint32_t G, const uint32_t *__restrict__ hdr,
+                                                    uint32_t *__restrict__ c4start, uint32_t *__restrict__ g4cur,
+                                                    uint32_t *__restrict__ start, uint32_t nbk)
+{
+    __shared__ uint32_t wsum[16];
+    if (hdr[H_B4] != 1u)
+        return;
+    const uint32_t m = hdr[H_B4_NC] * G; // <= 32,768
+    const uint32_t per = (m + 1023u) / 1024u, tid = threadIdx.x, i0 = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t i = 0; i < per; ++i)
+        sum += i0 + i < m ? g4count[i0 + i] : 0u;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if ((tid & 63u) >= (uint32_t)d)
+            incl += t;
+    }
+    if ((tid & 63u) == 63u)
+        wsum[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum, total = 0;
+    for (uint32_t w = 0; w < 16; ++w) {
+        if (w < (tid >> 6))
+            run += wsum[w];
+        total += wsum[w];
+    }
+    for (uint32_t i = 0; i < per; ++i)
+        if (i0 + i < m) {
+            c4start[i0 + i] = run;
+            g4cur[i0 + i] = run;
+            run += g4count[i0 + i];
+        }
+    if (tid == 0) {
+        c4start[m] = total;
+        start[nbk] = total;
+    }
+}
+
+// level 1 of the sliced build.  Work item = (batch of B sketches, part r of the value range): the batch's B slices
+// pos[q][r] .. pos[q][r + 1], SLOTS hashes of each per round (a longer slice takes further rounds), ordered by coarse bucket
+// in the LDS stage -- count with the atomic's return value as the rank, scan, one slice of every bucket from the global
+// cursor, placement -- and written out as runs, a quarter wave per coarse bucket (a stage item does not say which bucket it
+// belongs to, so the write-out goes bucket by bucket, not item by item).  The bounds of the NEXT work item are fetched while
+// this one is worked on: they are a round trip that nothing else of a work item can start without.
+template <int B, int SLOTS>
+__global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__restrict__ sk, uint32_t n, uint32_t s,
+                                                          const uint8_t *__restrict__ flags, const uint16_t *__restrict__ pos,
+                                                          const uint32_t *__restrict__ hdr, uint32_t G, uint32_t *__restrict__ g4cur,
+                                                          uint32_t *__restrict__ citems4)
+{
+    static_assert(B * SLOTS == (int)B4_STAGE && (B & (B - 1)) == 0 && B >= 64 && 65536 % B == 0, "a batch fills the stage and lies in one id group");
+    constexpr uint32_t T = 1024, SPT = B4_STAGE / T, QSTEP = T / SLOTS; // slot i = tid + u * T: sketch (tid / SLOTS) + u * QSTEP of the batch
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds4[];
+    uint32_t *stage = lds4;                         // B4_STAGE (+ 64 words the empty slots' items go to)
+    uint32_t *cnt = stage + B4_STAGE + 64;          // B4_CPP_MAX (+ 64 words the empty slots count into)
+    uint32_t *lstart = cnt + B4_CPP_MAX + 64;       // B4_CPP_MAX + 1 (+ padding)
+    uint32_t *gbase = lstart + B4_CPP_MAX + 16;     // B4_CPP_MAX
+    uint32_t *spl = gbase + B4_CPP_MAX;             // 2 x B: start | length << 16 of this and of the next work item's slices
+    __shared__ uint32_t wsum[T / 64];
+    if (hdr[H_B4] != 1u)
+        return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t R = hdr[H_B4_R], cpp = hdr[H_B4_CPP];
+    const uint32_t nwork = ((n + B - 1) / B) * R; // (<= 1024 batches x 64 parts)
+    auto fetch = [&](uint32_t w) -> uint32_t { // slice r of sketch (w / R) * B + tid: start | length << 16 (0: none)
+        const uint32_t batch = w / R, r = w - batch * R, q = batch * B + tid;
+        if (q >= n || flags[q])
+            return 0u;
+        const uint16_t *pq = pos + q * (R + 1u) + r;
+        const uint32_t a = pq[0], b = pq[1];
+        return a | ((b - a) << 16);
+    };
+    uint32_t w = blockIdx.x;
+    uint32_t nxt = (tid < (uint32_t)B && w < nwork) ? fetch(w) : 0u;
+    uint32_t cur = 0;
+    const uint32_t qt = tid / SLOTS, et = tid % SLOTS;
+    for (; w < nwork; w += gridDim.x, cur ^= (uint32_t)B) {
+        if (tid < (uint32_t)B)
+            spl[cur + tid] = nxt;
+        __syncthreads(); // the bounds are there; everybody is through with the previous work item's stage
+        uint32_t maxlen = 0;
+#pragma unroll
+        for (int j = 0; j < B / 64; ++j)
+            maxlen = max(maxlen, spl[cur + j * 64 + lane] >> 16);
+        maxlen = dpp_wave_max(maxlen);
+        {
+            const uint32_t w2 = w + gridDim.x;
+            nxt = (tid < (uint32_t)B && w2 < nwork) ? fetch(w2) : 0u;
+        }
+        const uint32_t batch = w / R, r = w - batch * R, q0 = batch * B, cb = r * cpp, g = q0 >> 16;
+        // the batch's sketches as ONE buffer: a slot without a hash asks beyond its end and reads 0 -- no branch around a load
+        const uint32_t nb = min((uint32_t)B, n - q0);
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(sk + (size_t)q0 * s), 0, (int)(nb * s * 4u), 0x00020000);
+        for (uint32_t e0 = 0; e0 < maxlen; e0 += SLOTS) { // one round unless a slice is longer than its slots
+            if (tid < cpp)
+                cnt[tid] = 0;
+            __syncthreads();
+            uint32_t v[SPT], in = 0;
+            const uint32_t e = et + e0, at0 = qt * s + e;
+#pragma unroll
+            for (uint32_t u = 0; u < SPT; ++u) {
+                // (the sketch's offset inside the batch rides in the load's scalar offset: sixteen per-slot vector offsets,
+                // loop invariants all, are what the compiler would otherwise hoist out of the loops and spill)
+                const uint32_t plv = spl[cur + qt + u * QSTEP];
+                const bool ok = e < (plv >> 16);
+                v[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, ok ? (int)((at0 + (plv & 0xFFFFu)) * 4u) : -1,
+                                                                      (int)(u * QSTEP * s * 4u), 0);
+                in |= (ok ? 1u : 0u) << u;
+            }
+            // count (a slot without a hash counts into a word of its own lane behind the counters: no branch per slot).
+            // v becomes [bucket inside the part : 16 | value & 0xFFFF : 16] -- all the placement needs
+#pragma unroll
+            for (uint32_t u = 0; u < SPT; ++u) {
+                v[u] -= cb << 16;
+                __hip_atomic_fetch_add(&cnt[(in >> u & 1u) ? v[u] >> 16 : B4_CPP_MAX + lane], 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < SPT; ++u)
+                asm volatile("" : "+v"(v[u])); // (the placement works its addresses out again: sixteen registers, not thirty-two)
+            __syncthreads();
+            // exclusive scan of cnt[0..cpp) -> lstart, and back into cnt as the buckets' cursors; my slice of every coarse
+            // bucket -> gbase (the atomic's round trip runs under the scan; its result is not needed before the write-out)
+            const uint32_t vc = tid < cpp ? cnt[tid] : 0u;
+            const uint32_t slice = vc ? atomicAdd(&g4cur[(cb + tid) * G + g], vc) : 0u;
+            const uint32_t incl = dpp_incl_scan(vc);
+            if (lane == 63u)
+                wsum[wv] = incl;
+            __syncthreads();
+            uint32_t pre = 0, tot = 0;
+#pragma unroll
+            for (uint32_t ww = 0; ww < T / 64; ++ww) {
+                const uint32_t x = wsum[ww];
+                pre += ww < wv ? x : 0u;
+                tot += x;
+            }
+            if (tid < cpp) {
+                lstart[tid] = pre + incl - vc;
+                cnt[tid] = pre + incl - vc;
+                gbase[tid] = slice;
+            }
+            if (tid == 0)
+                lstart[cpp] = tot;
+            __syncthreads();
+            // placement: a second atomic on the bucket's cursor gives the item's slot -- as many LDS operations as reading the
+            // bucket's start and adding a rank kept since the count, and sixteen registers less (the kernel lives on 64)
+            uint32_t idb = (q0 + qt) & 0xFFFFu;
+            asm volatile("" : "+v"(idb)); // (not sixteen hoisted id registers either)
+#pragma unroll
+            for (uint32_t u0 = 0; u0 < SPT; u0 += 8) { // eight atomics in flight, then their eight stores; no branch per slot:
+                uint32_t at[8];                         // an empty slot's item goes to a word of its lane behind the stage
+#pragma unroll
+                for (uint32_t u = u0; u < u0 + 8; ++u)
+                    at[u - u0] = atomicAdd(&cnt[(in >> u & 1u) ? v[u] >> 16 : B4_CPP_MAX + lane], 1u);
+#pragma unroll
+                for (uint32_t u = u0; u < u0 + 8; ++u)
+                    stage[(in >> u & 1u) ? at[u - u0] : B4_STAGE + lane] = ((v[u] << 16) | idb) + u * QSTEP;
+            }
+            __syncthreads();
+            // write-out: a quarter wave per coarse bucket (runs are a few dozen items)
+            for (uint32_t c = tid >> 4; c < cpp; c += T / 16) {
+                const uint32_t ls = lstart[c], nn = lstart[c + 1u] - ls, gb = gbase[c];
+                for (uint32_t j = tid & 15u; j < nn; j += 16)
+                    citems4[gb + j] = stage[ls + j];
+            }
+        }
+    }
+}
+
+// level 2 of the sliced build: a workgroup per coarse bucket (value >> 16).  Up to CAP x T intermediate items sit in the
+// threads' registers -- ONE read of them; the fine histogram (and, as the atomic's return value, every item's rank inside its
+// fine bucket) in LDS; the final compact items written by the bucket's only owner.  A larger coarse bucket (a skewed input)
+// takes two passes over its intermediate items.  Then, in a bucket the check pass marked, the repeated hashes get their
+// occurrence numbers (see struct Layout).
+template <int T, int CAP>
+__global__ __launch_bounds__(T) void fine4_kernel(const uint32_t *__restrict__ citems4, const uint32_t *__restrict__ c4start, uint32_t G,
+                                                 uint32_t *__restrict__ hdr, uint32_t *__restrict__ start,
+                                                 uint32_t *__restrict__ items32, const uint32_t *__restrict__ dupmap,
+                                                 const uint2 *__restrict__ duplist, uint32_t ndw, uint32_t field_bits)
+{
+    __shared__ uint32_t hist[4096];
     __shared__ uint32_t ws[T / 64];
-    const uint32_t fpc = 1u << fpc_log2;
-    const uint32_t shift = hdr[H_SHIFT];
-    const bool compact = hdr[H_FMT] != 0u;
-    uint32_t *items32 = reinterpret_cast<uint32_t *>(items);
-    const uint32_t id_mask = (1u << id_bits) - 1u, low_mask = (1u << shift) - 1u, kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
-    const int tid = threadIdx.x;
+    if (hdr[H_B4] != 1u)
+        return;
+    const uint32_t nc = hdr[H_B4_NC], shift = hdr[H_SHIFT], fpc_log2 = 16u - shift, fpc = 1u << fpc_log2;
+    const uint32_t low_mask = (1u << shift) - 1u, kmul = (uint32_t)(((1ull << 32) + ndw - 1) / ndw);
+    const uint32_t occ_mask = ((1u << (11u - shift)) - 1u) << CK_LOW;
+    const uint32_t tid = threadIdx.x;
     unsigned long long sq = 0;
-    for (uint32_t c = cfirst + blockIdx.x; c < nc; c += gridDim.x) {
-        const uint32_t lo = cstart[c], cntc = cstart[c + 1] - lo;
-        if (cntc > SL_CAP * (uint32_t)T)
-            continue; // fine_kernel<false>'s
+    uint32_t nover = 0;
+    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const uint32_t lo = c4start[c * G], mid = c4start[c * G + G - 1u], cntc = c4start[c * G + G] - lo;
+        // the compact item of intermediate item `item` at position p of the bucket: as fine_kernel's, occurrence number 0
+        auto compact_of = [&](uint32_t item, uint32_t col) -> uint32_t {
+            const uint32_t k = __umulhi(col, kmul); // col / ndw (exact: see rowjoin_dense_kernel)
+            return (((item >> 16) & low_mask) << (32u - shift)) | (1u << CK_LOW) | ((col - k * ndw) << 5) | (k * field_bits);
+        };
         __syncthreads();
         for (uint32_t f = tid; f < fpc; f += T)
             hist[f] = 0;
         __syncthreads();
-        uint2 it[SL_CAP];
-        uint32_t rk[SL_CAP];
+        const bool inreg = cntc <= (uint32_t)CAP * T; // (uniform)
+        uint32_t it[CAP], rk[CAP];
+        if (inreg) {
 #pragma unroll
-        for (int u = 0; u < (int)SL_CAP; ++u)
-            it[u] = (uint32_t)(tid + u * T) < cntc ? citems[lo + tid + u * T] : make_uint2(0u, 0u);
+            for (int u = 0; u < CAP; ++u)
+                it[u] = tid + (uint32_t)u * T < cntc ? citems4[lo + tid + (uint32_t)u * T] : 0u;
 #pragma unroll
-        for (int u = 0; u < (int)SL_CAP; ++u)
-            rk[u] = (uint32_t)(tid + u * T) < cntc ? atomicAdd(&hist[(it[u].x >> shift) & (fpc - 1u)], 1u) : 0u;
+            for (int u = 0; u < CAP; ++u)
+                rk[u] = tid + (uint32_t)u * T < cntc ? atomicAdd(&hist[it[u] >> (16u + shift)], 1u) : 0u;
+        } else {
+            ++nover;
+            for (uint32_t p = tid; p < cntc; p += T)
+                atomicAdd(&hist[citems4[lo + p] >> (16u + shift)], 1u);
+        }
         __syncthreads();
-        // exclusive scan of hist[0..fpc): PER consecutive entries per thread (fpc <= FPC_MAX = 8 x 1024)
-        constexpr int PERMAX = (int)(FPC_MAX / T);
+        // exclusive scan of hist[0..fpc): PER consecutive entries per thread
+        constexpr int PERMAX = (4096 + T - 1) / T;
         const uint32_t per = (fpc + T - 1) / T;
-        uint32_t v[PERMAX], sum = 0;
+        uint32_t hv[PERMAX], sum = 0;
 #pragma unroll
         for (int i = 0; i < PERMAX; ++i) {
             const uint32_t f = tid * per + i;
-            v[i] = ((uint32_t)i < per && f < fpc) ? hist[f] : 0u;
-            sum += v[i];
-            sq += (unsigned long long)v[i] * v[i];
+            hv[i] = ((uint32_t)i < per && f < fpc) ? hist[f] : 0u;
+            sum += hv[i];
+            sq += (unsigned long long)hv[i] * hv[i];
         }
         uint32_t incl = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t t = __shfl_up(incl, d, 64);
-            if ((tid & 63) >= d)
+            if ((tid & 63u) >= (uint32_t)d)
                 incl += t;
         }
-        if ((tid & 63) == 63)
+        if ((tid & 63u) == 63u)
             ws[tid >> 6] = incl;
         __syncthreads();
         uint32_t run = lo + incl - sum;
-        for (int w = 0; w < (tid >> 6); ++w)
+        for (uint32_t w = 0; w < (tid >> 6); ++w)
             run += ws[w];
 #pragma unroll
         for (int i = 0; i < PERMAX; ++i) {
             const uint32_t f = tid * per + i;
             if ((uint32_t)i < per && f < fpc) {
                 start[((size_t)c << fpc_log2) + f] = run;
-                hist[f] = run; // the fine bucket's first position
+                hist[f] = run; // the fine bucket's first position (two-pass path: its write cursor)
             }
-            run += v[i];
+            run += hv[i];
         }
         __syncthreads();
+        if (inreg) {
 #pragma unroll
-        for (int u = 0; u < (int)SL_CAP; ++u)
-            if ((uint32_t)(tid + u * T) < cntc) {
-                const uint32_t at = hist[(it[u].x >> shift) & (fpc - 1u)] + rk[u];
-                if (compact) { // as fine_kernel
-                    const uint32_t col = it[u].y & id_mask, occ = it[u].y >> id_bits;
-                    const uint32_t k = __umulhi(col, kmul);
-                    const uint32_t occ1 = (occ + 1u) << CK_LOW;
-                    const uint32_t hi_part = shift ? (((it[u].x & low_mask) << (32u - shift)) | occ1) : occ1;
-                    items32[at] = hi_part | ((col - k * ndw) << 5) | (k * field_bits);
-                } else {
-                    items[at] = it[u];
+            for (int u = 0; u < CAP; ++u) {
+                const uint32_t p = tid + (uint32_t)u * T;
+                if (p < cntc)
+                    items32[hist[it[u] >> (16u + shift)] + rk[u]] =
+                        compact_of(it[u], (it[u] & 0xFFFFu) | ((G == 2u && lo + p >= mid) ? 65536u : 0u));
+            }
+        } else {
+            for (uint32_t p = tid; p < cntc; p += T) {
+                const uint32_t item = citems4[lo + p];
+                items32[atomicAdd(&hist[item >> (16u + shift)], 1u)] =
+                    compact_of(item, (item & 0xFFFFu) | ((G == 2u && lo + p >= mid) ? 65536u : 0u));
+            }
+        }
+        if (dupmap[c >> 5] >> (c & 31u) & 1u) {
+            // repeated hashes of this coarse bucket: record (value, id | number << 17) -> the number-th (0-based) of the equal
+            // items of its fine bucket, in slot order, gets the number (the first copy keeps 0: it is not in the list)
+            __threadfence();
+            __syncthreads();
+            const uint32_t ndup = min(hdr[H_B4_NDUP], B4_DUP_MAX);
+            for (uint32_t j = tid; j < ndup; j += T) {
+                const uint2 rec = duplist[j];
+                if ((rec.x >> 16) != c)
+                    continue;
+                const uint32_t f = (rec.x & 0xFFFFu) >> shift, number = rec.y >> 17;
+                const size_t fb = ((size_t)c << fpc_log2) + f;
+                const uint32_t b0 = __hip_atomic_load(&start[fb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t b1 = f + 1u < fpc ? __hip_atomic_load(&start[fb + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : lo + cntc;
+                const uint32_t want = compact_of(rec.x << 16, rec.y & 0x1FFFFu);
+                uint32_t seen = 0;
+                for (uint32_t at = b0; at < b1; ++at) {
+                    const uint32_t got = __hip_atomic_load(&items32[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (((got ^ want) & ~occ_mask) == 0u && seen++ == number) {
+                        __hip_atomic_store(&items32[at], (want & ~occ_mask) | ((number + 1u) << CK_LOW), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         sq += __shfl_xor(sq, d, 64);
-    if ((tid & 63) == 0 && sq)
+    if ((tid & 63u) == 0 && sq)
         atomicAdd(reinterpret_cast<unsigned long long *>(&hdr[H_EST_LO]), sq);
+    if (nover && tid == 0)
+        atomicAdd(&hdr[H_B4_OVER], nover);
 }
 
 // sparse / generic decision from the index's self-join size
@@ -1710,7 +1924,7 @@ static DenseGeom dense_geom(uint32_t sx, uint32_t sy, uint64_t ny)
 // what: 1 = build the index of Y, 2 = join X against the index in the workspace, 3 = both
 static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32_t sx, const uint32_t *d_Y, uint64_t ny,
                               uint32_t sy, uint16_t *d_counts, uint64_t ld, void *d_work, size_t work_bytes,
-                              polyhip_stream_t stream, uint32_t part = 0, uint32_t nparts = 1)
+                              polyhip_stream_t stream, uint32_t part = 0, uint32_t nparts = 1, bool parts_api = false)
 {
     bool build = what & 1;
     const bool join = what & 2;
@@ -1741,6 +1955,9 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     uint2 *citems = reinterpret_cast<uint2 *>(w + L.off_citems);
     uint2 *items = reinterpret_cast<uint2 *>(w + L.off_items);
     uint16_t *pos = reinterpret_cast<uint16_t *>(w + L.off_pos);
+    uint32_t *g4count = reinterpret_cast<uint32_t *>(w + L.off_g4count), *dupmap = reinterpret_cast<uint32_t *>(w + L.off_dup),
+             *c4start = reinterpret_cast<uint32_t *>(w + L.off_c4start), *g4cur = reinterpret_cast<uint32_t *>(w + L.off_g4cur);
+    uint2 *duplist = reinterpret_cast<uint2 *>(w + L.off_duplist);
 
     // the join packs the Y sketch id into 24 bits and stages an X row in LDS
     const int force = (ny > (1ull << k2::ID_BITS_MAX) || sx > k2::S_MAX) ? 1 : 0;
@@ -1772,21 +1989,46 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         // header, Y flags and the histogram start at zero
         PH_HIP(hipMemsetAsync(w, 0, L.off_irrY, st));
         PH_HIP(hipMemsetAsync(gcount, 0, (size_t)L.nc * 4, st));
+        // The sliced build on 4-byte intermediate items (struct Layout) where the HOST's conditions hold -- compact items may be
+        // made, SketchSize <= 1024, at most 131,072 sketches, the whole index in one go (the parts API and the item exchange keep
+        // the two-level build's coarse buckets) --; the device's conditions (the largest value, the bucket shift, how often a
+        // sketch repeats a hash) are decided by plan4_kernel / lists_kernel in hdr[H_B4], and BOTH builds are launched: the
+        // kernels of the one that is not to run return at once.  POLYHIP_K2_B4=0 (and POLYHIP_K2_STAGE=0): the two-level build.
+        const bool b4 = allow_compact && sy <= 1024 && ny <= 131072 && nparts == 1 && !parts_api && !env_is("POLYHIP_K2_B4", '0') &&
+                        !env_is("POLYHIP_K2_STAGE", '0');
+        const uint32_t G4 = ny > 65536 ? 2u : 1u;
+        const bool slots64 = env_is("POLYHIP_K2_B4_SLOTS", '6');
+        if (b4)
+            PH_HIP(hipMemsetAsync(g4count, 0, L.off_duplist - L.off_g4count, st)); // the histogram and the dupmap
         hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st, d_Y,
                            ny, sy, hdr);
-        if (L.sliced) // 256 workgroups of 16 waves: 8,192 coarse counters per workgroup are flushed with a global atomic each
-            hipLaunchKernelGGL(k2::check_kernel<true>, dim3((unsigned)std::min<uint64_t>((ny + 15) / 16, 256)), dim3(1024), (size_t)L.nc * 4,
-                               st, d_Y, ny, sy, flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount, pos,
-                               L.nc_log2 - k2::SL_R_LOG2);
-        else
-            hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(ny)), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy,
-                               flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount, (uint16_t *)nullptr, 0u);
+        if (b4) {
+            uint32_t slice_len = slots64 ? 41u : 83u; // ~0.65 of a sketch's slots per round: a slice beyond them costs a round
+            if (const char *e = getenv("POLYHIP_K2_B4_TL")) {
+                const long v = strtol(e, nullptr, 10);
+                if (v >= 8 && v <= 1024)
+                    slice_len = (uint32_t)v;
+            }
+            hipLaunchKernelGGL(k2::plan4_kernel, dim3(1), dim3(64), 0, st, hdr, L.nbk_log2, sy, slice_len);
+            const size_t smem = (size_t)k2::B4_NC_MAX * 4;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::check4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)smem));
+            hipLaunchKernelGGL(k2::check4_kernel, dim3((unsigned)std::min<uint64_t>((ny + 15) / 16, 256)), dim3(1024), smem, st, d_Y, ny, sy,
+                               flagsY, hdr, force, max_occ, G4, g4count, dupmap, duplist, pos);
+        }
+        hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(ny)), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy,
+                           flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount, 0u);
         hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                            flagsX, (uint64_t)0, flagsY, ny, irrX, regX, irrY, hdr, L.nbk_log2, allow_compact ? 1 : 0);
+        if (b4) // the sliced build was planned and then called off (hdr[H_B4] == 2): the two-level build's histogram after all
+            hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(ny)), dim3(k2::THREADS), (size_t)L.nc * 4, st, d_Y, ny, sy,
+                               flagsY, hdr, force, max_occ, L.nbk_log2, L.fpc_log2, L.nc, gcount, 2u);
         // ---- inverted index of the Y side: two-level partition by value
         const uint32_t per_batch = std::max<uint32_t>(1u, k2::BATCH_ITEMS / sy);
         const unsigned batches = (unsigned)((ny + per_batch - 1) / per_batch);
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, gcount, L.nc, cstart, gcur, start, L.nbk);
+        if (b4) // (after coarse_scan_kernel: both write start[nbk])
+            hipLaunchKernelGGL(k2::scan4_kernel, dim3(1), dim3(1024), 0, st, g4count, G4, hdr, c4start, g4cur, start, L.nbk);
         // one part of the index (multi-rank build): the coarse buckets [c0, c1) only, every item at its final place.  The
         // bounds come from the coarse histogram -- the one point where the host has to look at device data.
         uint32_t c0 = 0, c1 = L.nc;
@@ -1799,16 +2041,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             c1 = b[part + 1];
         }
         // level-1 scatter: through LDS when a sketch fits the stage (POLYHIP_K2_STAGE=0: the direct scatter, testing aid)
-        if (L.sliced) {
-            const uint32_t ncl = L.nc >> k2::SL_R_LOG2;
-            const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)ncl * 12;
-            const uint64_t witems = ((ny + 63) / 64) * k2::SL_R;
-            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_sliced_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-            hipLaunchKernelGGL(k2::coarse_scatter_sliced_kernel, dim3((unsigned)std::min<uint64_t>(witems, PH_K2_STAGE_GRID)),
-                               dim3(k2::STAGE_THREADS), smem, st, d_Y, ny, sy, flagsY, pos, hdr, L.fpc_log2, ncl, id_bits, c0, c1, gcur,
-                               citems, 0u);
-        } else if (sy <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0')) {
+        if (sy <= k2::STAGE_ITEMS && L.nc <= 1024 && !env_is("POLYHIP_K2_STAGE", '0')) {
             const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / sy);
             const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
@@ -1819,14 +2052,21 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
             hipLaunchKernelGGL(k2::coarse_scatter_kernel, dim3(batches), dim3(k2::THREADS), (size_t)L.nc * 8, st, d_Y, ny, sy,
                                flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems, 0u);
         }
-        if (c1 > c0 && L.sliced)
-            hipLaunchKernelGGL(k2::fine_lds_kernel, dim3(std::min<uint32_t>(c1 - c0, 256u * 2u)), dim3(k2::FINE_LDS_THREADS), 0, st, citems,
-                               cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
-        if (c1 > c0) // (sliced: only the coarse buckets beyond what fine_lds_kernel's registers hold)
+        if (b4) {
+            const size_t smem = ((size_t)k2::B4_STAGE + 64 + 3 * (size_t)k2::B4_CPP_MAX + 64 + 16 + 2 * (slots64 ? 256 : 128)) * 4;
+            auto kern = slots64 ? k2::scatter4_kernel<256, 64> : k2::scatter4_kernel<128, 128>;
+            PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            hipLaunchKernelGGL(kern, dim3(512), dim3(1024), smem, st, d_Y, (uint32_t)ny, sy, flagsY, pos, hdr, G4, g4cur,
+                               reinterpret_cast<uint32_t *>(citems));
+        }
+        if (c1 > c0)
             hipLaunchKernelGGL(k2::fine_kernel<false>, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st, citems,
                                cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits,
-                               (const uint2 *const *)nullptr, (const uint32_t *)nullptr, 0u, 0u,
-                               L.sliced ? k2::SL_CAP * (uint32_t)k2::FINE_LDS_THREADS : 0u);
+                               (const uint2 *const *)nullptr, (const uint32_t *)nullptr, 0u, 0u);
+        if (b4)
+            hipLaunchKernelGGL((k2::fine4_kernel<1024, 32>), dim3(512), dim3(1024), 0, st, reinterpret_cast<const uint32_t *>(citems), c4start,
+                               G4, hdr, start, reinterpret_cast<uint32_t *>(items), dupmap, duplist, gB.ndw ? gB.ndw : 8u,
+                               (uint32_t)gB.bits);
         PH_HIP(hipGetLastError());
     }
     if (!join)
@@ -1837,7 +2077,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         hipLaunchKernelGGL(reset_x_kernel, dim3(1), dim3(1), 0, st, hdr);
     PH_HIP(hipMemsetAsync(flagsX, 0, nx, st));
     hipLaunchKernelGGL(k2::check_kernel<false>, dim3(k2::check_grid(nx)), dim3(k2::THREADS), 0, st, d_X, nx, sx, flagsX, hdr, force,
-                       0xFFFFFFFEu, 0u, 0u, 0u, (uint32_t *)nullptr, (uint16_t *)nullptr, 0u);
+                       0xFFFFFFFEu, 0u, 0u, 0u, (uint32_t *)nullptr, 0u);
     hipLaunchKernelGGL(k2::lists_kernel, dim3((unsigned)((nx + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
                        flagsX, nx, flagsY, (uint64_t)0, irrX, regX, irrY, hdr, L.nbk_log2, -1);
     // Merging every pair costs nx*ny*(sx+sy) dependent steps.  The join compares every X
@@ -1944,7 +2184,7 @@ int polyhip_mash_index_build_part_dev(const uint32_t *d_Y, uint64_t ny, uint32_t
                                       void *d_work, size_t work_bytes, polyhip_stream_t stream)
 {
     PH_REQUIRE(nparts >= 1 && part < nparts, "polyhip_mash_index_build_part: part %u of %u", part, nparts);
-    return shared_counts_impl(1, nullptr, 0, 1, d_Y, ny, sy, nullptr, 0, d_work, work_bytes, stream, part, nparts);
+    return shared_counts_impl(1, nullptr, 0, 1, d_Y, ny, sy, nullptr, 0, d_work, work_bytes, stream, part, nparts, true);
 }
 
 int polyhip_mash_index_part_spans(uint64_t ny, uint32_t sy, uint32_t nparts, const void *d_work, size_t work_bytes,
@@ -1975,6 +2215,20 @@ int polyhip_mash_index_format_dev(const void *d_work, uint32_t *item_bytes)
     uint32_t h[k2::H_WORDS];
     PH_HIP(hipMemcpy(h, d_work, sizeof h, hipMemcpyDeviceToHost));
     *item_bytes = h[k2::H_FMT] ? 4u : 8u;
+    return POLYHIP_OK;
+}
+
+int polyhip_mash_index_build_info_dev(const void *d_work, uint32_t info[6])
+{
+    PH_REQUIRE(d_work && info, "polyhip_mash_index_build_info: null pointer");
+    uint32_t h[k2::H_WORDS];
+    PH_HIP(hipMemcpy(h, d_work, sizeof h, hipMemcpyDeviceToHost));
+    info[0] = h[k2::H_B4];
+    info[1] = h[k2::H_B4_NC];
+    info[2] = h[k2::H_B4_R];
+    info[3] = h[k2::H_B4_CPP];
+    info[4] = h[k2::H_B4_OVER];
+    info[5] = h[k2::H_B4_NDUP];
     return POLYHIP_OK;
 }
 
@@ -2267,14 +2521,10 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         const View v = view(x);
         const uint64_t m = x.i1 - x.i0;
         PH_HIP(hipMemcpyAsync(v.hdr + k2::H_MAXVAL, &maxval, 4, hipMemcpyHostToDevice, st));
-        if (m && L.sliced)
-            hipLaunchKernelGGL(k2::check_kernel<true>, dim3((unsigned)std::min<uint64_t>((m + 15) / 16, 256)), dim3(1024), (size_t)L.nc * 4, st,
-                               x.sk + x.i0 * (uint64_t)s, m, s, v.flagsY + x.i0, v.hdr, 0, max_occ, L.nbk_log2, L.fpc_log2, L.nc,
-                               v.gcount, v.pos + x.i0 * (k2::SL_R + 1), L.nc_log2 - k2::SL_R_LOG2);
-        else if (m)
+        if (m)
             hipLaunchKernelGGL(k2::check_kernel<true>, dim3(k2::check_grid(m)), dim3(k2::THREADS), (size_t)L.nc * 4, st,
                                x.sk + x.i0 * (uint64_t)s, m, s, v.flagsY + x.i0, v.hdr, 0, max_occ, L.nbk_log2, L.fpc_log2, L.nc,
-                               v.gcount, (uint16_t *)nullptr, 0u);
+                               v.gcount, 0u);
         PH_HIP(hipGetLastError());
         x.h_gcount.assign(L.nc, 0);
         std::vector<uint8_t> fl(m);
@@ -2323,16 +2573,7 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         hipLaunchKernelGGL(k2::coarse_scan_kernel, dim3(1), dim3(1024), 0, st, v.gcount, L.nc, v.cstart, v.gcur, v.start, L.nbk);
         if (m) {
             const uint32_t *sk = x.sk + x.i0 * (uint64_t)s;
-            if (L.sliced) {
-                const uint32_t ncl = L.nc >> k2::SL_R_LOG2;
-                const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)ncl * 12;
-                PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_sliced_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-                hipLaunchKernelGGL(k2::coarse_scatter_sliced_kernel,
-                                   dim3((unsigned)std::min<uint64_t>(((m + 63) / 64) * k2::SL_R, PH_K2_STAGE_GRID)), dim3(k2::STAGE_THREADS),
-                                   smem, st, sk, m, s, v.flagsY + x.i0, v.pos + x.i0 * (k2::SL_R + 1), v.hdr, L.fpc_log2, ncl, id_bits,
-                                   0u, L.nc, v.gcur, v.citems, (uint32_t)x.i0);
-            } else if (staged) {
+            if (staged) {
                 const uint32_t pb = std::max<uint32_t>(1u, k2::STAGE_ITEMS / s);
                 const size_t smem = (size_t)k2::STAGE_ITEMS * 8 + (size_t)L.nc * 12;
                 PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::coarse_scatter_staged_kernel),
@@ -2408,7 +2649,7 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
             PH_HIP(hipMemcpyAsync(x.segtab.p, lo.data(), lo.size() * 4, hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL(k2::fine_kernel<true>, dim3(std::min<uint32_t>(c1 - c0, 256u * 8u)), dim3(k2::FINE_THREADS), 0, st,
                                v.citems, v.cstart, c0, c1, L.fpc_log2, v.hdr, v.start, v.items, id_bits, gY.ndw ? gY.ndw : 8u,
-                               (uint32_t)gY.bits, x.segptr.as<const uint2 *>(), x.segtab.as<uint32_t>(), (uint32_t)N, ncp, 0u);
+                               (uint32_t)gY.bits, x.segptr.as<const uint2 *>(), x.segtab.as<uint32_t>(), (uint32_t)N, ncp);
             PH_HIP(hipGetLastError());
             PH_HIP(hipStreamSynchronize(st)); // (the tables are host vectors of this scope)
         } else {

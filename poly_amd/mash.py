@@ -215,6 +215,14 @@ def index_item_bytes(work_t) -> int:
     return int(b.value)
 
 
+def index_build_info(work_t) -> dict:
+    """which index build ran and its geometry -- polyhip_mash_index_build_info_dev"""
+    import ctypes as C
+    info = (C.c_uint32 * 6)()
+    _lib.check(_lib.lib().polyhip_mash_index_build_info_dev(work_t.data_ptr(), info))
+    return dict(zip(("build", "coarse", "parts", "coarse_per_part", "two_pass_buckets", "repeated"), (int(x) for x in info)))
+
+
 def index_finalize_dev(ny: int, sy: int, work_t, stream=None) -> None:
     _lib.check(_lib.lib().polyhip_mash_index_finalize_dev(ny, sy, work_t.data_ptr(),
                                                           work_t.numel() * work_t.element_size(), _lib.stream_ptr(stream)))

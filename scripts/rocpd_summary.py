@@ -39,6 +39,14 @@ def pmc_rows(cur):
         return []
 
 
+def _short(name, width):
+    """the kernel's name without its argument list; a long one keeps its FRONT (namespace and kernel name -- what
+    scripts/traffic_json.py and bench.py select kernels by; round 4 cut from the left and lost `polyhip::fq::` of the two
+    templated feeder kernels) and loses the tail of its template arguments"""
+    base = name.split("(")[0]
+    return base if len(base) <= width else base[:width - 3] + "..."
+
+
 def main():
     db = sqlite3.connect(sys.argv[1])
     title = sys.argv[2] if len(sys.argv) > 2 else sys.argv[1]
@@ -48,14 +56,14 @@ def main():
     print("| kernel | calls | total ms | mean ms | % |")
     print("|---|---:|---:|---:|---:|")
     for name, calls, total, avg, pct in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-        short = name.split("(")[0][-70:]
+        short = _short(name, 110)
         print(f"| `{short}` | {calls} | {total/1e3:.3f} | {avg/1e3:.4f} | {pct:.2f} |")
     rows = pmc_rows(cur)
     if rows:
         print("\n| kernel | counter | dispatches | sum | per dispatch |")
         print("|---|---|---:|---:|---:|")
         for name, cn, n, v in rows:
-            short = name.split("(")[0][-50:]
+            short = _short(name, 110)
             print(f"| `{short}` | {cn} | {n} | {v:.6g} | {v/n:.6g} |")
 
 
