@@ -114,6 +114,7 @@ constexpr uint32_t B4_RMAX = 64;       // parts of the value range at most (pos:
 constexpr uint32_t B4_CPP_MAX = 1024;  // coarse buckets per part at most (level 1's counters in LDS)
 constexpr uint32_t B4_NC_MAX = 16384;  // coarse buckets at most (largest value < 2^30)
 constexpr uint32_t B4_STAGE = 16384;   // items of a level-1 stage (64 KB: two workgroups per CU)
+constexpr uint32_t b4_cpp_max(int batch) { return batch > 256 ? 512u : B4_CPP_MAX; } // (level 1's LDS: two workgroups per CU)
 constexpr uint32_t B4_DUP_MAX = 65536; // records of repeated hashes the build numbers itself; more: the two-level build
 
 static inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(FINE_THREADS, 8) void fine_kernel(const uint2 *__re
 
 // ---- the sliced build on 4-byte intermediate items (B4; the plan is at struct Layout) ---------------------------------------
 // geometry from the largest value: one thread, between maxlast_kernel and the check pass
-__global__ void plan4_kernel(uint32_t *__restrict__ hdr, uint32_t nbk_log2, uint32_t s, uint32_t slice_len)
+__global__ void plan4_kernel(uint32_t *__restrict__ hdr, uint32_t nbk_log2, uint32_t s, uint32_t slice_len, uint32_t cpp_max)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -711,8 +712,8 @@ __global__ void plan4_kernel(uint32_t *__restrict__ hdr, uint32_t nbk_log2, uint
     const uint32_t nce = (maxval >> 16) + 1u; // coarse buckets that can hold an item
     // parts of the value range: a sketch's slice of one part is ~slice_len hashes when the sketch spreads over the whole range
     uint32_t R = min(max((s + slice_len - 1u) / slice_len, 1u), B4_RMAX);
-    uint32_t cpp = min(max((nce + R - 1u) / R, 2u), B4_CPP_MAX);
-    R = (nce + cpp - 1u) / cpp; // <= 16 when cpp was capped (nce <= 16,384), else <= the first R
+    uint32_t cpp = min(max((nce + R - 1u) / R, 2u), cpp_max); // (cpp_max: what level 1's stage shape keeps in LDS, 512 or 1024)
+    R = (nce + cpp - 1u) / cpp; // <= 32 when cpp was capped (nce <= 16,384), else <= the first R
     hdr[H_B4_NC] = 1u << (bits - 16u);
     hdr[H_B4_R] = R;
     hdr[H_B4_CPP] = cpp;
@@ -806,6 +807,8 @@ __global__ __launch_bounds__(1024) void check4_kernel(const uint32_t *__restrict
             for (int u = 0; u < 16; ++u) {
                 const uint32_t e = (uint32_t)u * 64u + lane;
                 const uint32_t nv = next_of(u); // (by every lane: a cross-lane read of a lane that sits out a branch returns 0)
+                // (working a part out once per element and passing it to the lane below by DPP was measured: 0.241 against
+                // 0.211 ms -- the readfirstlane for lane 63 waits where the two multiplies did not)
                 if (e < s) {
                     atomicAdd(&lh[x[u] >> 16], 1u);
                     const uint32_t ra = b4_part(x[u], magic, R);
@@ -833,7 +836,8 @@ __global__ __launch_bounds__(1024) void check4_kernel(const uint32_t *__restrict
         atomicMax(&hdr[H_MAXMULT], multmax);
 }
 
-// exclusive scan of g4count[NC * G] -> c4start[NC * G + 1], g4cur = copy; one workgroup, up to 32 consecutive counters per thread
+// exclusive scan of g4count[NC * G] -> c4start[NC * G + 1], g4cur = copy; one workgroup, a thread's (up to 32) consecutive
+// counters in registers from ONE round of 16-byte loads (counter by counter, twice over, the kernel took 33 us)
 __global__ __launch_bounds__(1024) void scan4_kernel(const uint32_t *__restrict__ g4count, uint32_t G, const uint32_t *__restrict__ hdr,
                                                     uint32_t *__restrict__ c4start, uint32_t *__restrict__ g4cur,
                                                     uint32_t *__restrict__ start, uint32_t nbk)
@@ -841,18 +845,18 @@ __global__ __launch_bounds__(1024) void scan4_kernel(const uint32_t *__restrict_
     __shared__ uint32_t wsum[16];
     if (hdr[H_B4] != 1u)
         return;
-    const uint32_t m = hdr[H_B4_NC] * G; // <= 32,768
-    const uint32_t per = (m + 1023u) / 1024u, tid = threadIdx.x, i0 = tid * per;
-    uint32_t sum = 0;
-    for (uint32_t i = 0; i < per; ++i)
-        sum += i0 + i < m ? g4count[i0 + i] : 0u;
-    uint32_t incl = sum;
+    const uint32_t m = hdr[H_B4_NC] * G; // <= 32,768 = the array's size: whole 16-byte pieces can be read, what lies behind m is zero
+    const uint32_t per = (((m + 1023u) / 1024u) + 3u) & ~3u, tid = threadIdx.x, i0 = tid * per;
+    uint32_t v[32], sum = 0;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(incl, d, 64);
-        if ((tid & 63u) >= (uint32_t)d)
-            incl += t;
+    for (uint32_t i = 0; i < 32; i += 4) {
+        uint4 x = make_uint4(0u, 0u, 0u, 0u);
+        if (i < per && i0 + i < m)
+            x = *reinterpret_cast<const uint4 *>(g4count + i0 + i);
+        v[i] = x.x, v[i + 1] = x.y, v[i + 2] = x.z, v[i + 3] = x.w;
+        sum += x.x + x.y + x.z + x.w;
     }
+    const uint32_t incl = dpp_incl_scan(sum);
     if ((tid & 63u) == 63u)
         wsum[tid >> 6] = incl;
     __syncthreads();
@@ -862,12 +866,14 @@ __global__ __launch_bounds__(1024) void scan4_kernel(const uint32_t *__restrict_
             run += wsum[w];
         total += wsum[w];
     }
-    for (uint32_t i = 0; i < per; ++i)
-        if (i0 + i < m) {
+#pragma unroll
+    for (uint32_t i = 0; i < 32; ++i) {
+        if (i < per && i0 + i < m) {
             c4start[i0 + i] = run;
             g4cur[i0 + i] = run;
-            run += g4count[i0 + i];
         }
+        run += v[i];
+    }
     if (tid == 0) {
         c4start[m] = total;
         start[nbk] = total;
@@ -889,30 +895,40 @@ __global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__res
     static_assert(B * SLOTS == (int)B4_STAGE && (B & (B - 1)) == 0 && B >= 64 && 65536 % B == 0, "a batch fills the stage and lies in one id group");
     constexpr uint32_t T = 1024, SPT = B4_STAGE / T, QSTEP = T / SLOTS; // slot i = tid + u * T: sketch (tid / SLOTS) + u * QSTEP of the batch
     extern __shared__ __attribute__((aligned(16))) uint32_t lds4[];
+    constexpr uint32_t CPPM = b4_cpp_max(B);        // coarse buckets per part at most (plan4_kernel was told)
     uint32_t *stage = lds4;                         // B4_STAGE (+ 64 words the empty slots' items go to)
-    uint32_t *cnt = stage + B4_STAGE + 64;          // B4_CPP_MAX (+ 64 words the empty slots count into)
-    uint32_t *lstart = cnt + B4_CPP_MAX + 64;       // B4_CPP_MAX + 1 (+ padding)
-    uint32_t *gbase = lstart + B4_CPP_MAX + 16;     // B4_CPP_MAX
-    uint32_t *spl = gbase + B4_CPP_MAX;             // 2 x B: start | length << 16 of this and of the next work item's slices
+    uint32_t *cnt = stage + B4_STAGE + 64;          // CPPM (+ 64 words the empty slots count into)
+    uint32_t *lstart = cnt + CPPM + 64;             // CPPM + 1 (+ padding)
+    uint32_t *gbase = lstart + CPPM + 16;           // CPPM
+    uint32_t *spl = gbase + CPPM;                   // 2 x B: start | length << 16 of this and of the next work item's slices
     __shared__ uint32_t wsum[T / 64];
     if (hdr[H_B4] != 1u)
         return;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t R = hdr[H_B4_R], cpp = hdr[H_B4_CPP];
-    const uint32_t nwork = ((n + B - 1) / B) * R; // (<= 1024 batches x 64 parts)
-    auto fetch = [&](uint32_t w) -> uint32_t { // slice r of sketch (w / R) * B + tid: start | length << 16 (0: none)
-        const uint32_t batch = w / R, r = w - batch * R, q = batch * B + tid;
+    // Work items in an XCD-aware order.  Workgroup b runs on XCD b % 8 (round-robin dispatch), and an XCD has its own L2: the
+    // batches are dealt to the XCDs (batch % 8), and an XCD's workgroups take its batches' work items in order -- so the
+    // parts of ONE batch, whose slices share the cache lines at their ends, are read through one L2 at about the same time
+    // (dealt out w = blockIdx.x, + gridDim.x, ... the kernel fetched 1.87 x the sketches' bytes: profiles/r05a_k2_fetch.md).
+    // The XCD's workgroups take the list ROUND ROBIN: neighbours run at the same time, and the second request for a line meets
+    // the first in the L2.  (A contiguous run of the list per workgroup -- neighbouring parts one after the other on one CU --
+    // was measured too and fetched MORE, 0.89 against 0.70 GB at 64 slots: at full rate an XCD's 4 MB of L2 turn over in a
+    // few microseconds, a work item takes ~40; profiles/r05c_k2_contiguous_runs.log.)
+    const uint32_t xcd = blockIdx.x & 7u, wg_x = gridDim.x >> 3, nbat = (n + B - 1) / B;
+    const uint32_t nwork = ((nbat + 7u - xcd) >> 3) * R; // this XCD's work items (<= 1024 batches x 64 parts)
+    auto fetch = [&](uint32_t w) -> uint32_t { // slice r of sketch batch * B + tid: start | length << 16 (0: none)
+        const uint32_t bx = w / R, r = w - bx * R, batch = xcd + 8u * bx, q = batch * B + tid;
         if (q >= n || flags[q])
             return 0u;
         const uint16_t *pq = pos + q * (R + 1u) + r;
         const uint32_t a = pq[0], b = pq[1];
         return a | ((b - a) << 16);
     };
-    uint32_t w = blockIdx.x;
+    uint32_t w = blockIdx.x >> 3;
     uint32_t nxt = (tid < (uint32_t)B && w < nwork) ? fetch(w) : 0u;
     uint32_t cur = 0;
     const uint32_t qt = tid / SLOTS, et = tid % SLOTS;
-    for (; w < nwork; w += gridDim.x, cur ^= (uint32_t)B) {
+    for (; w < nwork; w += wg_x, cur ^= (uint32_t)B) {
         if (tid < (uint32_t)B)
             spl[cur + tid] = nxt;
         __syncthreads(); // the bounds are there; everybody is through with the previous work item's stage
@@ -922,10 +938,10 @@ __global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__res
             maxlen = max(maxlen, spl[cur + j * 64 + lane] >> 16);
         maxlen = dpp_wave_max(maxlen);
         {
-            const uint32_t w2 = w + gridDim.x;
+            const uint32_t w2 = w + wg_x;
             nxt = (tid < (uint32_t)B && w2 < nwork) ? fetch(w2) : 0u;
         }
-        const uint32_t batch = w / R, r = w - batch * R, q0 = batch * B, cb = r * cpp, g = q0 >> 16;
+        const uint32_t bx = w / R, r = w - bx * R, q0 = (xcd + 8u * bx) * B, cb = r * cpp, g = q0 >> 16;
         // the batch's sketches as ONE buffer: a slot without a hash asks beyond its end and reads 0 -- no branch around a load
         const uint32_t nb = min((uint32_t)B, n - q0);
         const __amdgpu_buffer_rsrc_t rs =
@@ -951,7 +967,7 @@ __global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__res
 #pragma unroll
             for (uint32_t u = 0; u < SPT; ++u) {
                 v[u] -= cb << 16;
-                __hip_atomic_fetch_add(&cnt[(in >> u & 1u) ? v[u] >> 16 : B4_CPP_MAX + lane], 1u, __ATOMIC_RELAXED,
+                __hip_atomic_fetch_add(&cnt[(in >> u & 1u) ? v[u] >> 16 : CPPM + lane], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
 #pragma unroll
@@ -990,7 +1006,7 @@ __global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__res
                 uint32_t at[8];                         // an empty slot's item goes to a word of its lane behind the stage
 #pragma unroll
                 for (uint32_t u = u0; u < u0 + 8; ++u)
-                    at[u - u0] = atomicAdd(&cnt[(in >> u & 1u) ? v[u] >> 16 : B4_CPP_MAX + lane], 1u);
+                    at[u - u0] = atomicAdd(&cnt[(in >> u & 1u) ? v[u] >> 16 : CPPM + lane], 1u);
 #pragma unroll
                 for (uint32_t u = u0; u < u0 + 8; ++u)
                     stage[(in >> u & 1u) ? at[u - u0] : B4_STAGE + lane] = ((v[u] << 16) | idb) + u * QSTEP;
@@ -1011,8 +1027,43 @@ __global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__res
 // fine bucket) in LDS; the final compact items written by the bucket's only owner.  A larger coarse bucket (a skewed input)
 // takes two passes over its intermediate items.  Then, in a bucket the check pass marked, the repeated hashes get their
 // occurrence numbers (see struct Layout).
+// One more of counter hist[key], returning its value before: the rank of this lane's item inside its fine bucket (or, on a
+// cursor, its slot).  The copies of one hash that a family of related sketches holds arrive TOGETHER -- level 1 wrote them as
+// one run -- so the 64 lanes of a wave mostly hold one or two keys, and 64 atomics on one LDS address serialise (the first
+// version of fine4_kernel spent 21 us per coarse bucket that way: profiles/r05a_k2_stats.md).  So the key of the wave's first
+// lane is counted ONCE, by that lane, for all the lanes that hold it (ballot, popcount, the lane's rank among them from
+// mbcnt), then the first remaining lane's key likewise; lanes left after two rounds -- distinct keys -- take the plain atomic.
+__device__ __forceinline__ uint32_t ranked_add(uint32_t *hist, uint32_t key, bool valid)
+{
+    const uint32_t lane = __lane_id();
+    unsigned long long rem = __ballot(valid);
+    uint32_t rk = 0;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (rem == 0ull)
+            break;
+        const int src = __builtin_ctzll(rem);
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, src);
+        const unsigned long long m = __ballot(valid && key == k) & rem;
+        const uint32_t c = (uint32_t)__builtin_popcountll(m);
+        if (c < 4u)
+            break; // (a handful of equal keys costs less as plain atomics than as a round of this)
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        uint32_t base = 0;
+        if (lane == (uint32_t)src)
+            base = atomicAdd(&hist[k], c);
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, src);
+        if (m >> lane & 1ull)
+            rk = base + below;
+        rem &= ~m;
+    }
+    if (rem >> lane & 1ull)
+        rk = atomicAdd(&hist[key], 1u);
+    return rk;
+}
+
 template <int T, int CAP>
-__global__ __launch_bounds__(T) void fine4_kernel(const uint32_t *__restrict__ citems4, const uint32_t *__restrict__ c4start, uint32_t G,
+__global__ __launch_bounds__(T, 4) void fine4_kernel(const uint32_t *__restrict__ citems4, const uint32_t *__restrict__ c4start, uint32_t G,
                                                  uint32_t *__restrict__ hdr, uint32_t *__restrict__ start,
                                                  uint32_t *__restrict__ items32, const uint32_t *__restrict__ dupmap,
                                                  const uint2 *__restrict__ duplist, uint32_t ndw, uint32_t field_bits)
@@ -1039,18 +1090,49 @@ __global__ __launch_bounds__(T) void fine4_kernel(const uint32_t *__restrict__ c
             hist[f] = 0;
         __syncthreads();
         const bool inreg = cntc <= (uint32_t)CAP * T; // (uniform)
-        uint32_t it[CAP], rk[CAP];
+        static_assert(CAP % 8 == 0, "items are loaded, and placed, eight per thread at a time");
+        // The coarse bucket as a buffer, for loads and for stores: an item beyond its end reads as 0 and a store beyond it is
+        // dropped, so a thread's loads go out back to back with no branch between them.  (With `p < cntc ? load : 0` the
+        // compiler put every load behind a branch of its own and waited for each before ranking the item in front of it:
+        // fifteen HBM round trips per bucket, 19 us of them -- profiles/r05b_k2_stats_slots64.md, fine4 0.50 ms.)
+        const __amdgpu_buffer_rsrc_t rin =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(citems4 + lo), 0, (int)(cntc * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(items32 + lo, 0, (int)(cntc * 4u), 0x00020000);
+        const uint32_t hasdup = dupmap[c >> 5] >> (c & 31u) & 1u; // (asked for now, looked at behind the placement)
+        uint32_t it[CAP], rk2[CAP / 2]; // (an item's rank is below 2^16 here: two per register, the kernel lives on 128)
+        // Which item a lane takes.  A family's copies of one hash arrive TOGETHER (level 1 wrote them as one run), and 64
+        // atomics on ONE LDS address serialise: with lane l on item l the rank phase was half the kernel (ablation,
+        // profiles/r05d_f4_ablation.log: 0.24 of 0.465 ms), and counting a wave's common key once (ballot, popcount, mbcnt:
+        // ranked_add) cost as many instructions as it saved cycles.  So a wave's lanes take eight 32-byte pieces that lie
+        // T / 8 items apart: eight-way conflicts at worst, loads still whole sectors, no instruction more per item.
+#ifndef PH_K2_F4_PIECE_LOG2
+#define PH_K2_F4_PIECE_LOG2 3
+#endif
+        constexpr uint32_t PL = PH_K2_F4_PIECE_LOG2, PPW = 64u >> PL; // lanes per piece (log2), pieces per wave
+        const uint32_t ptid = ((((tid >> PL) & (PPW - 1u)) * (T / 64) + (tid >> 6)) << PL) | (tid & ((1u << PL) - 1u));
         if (inreg) {
 #pragma unroll
-            for (int u = 0; u < CAP; ++u)
-                it[u] = tid + (uint32_t)u * T < cntc ? citems4[lo + tid + (uint32_t)u * T] : 0u;
+            for (int u = 0; u < CAP; ++u) // (all of them, whatever the bucket's size: a load beyond the end costs an issue slot)
+                it[u] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, (int)(ptid * 4u), (int)((uint32_t)u * T * 4u), 0);
 #pragma unroll
-            for (int u = 0; u < CAP; ++u)
-                rk[u] = tid + (uint32_t)u * T < cntc ? atomicAdd(&hist[it[u] >> (16u + shift)], 1u) : 0u;
+            for (int u = 0; u < CAP; ++u) {
+                if ((uint32_t)u * T >= cntc)
+                    break; // (uniform)
+#if defined(PH_K2_F4_NORANK)
+                const uint32_t r = tid & 7u;
+#elif defined(PH_K2_F4_RANKED)
+                const uint32_t r = ranked_add(hist, it[u] >> (16u + shift), ptid + (uint32_t)u * T < cntc);
+#else
+                const uint32_t r = ptid + (uint32_t)u * T < cntc ? atomicAdd(&hist[it[u] >> (16u + shift)], 1u) : 0u;
+#endif
+                rk2[u / 2] = (u & 1) ? rk2[u / 2] | (r << 16) : r;
+            }
         } else {
             ++nover;
-            for (uint32_t p = tid; p < cntc; p += T)
-                atomicAdd(&hist[citems4[lo + p] >> (16u + shift)], 1u);
+            for (uint32_t p0 = 0; p0 < cntc; p0 += T) {
+                const bool ok = p0 + tid < cntc;
+                (void)ranked_add(hist, ok ? citems4[lo + p0 + tid] >> (16u + shift) : 0u, ok);
+            }
         }
         __syncthreads();
         // exclusive scan of hist[0..fpc): PER consecutive entries per thread
@@ -1064,13 +1146,7 @@ __global__ __launch_bounds__(T) void fine4_kernel(const uint32_t *__restrict__ c
             sum += hv[i];
             sq += (unsigned long long)hv[i] * hv[i];
         }
-        uint32_t incl = sum;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d, 64);
-            if ((tid & 63u) >= (uint32_t)d)
-                incl += t;
-        }
+        const uint32_t incl = dpp_incl_scan(sum);
         if ((tid & 63u) == 63u)
             ws[tid >> 6] = incl;
         __syncthreads();
@@ -1082,27 +1158,44 @@ __global__ __launch_bounds__(T) void fine4_kernel(const uint32_t *__restrict__ c
             const uint32_t f = tid * per + i;
             if ((uint32_t)i < per && f < fpc) {
                 start[((size_t)c << fpc_log2) + f] = run;
-                hist[f] = run; // the fine bucket's first position (two-pass path: its write cursor)
+                hist[f] = run - lo; // the fine bucket's first position inside the coarse bucket (two-pass path: its write cursor)
             }
             run += hv[i];
         }
         __syncthreads();
         if (inreg) {
 #pragma unroll
-            for (int u = 0; u < CAP; ++u) {
-                const uint32_t p = tid + (uint32_t)u * T;
-                if (p < cntc)
-                    items32[hist[it[u] >> (16u + shift)] + rk[u]] =
-                        compact_of(it[u], (it[u] & 0xFFFFu) | ((G == 2u && lo + p >= mid) ? 65536u : 0u));
+            for (int u0 = 0; u0 < CAP; u0 += 8) {
+                if ((uint32_t)u0 * T >= cntc)
+                    break; // (uniform)
+                uint32_t at[8];
+#pragma unroll
+                for (int u = u0; u < u0 + 8; ++u) // eight LDS reads in flight (an item beyond the end reads hist[0]: harmless)
+                    at[u - u0] = hist[it[u] >> (16u + shift)] + ((u & 1) ? rk2[u / 2] >> 16 : rk2[u / 2] & 0xFFFFu);
+#pragma unroll
+                for (int u = u0; u < u0 + 8; ++u) {
+                    const uint32_t p = ptid + (uint32_t)u * T;
+#if defined(PH_K2_F4_NOSTORE)
+                    if (at[u - u0] == 0xFFFFFFFFu)
+#elif defined(PH_K2_F4_LINSTORE)
+                    at[u - u0] = p;
+#endif
+                    __builtin_amdgcn_raw_buffer_store_b32(
+                        compact_of(it[u], (it[u] & 0xFFFFu) | ((G == 2u && lo + p >= mid) ? 65536u : 0u)), rout,
+                        p < cntc ? (int)(at[u - u0] * 4u) : -1, 0, 0);
+                }
             }
         } else {
-            for (uint32_t p = tid; p < cntc; p += T) {
-                const uint32_t item = citems4[lo + p];
-                items32[atomicAdd(&hist[item >> (16u + shift)], 1u)] =
-                    compact_of(item, (item & 0xFFFFu) | ((G == 2u && lo + p >= mid) ? 65536u : 0u));
+            for (uint32_t p0 = 0; p0 < cntc; p0 += T) {
+                const uint32_t p = p0 + tid;
+                const bool ok = p < cntc;
+                const uint32_t item = ok ? citems4[lo + p] : 0u;
+                const uint32_t at = ranked_add(hist, item >> (16u + shift), ok);
+                if (ok)
+                    items32[lo + at] = compact_of(item, (item & 0xFFFFu) | ((G == 2u && lo + p >= mid) ? 65536u : 0u));
             }
         }
-        if (dupmap[c >> 5] >> (c & 31u) & 1u) {
+        if (hasdup) {
             // repeated hashes of this coarse bucket: record (value, id | number << 17) -> the number-th (0-based) of the equal
             // items of its fine bucket, in slot order, gets the number (the first copy keeps 0: it is not in the list)
             __threadfence();
@@ -1997,19 +2090,21 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         const bool b4 = allow_compact && sy <= 1024 && ny <= 131072 && nparts == 1 && !parts_api && !env_is("POLYHIP_K2_B4", '0') &&
                         !env_is("POLYHIP_K2_STAGE", '0');
         const uint32_t G4 = ny > 65536 ? 2u : 1u;
-        const bool slots64 = env_is("POLYHIP_K2_B4_SLOTS", '6');
+        // level 1's stage shape: sketches per batch x slots per sketch and round (POLYHIP_K2_B4_SLOTS=128|64|32: measuring aid)
+        const int slots = env_is("POLYHIP_K2_B4_SLOTS", '1') ? 128 : env_is("POLYHIP_K2_B4_SLOTS", '3') ? 32 : 64;
+        const int bsk = (int)k2::B4_STAGE / slots;
         if (b4)
             PH_HIP(hipMemsetAsync(g4count, 0, L.off_duplist - L.off_g4count, st)); // the histogram and the dupmap
         hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st, d_Y,
                            ny, sy, hdr);
         if (b4) {
-            uint32_t slice_len = slots64 ? 41u : 83u; // ~0.65 of a sketch's slots per round: a slice beyond them costs a round
+            uint32_t slice_len = (uint32_t)slots * 41u / 64u; // ~0.65 of a sketch's slots per round: a slice beyond them costs a round
             if (const char *e = getenv("POLYHIP_K2_B4_TL")) {
                 const long v = strtol(e, nullptr, 10);
                 if (v >= 8 && v <= 1024)
                     slice_len = (uint32_t)v;
             }
-            hipLaunchKernelGGL(k2::plan4_kernel, dim3(1), dim3(64), 0, st, hdr, L.nbk_log2, sy, slice_len);
+            hipLaunchKernelGGL(k2::plan4_kernel, dim3(1), dim3(64), 0, st, hdr, L.nbk_log2, sy, slice_len, k2::b4_cpp_max(bsk));
             const size_t smem = (size_t)k2::B4_NC_MAX * 4;
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k2::check4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)smem));
@@ -2053,8 +2148,8 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
                                flagsY, hdr, L.fpc_log2, L.nc, per_batch, id_bits, c0, c1, gcur, citems, 0u);
         }
         if (b4) {
-            const size_t smem = ((size_t)k2::B4_STAGE + 64 + 3 * (size_t)k2::B4_CPP_MAX + 64 + 16 + 2 * (slots64 ? 256 : 128)) * 4;
-            auto kern = slots64 ? k2::scatter4_kernel<256, 64> : k2::scatter4_kernel<128, 128>;
+            const size_t smem = ((size_t)k2::B4_STAGE + 64 + 3 * (size_t)k2::b4_cpp_max(bsk) + 64 + 16 + 2 * (size_t)bsk) * 4;
+            auto kern = slots == 128 ? k2::scatter4_kernel<128, 128> : slots == 32 ? k2::scatter4_kernel<512, 32> : k2::scatter4_kernel<256, 64>;
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
             hipLaunchKernelGGL(kern, dim3(512), dim3(1024), smem, st, d_Y, (uint32_t)ny, sy, flagsY, pos, hdr, G4, g4cur,
                                reinterpret_cast<uint32_t *>(citems));
@@ -2064,9 +2159,16 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
                                cstart, c0, c1, L.fpc_log2, hdr, start, items, id_bits, gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits,
                                (const uint2 *const *)nullptr, (const uint32_t *)nullptr, 0u, 0u);
         if (b4)
-            hipLaunchKernelGGL((k2::fine4_kernel<1024, 32>), dim3(512), dim3(1024), 0, st, reinterpret_cast<const uint32_t *>(citems), c4start,
-                               G4, hdr, start, reinterpret_cast<uint32_t *>(items), dupmap, duplist, gB.ndw ? gB.ndw : 8u,
-                               (uint32_t)gB.bits);
+        {
+            if (env_is("POLYHIP_K2_B4_FINE", '5')) // (measuring aid: two 512-thread workgroups per CU, 32 items per thread)
+                hipLaunchKernelGGL((k2::fine4_kernel<512, 32>), dim3(1024), dim3(512), 0, st, reinterpret_cast<const uint32_t *>(citems),
+                                   c4start, G4, hdr, start, reinterpret_cast<uint32_t *>(items), dupmap, duplist,
+                                   gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
+            else
+                hipLaunchKernelGGL((k2::fine4_kernel<1024, 32>), dim3(512), dim3(1024), 0, st, reinterpret_cast<const uint32_t *>(citems),
+                                   c4start, G4, hdr, start, reinterpret_cast<uint32_t *>(items), dupmap, duplist,
+                                   gB.ndw ? gB.ndw : 8u, (uint32_t)gB.bits);
+        }
         PH_HIP(hipGetLastError());
     }
     if (!join)

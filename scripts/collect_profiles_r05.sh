@@ -29,6 +29,13 @@ k2)
   run ${R}_k2_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_fetch -o x -- python scripts/quick_k2c.py
   run ${R}_k2_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_write -o x -- python scripts/quick_k2c.py
   ;;
+k2stats)
+  run ${R}_k2_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_k2_stats -o x -- python scripts/quick_k2c.py
+  ;;
+k2traffic)
+  run ${R}_k2_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_fetch -o x -- python scripts/quick_k2c.py
+  run ${R}_k2_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k2_write -o x -- python scripts/quick_k2c.py
+  ;;
 k3)
   POLYHIP_SW_OVERLAP=0 run ${R}_k3_stats_nooverlap --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_k3_stats_nooverlap -o x -- python scripts/quick_k3tb.py
   ;;

@@ -17,8 +17,9 @@ work = torch.empty(mash.shared_counts_workspace_bytes(nrows, s, N, s), dtype=tor
 KEYS = ("POLYHIP_K2_B4", "POLYHIP_K2_B4_SLOTS", "POLYHIP_K2_B4_TL")
 variants = [("two-level", {"POLYHIP_K2_B4": "0"}), ("b4 default", {})]
 if len(sys.argv) > 1 and sys.argv[1] == "sweep":
-    variants += [(f"b4 slots128 tl{t}", {"POLYHIP_K2_B4_TL": str(t)}) for t in (64, 72, 92, 100, 125)]
-    variants += [(f"b4 slots64 tl{t}", {"POLYHIP_K2_B4_SLOTS": "64", "POLYHIP_K2_B4_TL": str(t)}) for t in (32, 36, 41, 46, 50)]
+    variants += [(f"b4 slots128 tl{t}", {"POLYHIP_K2_B4_SLOTS": "128", "POLYHIP_K2_B4_TL": str(t)}) for t in (72, 83, 92)]
+    variants += [(f"b4 slots64 tl{t}", {"POLYHIP_K2_B4_SLOTS": "64", "POLYHIP_K2_B4_TL": str(t)}) for t in (36, 41, 46)]
+    variants += [(f"b4 slots32 tl{t}", {"POLYHIP_K2_B4_SLOTS": "32", "POLYHIP_K2_B4_TL": str(t)}) for t in (16, 18, 20, 23)]
 ref = None
 for tag, env in variants:
     for k in KEYS:

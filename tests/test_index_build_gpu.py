@@ -67,7 +67,7 @@ def _check_rows(counts, X, Y, rows):
             assert int(counts[i, j]) == orc.mash_shared(X[i], Y[j]), (i, j)
 
 
-@pytest.mark.parametrize("slots", ["128", "64"])
+@pytest.mark.parametrize("slots", ["128", "64", "32"])
 def test_sliced_build_equals_two_level_build_and_oracle(mash, monkeypatch, slots):
     rng = np.random.default_rng(501)
     S = _families(rng, 60, 50, 500, 26)   # 3000 sketches x 500: 2^17 buckets, shift 9, 1024 coarse buckets
@@ -127,7 +127,7 @@ def test_slices_longer_than_a_round_and_sketches_of_other_scales(mash, monkeypat
     mid = _families(rng, 10, 40, 400, 22)
     S = np.concatenate([wide, narrow, mid])
     S = S[rng.permutation(len(S))]
-    for slots in ("128", "64"):
+    for slots in ("128", "64", "32"):
         got, info = _counts(mash, S, S, monkeypatch, {"POLYHIP_K2_B4_SLOTS": slots})
         assert info["build"] == 1
         old, _ = _counts(mash, S, S, monkeypatch, {"POLYHIP_K2_B4": "0"})
