@@ -174,16 +174,24 @@ static Layout layout(uint64_t nx, uint32_t sx, uint64_t ny, uint32_t sy)
 
 // ---- the largest value of the Y side: an ascending sketch ends with its largest value, and a sketch that is not
 // ascending never enters the index -- one load per sketch gives the bucket shift before the sketches are read at all
-__global__ __launch_bounds__(THREADS) void maxlast_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
-                                                         uint32_t *__restrict__ hdr)
+__global__ __launch_bounds__(1024) void maxlast_kernel(const uint32_t *__restrict__ sk, uint64_t n, uint32_t s,
+                                                      uint32_t *__restrict__ hdr)
 {
-    const uint64_t q = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
-    uint32_t v = q < n ? sk[q * s + (s - 1)] : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-        atomicMax(&hdr[H_MAXVAL], v);
+    // grid-stride, one atomic per WORKGROUP: a thousand and a half wave-level atomicMax on one word took most of the
+    // kernel's 21 us (profiles/r05c_k2_stats.md)
+    __shared__ uint32_t wmax[16];
+    uint32_t v = 0;
+    for (uint64_t q = (uint64_t)blockIdx.x * 1024 + threadIdx.x; q < n; q += (uint64_t)gridDim.x * 1024)
+        v = max(v, sk[q * s + (s - 1)]);
+    v = dpp_wave_max(v);
+    if ((threadIdx.x & 63) == 0)
+        wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        v = dpp_wave_max(threadIdx.x < 16 ? wmax[threadIdx.x] : 0u);
+        if (threadIdx.x == 0 && v > __hip_atomic_load(&hdr[H_MAXVAL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&hdr[H_MAXVAL], v);
+    }
 }
 
 __device__ __forceinline__ uint32_t bucket_shift(uint32_t maxval, uint32_t nbk_log2)
@@ -2095,8 +2103,7 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         const int bsk = (int)k2::B4_STAGE / slots;
         if (b4)
             PH_HIP(hipMemsetAsync(g4count, 0, L.off_duplist - L.off_g4count, st)); // the histogram and the dupmap
-        hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((ny + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st, d_Y,
-                           ny, sy, hdr);
+        hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)std::min<uint64_t>((ny + 1023) / 1024, 256)), dim3(1024), 0, st, d_Y, ny, sy, hdr);
         if (b4) {
             uint32_t slice_len = (uint32_t)slots * 41u / 64u; // ~0.65 of a sketch's slots per round: a slice beyond them costs a round
             if (const char *e = getenv("POLYHIP_K2_B4_TL")) {
@@ -2604,7 +2611,7 @@ int polyhip::k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t 
         PH_HIP(hipMemsetAsync(v.gcount, 0, (size_t)L.nc * 4, st));
         const uint64_t m = x.i1 - x.i0;
         if (m)
-            hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)((m + k2::THREADS - 1) / k2::THREADS)), dim3(k2::THREADS), 0, st,
+            hipLaunchKernelGGL(k2::maxlast_kernel, dim3((unsigned)std::min<uint64_t>((m + 1023) / 1024, 256)), dim3(1024), 0, st,
                                x.sk + x.i0 * (uint64_t)s, m, s, v.hdr);
         PH_HIP(hipGetLastError());
         PH_HIP(hipMemcpyAsync(&x.h_maxval, v.hdr + k2::H_MAXVAL, 4, hipMemcpyDeviceToHost, st));
