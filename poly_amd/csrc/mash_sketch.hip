@@ -41,7 +41,10 @@
 #include <vector>
 
 // PH_ABL != 0 only in scripts/ubench/k1_ablate.hip: knocks out one phase to measure its cost
-// (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage
+// (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage: the TILE pass.
+// The SLAB pass (round 5): 11 = stage + premix + hash only (no select, no bottom-s), 12 = no bottom-s, 14 = the per-read
+// prologue and barriers alone (no slabs, no bottom-s), 15 = no premix (the hash reads stale quads).  None of them marks a
+// row for the general kernel, so the timed launch is the slab kernel alone.
 #ifndef PH_WPE
 #define PH_WPE 6 // waves per SIMD the fast kernel is register-allocated for (6 workgroups per CU fit its LDS)
 #endif
@@ -949,19 +952,24 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
             S.template stage<0>(l1, h1);
             wave_sync();
             S.gload(i + 2, l1, h1);
-            S.template premix_unit<0>();
+            if (PH_ABL != 15)
+                S.template premix_unit<0>();
             wave_sync();
             S.template hash<1>(h);
         } else {
             S.template stage<1>(l1, h1);
             wave_sync();
             S.gload(i + 2, l1, h1);
-            S.template premix_unit<1>();
+            if (PH_ABL != 15)
+                S.template premix_unit<1>();
             wave_sync();
             S.template hash<0>(h);
         }
         const int64_t left = rv.nwin - ((int64_t)i << 8); // windows of the read from this slab on
-        if (__builtin_expect(left >= 256, 1)) {
+        if (PH_ABL == 11) { // keeps the hashes alive, stores (almost) never
+            if ((h[0] ^ h[1] ^ h[2] ^ h[3]) == 0x12345u)
+                seg[0] = h[0];
+        } else if (__builtin_expect(left >= 256, 1)) {
             append_own<false>(seg, capw, cnt, h, 4u, tauq);
         } else {
             const int64_t mine = left - 4 * S.lane;
@@ -1005,10 +1013,15 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB
                 tauq = (uint32_t)((target << 32) / (uint64_t)rv.nwin) | 0xFFFFu;
         }
         __syncthreads(); // the previous read is done with LDS
-        const uint32_t cw = run_slabs<KS>(sm, rv, n_seq_dw, n_P_w, seg, capw, tauq);
+        const uint32_t cw = PH_ABL == 14 ? tauq >> 31 : run_slabs<KS>(sm, rv, n_seq_dw, n_P_w, seg, capw, tauq);
         if ((tid & 63) == 0)
             sm.misc[10 + wave] = cw;
         __syncthreads();
+        if (PH_ABL == 11 || PH_ABL == 12 || PH_ABL == 14) { // no bottom-s, and no mark either (the general kernel stays out)
+            if (sm.misc[10] + sm.misc[11] + sm.misc[12] + sm.misc[13] == 0xFFFFFFF0u)
+                outp[0] = cw;
+            continue;
+        }
         const uint32_t c0 = sm.misc[10], c1 = sm.misc[11], c2 = sm.misc[12], c3 = sm.misc[13];
         const uint32_t C = c0 + c1 + c2 + c3;
         const bool ok = max(max(c0, c1), max(c2, c3)) <= capw && C >= s && C <= capf; // enough survivors, none lost

@@ -1,6 +1,7 @@
 // Phase ablation of K1 (mash_sketch.hip): build once per PH_ABL value, run on the GPU box.
-//   for a in 0 1 2 3 4 5 6; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DPH_ABL=$a -I include -I poly_amd/csrc \
-//       scripts/ubench/k1_ablate.hip poly_amd/csrc/runtime.hip -o scripts/ubench/k1_ablate_$a; done
+//   for a in 0 11 12 14 15; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DPH_ABL=$a -I include -I poly_amd/csrc \
+//       scripts/ubench/k1_ablate.hip poly_amd/csrc/runtime.hip poly_amd/csrc/multi_device.hip -o scripts/ubench/k1_ablate_$a; done
+// (0..7: the tile pass's probes of round 1; 11..15: the slab pass's, round 5)
 #include "../../poly_amd/csrc/mash_sketch.hip"
 #include <cstdio>
 #include <vector>
@@ -29,7 +30,8 @@ int main()
     for (size_t i = 0; i < ho.size(); ++i) { sum += ho[i] * (uint64_t)(i % 1000003 + 1); x ^= ho[i]; }
     const k1::Launch PL = k1::plan(k, s);
     printf("checksum %016llx %08llx  smem_slab %zu capw %u capf_slab %u  ", (unsigned long long)sum, (unsigned long long)x, PL.smem_slab, PL.capw, PL.capf_slab);
-    static const char *what[] = {"full kernel", "no premix", "1 chain block of 5", "no tail/fmix", "no select stores", "no bottom_s", "no global loads", "2 workgroups per CU"};
-    printf("PH_ABL=%d %-20s %.3f ms per 100k reads\n", PH_ABL, what[PH_ABL], ms);
+    static const char *what[] = {"full kernel", "no premix", "1 chain block of 5", "no tail/fmix", "no select stores", "no bottom_s", "no global loads", "2 workgroups per CU",
+                                 "", "", "", "slab: stage + premix + hash only", "slab: no bottom-s", "", "slab: per-read prologue + barriers only", "slab: no premix"};
+    printf("PH_ABL=%d %-40s %.3f ms per 100k reads\n", PH_ABL, what[PH_ABL], ms);
     return 0;
 }
