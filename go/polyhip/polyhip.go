@@ -131,6 +131,25 @@ func MashSketchDistanceMatrix(seqs []byte, offs []uint64, k, s int, sketches []u
 	})
 }
 
+// MatrixInfo is polyhip_matrix_info: what the calling OS thread's last MashSketchDistanceMatrix did -- which path, over how
+// many devices, its device-to-device copies by transport (Peer: xGMI with peer access on; Staged: no peer access, bounced
+// through host memory by the runtime; Local: both ends on one device) and the wall time of its rounds.
+type MatrixInfo struct {
+	Path, Devices                         int
+	PeerCopies, StagedCopies, LocalCopies int
+	BytesPeer, BytesStaged, BytesLocal    uint64
+	MsSketch, MsIndex, MsJoin             float64
+}
+
+// LastMatrixInfo must run on the OS thread that made the call (runtime.LockOSThread around both).
+func LastMatrixInfo() (MatrixInfo, error) {
+	var ci C.polyhip_matrix_info
+	err := call(func() C.int { return C.polyhip_mash_sketch_distance_matrix_last_info((*C.polyhip_matrix_info)(unsafe.Pointer(&ci))) })
+	return MatrixInfo{Path: int(ci.path), Devices: int(ci.devices), PeerCopies: int(ci.peer_copies), StagedCopies: int(ci.staged_copies),
+		LocalCopies: int(ci.local_copies), BytesPeer: uint64(ci.bytes_peer), BytesStaged: uint64(ci.bytes_staged),
+		BytesLocal: uint64(ci.bytes_local), MsSketch: float64(ci.ms_sketch), MsIndex: float64(ci.ms_index), MsJoin: float64(ci.ms_join)}, err
+}
+
 // MashSketchBatch: out is n*s uint32, in/out (prior Sketches), see polyhip_mash_sketch_batch.
 func MashSketchBatch(seqs []byte, offs []uint64, k, s int, out []uint32) error {
 	return call(func() C.int {

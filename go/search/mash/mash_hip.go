@@ -86,3 +86,77 @@ func SketchDistanceMatrix(seqs []string, kmerSize, sketchSize int) ([]*Mash, []f
 	}
 	return ms, dist
 }
+
+// SharedCounts is an all-vs-all result kept as the INTEGERS the reference divides (mash.go:134:
+// float64(sameHashes) / float64(smallerSketch.SketchSize)): n*n uint16 -- 20 GB at BASELINE configs[2]'s 100,000 sketches,
+// where the float64 matrix DistanceMatrix / SketchDistanceMatrix return would be 80 GB.  Nothing is lost: Similarity and
+// Distance of a pair are derived on demand, bit for bit what (*Mash).Similarity / Distance return.
+type SharedCounts struct {
+	N          int      // sketches on either side
+	SketchSize int      // the (common) SketchSize: the divisor of mash.go:134
+	Counts     []uint16 // Counts[i*N+j] = sameHashes of ms[i].Similarity(ms[j])
+}
+
+// Same is sameHashes of the pair (mash.go:108,121-123).
+func (c *SharedCounts) Same(i, j int) int { return int(c.Counts[i*c.N+j]) }
+
+// Similarity is ms[i].Similarity(ms[j]) (mash.go:134): one float64 division of two integers, as in the reference.
+func (c *SharedCounts) Similarity(i, j int) float64 {
+	return float64(c.Counts[i*c.N+j]) / float64(c.SketchSize)
+}
+
+// Distance is ms[i].Distance(ms[j]) (mash.go:138-140).
+func (c *SharedCounts) Distance(i, j int) float64 { return 1 - c.Similarity(i, j) }
+
+// Row is sketch i's counts against every sketch (a view, not a copy).
+func (c *SharedCounts) Row(i int) []uint16 { return c.Counts[i*c.N : (i+1)*c.N : (i+1)*c.N] }
+
+// SharedCountsMatrix is DistanceMatrix without the float64 matrix: the shared-hash counts of every ordered pair of
+// sketches of one SketchSize (<= 65535, what a uint16 holds).  Small inputs run the reference's merge.
+func SharedCountsMatrix(ms []*Mash) *SharedCounts {
+	if len(ms) == 0 {
+		return &SharedCounts{}
+	}
+	n, s := len(ms), ms[0].SketchSize
+	res := &SharedCounts{N: n, SketchSize: s, Counts: make([]uint16, n*n)}
+	if n*n < polyhip.MinDistancePairs {
+		for i, a := range ms {
+			for j, b := range ms {
+				// similarityCPU returns sameHashes / SketchSize; the product with SketchSize is an integer below 2^16,
+				// which float64 holds exactly, and the +0.5 guards the last-bit rounding of the division
+				res.Counts[i*n+j] = uint16(a.similarityCPU(b)*float64(s) + 0.5)
+			}
+		}
+		return res
+	}
+	flat := make([]uint32, 0, n*s)
+	for _, m := range ms {
+		flat = append(flat, m.Sketches...)
+	}
+	if err := polyhip.MashDistanceMatrix(flat, n, s, flat, n, s, res.Counts, nil); err != nil {
+		panic(err)
+	}
+	return res
+}
+
+// SketchSharedCounts is BASELINE configs[2] at size in one call: every sequence sketched (mash.go:59-104) and the shared
+// counts of every ordered pair (mash.go:107-135), the sketches staying in HBM in between -- SketchDistanceMatrix with the
+// n*n uint16 counts in place of n*n float64 (at 100,000 sketches: 20 GB, not 80).  With polyhip.SetDevices /
+// POLYHIP_DEVICES the reads shard over the node's GPUs (see SketchDistanceMatrix).
+func SketchSharedCounts(seqs []string, kmerSize, sketchSize int) ([]*Mash, *SharedCounts) {
+	n := len(seqs)
+	if n == 0 {
+		return nil, &SharedCounts{}
+	}
+	buf, offs := polyhip.Pack(seqs)
+	sk := make([]uint32, n*sketchSize+1)
+	res := &SharedCounts{N: n, SketchSize: sketchSize, Counts: make([]uint16, n*n)}
+	if err := polyhip.MashSketchDistanceMatrix(buf, offs, kmerSize, sketchSize, sk, res.Counts, nil); err != nil {
+		panic(err)
+	}
+	ms := make([]*Mash, n)
+	for i := range ms {
+		ms[i] = &Mash{KmerSize: kmerSize, SketchSize: sketchSize, Sketches: sk[i*sketchSize : (i+1)*sketchSize : (i+1)*sketchSize]}
+	}
+	return ms, res
+}

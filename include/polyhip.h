@@ -267,6 +267,21 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs,
 /* the calling thread's last polyhip_mash_sketch_distance_matrix: 0 = one device, 1 = a device list with the item exchange,
  * 2 = a device list with the sketch gather (tests) */
 int polyhip_mash_sketch_distance_matrix_last_path(void);
+/* What the calling thread's last polyhip_mash_sketch_distance_matrix did (round 5: so that the first run on more than one
+ * physical GPU explains itself).  path as above; devices = entries of the device list (1 without one); the device-to-device
+ * copies of the call -- rows of sketches on the gather path, index items and finished index parts on the exchange path --
+ * counted by TRANSPORT: peer (hipDeviceCanAccessPeer said yes and peer access is on: xGMI), staged (it said no: the runtime
+ * bounces the copy through host memory -- correct, and several times slower) and local (both ends on one device: a list
+ * that names a device twice); the bytes they moved; wall milliseconds of the call's rounds as the calling thread saw them
+ * (each round ends when its slowest device does): sketching, the index (exchange path: its five rounds; gather path: 0,
+ * the index is built inside the join), and the join incl. the rows' way back to the host. */
+typedef struct polyhip_matrix_info {
+    int32_t path, devices;
+    int32_t peer_copies, staged_copies, local_copies, reserved;
+    uint64_t bytes_peer, bytes_staged, bytes_local;
+    double ms_sketch, ms_index, ms_join;
+} polyhip_matrix_info;
+int polyhip_mash_sketch_distance_matrix_last_info(polyhip_matrix_info *info);
 
 /* ---- K3: search/align SmithWaterman  (search/align/align.go:171-232) ---- */
 /*
@@ -446,7 +461,10 @@ int polyhip_sw_last_packed_half(void);
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
  * kernel for reads of 153..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off), 5 = the half-float byte-profile
  * kernel with TWO LANES per pair (four bands of 64 rows) for reads of 153..256 symbols against one reference under the
- * half-float condition below (POLYHIP_TB_HALF2=0 or POLYHIP_TB_F16=0: path 4 instead; testing aids). */
+ * half-float condition below (POLYHIP_TB_HALF2=0 or POLYHIP_TB_F16=0: path 4 instead; testing aids), 6 = the half-float
+ * kernel for EVERY PAIR ITS OWN B (reads against reads): reads of at most 152 symbols, at most six symbol codes, score
+ * given, the half-float condition -- a lane builds its own profile from its pair's B symbols (tb_pair16_kernel;
+ * POLYHIP_TB_PAIR16=0 or POLYHIP_TB_F16=0: path 2 instead; testing aids). */
 int polyhip_sw_traceback_last_path(void);
 /* 1 when that call's byte-profile kernel (path 1) ran in its half-float form (gfx950: packed halves, two bands of rows
  * per lane, nine instructions per cell pair instead of eighteen) -- taken under the packed score pass's condition

@@ -56,6 +56,7 @@ SIGNATURES = {
     "polyhip_mash_distance_matrix": (C.c_int, [_vp, _u64, _u32, _vp, _u64, _u32, _vp, _vp]),
     "polyhip_mash_sketch_distance_matrix": (C.c_int, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "polyhip_mash_sketch_distance_matrix_last_path": (C.c_int, []),
+    "polyhip_mash_sketch_distance_matrix_last_info": (C.c_int, [_vp]),
     "polyhip_scoring_create": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.POINTER(C.c_void_p)]),
     "polyhip_scoring_destroy": (C.c_int, [_vp]),
     "polyhip_sw_workspace_bytes": (C.c_size_t, [_vp, _u64, _u32, _u64, C.c_int]),

@@ -72,6 +72,18 @@ struct StreamFree {
     }
 };
 
+// Waits for a stream on EVERY way out of a scope that has asynchronous device-to-host copies into its own locals (or into
+// the caller's buffers) in flight: a failed HIP call further down would otherwise return while those copies are still
+// pending and turn into writes to freed host memory (round-4 advice).  On the normal path the scope has synchronised
+// already and this costs one more, immediate, wait.
+struct SyncOnExit {
+    hipStream_t st;
+    explicit SyncOnExit(hipStream_t s) : st(s) {}
+    SyncOnExit(const SyncOnExit &) = delete;
+    SyncOnExit &operator=(const SyncOnExit &) = delete;
+    ~SyncOnExit() { (void)hipStreamSynchronize(st); }
+};
+
 // Testing aids: NAME=0 (or =1) in the environment, read per call, switches one kernel variant off (or on) so that
 // the parity tests can cross-check the variants; never needed in production.
 inline bool env_is(const char *name, char value)
@@ -109,6 +121,25 @@ struct AuxStream {
     hipStream_t s = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     int dev = -1; // the device it was made on: a thread that moves to another device gets a new one
+    AuxStream() = default;
+    AuxStream(const AuxStream &) = delete;
+    AuxStream &operator=(const AuxStream &) = delete;
+    // the thread's four cached entries go with the thread (a worker of a device list that is replaced: round-4 advice -- every
+    // polyhip_set_devices leaked up to 4 streams and 8 events per worker).  A process that is exiting has lost its HIP
+    // runtime already; its objects are left alone (hipStreamQuery then fails, and nothing is destroyed).
+    ~AuxStream()
+    {
+        if (!s)
+            return;
+        const hipError_t q = hipStreamQuery(s);
+        if (q != hipSuccess && q != hipErrorNotReady)
+            return;
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamDestroy(s);
+        for (int q2 = 0; q2 < 2; ++q2)
+            if (ev[q2])
+                (void)hipEventDestroy(ev[q2]);
+    }
     hipError_t init()
     {
         int cur = -1;

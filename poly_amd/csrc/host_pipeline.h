@@ -3,6 +3,7 @@
 // download of chunk c-1.  Nothing here touches the null stream: concurrent goroutines (cgo calls arrive on arbitrary OS
 // threads) do not serialise on it.
 #pragma once
+#include <atomic>
 
 #include <algorithm>
 #include <condition_variable>
@@ -290,8 +291,25 @@ uint64_t k2_rows_per_block(uint64_t nx, uint64_t ny, bool counts, bool dist);
 // that device's n x s array of which rows [i0, i1) are valid.  On return *built says whether every device's `work` holds
 // the whole index (false: the set has an irregular sketch, the geometry is not the dense join's, or the input is so
 // dense that the merge would take it -- the caller gathers the sketches instead).
+// device-to-device copies of one polyhip_mash_sketch_distance_matrix call, by transport (polyhip_matrix_info); the workers
+// of a device list count into one of these
+struct K2XferStats {
+    std::atomic<int> peer{0}, staged{0}, local{0};
+    std::atomic<uint64_t> bytes_peer{0}, bytes_staged{0}, bytes_local{0};
+    // 0 = local (one device), 1 = peer access on, 2 = no peer access: staged through the host by the runtime
+    void count(int transport, uint64_t bytes)
+    {
+        (transport == 0 ? local : transport == 1 ? peer : staged).fetch_add(1, std::memory_order_relaxed);
+        (transport == 0 ? bytes_local : transport == 1 ? bytes_peer : bytes_staged).fetch_add(bytes, std::memory_order_relaxed);
+    }
+};
+// makes `other`'s memory reachable from device `me` (the calling thread's current device) if the hardware allows it;
+// *transport as K2XferStats::count's
+int k2_enable_peer(int me, int other, int *transport);
+
 struct K2XShard {
     int dev = -1;
+    K2XferStats *stats = nullptr;
     uint64_t i0 = 0, i1 = 0;
     const uint32_t *sk = nullptr;
     DevBuf work;

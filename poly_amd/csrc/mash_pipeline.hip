@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -27,12 +28,21 @@ using namespace polyhip;
 namespace {
 
 thread_local int g_last_path = 0;
+thread_local polyhip_matrix_info g_last_info = {};
+
+double ms_since(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
 
 // one device's part: its copy of the sketch array, the reads it sketched
 struct SketchShard {
     uint64_t i0 = 0, i1 = 0; // reads [i0, i1)
     int dev = -1;
-    DevBuf dSk;              // n * s hashes: rows [i0, i1) after round A, everything after the pull
+    DevBuf dSk;              // the device's sketch rows: ITS OWN rows [i0, i1) on a device list -- the item exchange never needs
+                             // another device's rows, and the gather re-allocates (widen) --, all n on one device
+    uint64_t row0 = 0;       // dSk's first row (sk() is the array's virtual base: row r lives at sk() + r * s)
+    uint32_t *sk(uint32_t s) const { return dSk.as<uint32_t>() - row0 * (uint64_t)s; }
     int panic = POLYHIP_OK;  // SketchSize < 2: the first panicking sequence is named, the rest is still sketched
     std::string panic_text;
 };
@@ -43,14 +53,17 @@ int sketch_shard(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint3
                  SketchShard &sh)
 {
     PH_HIP(hipGetDevice(&sh.dev));
-    PH_HIP(sh.dSk.alloc(n * (size_t)s * 4));
     const uint64_t m_all = sh.i1 - sh.i0;
+    // own rows only (round-4 verdict: every device used to allocate all n rows even where it never reads the others')
+    sh.row0 = sh.i0;
+    PH_HIP(sh.dSk.alloc(std::max<uint64_t>(m_all, 1) * (size_t)s * 4));
+    (void)n;
     if (m_all == 0)
         return POLYHIP_OK;
     HostStreams &hs = host_streams();
     PH_HIP(hs.init());
     const uint64_t row = (uint64_t)s * 4;
-    uint32_t *d_rows = sh.dSk.as<uint32_t>() + sh.i0 * (uint64_t)s;
+    uint32_t *d_rows = sh.dSk.as<uint32_t>(); // = sk(s) + i0 * s
     // a row of a read with fewer than s windows keeps (part of) its prior state (mash.go:81-84): the caller's rows if it
     // passed any, zeros (= mash.New) otherwise
     bool need_prior = false;
@@ -98,8 +111,26 @@ int sketch_shard(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint3
 }
 
 // Round B: pull the other shards' rows from their devices, then this device's block of matrix rows
+// (two md::run rounds: every device first widens its array to all n rows, keeping its own -- only then may anybody pull)
+int widen_shard(SketchShard &sh, uint64_t n, uint32_t s)
+{
+    if (sh.row0 == 0 && sh.i0 == 0 && sh.i1 == n)
+        return POLYHIP_OK; // one shard holds everything already
+    HostStreams &hs = host_streams();
+    PH_HIP(hs.init());
+    DevBuf full;
+    PH_HIP(full.alloc(n * (size_t)s * 4));
+    if (sh.i1 > sh.i0)
+        PH_HIP(hipMemcpyAsync(full.as<uint32_t>() + sh.i0 * (uint64_t)s, sh.dSk.p, (sh.i1 - sh.i0) * (uint64_t)s * 4,
+                              hipMemcpyDeviceToDevice, hs.s[0]));
+    PH_HIP(hipStreamSynchronize(hs.s[0]));
+    std::swap(sh.dSk.p, full.p); // (`full` now frees the own-rows array)
+    sh.row0 = 0;
+    return POLYHIP_OK;
+}
+
 int join_shard(std::vector<SketchShard> &all, size_t me, uint64_t n, uint32_t s, uint64_t r0, uint64_t r1, uint16_t *counts,
-               double *dist)
+               double *dist, K2XferStats *stats)
 {
     SketchShard &sh = all[me];
     HostStreams &hs = host_streams();
@@ -108,27 +139,21 @@ int join_shard(std::vector<SketchShard> &all, size_t me, uint64_t n, uint32_t s,
         const SketchShard &o = all[q];
         if (q == me || o.i1 == o.i0)
             continue;
-        if (o.dev != sh.dev) {
-            int can = 0;
-            PH_HIP(hipDeviceCanAccessPeer(&can, sh.dev, o.dev));
-            if (can) {
-                const hipError_t e = hipDeviceEnablePeerAccess(o.dev, 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-                    PH_HIP(e);
-                (void)hipGetLastError(); // "already enabled" is sticky otherwise
-            } // without peer access the runtime stages the copy through the host: slower, still correct
-        }
-        const uint64_t a = o.i0 * (uint64_t)s;
-        PH_HIP(hipMemcpyPeerAsync(sh.dSk.as<uint32_t>() + a, sh.dev, o.dSk.as<uint32_t>() + a, o.dev, (o.i1 - o.i0) * (uint64_t)s * 4,
-                                  hs.s[0]));
+        int tr = 0;
+        if (int e = k2_enable_peer(sh.dev, o.dev, &tr))
+            return e;
+        const uint64_t a = o.i0 * (uint64_t)s, bytes = (o.i1 - o.i0) * (uint64_t)s * 4;
+        PH_HIP(hipMemcpyPeerAsync(sh.sk(s) + a, sh.dev, o.sk(s) + a, o.dev, bytes, hs.s[0]));
+        if (stats)
+            stats->count(tr, bytes);
     }
     if (r0 == r1 || !(counts || dist)) {
         PH_HIP(hipStreamSynchronize(hs.s[0]));
         return POLYHIP_OK;
     }
     // ordered behind the pulls on the thread's first stream
-    return k2_rows_to_host(sh.dSk.as<uint32_t>() + r0 * (uint64_t)s, r1 - r0, s, sh.dSk.as<uint32_t>(), n, s,
-                           counts ? counts + r0 * n : nullptr, dist ? dist + r0 * n : nullptr);
+    return k2_rows_to_host(sh.sk(s) + r0 * (uint64_t)s, r1 - r0, s, sh.sk(s), n, s, counts ? counts + r0 * n : nullptr,
+                           dist ? dist + r0 * n : nullptr);
 }
 
 } // namespace
@@ -141,12 +166,30 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs, const uint64_t *off
     if (n == 0)
         return POLYHIP_OK;
     PH_REQUIRE(seqs && offsets, "polyhip_mash_sketch_distance_matrix: null pointer");
-    PH_REQUIRE(s <= 65535, "polyhip_mash_sketch_distance_matrix: SketchSize %u > 65535 (the matrix holds 16-bit counts)", s);
+    // the matrix's limits apply where a matrix is asked for: with counts == dist == NULL the call only sketches, as
+    // polyhip_mash_sketch_batch does for any SketchSize (round-4 advice)
+    PH_REQUIRE(!(counts || dist) || s <= 65535,
+               "polyhip_mash_sketch_distance_matrix: SketchSize %u > 65535 (the matrix holds 16-bit counts)", s);
+    PH_REQUIRE(!(counts || dist) || n < (1ull << 31), "polyhip_mash_sketch_distance_matrix: %llu sketches, the matrix takes fewer than 2^31",
+               (unsigned long long)n);
+    g_last_info = polyhip_matrix_info{};
+    K2XferStats stats;
+    auto publish = [&](int rc) { // the transports and the path of this call, whatever way it ends
+        g_last_info.path = g_last_path;
+        g_last_info.peer_copies = stats.peer.load();
+        g_last_info.staged_copies = stats.staged.load();
+        g_last_info.local_copies = stats.local.load();
+        g_last_info.bytes_peer = stats.bytes_peer.load();
+        g_last_info.bytes_staged = stats.bytes_staged.load();
+        g_last_info.bytes_local = stats.bytes_local.load();
+        return rc;
+    };
     if (s == 0 && (counts || dist)) // Similarity indexes Sketches[-1] (mash.go:117) whatever Sketch did before
         return polyhip_mash_shared_counts_dev(nullptr, n, 0, nullptr, n, 0, nullptr, 0, nullptr, 0, nullptr);
     std::shared_ptr<md::Pool> P = md::pool();
     const size_t nsh = P ? md::size(*P) : 1;
     g_last_path = P ? 2 : 0;
+    g_last_info.devices = (int32_t)nsh;
     const uint64_t row = (uint64_t)s * 4;
     const std::vector<uint64_t> cut = md::split(n, nsh, [&](uint64_t i) { return offsets[i] - offsets[0] + i * row; });
     std::vector<SketchShard> sh(nsh);
@@ -158,15 +201,17 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs, const uint64_t *off
     auto round_b = [&](size_t q) {
         // matrix rows are cut evenly, whatever the reads' sizes were: every device holds every sketch by now
         const uint64_t r0 = (uint64_t)(((unsigned __int128)n * q) / nsh), r1 = (uint64_t)(((unsigned __int128)n * (q + 1)) / nsh);
-        const int rc = join_shard(sh, q, n, s, r0, r1, counts, dist);
+        const int rc = join_shard(sh, q, n, s, r0, r1, counts, dist, &stats);
         return rc;
     };
+    auto t0 = std::chrono::steady_clock::now();
     int rc = P ? md::run(*P, round_a) : round_a(0);
+    g_last_info.ms_sketch = ms_since(t0);
     if (rc != POLYHIP_OK)
-        return rc;
+        return publish(rc);
     for (size_t q = 0; q < nsh; ++q) // SketchSize 1: the reference panics in Sketch, before any distance is asked for
         if (sh[q].panic != POLYHIP_OK)
-            return set_error(sh[q].panic, "%s", sh[q].panic_text.c_str());
+            return publish(set_error(sh[q].panic, "%s", sh[q].panic_text.c_str()));
     // Round B without gathering the sketches (round 4; POLYHIP_K2_EXCHANGE=0: the gather, testing aid and the way back):
     // the devices build ONE index together -- level 1 on their own rows, items exchanged by value range, level 2 on 1/N of the
     // range, finished parts exchanged (k2_exchange_index, mash_distance.hip) -- and every device joins the rows it sketched.
@@ -177,31 +222,64 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs, const uint64_t *off
             xs[q].dev = sh[q].dev;
             xs[q].i0 = sh[q].i0;
             xs[q].i1 = sh[q].i1;
-            xs[q].sk = sh[q].dSk.as<uint32_t>();
+            xs[q].sk = sh[q].sk(s); // (virtual base: the exchange reads rows [i0, i1) only)
+            xs[q].stats = &stats;
             rows_blk = std::max(rows_blk, k2_rows_per_block(sh[q].i1 - sh[q].i0, n, counts != nullptr, dist != nullptr));
         }
         bool built = false;
+        t0 = std::chrono::steady_clock::now();
         rc = k2_exchange_index(*P, xs, n, s, rows_blk, &built);
+        g_last_info.ms_index = ms_since(t0);
         if (rc != POLYHIP_OK)
-            return rc;
-        if (built)
+            return publish(rc);
+        if (built) {
             g_last_path = 1;
-        if (built)
-            return md::run(*P, [&](size_t q) {
+            t0 = std::chrono::steady_clock::now();
+            rc = md::run(*P, [&](size_t q) {
                 const uint64_t i0 = sh[q].i0, m = sh[q].i1 - i0;
                 if (m == 0)
                     return (int)POLYHIP_OK;
-                const uint32_t *sk = sh[q].dSk.as<uint32_t>();
-                return k2_rows_to_host(sk + i0 * (uint64_t)s, m, s, sk, n, s, counts ? counts + i0 * n : nullptr,
-                                       dist ? dist + i0 * n : nullptr, xs[q].work.p, xs[q].work_bytes);
+                // Y = the array's virtual base: a device holds ITS rows only, and the join reads Y's raw sketches nowhere
+                // but in the merge (irregular sketches, overflow rows, "merge everything"), which k2_exchange_index ruled
+                // out before it reported the index as built.  That exclusion is re-checked on what the join DID:
+                const uint32_t *sk = sh[q].sk(s);
+                if (int e = k2_rows_to_host(sk + i0 * (uint64_t)s, m, s, sk, n, s, counts ? counts + i0 * n : nullptr,
+                                            dist ? dist + i0 * n : nullptr, xs[q].work.p, xs[q].work_bytes))
+                    return e;
+                uint32_t mode = 0, nirrx = 0, nirry = 0, novf = 0;
+                if (int e = polyhip_mash_shared_counts_mode_dev(xs[q].work.p, &mode, &nirrx, &nirry, &novf, nullptr))
+                    return e;
+                if (mode != 0 || nirrx || nirry || novf)
+                    return set_error(POLYHIP_ERR_HIP, "polyhip_mash_sketch_distance_matrix: the join behind the item exchange took the merge "
+                                     "(mode %u, irregular %u / %u, overflow rows %u), which reads sketches this device does not hold -- "
+                                     "a bug in k2_exchange_index's conditions; POLYHIP_K2_EXCHANGE=0 gathers the sketches instead",
+                                     mode, nirrx, nirry, novf);
+                return (int)POLYHIP_OK;
             });
+            g_last_info.ms_join = ms_since(t0);
+            return publish(rc);
+        }
         // (an irregular sketch, a join that is not the dense one, or an input the merge would take: gather after all)
     }
+    t0 = std::chrono::steady_clock::now();
+    if (P) { // every device widens its array to all n rows before anybody pulls
+        rc = md::run(*P, [&](size_t q) { return widen_shard(sh[q], n, s); });
+        if (rc != POLYHIP_OK)
+            return publish(rc);
+    }
     rc = P ? md::run(*P, round_b) : round_b(0);
+    g_last_info.ms_join = ms_since(t0);
     // the sketch arrays are freed by whoever drops `sh` (hipFree takes a pointer of any device)
-    return rc;
+    return publish(rc);
 }
 
 int polyhip_mash_sketch_distance_matrix_last_path(void) { return g_last_path; }
+
+int polyhip_mash_sketch_distance_matrix_last_info(polyhip_matrix_info *info)
+{
+    PH_REQUIRE(info, "polyhip_mash_sketch_distance_matrix_last_info: null pointer");
+    *info = g_last_info;
+    return POLYHIP_OK;
+}
 
 } // extern "C"

@@ -680,6 +680,7 @@ static int seqhash_batch_one(const uint8_t *seqs, const uint64_t *offsets, uint6
         PH_HIP(slot[q].dwork.alloc(wb));
     }
     std::vector<unsigned long long> hi(ch.count(), ~0ull); // per chunk: offset of its first byte >= 0x80
+    SyncOnExit wait0(hs.s[0]), wait1(hs.s[1]); // (downloads into `hi` and the caller's buffers may be in flight on any way out)
     auto download = [&](size_t c) -> hipError_t {
         Slot &S = slot[c & 1];
         const uint64_t i0 = ch.cut[c], m = ch.cut[c + 1] - i0;

@@ -157,6 +157,20 @@ def sketch_distance_matrix_last_path() -> int:
     return int(_lib.lib().polyhip_mash_sketch_distance_matrix_last_path())
 
 
+def sketch_distance_matrix_last_info() -> dict:
+    """polyhip_matrix_info of the calling thread's last sketch_distance_matrix_packed: path, devices, device-to-device copies
+    by transport (peer / staged through the host / local) with their bytes, wall ms of the sketch / index / join rounds"""
+    import ctypes as C
+
+    class Info(C.Structure):
+        _fields_ = [("path", C.c_int32), ("devices", C.c_int32), ("peer_copies", C.c_int32), ("staged_copies", C.c_int32),
+                    ("local_copies", C.c_int32), ("reserved", C.c_int32), ("bytes_peer", C.c_uint64), ("bytes_staged", C.c_uint64),
+                    ("bytes_local", C.c_uint64), ("ms_sketch", C.c_double), ("ms_index", C.c_double), ("ms_join", C.c_double)]
+    info = Info()
+    _lib.check(_lib.lib().polyhip_mash_sketch_distance_matrix_last_info(C.addressof(info)))
+    return {name: getattr(info, name) for name, _ in Info._fields_ if name != "reserved"}
+
+
 def SketchDistanceMatrix(seqs, k: int, s: int) -> np.ndarray:
     """Additive batch API (BASELINE configs[2]): dist[i][j] = Sketch(seqs[i]).Distance(Sketch(seqs[j]))."""
     buf, offs = _pack(seqs)

@@ -225,18 +225,27 @@ def test_reads_to_distance_matrix_by_item_exchange(ids, monkeypatch):
     buf, offs = _pack(reads)
     want_sk = orc.mash_sketch_batch(buf, offs, k, s)
     want_c, want_d = mash.distance_matrix_packed(want_sk, want_sk)
-    for mode in ({"POLYHIP_K2_STAGE": "1"}, {"POLYHIP_K2_STAGE": "0"}, {"POLYHIP_K2_SLICED": "1"}):  # the three level-1 scatters
+    for mode in ({"POLYHIP_K2_STAGE": "1"}, {"POLYHIP_K2_STAGE": "0"}):  # both level-1 scatters of the two-level build the exchange runs
         monkeypatch.delenv("POLYHIP_K2_STAGE", raising=False)
-        monkeypatch.delenv("POLYHIP_K2_SLICED", raising=False)
         for k_, v_ in mode.items():
             monkeypatch.setenv(k_, v_)
         with devices.devices(ids):
             monkeypatch.delenv("POLYHIP_K2_EXCHANGE", raising=False)
             sk, c, d = mash.sketch_distance_matrix_packed(buf, offs, k, s)
             assert mash.sketch_distance_matrix_last_path() == 1
+            # the call explains itself (round 5): an aliased list moves everything by LOCAL copies -- on distinct devices
+            # the same counts appear under peer (xGMI) or staged (through the host) -- and the rounds were timed
+            info = mash.sketch_distance_matrix_last_info()
+            assert info["path"] == 1 and info["devices"] == len(ids)
+            assert info["peer_copies"] == 0 and info["staged_copies"] == 0 and info["local_copies"] > 0 and info["bytes_local"] > 0
+            assert info["ms_sketch"] > 0 and info["ms_index"] > 0 and info["ms_join"] > 0
             monkeypatch.setenv("POLYHIP_K2_EXCHANGE", "0")
             sk2, c2, d2 = mash.sketch_distance_matrix_packed(buf, offs, k, s)
             assert mash.sketch_distance_matrix_last_path() == 2
+            info2 = mash.sketch_distance_matrix_last_info()
+            assert info2["path"] == 2 and info2["ms_index"] == 0 and info2["local_copies"] >= len(ids) - 1
+            # the gather moves every device the other devices' rows: (N - 1) x the sketch array, less the empty shards' nothing
+            assert info2["bytes_local"] == (len(ids) - 1) * len(reads) * s * 4
         monkeypatch.delenv("POLYHIP_K2_EXCHANGE", raising=False)
         assert (sk == want_sk).all() and (c == want_c).all() and (d == want_d).all()
         assert (sk2 == want_sk).all() and (c2 == want_c).all() and (d2 == want_d).all()
