@@ -72,6 +72,30 @@ struct StreamFree {
     }
 };
 
+// transform.complementTable (transform/transform.go:78-109) for UPPER-case letters; unmapped bytes -> 0x00.  (One copy for
+// primers.hip, seqhash.hip and least_rotation.hip's reverse-complement view.)
+__device__ __forceinline__ uint32_t dna_complement_upper(uint32_t up)
+{
+    switch (up) {
+    case 'A': return 'T';
+    case 'T': return 'A';
+    case 'C': return 'G';
+    case 'G': return 'C';
+    case 'B': return 'V';
+    case 'V': return 'B';
+    case 'D': return 'H';
+    case 'H': return 'D';
+    case 'K': return 'M';
+    case 'M': return 'K';
+    case 'R': return 'Y';
+    case 'Y': return 'R';
+    case 'N': return 'N';
+    case 'S': return 'S';
+    case 'W': return 'W';
+    default: return 0;
+    }
+}
+
 // Waits for a stream on EVERY way out of a scope that has asynchronous device-to-host copies into its own locals (or into
 // the caller's buffers) in flight: a failed HIP call further down would otherwise return while those copies are still
 // pending and turn into writes to freed host memory (round-4 advice).  On the normal path the scope has synchronised

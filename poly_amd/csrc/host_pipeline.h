@@ -320,6 +320,8 @@ struct K2XShard {
     uint64_t h_nirr = 0, h_est = 0;
     DevBuf segtab, segptr;
 };
+int k5_least_rotation_strands_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
+                                  uint64_t *d_rot_index, uint8_t *d_rotated, uint64_t *d_rot_rc, polyhip_stream_t stream);
 int k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t n, uint32_t s, uint64_t rows_blk, bool *built);
 
 } // namespace polyhip

@@ -89,6 +89,14 @@ template <class Ptr> __device__ __forceinline__ uint32_t word_at(Ptr s, uint64_t
     return ((uint32_t)s[p] << 24) | ((uint32_t)s[p + 1] << 16) | ((uint32_t)s[p + 2] << 8) | (uint32_t)s[p + 3];
 }
 
+// the reverse complement of g[0..n) as an indexable string (the global-memory search on a sequence LDS cannot hold)
+struct RcView {
+    const uint8_t *g;
+    uint64_t n;
+    const uint8_t *cmpT;
+    __device__ __forceinline__ uint32_t operator[](uint64_t p) const { return cmpT[g[n - 1 - p]]; }
+};
+
 // exact minimal rotation (smallest index) by the two-pointer algorithm, run by
 // ONE wave; cyc(p) reads the byte at cyclic position p < 2n
 template <class Ptr> __device__ uint64_t two_pointer_wave(Ptr s, uint64_t n)
@@ -137,13 +145,60 @@ __device__ __forceinline__ uint32_t word_lds(const uint32_t *__restrict__ L, uin
     return __builtin_bswap32(le);
 }
 
+// Reverse-complement view (round 5, seqhash.Hash of a double-stranded sequence, seqhash.go:180-193): the least rotation of
+// transform.ReverseComplement(s) is found on a copy staged in LDS in THAT order -- byte j of the staged string is the
+// complement of s[n - 1 - j] -- so the second strand is never written to memory (round 4 wrote it, 0.5 GB per 100k x 5 kb,
+// only to read it back here).  `cmpT`: the complement of every byte value (LDS).
+__device__ __forceinline__ uint32_t revcmp4(uint32_t w, const uint8_t *__restrict__ cmpT)
+{
+    return (uint32_t)cmpT[w >> 24] | ((uint32_t)cmpT[(w >> 16) & 0xFFu] << 8) | ((uint32_t)cmpT[(w >> 8) & 0xFFu] << 16) |
+           ((uint32_t)cmpT[w & 0xFFu] << 24);
+}
+// stage s[0..n) (rc: its reverse complement) + WRAP wrapped bytes into lds: 16 bytes per thread and step, read from the
+// sequence's own (unaligned) address, written to aligned LDS; the last n % 16 singly.  first / step: the thread's place.
+__device__ __forceinline__ void stage_sequence(uint8_t *__restrict__ lds, const uint8_t *__restrict__ g, uint32_t n32, bool rc,
+                                               const uint8_t *__restrict__ cmpT, uint32_t first, uint32_t step)
+{
+    const uint32_t n16 = n32 >> 4;
+    uint4 *L4 = reinterpret_cast<uint4 *>(lds);
+    if (!rc) {
+        for (uint32_t t = first; t < n16; t += step) {
+            uint4 v;
+            __builtin_memcpy(&v, g + 16u * t, 16);
+            L4[t] = v;
+        }
+        if (first < (n32 & 15u))
+            lds[16u * n16 + first] = g[16u * n16 + first];
+        if (first < WRAP) // s[0..] again behind s[n-1] (n may be tiny: cyclic)
+            lds[n32 + first] = g[n32 >= WRAP ? first : first % n32];
+    } else {
+        for (uint32_t t = first; t < n16; t += step) { // staged bytes [16 t, 16 t + 16) = complement of s[n-16t-16 .. n-16t) reversed
+            uint4 v, o;
+            __builtin_memcpy(&v, g + (n32 - 16u * t - 16u), 16);
+            o.x = revcmp4(v.w, cmpT);
+            o.y = revcmp4(v.z, cmpT);
+            o.z = revcmp4(v.y, cmpT);
+            o.w = revcmp4(v.x, cmpT);
+            L4[t] = o;
+        }
+        if (first < (n32 & 15u))
+            lds[16u * n16 + first] = cmpT[g[n32 - 1u - (16u * n16 + first)]];
+        if (first < WRAP) {
+            const uint32_t j = n32 >= WRAP ? first : first % n32;
+            lds[n32 + first] = cmpT[g[n32 - 1u - j]];
+        }
+    }
+}
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *__restrict__ seqs,
                                                                 const uint64_t *__restrict__ offs, uint64_t nseq,
                                                                 uint64_t lds_seq_bytes, uint64_t *__restrict__ rot,
-                                                                uint8_t *__restrict__ rotated, uint32_t chunk)
+                                                                uint8_t *__restrict__ rotated, uint32_t chunk, int rc)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint8_t cmpT[256];
+    cmpT[threadIdx.x] = (uint8_t)dna_complement_upper(threadIdx.x); // THREADS == 256; visible after the first barrier
     __shared__ uint32_t listA[LIST_CAP], listB[LIST_CAP];
     __shared__ uint32_t red[2][THREADS / 64];
     __shared__ uint32_t cnt, cntq;
@@ -186,19 +241,9 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         // ---- stage the sequence (+ WRAP wrapped bytes so a word or an output piece never wraps): 16 bytes per thread
         // and step, read from the sequence's own (unaligned) address, written to aligned LDS; the last n % 16 singly
         __syncthreads();
-        if (IN_LDS) {
-            const uint32_t n32 = (uint32_t)n, n16 = n32 >> 4;
-            uint4 *L4 = reinterpret_cast<uint4 *>(lds);
-            for (uint32_t t = tid; t < n16; t += THREADS) {
-                uint4 v;
-                __builtin_memcpy(&v, g + 16u * t, 16);
-                L4[t] = v;
-            }
-            if ((uint32_t)tid < (n32 & 15u))
-                lds[16u * n16 + tid] = g[16u * n16 + tid];
-            if (tid < (int)WRAP) // s[0..] again behind s[n-1] (n may be tiny: cyclic)
-                lds[n32 + tid] = g[n32 >= WRAP ? (uint32_t)tid : (uint32_t)tid % n32];
-        }
+        if (IN_LDS)
+            stage_sequence(lds, g, (uint32_t)n, rc != 0, cmpT, (uint32_t)tid, THREADS);
+        auto gbyte = [&](uint64_t p) -> uint32_t { return rc ? cmpT[g[n - 1 - p]] : g[p]; }; // byte p < n of the searched string
         if (tid == 0) {
             cnt = 0;
             cntq = 0;
@@ -207,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
         __syncthreads();
 
         auto byte_at = [&](uint64_t p) -> uint32_t { // cyclic position p < 2n
-            return IN_LDS ? lds[p >= n ? p - n : p] : g[p >= n ? p - n : p];
+            return IN_LDS ? lds[p >= n ? p - n : p] : gbyte(p >= n ? p - n : p);
         };
         // `ne`: the length the search runs on.  A sequence that is an exact repetition of a block of d bytes (a tandem
         // repeat that closes on itself) has its least rotation -- smallest index -- inside the first block, and it is
@@ -221,8 +266,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                     return word_lds(L, (uint32_t)p);
                 return word_at(lds, p); // n = 2, 3: the wrapped bytes cover it
             }
-            return ((uint32_t)g[p] << 24) | ((uint32_t)g[(p + 1) % n] << 16) | ((uint32_t)g[(p + 2) % n] << 8) |
-                   (uint32_t)g[(p + 3) % n];
+            return (gbyte(p) << 24) | (gbyte((p + 1) % n) << 16) | (gbyte((p + 2) % n) << 8) | gbyte((p + 3) % n);
         };
 
     search:
@@ -376,7 +420,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                 if (IN_LDS)
                     r = two_pointer_wave(lds, ne);
                 else
-                    r = two_pointer_wave(g, ne);
+                    r = rc ? two_pointer_wave(RcView{g, n, cmpT}, ne) : two_pointer_wave(g, ne);
                 if (tid == 0)
                     answer = r;
             }
@@ -400,7 +444,7 @@ __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *
                 }
                 uint64_t r;
                 if (wserial)
-                    r = IN_LDS ? two_pointer_wave(lds, ne) : two_pointer_wave(g, ne);
+                    r = IN_LDS ? two_pointer_wave(lds, ne) : rc ? two_pointer_wave(RcView{g, n, cmpT}, ne) : two_pointer_wave(g, ne);
                 else
                     r = wave_min(alive ? p : 0xFFFFFFFFu);
                 if (tid == 0)
@@ -478,9 +522,14 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) // set bits of ma
 __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t *__restrict__ seqs,
                                                                  const uint64_t *__restrict__ offs, uint64_t nseq,
                                                                  uint32_t lds_seq_bytes, uint64_t *__restrict__ rot,
-                                                                 uint8_t *__restrict__ rotated)
+                                                                 uint8_t *__restrict__ rotated, uint64_t *__restrict__ rot_rc)
 {
+    // rot_rc != nullptr: ALSO the least rotation of the reverse complement (a second staging of the same bytes, in that
+    // order, while they are still in this CU's caches; the strand itself is never written anywhere)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
+    __shared__ uint8_t cmpT[256];
+    cmpT[threadIdx.x] = (uint8_t)dna_complement_upper(threadIdx.x); // 256 threads
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint8_t *lds = lds_all + (size_t)wv * (lds_seq_bytes + 2u * WLIST * 2u);
     uint32_t *L = reinterpret_cast<uint32_t *>(lds);
@@ -491,33 +540,28 @@ __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t 
         const uint64_t n = offs[q + 1] - o0;
         const uint8_t *g = seqs + o0;
         if (n <= 1) {
-            if (lane == 0)
+            if (lane == 0) {
                 rot[q] = 0;
+                if (rot_rc)
+                    rot_rc[q] = 0;
+            }
             if (rotated && n == 1 && lane == 0)
                 rotated[o0] = g[0];
             continue;
         }
         if (n + WRAP > lds_seq_bytes) {
-            if (lane == 0)
+            if (lane == 0) {
                 rot[q] = MARK;
+                if (rot_rc)
+                    rot_rc[q] = MARK;
+            }
             continue;
         }
         const uint32_t n32 = (uint32_t)n;
+        for (int strand = 0; strand < (rot_rc ? 2 : 1); ++strand) {
         // ---- stage (+ WRAP wrapped bytes), 16 bytes per lane and step
         wave_sync();
-        {
-            const uint32_t n16 = n32 >> 4;
-            uint4 *L4 = reinterpret_cast<uint4 *>(lds);
-            for (uint32_t t = lane; t < n16; t += 64) {
-                uint4 v;
-                __builtin_memcpy(&v, g + 16u * t, 16);
-                L4[t] = v;
-            }
-            if (lane < (n32 & 15u))
-                lds[16u * n16 + lane] = g[16u * n16 + lane];
-            if (lane < WRAP)
-                lds[n32 + lane] = g[n32 >= WRAP ? lane : lane % n32];
-        }
+        stage_sequence(lds, g, n32, strand != 0, cmpT, lane, 64u);
         wave_sync();
 
         uint32_t ne = n32; // the length the search runs on (an exact repetition restarts on its first block)
@@ -680,8 +724,8 @@ __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t 
                 r = two_pointer_wave(lds, (uint64_t)ne);
         }
         if (lane == 0)
-            rot[q] = r;
-        if (rotated) { // RotateSequence: (s + s)[r : r + n], seqhash.go:131-137
+            (strand ? rot_rc : rot)[q] = r;
+        if (rotated && strand == 0) { // RotateSequence: (s + s)[r : r + n], seqhash.go:131-137
             uint8_t *out = rotated + o0;
             const uint32_t r32 = (uint32_t)r;
             if (n32 >= 32) {
@@ -709,6 +753,7 @@ __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t 
                 out[lane] = (uint8_t)byte_at(lane + r32);
             }
         }
+        } // strand
     }
 }
 
@@ -719,8 +764,13 @@ using namespace polyhip;
 
 extern "C" {
 
-int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
-                                     uint64_t *d_rot_index, uint8_t *d_rotated, polyhip_stream_t stream)
+} // extern "C"
+
+// d_rot_rc != nullptr: also the least rotation of every sequence's reverse complement (upper-case letters, the complement
+// table of transform.go:78-109) -- what seqhash.Hash needs for a circular double-stranded sequence (seqhash.go:180-193) --
+// from ONE staging of the bytes per kernel, the second strand never written to memory
+int polyhip::k5_least_rotation_strands_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
+                                           uint64_t *d_rot_index, uint8_t *d_rotated, uint64_t *d_rot_rc, polyhip_stream_t stream)
 {
     if (n == 0)
         return POLYHIP_OK;
@@ -739,7 +789,7 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k5::least_rotation_wave_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(k5::least_rotation_wave_kernel, dim3(blocks), dim3(256), smem, st, d_seqs, d_offsets, n, lds_w,
-                           d_rot_index, d_rotated);
+                           d_rot_index, d_rotated, d_rot_rc);
         PH_HIP(hipGetLastError());
     }
     if (max_len + k5::WRAP <= lds_w)
@@ -756,15 +806,29 @@ int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_of
     PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)lds_seq));
     hipLaunchKernelGGL(kl, dim3(blocks), dim3(k5::THREADS), lds_seq, st, d_seqs, d_offsets, n, lds_seq, d_rot_index,
-                       d_rotated, chunk);
+                       d_rotated, chunk, 0);
+    if (d_rot_rc) // the marked sequences' other strand: the same kernel on the reverse-complement view
+        hipLaunchKernelGGL(kl, dim3(blocks), dim3(k5::THREADS), lds_seq, st, d_seqs, d_offsets, n, lds_seq, d_rot_rc,
+                           (uint8_t *)nullptr, chunk, 1);
     PH_HIP(hipGetLastError());
     // 3. the same search reading global memory for what LDS cannot hold
     if (max_len + k5::WRAP > lds_seq) {
         hipLaunchKernelGGL((k5::least_rotation_kernel<false>), dim3(blocks), dim3(k5::THREADS), 0, st, d_seqs, d_offsets,
-                           n, lds_seq, d_rot_index, d_rotated, chunk);
+                           n, lds_seq, d_rot_index, d_rotated, chunk, 0);
+        if (d_rot_rc)
+            hipLaunchKernelGGL((k5::least_rotation_kernel<false>), dim3(blocks), dim3(k5::THREADS), 0, st, d_seqs, d_offsets,
+                               n, lds_seq, d_rot_rc, (uint8_t *)nullptr, chunk, 1);
         PH_HIP(hipGetLastError());
     }
     return POLYHIP_OK;
+}
+
+extern "C" {
+
+int polyhip_least_rotation_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
+                                     uint64_t *d_rot_index, uint8_t *d_rotated, polyhip_stream_t stream)
+{
+    return k5_least_rotation_strands_dev(d_seqs, d_offsets, n, max_len, d_rot_index, d_rotated, nullptr, stream);
 }
 
 // the single-device body; `rotated` is indexed by the caller's offsets (a shard passes the whole batch's buffers)

@@ -106,29 +106,8 @@ __device__ __forceinline__ uint32_t nt_code(uint32_t up)
     return up == 'A' ? 0u : up == 'C' ? 1u : up == 'G' ? 2u : up == 'T' ? 3u : 4u;
 }
 
-// transform.complementTable restricted to upper case (the input has been
-// upper-cased, primers.go:71): IUPAC pairs, everything else -> 0x00
-__device__ __forceinline__ uint32_t complement_upper(uint32_t up)
-{
-    switch (up) {
-    case 'A': return 'T';
-    case 'T': return 'A';
-    case 'C': return 'G';
-    case 'G': return 'C';
-    case 'B': return 'V';
-    case 'V': return 'B';
-    case 'D': return 'H';
-    case 'H': return 'D';
-    case 'K': return 'M';
-    case 'M': return 'K';
-    case 'R': return 'Y';
-    case 'Y': return 'R';
-    case 'N': return 'N';
-    case 'S': return 'S';
-    case 'W': return 'W';
-    default: return 0;
-    }
-}
+// transform.complementTable restricted to upper case (the input has been upper-cased, primers.go:71): IUPAC pairs,
+// everything else -> 0x00 -- dna_complement_upper, common.h
 
 __device__ __forceinline__ double melting(double dH, double dS, double rlog)
 {
@@ -197,7 +176,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_K4_W
         const uint64_t g = b0 + t;
         const uint32_t u = g < len ? ascii_upper(seq[g]) : 0xFFu;
         up[t] = (uint8_t)u;
-        cp[t] = (uint8_t)complement_upper(u);
+        cp[t] = (uint8_t)dna_complement_upper(u);
         cd[t] = (uint8_t)nt_code(u);
     }
     __syncthreads();
@@ -381,7 +360,7 @@ __global__ __launch_bounds__(THREADS) void batch_kernel(const uint8_t *__restric
     }
     bool pal = true;
     for (uint64_t t = 0; t < L && pal; ++t)
-        pal = ascii_upper(s[t]) == complement_upper(ascii_upper(s[L - 1 - t]));
+        pal = ascii_upper(s[t]) == dna_complement_upper(ascii_upper(s[L - 1 - t]));
     double h = 0.0, e = 0.0;
     h += 0.2;
     e += -5.7;

@@ -91,11 +91,60 @@ __device__ void compress(const uint32_t cv[8], const uint32_t block[16], uint64_
     out[7] = s7 ^ s15;
 }
 
-// chaining value of chunk `idx` of the string data[rot..len) + data[0..rot) -- the rotation `rot` of data[0..len), never
+// A candidate of seqhash.go:180-193 as it is READ (round 5): the normalised strand itself, or -- rc -- its reverse complement,
+// byte p of which is cmpT[data[len - 1 - p]].  Round 4 wrote the second strand out (0.5 GB per 100k x 5 kb, a kernel's worth
+// of traffic) only for K5, the comparison and BLAKE3 to read it back; now all three read it through this view.
+struct Strand {
+    const uint8_t *data; // the normalised sequence
+    uint64_t len;
+    bool rc;
+    const uint8_t *cmpT; // complement of every byte value (LDS), used when rc
+    __device__ __forceinline__ uint32_t byte(uint64_t p) const { return rc ? cmpT[data[len - 1 - p]] : data[p]; }
+};
+
+// 64 bytes from an arbitrary address: aligned dwords funnelled to the data's own alignment (the 17th dword is only touched
+// when it holds bytes of the block)
+__device__ __forceinline__ void load16(const uint8_t *p, uint32_t (&o)[16])
+{
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = (uint32_t)(addr & 3u);
+    const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+    uint32_t d[17];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        d[i] = gd[i];
+    d[16] = sh ? gd[16] : 0u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+}
+
+// bytes [p, p + 64) of the strand as 16 little-endian words; p may be negative or run past the end by up to 63 bytes (the
+// bytes there are the neighbouring sequence's or the workspace's padding: the caller masks them)
+__device__ __forceinline__ void strand_block(const Strand &S, int64_t p, uint32_t (&w)[16])
+{
+    if (!S.rc) {
+        load16(S.data + p, w);
+    } else {
+        // strand bytes p .. p+63 are the complements of data[len-1-p], data[len-2-p], ...: the 64 bytes that END at
+        // data[len-1-p], reversed
+        uint32_t d[16];
+        load16(S.data + ((int64_t)S.len - 64 - p), d);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const uint32_t x = d[15 - i];
+            w[i] = (uint32_t)S.cmpT[x >> 24] | ((uint32_t)S.cmpT[(x >> 16) & 0xFFu] << 8) | ((uint32_t)S.cmpT[(x >> 8) & 0xFFu] << 16) |
+                   ((uint32_t)S.cmpT[x & 0xFFu] << 24);
+        }
+    }
+}
+
+// chaining value of chunk `idx` of the string S[rot..len) + S[0..rot) -- the rotation `rot` of the strand, never
 // materialised (round 3 wrote both strands' rotated copies out, 1 GB per 100k x 5 kb, only to read them back here) --;
 // root = this chunk is the whole input
-__device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_t rot, uint64_t idx, bool root, uint32_t cv[8])
+__device__ void chunk_cv(const Strand &S, uint64_t rot, uint64_t idx, bool root, uint32_t cv[8])
 {
+    const uint64_t len = S.len;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         cv[i] = c_iv[i];
@@ -105,33 +154,18 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
     for (uint32_t b = 0; b < nblocks; ++b) {
         const uint64_t off = base + (uint64_t)b * 64;
         const uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
-        const uint64_t src = off + rot >= len ? off + rot - len : off + rot; // where the block starts in data[] (rot < len, off < len)
+        const uint64_t src = off + rot >= len ? off + rot - len : off + rot; // where the block starts in the strand (rot < len, off < len)
         uint32_t w[16];
-        // 64 bytes from an arbitrary address: aligned dwords funnelled to the data's own alignment (the 17th dword is only
-        // touched when it holds bytes of the block)
-        auto load16 = [](const uint8_t *p, uint32_t (&o)[16]) {
-            const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
-            const uint32_t sh = (uint32_t)(addr & 3u);
-            const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
-            uint32_t d[17];
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                d[i] = gd[i];
-            d[16] = sh ? gd[16] : 0u;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-        };
         if (blen == 64) {
-            load16(data + src, w); // (past the end of data[] these are the next sequence's bytes or the workspace's padding)
+            strand_block(S, (int64_t)src, w); // (past the end of the strand these are foreign bytes: masked below)
             if (src + 64 > len) {
-                // the one block per rotated sequence that runs over the end of data[]: its first m bytes are the string's
+                // the one block per rotated sequence that runs over the end of the strand: its first m bytes are the string's
                 // last ones, the rest its first ones -- a second funnelled load, placed so that byte i of the block is byte
                 // i of both, and a select per dword (a byte-by-byte path here stalled the whole wave behind the one lane
                 // in sixty-four that needed it: 0.20 -> 0.45 ms for the chunk kernel)
                 const uint32_t m = (uint32_t)(len - src); // 1 .. 63
                 uint32_t v[16];
-                load16(data - m, v); // >= 63 bytes in front of data[]: the previous sequence or the workspace's front padding
+                strand_block(S, -(int64_t)m, v); // >= 63 bytes in front of / behind the sequence: a neighbour or the padding
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     const uint32_t lo = 4u * (uint32_t)i;
@@ -151,7 +185,7 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t p = 4 * i + j;
                     if (p < blen)
-                        x |= (uint32_t)data[src + p >= len ? src + p - len : src + p] << (8 * j); // the string's last, short block
+                        x |= S.byte(src + p >= len ? src + p - len : src + p) << (8 * j); // the string's last, short block
                 }
                 w[i] = x;
             }
@@ -173,29 +207,6 @@ __device__ void chunk_cv(const uint8_t *__restrict__ data, uint64_t len, uint64_
 }
 
 __device__ __forceinline__ uint32_t ascii_upper(uint32_t b) { return (b - 'a' < 26u) ? b - 32u : b; }
-
-// transform.complementTable (transform.go:78-109), upper case rows; unmapped bytes -> 0x00
-__device__ __forceinline__ uint32_t complement_upper(uint32_t up)
-{
-    switch (up) {
-    case 'A': return 'T';
-    case 'T': return 'A';
-    case 'C': return 'G';
-    case 'G': return 'C';
-    case 'B': return 'V';
-    case 'V': return 'B';
-    case 'D': return 'H';
-    case 'H': return 'D';
-    case 'K': return 'M';
-    case 'M': return 'K';
-    case 'R': return 'Y';
-    case 'Y': return 'R';
-    case 'N': return 'N';
-    case 'S': return 'S';
-    case 'W': return 'W';
-    default: return 0;
-    }
-}
 
 __device__ __forceinline__ bool in_set(uint32_t c, const char *set)
 {
@@ -222,20 +233,19 @@ __device__ __forceinline__ uint32_t load4(const uint8_t *p)
 // first and behind the last aligned dword singly.
 __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restrict__ seqs,
                                                          const uint64_t *__restrict__ offs, uint64_t n, int seq_type,
-                                                         int want_rc, uint8_t *__restrict__ norm,
-                                                         uint8_t *__restrict__ rc, uint32_t *__restrict__ err,
+                                                         uint8_t *__restrict__ norm, uint32_t *__restrict__ err,
                                                          unsigned long long *__restrict__ first_non_ascii)
 {
+    // (the reverse complement is not written any more: K5, the comparison and BLAKE3 read it through `Strand`)
     __shared__ unsigned long long first_bad; // (position << 8) | letter
     __shared__ unsigned long long first_hi;  // position of the sequence's first byte >= 0x80 (the host flavour refuses those)
-    __shared__ uint8_t upL[256], cmpL[256], okL[256];
+    __shared__ uint8_t upL[256], okL[256];
     {
         const uint32_t b = threadIdx.x; // THREADS == 256
         uint32_t c = ascii_upper(b);
         if (seq_type == 1 && c == 'U') // seqhash.go:146-148
             c = 'T';
         upL[b] = (uint8_t)c;
-        cmpL[b] = (uint8_t)complement_upper(c); // transform.go:15-23, of the normalised letter
         okL[b] = seq_type == 2 ? in_set(c, "ACDEFGHIKLMNPQRSTVWYUO*BXZ") : in_set(c, "ATUGCYRSWKMBDHVNZ");
     }
     for (uint64_t q = blockIdx.x; q < n; q += gridDim.x) {
@@ -252,13 +262,11 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
             if (b & 0x80u)
                 atomicMin(&first_hi, (unsigned long long)t);
         };
-        auto one = [&](uint64_t t) { // byte t of the sequence -> norm[t], rc[len-1-t]
+        auto one = [&](uint64_t t) { // byte t of the sequence -> norm[t]
             const uint32_t b = src[t], c = upL[b];
             if (!okL[b])
                 flag(t, b);
             norm[o0 + t] = (uint8_t)c;
-            if (want_rc)
-                rc[o0 + (len - 1 - t)] = cmpL[b];
         };
         if (len < 16) {
             for (uint64_t t = threadIdx.x; t < len; t += THREADS)
@@ -291,23 +299,6 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
                     od[d] = o;
                 }
             }
-            // reverse complement: output byte u is the complement of input byte len-1-u
-            if (want_rc) {
-                uint8_t *dst = rc + o0;
-                const uint64_t head = (4 - (reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u;
-                const uint64_t nd = (len - head) >> 2, tail0 = head + 4 * nd;
-                if (threadIdx.x < head || (threadIdx.x >= 4 && threadIdx.x - 4 < len - tail0)) {
-                    const uint64_t u = threadIdx.x < 4 ? threadIdx.x : tail0 + (threadIdx.x - 4);
-                    dst[u] = cmpL[src[len - 1 - u]];
-                }
-                uint32_t *od = reinterpret_cast<uint32_t *>(dst + head);
-                for (uint64_t d = threadIdx.x; d < nd; d += THREADS) {
-                    const uint64_t u = head + 4 * d;           // output bytes u .. u+3
-                    const uint32_t w = load4(src + (len - 4 - u)); // input bytes len-4-u .. len-1-u, to be reversed
-                    od[d] = (uint32_t)cmpL[w >> 24] | ((uint32_t)cmpL[(w >> 16) & 0xFFu] << 8) |
-                            ((uint32_t)cmpL[(w >> 8) & 0xFFu] << 16) | ((uint32_t)cmpL[w & 0xFFu] << 24);
-                }
-            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -318,14 +309,16 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
     }
 }
 
-// sort.Strings(...)[0] (seqhash.go:180-193): sel[q] = 1 when the second candidate is the bytewise smaller one.
-// One wave per sequence, 64 bytes per step, out at the first difference.
-__global__ __launch_bounds__(THREADS) void select_kernel(const uint8_t *__restrict__ cand0,
-                                                        const uint8_t *__restrict__ cand1,
-                                                        const uint64_t *__restrict__ offs, uint64_t n,
+// sort.Strings(...)[0] (seqhash.go:180-193): sel[q] = 1 when the second candidate -- the (rotated) reverse complement, read
+// through the complement table -- is the bytewise smaller one.  One wave per sequence, 64 bytes per step, out at the first
+// difference.
+__global__ __launch_bounds__(THREADS) void select_kernel(const uint8_t *__restrict__ norm, const uint64_t *__restrict__ offs, uint64_t n,
                                                         const uint64_t *__restrict__ rot0, const uint64_t *__restrict__ rot1,
                                                         uint32_t *__restrict__ sel)
 {
+    __shared__ uint8_t cmpT[256];
+    cmpT[threadIdx.x] = (uint8_t)dna_complement_upper(threadIdx.x); // THREADS == 256
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint64_t nw = (uint64_t)gridDim.x * (THREADS / 64);
     for (uint64_t q = (uint64_t)blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6); q < n; q += nw) {
@@ -335,7 +328,7 @@ __global__ __launch_bounds__(THREADS) void select_kernel(const uint8_t *__restri
         for (uint64_t t0 = 0; t0 < len; t0 += 64) {
             const uint64_t t = t0 + lane;
             const uint64_t ta = t + r0 >= len ? t + r0 - len : t + r0, tb = t + r1 >= len ? t + r1 - len : t + r1;
-            const uint32_t a = t < len ? cand0[o0 + ta] : 0u, b = t < len ? cand1[o0 + tb] : 0u;
+            const uint32_t a = t < len ? norm[o0 + ta] : 0u, b = t < len ? cmpT[norm[o0 + (len - 1 - tb)]] : 0u;
             const uint64_t ne = __ballot(a != b);
             if (ne) {
                 const int f = __builtin_ctzll(ne);
@@ -357,13 +350,15 @@ __device__ __forceinline__ uint64_t cv_base(uint64_t bytes_before, uint64_t q) {
 // chaining values of every chunk of every multi-chunk sequence, ONE THREAD PER CHUNK over the whole batch
 // (a chunk's 16 blocks chain, so the chunk is the unit of parallelism): slot g belongs to the sequence q
 // with cv_base(q) <= g < cv_base(q + 1) (binary search), its value goes to level A of that sequence's tree.
-__global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restrict__ cand0,
-                                                       const uint8_t *__restrict__ cand1,
+__global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restrict__ norm, int two_strands,
                                                        const uint64_t *__restrict__ offs, uint64_t n, uint64_t max_chunks,
                                                        const uint64_t *__restrict__ rot0, const uint64_t *__restrict__ rot1,
                                                        const uint32_t *__restrict__ sel, const uint32_t *__restrict__ err,
                                                        uint32_t *__restrict__ cvbuf)
 {
+    __shared__ uint8_t cmpT[256];
+    cmpT[threadIdx.x] = (uint8_t)dna_complement_upper(threadIdx.x); // THREADS == 256
+    __syncthreads();
     const uint64_t g = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (g >= max_chunks)
         return;
@@ -382,11 +377,11 @@ __global__ __launch_bounds__(THREADS) void chunk_kernel(const uint8_t *__restric
     const uint64_t c = g - qbase;
     if (c >= nchunks || nchunks == 1 || err[q] != 0u)
         return; // behind the batch's last chunk; single-chunk sequences are the root compression's business
-    const bool second = cand1 && sel[q];
-    const uint8_t *data = (second ? cand1 : cand0) + o0;
+    const bool second = two_strands && sel[q];
+    const Strand S{norm + o0, len, second, cmpT};
     const uint64_t rot = second ? (rot1 ? rot1[q] : 0) : (rot0 ? rot0[q] : 0);
     uint32_t cv[8];
-    chunk_cv(data, len, rot, c, false, cv);
+    chunk_cv(S, rot, c, false, cv);
     uint32_t *A = cvbuf + qbase * 16;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -419,13 +414,16 @@ __device__ __forceinline__ void format_hash(const uint32_t (&root)[8], uint32_t 
 // busy and it costs a twentieth of that.  Level-by-level pairing with the odd value promoted (= BLAKE3's left-full tree),
 // ping-pong between the two halves of the sequence's slot range.
 constexpr uint64_t SMALL_CHUNKS = 64;
-__global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__restrict__ cand0, const uint8_t *__restrict__ cand1,
+__global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__restrict__ norm, int two_strands,
                                                             const uint64_t *__restrict__ offs, uint64_t n,
                                                             const uint64_t *__restrict__ rot0, const uint64_t *__restrict__ rot1,
                                                             uint32_t *__restrict__ cvbuf, const uint32_t *__restrict__ sel,
                                                             const uint32_t *__restrict__ err, uint32_t prefix_letters,
                                                             char *__restrict__ out)
 {
+    __shared__ uint8_t cmpT[256];
+    cmpT[threadIdx.x] = (uint8_t)dna_complement_upper(threadIdx.x); // THREADS == 256
+    __syncthreads();
     const uint64_t q = (uint64_t)blockIdx.x * THREADS + threadIdx.x;
     if (q >= n)
         return;
@@ -440,9 +438,9 @@ __global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__re
         return; // hash_kernel's
     uint32_t root[8];
     if (nchunks == 1) {
-        const bool second = cand1 && sel[q];
-        const uint8_t *data = (second ? cand1 : cand0) + o0;
-        chunk_cv(data, len, len ? (second ? (rot1 ? rot1[q] : 0) : (rot0 ? rot0[q] : 0)) : 0, 0, true, root);
+        const bool second = two_strands && sel[q];
+        const Strand S{norm + o0, len, second, cmpT};
+        chunk_cv(S, len ? (second ? (rot1 ? rot1[q] : 0) : (rot0 ? rot0[q] : 0)) : 0, 0, true, root);
     } else {
         uint32_t *A = cvbuf + cv_base(o0 - offs[0], q) * 16, *B = A + nchunks * 8; // level A was filled by chunk_kernel
         uint64_t m = nchunks;
@@ -481,9 +479,7 @@ __global__ __launch_bounds__(THREADS) void hash_small_kernel(const uint8_t *__re
 }
 
 // the same for sequences of MORE than SMALL_CHUNKS chunks: a workgroup per sequence, a level's pairs side by side
-__global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint8_t *__restrict__ cand0,
-                                                       const uint8_t *__restrict__ cand1,
-                                                       const uint64_t *__restrict__ offs, uint64_t n,
+__global__ __launch_bounds__(BTHREADS) void hash_kernel(const uint64_t *__restrict__ offs, uint64_t n,
                                                        uint32_t *__restrict__ cvbuf, const uint32_t *__restrict__ sel,
                                                        const uint32_t *__restrict__ err, uint32_t prefix_letters,
                                                        char *__restrict__ out)
@@ -555,7 +551,8 @@ static Layout layout(uint64_t n, uint64_t total_bytes, int circular, int ds)
     Layout L;
     size_t o = 256; // front padding: a block that wraps around a rotated sequence loads up to 63 bytes in front of it
     L.off_norm = o; o += al(total_bytes + 16);
-    L.off_rc = o; o += ds ? al(total_bytes + 16) : 0;
+    L.off_rc = o; // (round 5: the reverse complement is read through the complement table, never written)
+    (void)ds;
     L.off_rot0 = o; // (the rotated copies of round 3 are gone: a rotation is an index, applied where the bytes are read)
     L.off_rot1 = o;
     L.off_rotidx = o; o += circular ? al(2 * n * 8) : 0; // least-rotation index of the strand and of its reverse complement
@@ -596,7 +593,7 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     PH_REQUIRE(work_bytes >= L.total, "polyhip_seqhash_batch: workspace too small (%zu < %zu)", work_bytes, L.total);
     hipStream_t st = as_stream(stream);
     uint8_t *w = static_cast<uint8_t *>(d_work);
-    uint8_t *norm = w + L.off_norm, *rc = double_stranded ? w + L.off_rc : nullptr;
+    uint8_t *norm = w + L.off_norm;
     uint64_t *rotidx = reinterpret_cast<uint64_t *>(w + L.off_rotidx);
     const uint64_t *r0 = nullptr, *r1 = nullptr;
     uint32_t *cvbuf = reinterpret_cast<uint32_t *>(w + L.off_cv);
@@ -607,38 +604,35 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     // would treat as UTF-8; polyhip_seqhash_batch reads it back and refuses the call, a device-pointer caller may)
     unsigned long long *non_ascii = reinterpret_cast<unsigned long long *>(w);
     PH_HIP(hipMemsetAsync(non_ascii, 0xFF, 8, st));
-    hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type,
-                       double_stranded ? 1 : 0, norm, rc, d_err, non_ascii);
+    hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, d_err,
+                       non_ascii);
     PH_HIP(hipGetLastError());
-    const uint8_t *c0 = norm, *c1 = rc;
-    if (circular) { // the index only: the rotated strings are never written (select / chunk / hash read through the index)
-        int r = polyhip_least_rotation_batch_dev(norm, d_offsets, n, max_len, rotidx, nullptr, stream);
+    if (circular) { // the indexes only: neither the rotated strings nor the second strand are ever written -- ONE K5 pass
+                    // stages every sequence once and searches it in both reading directions
+        const int r = k5_least_rotation_strands_dev(norm, d_offsets, n, max_len, rotidx, nullptr, double_stranded ? rotidx + n : nullptr,
+                                                    stream);
         if (r != POLYHIP_OK)
             return r;
         r0 = rotidx;
-        if (double_stranded) {
-            r = polyhip_least_rotation_batch_dev(rc, d_offsets, n, max_len, rotidx + n, nullptr, stream);
-            if (r != POLYHIP_OK)
-                return r;
+        if (double_stranded)
             r1 = rotidx + n;
-        }
     }
     const uint32_t letters = (uint32_t)(seq_type == 0 ? 'D' : seq_type == 1 ? 'R' : 'P') |
                              ((uint32_t)(circular ? 'C' : 'L') << 8) | ((uint32_t)(double_stranded ? 'D' : 'S') << 16);
-    if (c1) {
+    const int two = double_stranded ? 1 : 0;
+    if (two) {
         const unsigned sblocks = (unsigned)std::min<uint64_t>((n + 3) / 4, 256ull * 32ull);
-        hipLaunchKernelGGL(s2::select_kernel, dim3(sblocks), dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, r0, r1, sel);
+        hipLaunchKernelGGL(s2::select_kernel, dim3(sblocks), dim3(s2::THREADS), 0, st, norm, d_offsets, n, r0, r1, sel);
     }
     {
         const uint64_t max_chunks = total_bytes / s2::CHUNK + n + 1; // >= the batch's chunk count
         hipLaunchKernelGGL(s2::chunk_kernel, dim3((unsigned)((max_chunks + s2::THREADS - 1) / s2::THREADS)),
-                           dim3(s2::THREADS), 0, st, c0, c1, d_offsets, n, max_chunks, r0, r1, sel, d_err, cvbuf);
+                           dim3(s2::THREADS), 0, st, norm, two, d_offsets, n, max_chunks, r0, r1, sel, d_err, cvbuf);
     }
-    hipLaunchKernelGGL(s2::hash_small_kernel, dim3((unsigned)((n + s2::THREADS - 1) / s2::THREADS)), dim3(s2::THREADS), 0, st, c0, c1,
+    hipLaunchKernelGGL(s2::hash_small_kernel, dim3((unsigned)((n + s2::THREADS - 1) / s2::THREADS)), dim3(s2::THREADS), 0, st, norm, two,
                        d_offsets, n, r0, r1, cvbuf, sel, d_err, letters, d_out);
     if (max_len > s2::SMALL_CHUNKS * s2::CHUNK) // some sequence has more chunks than one thread should merge
-        hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, c0, c1, d_offsets, n, cvbuf, sel, d_err,
-                           letters, d_out);
+        hipLaunchKernelGGL(s2::hash_kernel, dim3(blocks), dim3(s2::BTHREADS), 0, st, d_offsets, n, cvbuf, sel, d_err, letters, d_out);
     PH_HIP(hipGetLastError());
     return POLYHIP_OK;
 }
