@@ -243,6 +243,7 @@ def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
     dist = torch.empty((nrows, N), dtype=torch.float64, device=dev)
     ms_d = _time(lambda: mash.distance_from_counts_dev(counts, s, s, dist), 3)
     mode = mash.shared_counts_mode(work)
+    index_info = mash.index_build_info(work)  # which index build ran (1 = the sliced build) and its geometry
     nonzero = int((counts != 0).sum())
     pairs = nrows * N
     # 8 x 8 cells for bench.py's oracle comparison: 8 rows of the block, each against 4 columns of its own family (hundreds
@@ -264,10 +265,11 @@ def distance(dev, nfam: int = 1000, copies: int = 100, rows_div: int = 8):
            "pairs_per_s_counts_plus_fp64_distance": pairs / (ms + ms_d) * 1e3, "distance_ms": ms_d,
            "algorithmic_GBs_fp64_out": pairs * 8 / (ms + ms_d) * 1e3 / 1e9,
            # 2 B of u16 count per ordered pair is the algorithmic traffic of the counts call
-           "roofline": {"bound": "hbm", "achieved": pairs * 2 / ms * 1e3 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": pairs * 2 / ms * 1e3 / 1e9 / HBM_PEAK_GBS,
-                        "frac_join_only": pairs * 2 / ms_join * 1e3 / 1e9 / HBM_PEAK_GBS,
-                        "kernel": "polyhip::k2::rowjoin_dense_kernel<10> (+ the index build in counts_ms)"},
+           "roofline": dict(_hbm_roofline("mash_distance", pairs * 2, ms,
+                                          "polyhip::k2::rowjoin_dense_kernel<10, true, true> + the index build in counts_ms "
+                                          "(check4 / scatter4 / fine4: the sliced build on 4-byte intermediate items)"),
+                            frac_join_only=pairs * 2 / ms_join * 1e3 / 1e9 / HBM_PEAK_GBS),
+           "index_build": index_info,
            "join_mode": mode[0], "nonzero_pairs": nonzero, "_spot": spot}
     # the path's collective through the C ABI on a 1-rank communicator (libpolyhip's own RCCL calls; at N ranks
     # bench.py --gpus N times the real exchange) and the index built as 8 parts, as 8 ranks would

@@ -12,7 +12,7 @@ run() { # tag, rocprof args..., -- cmd
   if [ -n "$f" ]; then ( cd $ROOT && python scripts/rocpd_summary.py $f "$tag" > gpurun_out/$tag.md 2>&1 ); else echo "no db for $tag"; tail -5 $out/run.log; fi
   rm -rf $out
 }
-SETS="${@:-bench k1 k2 k3 legs}"
+SETS="${@:-bench k1 k2 k3 legs json}"
 for s in $SETS; do case $s in
 bench)
   run ${R}_bench_stats --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_bench_stats -o x -- python bench.py --no-extra --no-cpu-baseline
@@ -38,6 +38,7 @@ k2traffic)
   ;;
 k3)
   POLYHIP_SW_OVERLAP=0 run ${R}_k3_stats_nooverlap --kernel-trace --stats -d $ROOT/gpurun_out/prof_${R}_k3_stats_nooverlap -o x -- python scripts/quick_k3tb.py
+  POLYHIP_SW_OVERLAP=0 run ${R}_k3_pmc_nooverlap --pmc SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d $ROOT/gpurun_out/prof_${R}_k3_pmc_nooverlap -o x -- python scripts/quick_k3tb.py
   ;;
 legs)
   for g in A B; do
@@ -45,7 +46,9 @@ legs)
     run ${R}_legs${g}_fetch --pmc FETCH_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_legs${g}_fetch -o x -- python scripts/quick_legs.py $g
     run ${R}_legs${g}_write --pmc WRITE_SIZE --kernel-trace -d $ROOT/gpurun_out/prof_${R}_legs${g}_write -o x -- python scripts/quick_legs.py $g
   done
-  ( cd $ROOT && python scripts/traffic_json.py $R gpurun_out > gpurun_out/traffic.json )
+  ;;
+json)
+  ( cd $ROOT && python scripts/traffic_json.py $R gpurun_out > gpurun_out/traffic.json; python scripts/issue_json.py $R gpurun_out > gpurun_out/issue_json.log 2>&1 )
   ;;
 esac; done
 for t in $(cd $ROOT/gpurun_out && ls ${R}_*.md 2>/dev/null); do echo "== $t"; grep -E "polyhip" $ROOT/gpurun_out/$t | head -8 | cut -c1-170; done

@@ -7,6 +7,7 @@ Per leg: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 summed o
 gfx950 corrections of MI355X_MICROARCH.md's HBM section (FETCH_SIZE counts half of what a streaming read moves on this
 part: calibrated in profiles/r01_calib_fetch.md; WRITE_SIZE x 1: profiles/r01_calib_write.md)."""
 import json
+import os
 import re
 import sys
 
@@ -22,6 +23,34 @@ LEGS = {  # leg -> (group, namespace markers: SUBSTRINGS of the kernel name -- r
 }
 
 
+def counter_per_dispatch(path, counter):
+    """kernel -> counter value per DISPATCH (the table's last column)"""
+    out = {}
+    for line in open(path):
+        m = re.match(r"\| `(.*)` \| (\w+) \| (\d+) \| ([0-9.e+]+) \| ([0-9.e+]+) \|", line)
+        if m and m.group(2) == counter:
+            out[m.group(1)] = float(m.group(5))
+    return out
+
+
+def k2_leg(rnd, d):
+    """K2's one-shot row block (scripts/quick_k2c.py: one index build, five joins against it, three one-shot calls): every
+    `::k2::` kernel runs once per one-shot call, so the call's traffic is the sum of the kernels' per-dispatch values"""
+    try:
+        f = counter_per_dispatch(f"{d}/{rnd}_k2_fetch.md", "FETCH_SIZE")
+        w = counter_per_dispatch(f"{d}/{rnd}_k2_write.md", "WRITE_SIZE")
+    except OSError:
+        return None
+    ks = sorted(set(k for k in list(f) + list(w) if "::k2::" in k))
+    rd = 2 * sum(f.get(k, 0.0) for k in ks) * 1024
+    wr = sum(w.get(k, 0.0) for k in ks) * 1024
+    return {"hbm_bytes_per_launch": rd + wr, "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "kernels": ks,
+            "per_kernel_MB": {k: round((2 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024 / 1e6, 1) for k in ks},
+            "source": f"profiles/{rnd}_k2_fetch.md + profiles/{rnd}_k2_write.md (rocprofv3 --pmc passes of scripts/quick_k2c.py; per-dispatch "
+                      "FETCH_SIZE x 2 and WRITE_SIZE x 1 KB of every polyhip::k2 kernel, summed: one one-shot row block = index build + "
+                      "join); NOT measured by the bench run"}
+
+
 def counter_sums(path, counter):
     out = {}
     for line in open(path):
@@ -35,6 +64,8 @@ def main():
     rnd, d = sys.argv[1], sys.argv[2]
     res = {}
     for leg, (grp, prefixes) in LEGS.items():
+        if not os.path.exists(f"{d}/{rnd}_legs{grp}_fetch.md"):
+            continue
         f = counter_sums(f"{d}/{rnd}_legs{grp}_fetch.md", "FETCH_SIZE")
         w = counter_sums(f"{d}/{rnd}_legs{grp}_write.md", "WRITE_SIZE")
         pick = lambda t: sum(v for k, v in t.items() if any(p in k for p in prefixes))
@@ -44,6 +75,9 @@ def main():
                     "source": f"profiles/{rnd}_legs{grp}_fetch.md + profiles/{rnd}_legs{grp}_write.md (rocprofv3 --pmc passes of "
                               f"scripts/quick_legs.py {grp}: {CALLS} launches; FETCH_SIZE x 2 and WRITE_SIZE x 1 KB per MI355X_MICROARCH.md); "
                               "NOT measured by the bench run"}
+    k2 = k2_leg(rnd, d)
+    if k2:
+        res["mash_distance"] = k2
     print(json.dumps(res, indent=1))
 
 
