@@ -1426,8 +1426,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                                                                const uint32_t *__restrict__ hdr,
                                                                const uint32_t *__restrict__ rows, uint64_t ny,
                                                                uint32_t stripe_dwords, uint32_t id_bits,
-                                                               uint16_t *__restrict__ counts, uint64_t ld)
+                                                               uint16_t *__restrict__ counts, uint64_t ld, int zero_ahead)
 {
+    constexpr uint32_t NWAVES = DENSE_THREADS / 64;
     if (hdr[H_MODE] != MODE_SPARSE)
         return;
     if ((hdr[H_FMT] != 0u) != COMPACT) // the index says which item format it holds; the other instantiation has nothing to do
@@ -1498,6 +1499,46 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
         *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
     if constexpr (REG)
         lds_barrier();
+    // ZERO-AHEAD (round 5; MEASURED, NOT FASTER, opt-in: POLYHIP_K2_ZAHEAD=1).  A row's flush writes all its columns, zeros
+    // included, AFTER its walk, with the memory pipes idle during the walk and the LDS idle during the flush.  In this variant
+    // the zeros of the NEXT row go out during THIS row's walk -- a wave slips two 1 KB stores behind each group of bucket loads
+    // -- and what is left behind the walk is a scan of the LDS counters that writes the row's few hundred non-zero counts over
+    // its zeros and clears them.  Per 12,500 x 100,000 row block (profiles/r05e_join_zero_ahead_ablation.log): whole-row flush
+    // 1.154 ms, zero-ahead 1.179, zero-ahead with NO zeros written at all 0.983 -- so the flush costs 0.17 ms, not the 5.9 of
+    // 24 us per row the round-4 ablation suggested, and vmcnt counts a wave's loads and stores in ONE order: the next group's
+    // wait covers the stores slipped in front of it, and the walk slows by what the flush had cost.  Giving all the stores to
+    // the wave with spare time (a 1000-hash row: wave 15 holds 40 of 64 elements) made that wave the critical path (1.57 ms:
+    // one wave streams ~8 GB/s of such stores).  One stripe, 16-byte aligned rows; anything else keeps the whole-row flush.
+    const bool zahead = zero_ahead != 0 && one_stripe && ld % 8u == 0 && (reinterpret_cast<uintptr_t>(counts) & 15u) == 0;
+    const uint32_t row_bytes = (uint32_t)ny * 2u;                      // (one stripe: ny <= stripe_cols < 2^17)
+    const uint32_t wave_share = (((row_bytes + NWAVES - 1) / NWAVES) + 1023u) & ~1023u; // whole 1 KB wave stores
+    constexpr int per_group = 2;
+    int64_t zeroed = -1;                                               // the row whose zeros have been issued
+    uint8_t *zbase = nullptr;                                          // row being zero-filled by this wave
+    uint32_t zpos = 0, zend = 0;                                       // ... its share [zpos, zend) of the row's bytes
+    typedef uint32_t zvec_t __attribute__((ext_vector_type(4)));
+    auto zero_step = [&](int nstores) __attribute__((always_inline)) {
+        for (int q = 0; q < nstores && zpos < zend; ++q, zpos += 1024u) { // (wave-uniform)
+            const uint32_t at = zpos + (uint32_t)lane * 16u;
+#ifdef PH_K2_ZA_NOSTORE // ablation probe (no zeros written: wrong matrix)
+            if (at == 0xFFFFFFFFu)
+                zbase[0] = 0;
+            continue;
+#endif
+            if (at + 16u <= row_bytes) {
+                __builtin_nontemporal_store(zvec_t{0u, 0u, 0u, 0u}, reinterpret_cast<zvec_t *>(zbase + at));
+            } else if (at < row_bytes) { // the row's last, short piece (ny no multiple of 8)
+                for (uint32_t b = at; b < row_bytes; b += 2)
+                    *reinterpret_cast<uint16_t *>(zbase + b) = 0;
+            }
+        }
+    };
+    auto zero_begin = [&](int64_t row, bool) __attribute__((always_inline)) { // this wave's share of `row` becomes its pending zero-fill
+        zbase = reinterpret_cast<uint8_t *>(counts + (uint64_t)row * ld);
+        zpos = min((uint32_t)wave * wave_share, row_bytes);
+        zend = min(zpos + wave_share, row_bytes);
+        zend = zpos + ((zend - zpos + 1023u) & ~1023u); // (the last piece's lanes beyond the row store nothing)
+    };
     Pre cur, nxt;
     load_row(0, cur);
     load_bounds(cur);
@@ -1568,6 +1609,18 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
         nxt = nn;
         if (!work)
             continue;
+        if (zahead) {
+            if (zeroed != (int64_t)i) { // the workgroup's first row, or the row behind one the merge took: its zeros now, in the open
+                zero_begin((int64_t)i, true);
+                zero_step(1 << 20);
+            }
+            zeroed = -1;
+            zpos = zend = 0;
+            if (cur.i >= 0 && !cur.skip) { // (cur is the NEXT row by now)
+                zero_begin(cur.i, false);
+                zeroed = cur.i;
+            }
+        }
         const uint32_t nd = REG ? 0u : ndist;
         (void)nd;
         for (uint64_t c0 = 0; c0 < ny; c0 += stripe_cols) {
@@ -1625,6 +1678,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                             it[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 0, 0);
                             it[u][1] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 256, 0);
                         }
+                        zero_step(per_group); // a store wave: the next row's zeros ride behind this group's loads
 #pragma unroll
                         for (int u = 0; u < DENSE_U; ++u) {
                             const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
@@ -1652,6 +1706,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                             if (t + 64 < end[u])
                                 it[u][1] = items[t + 64];
                         }
+                        zero_step(per_group);
 #pragma unroll
                         for (int u = 0; u < DENSE_U; ++u) {
                             const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
@@ -1697,6 +1752,37 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                     }
                     walk_chunk(mval, mlim, mbeg, mend, min(64u, (nd - wave - NW * jb + NW - 1) / NW)); // my buckets in this chunk
                 }
+            }
+            if (zahead) {
+                zero_step(1 << 20); // what the walk's groups did not carry (a wave with few buckets, a short row)
+                // every zero of the next row (and, a row ago, of this one) is in L2 before anybody patches over it
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                // the row's non-zero counts over its zeros; the counters go back to zero where they were touched
+                uint16_t *prow = counts + i * ld;
+#ifdef PH_K2_NOFLUSH
+                for (uint32_t t = tid * 8; false && t < ndw; t += DENSE_THREADS * 8) {
+#else
+                for (uint32_t t = tid * 8; t < ndw; t += DENSE_THREADS * 8) {
+#endif
+                    const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
+                    const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
+                    if ((d0.x | d0.y | d0.z | d0.w | d1.x | d1.y | d1.z | d1.w) == 0u)
+                        continue;
+                    const uint32_t d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (d[q]) {
+                            dense[t + q] = 0;
+#pragma unroll
+                            for (uint32_t kf = 0; kf < PER; ++kf) {
+                                const uint32_t f = (d[q] >> (BITS * kf)) & FMASK, col = kf * ndw + t + (uint32_t)q;
+                                if (f && col < ncols)
+                                    prow[col] = (uint16_t)f;
+                            }
+                        }
+                }
+                lds_barrier();
+                continue;
             }
             lds_barrier();
             // flush the stripe whole, zeros included: field k of dwords [0, ndw) = columns [k * ndw, (k + 1) * ndw)
@@ -2217,7 +2303,8 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
         auto kern = regrow ? k2::rowjoin_dense_kernel<BITS_, COMPACT_, true> : k2::rowjoin_dense_kernel<BITS_, COMPACT_, false>; \
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(k2::DENSE_THREADS), smem, st, d_X, nx, sx, flagsX, start,                 \
-                           static_cast<const void *>(items), L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld);               \
+                           static_cast<const void *>(items), L.nbk, hdr, rows, ny, sdw, id_bits, d_counts, ld,                \
+                           env_is("POLYHIP_K2_ZAHEAD", '1') ? 1 : 0);                                                         \
     } while (0)
         // both item formats are launched when the index MAY be compact: the device decided (H_FMT), the instantiation
         // that does not match returns at once

@@ -21,7 +21,7 @@ def mash():
     return mash
 
 
-@pytest.fixture(autouse=True, params=["dense", "sparse", "wide", "staged", "twolevel"])
+@pytest.fixture(autouse=True, params=["dense", "sparse", "wide", "staged", "twolevel", "zahead"])
 def join_kind(request, monkeypatch):
     """every test runs twice: with the dense join in front (a counter per column in LDS; the default up to two
     stripes of columns; index built with the LDS-staged level-1 scatter) and with POLYHIP_K2_DENSE=0 (sparse LDS hash
@@ -31,6 +31,9 @@ def join_kind(request, monkeypatch):
     monkeypatch.delenv("POLYHIP_K2_COMPACT", raising=False)
     monkeypatch.delenv("POLYHIP_K2_REGROW", raising=False)
     monkeypatch.delenv("POLYHIP_K2_B4", raising=False)
+    monkeypatch.delenv("POLYHIP_K2_ZAHEAD", raising=False)
+    if request.param == "zahead":   # the dense join writing a row's zeros ahead, during the walk before (measured, not faster: opt-in)
+        monkeypatch.setenv("POLYHIP_K2_ZAHEAD", "1")
     if request.param == "twolevel":   # the two-level index build on 8-byte intermediate items where the sliced build (round 5) is the default
         monkeypatch.setenv("POLYHIP_K2_B4", "0")
     if request.param == "staged":   # the dense join with the row staged in LDS (the default keeps a row of <= 1024 hashes in registers)
@@ -304,7 +307,7 @@ def test_compact_items_where_they_fit_and_a_rebuild_where_not(mash, join_kind):
     work = torch.zeros(mash.shared_counts_workspace_bytes(N, 1200, N, 300), dtype=torch.uint8, device=dev)
     mash.index_build_dev(St, work)
     torch.cuda.synchronize()
-    assert mash.index_item_bytes(work) == (4 if join_kind in ("dense", "staged", "twolevel") else 8)
+    assert mash.index_item_bytes(work) == (4 if join_kind in ("dense", "staged", "twolevel", "zahead") else 8)
     ct = torch.zeros((N, N), dtype=torch.int16, device=dev)
     mash.shared_counts_reuse_dev(St, St, ct, work)
     torch.cuda.synchronize()
@@ -315,7 +318,7 @@ def test_compact_items_where_they_fit_and_a_rebuild_where_not(mash, join_kind):
     cx = torch.zeros((20, N), dtype=torch.int16, device=dev)
     mash.shared_counts_reuse_dev(Xt, St, cx, work)
     torch.cuda.synchronize()
-    assert mash.index_item_bytes(work) == (4 if join_kind in ("dense", "staged", "twolevel") else 8)
+    assert mash.index_item_bytes(work) == (4 if join_kind in ("dense", "staged", "twolevel", "zahead") else 8)
     assert (cx.cpu().numpy().view(np.uint16) == _oracle_counts(X, S)).all()
     # an index of 1100-hash sketches assumes 16-bit counters; X sketches of 300 hashes need 10-bit ones: not what the
     # build assumed -> rebuilt with 8-byte items, still right
@@ -324,7 +327,7 @@ def test_compact_items_where_they_fit_and_a_rebuild_where_not(mash, join_kind):
     wY = torch.zeros(mash.shared_counts_workspace_bytes(N, 300, len(Y), 1100), dtype=torch.uint8, device=dev)
     mash.index_build_dev(Yt, wY)
     torch.cuda.synchronize()
-    assert mash.index_item_bytes(wY) == (4 if join_kind in ("dense", "staged", "twolevel") else 8)
+    assert mash.index_item_bytes(wY) == (4 if join_kind in ("dense", "staged", "twolevel", "zahead") else 8)
     cyy = torch.zeros((len(Y), len(Y)), dtype=torch.int16, device=dev)
     mash.shared_counts_reuse_dev(Yt, Yt, cyy, wY)          # 16-bit counters, compact items
     torch.cuda.synchronize()
@@ -351,7 +354,7 @@ def test_compact_items_where_they_fit_and_a_rebuild_where_not(mash, join_kind):
     S3t = torch.from_numpy(S3.view(np.int32)).to(dev)
     mash.shared_counts_dev(S3t, S3t, ct, work)
     torch.cuda.synchronize()
-    assert mash.index_item_bytes(work) == (4 if join_kind in ("dense", "staged", "twolevel") else 8)
+    assert mash.index_item_bytes(work) == (4 if join_kind in ("dense", "staged", "twolevel", "zahead") else 8)
     assert (ct.cpu().numpy().view(np.uint16) == _oracle_counts(S3, S3)).all()
 
 
