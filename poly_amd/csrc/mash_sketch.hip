@@ -54,6 +54,9 @@
 #ifndef PH_ABL
 #define PH_ABL 0
 #endif
+#ifndef PH_BS_U
+#define PH_BS_U 4 // candidates a thread takes per trip of the bottom-s's loops (bottom_s_fast): 4 / 5 / 6 measure the same
+#endif
 // slab pass (scripts/ubench/k1_ablate.hip sweeps these): sigmas of head-room of the survivor target over s, of a
 // wave's segment and of the sorted buffer over their expectations, and the waves per SIMD it is allocated for
 #ifndef PH_SLAB_SIG
@@ -533,6 +536,7 @@ __device__ __forceinline__ void append4(uint32_t *__restrict__ counter, uint32_t
 // `src` / `first` / `step` / `cnt`: where this thread's candidates are -- the shared buffer (sm.cand, tid, THREADS, C)
 // or, for the slab pass, the thread's own wave's segment (segment, lane, 64, that wave's count).  FIN: the
 // candidates still lack fmix32's last `h ^= h >> 16` (the slab pass thresholds on the bits that step leaves alone).
+constexpr int BSU = PH_BS_U;
 template <bool FIN>
 __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t C, uint32_t nbf_log2,
                               uint32_t *__restrict__ outp, const uint32_t *__restrict__ src, uint32_t first,
@@ -552,15 +556,18 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
     if (tid == 0)
         sm.misc[8] = 0; // bins with more than BIG_BIN values
     __syncthreads();
-    // the loops over candidates are unrolled by four so that the LDS round trips of a thread's
-    // elements overlap instead of queueing behind each other
-    for (uint32_t i0 = first; i0 < cnt; i0 += 4 * step) {
-        uint32_t h[4];
+    // the loops over candidates are unrolled (PH_BS_U) so that the LDS round trips of a thread's elements overlap instead of
+    // queueing behind each other.  A wave's segment holds ~300 survivors and the sorted buffer ~1200, i.e. 4.7 per lane / per
+    // thread, so by four every loop runs a second, nearly empty trip -- but by five or six the kernel measures the same
+    // (1.46-1.50 ms per 100k reads all three, profiles/r05_k1_bottom_s_unroll.log): the bottom-s is its five barriers and
+    // the atomics' round trips, not its instruction count.
+    for (uint32_t i0 = first; i0 < cnt; i0 += BSU * step) {
+        uint32_t h[BSU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BSU; ++u)
             h[u] = i0 + u * step < cnt ? fin(src[i0 + u * step]) : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BSU; ++u)
             if (i0 + u * step < cnt)
                 atomicAdd(&bins[h[u] >> shift], 1u);
     }
@@ -602,37 +609,37 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
         }
     }
     __syncthreads();
-    for (uint32_t i0 = first; i0 < cnt; i0 += 4 * step) { // afterwards bins[b] = end of bin b
-        uint32_t h[4], at[4];
+    for (uint32_t i0 = first; i0 < cnt; i0 += BSU * step) { // afterwards bins[b] = end of bin b
+        uint32_t h[BSU], at[BSU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BSU; ++u)
             h[u] = i0 + u * step < cnt ? fin(src[i0 + u * step]) : 0u;
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BSU; ++u)
             if (i0 + u * step < cnt)
                 at[u] = atomicAdd(&bins[h[u] >> shift], 1u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BSU; ++u)
             if (i0 + u * step < cnt)
                 sm.binned[at[u]] = h[u];
     }
     __syncthreads();
     const uint32_t nbig = sm.misc[8];
     const bool by_waves = nbig <= BIG_LIST_CAP; // else the list is incomplete: rank every element the slow way
-    for (uint32_t j0 = tid; j0 < C; j0 += 4 * THREADS) {
-        uint32_t h[4], start[4], end[4];
+    for (uint32_t j0 = tid; j0 < C; j0 += BSU * THREADS) {
+        uint32_t h[BSU], start[BSU], end[BSU];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < BSU; ++u)
             h[u] = j0 + u * THREADS < C ? sm.binned[j0 + u * THREADS] : 0xFFFFFFFFu;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BSU; ++u) {
             const uint32_t b = h[u] >> shift;
             const bool live = j0 + u * THREADS < C;
             start[u] = live ? (b ? bins[b - 1] : 0u) : s;
             end[u] = live ? bins[b] : s;
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < BSU; ++u) {
             if (start[u] >= s)
                 continue;
             const uint32_t j = j0 + u * THREADS;
