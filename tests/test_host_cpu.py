@@ -220,36 +220,78 @@ def test_fasta_two_scans_in_one_pass_combination_rule():
         assert int(seg_start[SEGS]) == int(want[n])
 
 
-def test_slice_bounds_of_the_sliced_index_build():
-    """csrc/mash_distance.hip, check_kernel<true> with `pos`: where an ascending sketch crosses from one eighth of the value
-    range into the next.  The kernel writes pos[r] from the TRANSITIONS it sees (element e in eighth ra, element e + 1 in
-    eighth rb > ra: pos[ra + 1 .. rb] = e + 1; the first element: pos[0 .. its eighth] = 0; the last: pos[its eighth + 1 .. 8]
-    = s) -- restated here and compared with the definition: pos[r] = number of elements below eighth r."""
+def _plan4(maxval, nbk_log2, s, slice_len, cpp_max):
+    """csrc/mash_distance.hip plan4_kernel, restated: None = the two-level build"""
+    bits = max(maxval, 1).bit_length()
+    shift = bits - nbk_log2 if bits > nbk_log2 else 0
+    if bits < 17 or bits > 30 or shift < 4 or shift > 10:
+        return None
+    nce = (maxval >> 16) + 1
+    R = min(max((s + slice_len - 1) // slice_len, 1), 64)
+    cpp = min(max((nce + R - 1) // R, 2), cpp_max)
+    R = (nce + cpp - 1) // cpp
+    return dict(nc=1 << (bits - 16), R=R, cpp=cpp, magic=((1 << 32) + cpp - 1) // cpp, shift=shift, nce=nce)
+
+
+def test_geometry_and_slice_bounds_of_the_sliced_index_build():
+    """csrc/mash_distance.hip, round 5 (plan4_kernel, b4_part, check4_kernel's `pos`, fine4_kernel's lane permutation),
+    restated in plain integers.  (a) the geometry: the parts cover every coarse bucket that can hold an item, at most 64
+    parts (the pos table's row) of at most cpp_max coarse buckets (level 1's LDS counters), and the part of a coarse bucket by
+    ONE multiply-high equals the division for every coarse bucket below 2^16.  (b) the kernel writes pos[r] from the
+    TRANSITIONS a lane sees (element e in part ra, element e + 1 in part rb > ra: pos[ra + 1 .. rb] = e + 1; the first
+    element: pos[0 .. its part] = 0; the last: pos[its part + 1 .. R] = s): equal to the definition pos[r] = number of
+    elements below part r, and slice r holds exactly the elements of part r.  (c) the lane-to-item mapping of level 2 is a
+    permutation of the workgroup's threads whose waves take eight pieces of 8 consecutive items T / 8 apart."""
     rng = np.random.default_rng(8)
-    R = 8
-    for it in range(300):
+    for it in range(400):
+        bits = int(rng.integers(12, 33))
+        maxval = int(rng.integers(1 << (bits - 1), 1 << bits)) if bits < 33 else 0xFFFFFFFF
+        maxval = min(maxval, 0xFFFFFFFF)
+        nbk_log2 = int(rng.integers(11, 25))
         s = int(rng.integers(1, 1025))
-        rshift = int(rng.integers(0, 29))
-        top = min((R << rshift) - 1, 0xFFFFFFFF)
-        if it % 3 == 0:  # crowded into a few eighths (empty ones in between and at either end)
-            lo = int(rng.integers(0, top + 1))
-            x = np.sort(rng.integers(lo // 2, lo + 1, s, dtype=np.uint64)).astype(np.uint64)
+        slice_len = int(rng.choice([16, 20, 41, 83, 250, 1024]))
+        cpp_max = int(rng.choice([512, 1024]))
+        g = _plan4(maxval, nbk_log2, s, slice_len, cpp_max)
+        if g is None:
+            continue
+        assert g["nc"] >= g["nce"] and g["nc"] <= 16384 and 16 - g["shift"] <= 12
+        assert g["R"] * g["cpp"] >= g["nce"] and 1 <= g["R"] <= 64 and 2 <= g["cpp"] <= cpp_max
+        coarse = np.arange(0, min(g["nc"], 65536), dtype=np.uint64)
+        part = np.minimum((coarse * np.uint64(g["magic"])) >> np.uint64(32), g["R"] - 1)
+        assert (part == np.minimum(coarse // np.uint64(g["cpp"]), g["R"] - 1)).all(), (it, g)
+        # (b) a sketch below maxval, sometimes crowded into a few parts
+        R = g["R"]
+        if it % 3 == 0:
+            hi = int(rng.integers(1, maxval + 1))
+            x = np.sort(rng.integers(hi // 2, hi + 1, s, dtype=np.uint64))
         else:
-            x = np.sort(rng.integers(0, top + 1, s, dtype=np.uint64)).astype(np.uint64)
-        eighth = np.minimum(x >> np.uint64(rshift), R - 1).astype(np.int64)
+            x = np.sort(rng.integers(0, maxval + 1, s, dtype=np.uint64))
+        px = np.minimum(((x >> np.uint64(16)) * np.uint64(g["magic"])) >> np.uint64(32), R - 1).astype(np.int64)
         pos = np.full(R + 1, -1, np.int64)
         for e in range(s):  # every "lane" on its own, as the kernel
-            ra = eighth[e]
+            ra = px[e]
             if e == 0:
                 pos[0:ra + 1] = 0
             if e + 1 < s:
-                rb = eighth[e + 1]
+                rb = px[e + 1]
                 if rb > ra:
                     pos[ra + 1:rb + 1] = e + 1
             else:
                 pos[ra + 1:R + 1] = s
-        want = np.array([int((eighth < r).sum()) for r in range(R + 1)])
-        assert (pos == want).all(), (it, s, rshift)
-        # the slices tile the sketch, and slice r holds exactly the elements of eighth r
+        want = np.array([int((px < r).sum()) for r in range(R + 1)])
+        assert (pos == want).all(), (it, s, g)
         for r in range(R):
-            assert (eighth[pos[r]:pos[r + 1]] == r).all()
+            sl = x[pos[r]:pos[r + 1]]
+            assert (px[pos[r]:pos[r + 1]] == r).all()
+            assert ((sl >> np.uint64(16)) >= r * g["cpp"]).all() and ((sl >> np.uint64(16)) < (r + 1) * g["cpp"]).all() or r == R - 1
+    # config 3's own numbers (100,000 sketches of 1000, 2^23 buckets): what the profiles quote
+    g = _plan4((7370 << 16) - 1, 23, 1000, 41, 1024)
+    assert (g["nc"], g["R"], g["cpp"], g["shift"]) == (8192, 25, 295, 6)  # polyhip_mash_index_build_info_dev on the GPU box
+    # (c) fine4_kernel's ptid for T = 1024 and 512
+    for T in (1024, 512):
+        tid = np.arange(T)
+        ptid = ((((tid >> 3) & 7) * (T // 64) + (tid >> 6)) << 3) | (tid & 7)
+        assert sorted(ptid.tolist()) == list(range(T))
+        for w in range(T // 64):
+            pieces = sorted(set((ptid[w * 64:(w + 1) * 64] >> 3).tolist()))
+            assert len(pieces) == 8 and all(b - a == T // 64 for a, b in zip(pieces, pieces[1:]))
