@@ -1650,8 +1650,16 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
             // and occurrence number < multiplicity" is ONE subtract and ONE compare (an item of another value wraps or
             // overshoots; the all-zero word = no item fails too), the counter's byte offset and field shift are in the item
             auto consume_compact = [&](const uint32_t it, uint32_t key, uint32_t alim) {
+#if defined(PH_K2_J_NOCONSUME) // ablation probes (wrong counts): the walk without its consume / without its LDS atomics
+                if (it == 0x12345u && key == 77u)
+                    dense[0] = alim;
+#elif defined(PH_K2_J_NOATOM)
+                if (it - key < alim && it == 0x12345u)
+                    dense[0] = alim;
+#else
                 if (it - key < alim)
                     atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(dense) + ((it >> 3) & 0x3FFFCu)), 1u << (it & 31u));
+#endif
             };
             // Wave w owns the distinct values w, w + 16, w + 32, ...: lane l keeps the descriptor of the wave's l-th one
             // in registers (one LDS pass per 64 buckets) and the walk takes them from there by v_readlane -- bucket
@@ -1666,6 +1674,12 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                     // Buffer loads: a bucket is its own little buffer (base and size are scalars built on the scalar
                     // unit), every lane reads at the constant offset 4 * lane, and a lane beyond the bucket's end gets 0 =
                     // no item -- no address arithmetic, no bounds compare, no select on the vector unit.
+                    // (round 5, measured and not kept: ONE 8-byte load per lane -- items 2 l and 2 l + 1 -- instead of two 4-byte
+                    // ones, 1.26 against 1.17-1.21 ms per row block.  What the ablations say a row's walk IS
+                    // (profiles/r05f_join_ablation.log, r05f_join_flush_ablation.log): the consume and its LDS atomics are free
+                    // (1.165 without them, 1.166 with), every bucket read from ONE place in L1 still 0.94, no walk at all 0.57 of
+                    // which 0.43 are the flush's STORES at the HBM write rate (5.9 TB/s) and 0.15 everything else; with the walk
+                    // the stores cost 0.23: a wave's next loads wait behind its own flush stores -- vmcnt is one queue.)
                     const uint32_t lane4 = (uint32_t)lane * 4u;
                     for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
                         uint32_t it[DENSE_U][2], len[DENSE_U];
@@ -1674,11 +1688,15 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                         for (int u = 0; u < DENSE_U; ++u) {
                             const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
                             len[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u)) - b;
+#ifdef PH_K2_J_L1 // ablation probe (wrong counts): every bucket's items from ONE place (L1 hits)
+                            rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(items), 0, (int)(len[u] * 4u), 0x00020000);
+#else
                             rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(items + b), 0, (int)(len[u] * 4u), 0x00020000);
+#endif
                             it[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 0, 0);
                             it[u][1] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 256, 0);
                         }
-                        zero_step(per_group); // a store wave: the next row's zeros ride behind this group's loads
+                        zero_step(per_group); // (zero-ahead variant: the next row's zeros ride behind this group's loads)
 #pragma unroll
                         for (int u = 0; u < DENSE_U; ++u) {
                             const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
@@ -1798,10 +1816,14 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
 #else
                 for (uint32_t t = tid * 8; t < ndw; t += DENSE_THREADS * 8) {
 #endif
+#ifdef PH_K2_F_NOLDS // ablation probe: the flush without its LDS traffic (stores what the thread index says)
+                    const uint4 d0 = make_uint4(t, t, t, t), d1 = d0;
+#else
                     const uint4 d0 = *reinterpret_cast<const uint4 *>(dense + t);
                     const uint4 d1 = *reinterpret_cast<const uint4 *>(dense + t + 4);
                     *reinterpret_cast<uint4 *>(dense + t) = make_uint4(0, 0, 0, 0);
                     *reinterpret_cast<uint4 *>(dense + t + 4) = make_uint4(0, 0, 0, 0);
+#endif
                     const uint32_t d[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
                     for (uint32_t k = 0; k < PER; ++k) {
@@ -1815,6 +1837,9 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                         if (cb + t + 8 <= ncols) {
                             // written once, never read here: nontemporal, so the 2 B per pair do not push the index out of L2
                             const u32x4_t o = {f[0] | (f[1] << 16), f[2] | (f[3] << 16), f[4] | (f[5] << 16), f[6] | (f[7] << 16)};
+#ifdef PH_K2_F_NOSTORE // ablation probe: the flush without its global stores
+                            if (o.x == 0x12345u)
+#endif
                             __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(crow + cb + t));
                         } else {
 #pragma unroll
