@@ -234,9 +234,12 @@ __device__ __forceinline__ uint32_t load4(const uint8_t *p)
 __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restrict__ seqs,
                                                          const uint64_t *__restrict__ offs, uint64_t n, int seq_type,
                                                          uint8_t *__restrict__ norm, uint32_t *__restrict__ err,
-                                                         unsigned long long *__restrict__ first_non_ascii)
+                                                         unsigned long long *__restrict__ first_non_ascii,
+                                                         const uint32_t *__restrict__ any_bad)
 {
     // (the reverse complement is not written any more: K5, the comparison and BLAKE3 read it through `Strand`)
+    if (any_bad && *any_bad == 0u)
+        return; // normalise_stream_kernel did the whole batch and met no letter outside the alphabet: err[] stays zero
     __shared__ unsigned long long first_bad; // (position << 8) | letter
     __shared__ unsigned long long first_hi;  // position of the sequence's first byte >= 0x80 (the host flavour refuses those)
     __shared__ uint8_t upL[256], okL[256];
@@ -307,6 +310,58 @@ __global__ __launch_bounds__(THREADS) void prepare_kernel(const uint8_t *__restr
                 atomicMin(first_non_ascii, (unsigned long long)(o0 - offs[0]) + first_hi);
         }
     }
+}
+
+// The same normalisation as prepare_kernel for a batch WITHOUT a letter outside its alphabet -- the common case -- as one
+// streaming pass over the batch's bytes, 16 per thread, whatever sequence they belong to (the normalised copy has the batch's
+// own byte offsets): strings.ToUpper (:143) and U -> T (:146-148) through one 16-bit table entry per byte, bit 8 of which
+// says "not in the alphabet".  Such a byte only raises *any_bad: prepare_kernel -- a workgroup per sequence, two barriers and
+// three atomics per sequence: 0.33 ms per 100k x 5 kb, latency-bound -- then runs after all and reports the first offending
+// letter of every sequence exactly as before; without one it returns at once and err[] stays zero.
+__global__ __launch_bounds__(THREADS) void normalise_stream_kernel(const uint8_t *__restrict__ seqs, const uint64_t *__restrict__ offs,
+                                                                  uint64_t n, int seq_type, uint8_t *__restrict__ norm,
+                                                                  uint32_t *__restrict__ any_bad)
+{
+    const uint64_t b0 = offs[0], b1 = offs[n]; // the batch's bytes
+    __shared__ uint16_t upT[256];
+    {
+        const uint32_t b = threadIdx.x; // THREADS == 256
+        uint32_t c = ascii_upper(b);
+        if (seq_type == 1 && c == 'U')
+            c = 'T';
+        const bool ok = seq_type == 2 ? in_set(c, "ACDEFGHIKLMNPQRSTVWYUO*BXZ") : in_set(c, "ATUGCYRSWKMBDHVNZ");
+        upT[b] = (uint16_t)(c | (ok ? 0u : 0x100u));
+    }
+    __syncthreads();
+    // whole 16-byte pieces of the normalised copy [a0, a1) inside [b0, b1); the few bytes in front and behind singly
+    const uint64_t a0 = (b0 + 15) & ~15ull, a1 = b1 & ~15ull;
+    uint32_t bad = 0;
+    const uint64_t gtid = (uint64_t)blockIdx.x * THREADS + threadIdx.x, nth = (uint64_t)gridDim.x * THREADS;
+    if (a0 < a1) {
+        for (uint64_t p = gtid; p < (a1 - a0) >> 4; p += nth) {
+            uint4 v;
+            __builtin_memcpy(&v, seqs + a0 + 16 * p, 16); // (the caller's buffer may sit at any byte address)
+            uint32_t w[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t e0 = upT[w[i] & 0xFFu], e1 = upT[(w[i] >> 8) & 0xFFu], e2 = upT[(w[i] >> 16) & 0xFFu], e3 = upT[w[i] >> 24];
+                bad |= e0 | e1 | e2 | e3;
+                o[i] = (e0 & 0xFFu) | ((e1 & 0xFFu) << 8) | ((e2 & 0xFFu) << 16) | (e3 << 24);
+            }
+            *reinterpret_cast<uint4 *>(norm + a0 + 16 * p) = make_uint4(o[0], o[1], o[2], o[3]); // (norm is 256-byte aligned)
+        }
+    }
+    if (gtid < 32) { // up to 15 bytes in front of a0 and up to 15 behind a1 (or the whole of a batch shorter than a piece)
+        const uint64_t h1 = a0 < a1 ? a0 : b1;
+        const uint64_t t = gtid < 16 ? b0 + gtid : (a0 < a1 ? a1 + (gtid - 16) : b1);
+        if ((gtid < 16 && t < h1) || (gtid >= 16 && t < b1)) {
+            const uint32_t e = upT[seqs[t]];
+            bad |= e;
+            norm[t] = (uint8_t)e;
+        }
+    }
+    if (__ballot((bad & 0x100u) != 0u) != 0ull && (threadIdx.x & 63) == 0)
+        atomicOr(any_bad, 1u);
 }
 
 // sort.Strings(...)[0] (seqhash.go:180-193): sel[q] = 1 when the second candidate -- the (rotated) reverse complement, read
@@ -604,8 +659,19 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     // would treat as UTF-8; polyhip_seqhash_batch reads it back and refuses the call, a device-pointer caller may)
     unsigned long long *non_ascii = reinterpret_cast<unsigned long long *>(w);
     PH_HIP(hipMemsetAsync(non_ascii, 0xFF, 8, st));
+    // the streaming pass first (POLYHIP_S2_STREAM=0: the per-sequence pass alone, testing aid); the per-sequence pass behind it
+    // only works when a letter outside the alphabet was met
+    uint32_t *any_bad = reinterpret_cast<uint32_t *>(w + 8);
+    const bool streaming = !env_is("POLYHIP_S2_STREAM", '0');
+    if (streaming) {
+        PH_HIP(hipMemsetAsync(any_bad, 0, 4, st));
+        PH_HIP(hipMemsetAsync(d_err, 0, n * 4, st));
+        const uint64_t pieces = (total_bytes >> 4) + 2;
+        hipLaunchKernelGGL(s2::normalise_stream_kernel, dim3((unsigned)std::min<uint64_t>((pieces + s2::THREADS - 1) / s2::THREADS, 256ull * 16ull)),
+                           dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, any_bad);
+    }
     hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, d_err,
-                       non_ascii);
+                       non_ascii, streaming ? any_bad : (uint32_t *)nullptr);
     PH_HIP(hipGetLastError());
     if (circular) { // the indexes only: neither the rotated strings nor the second strand are ever written -- ONE K5 pass
                     // stages every sequence once and searches it in both reading directions
