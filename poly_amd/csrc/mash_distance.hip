@@ -1840,7 +1840,11 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
 #ifdef PH_K2_F_NOSTORE // ablation probe: the flush without its global stores
                             if (o.x == 0x12345u)
 #endif
+#ifdef PH_K2_F_PLAIN // measured: ordinary (temporal) stores instead of nontemporal ones
+                            *reinterpret_cast<u32x4_t *>(crow + cb + t) = o;
+#else
                             __builtin_nontemporal_store(o, reinterpret_cast<u32x4_t *>(crow + cb + t));
+#endif
                         } else {
 #pragma unroll
                             for (int q = 0; q < 8; ++q)
