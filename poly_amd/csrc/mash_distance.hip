@@ -818,7 +818,14 @@ __global__ __launch_bounds__(1024) void check4_kernel(const uint32_t *__restrict
                 // (working a part out once per element and passing it to the lane below by DPP was measured: 0.241 against
                 // 0.211 ms -- the readfirstlane for lane 63 waits where the two multiplies did not)
                 if (e < s) {
+#ifndef PH_K2_C4_NOHIST // ablation probes (a wrong index): the check pass without its histogram / without its part bounds
                     atomicAdd(&lh[x[u] >> 16], 1u);
+#endif
+#ifdef PH_K2_C4_NOPOS
+                    if (x[u] == 0x12345u)
+                        pq[0] = 1;
+                    continue;
+#endif
                     const uint32_t ra = b4_part(x[u], magic, R);
                     if (e == 0u)
                         for (uint32_t r = 0; r <= ra; ++r)

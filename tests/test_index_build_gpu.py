@@ -233,6 +233,16 @@ def test_hand_over_to_the_two_level_build(mash, monkeypatch):
     got, info = _counts(mash, rep, rep)
     assert info["build"] == 2 and info["item_bytes"] == 8
     _check_rows(got, rep, rep, (0, 4, 9, 599))
+    # more repeated hashes than the build's list of them holds (65,536 records): called off too, but the items stay compact
+    many = np.sort(rng.integers(0, 1 << 26, (70_000, 64), dtype=np.uint32), axis=1)
+    many[:, 1] = many[:, 0]                     # every sketch repeats its smallest hash once
+    Xm = many[::3500].copy()
+    got, info = _counts(mash, Xm, many)
+    assert info["build"] == 2 and info["item_bytes"] == 4 and info["repeated"] >= 70_000
+    cols = rng.choice(len(many), 150, replace=False)
+    for a in range(0, len(Xm), 4):
+        for j in list(cols) + [a * 3500]:
+            assert int(got[a, j]) == orc.mash_shared(Xm[a], many[j])
     # the parts API keeps the two-level build's coarse buckets
     import torch
     dev = torch.device("cuda:0")
