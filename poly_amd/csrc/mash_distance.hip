@@ -937,6 +937,8 @@ __global__ __launch_bounds__(1024, 8) void scatter4_kernel(const uint32_t *__res
             return 0u;
         const uint16_t *pq = pos + q * (R + 1u) + r;
         const uint32_t a = pq[0], b = pq[1];
+        if (b < a || b > s)
+            return 0u; // (never for a row check4_kernel wrote: a guard against thousands of rounds on a corrupted table)
         return a | ((b - a) << 16);
     };
     uint32_t w = blockIdx.x >> 3;
