@@ -43,7 +43,8 @@
 // PH_ABL != 0 only in scripts/ubench/k1_ablate.hip: knocks out one phase to measure its cost
 // (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage: the TILE pass.
 // The SLAB pass (round 5): 11 = stage + premix + hash only (no select, no bottom-s), 12 = no bottom-s, 14 = the per-read
-// prologue and barriers alone (no slabs, no bottom-s), 15 = no premix (the hash reads stale quads).  None of them marks a
+// prologue and barriers alone (no slabs, no bottom-s), 15 = no premix (the hash reads stale quads), 16 = ONE chain block of the
+// k / 4 (-11 instructions per k-mer), 17 = fmix32 cut to one multiply (-4): is the kernel bound by its instruction count at all?  None of them marks a
 // row for the general kernel, so the timed launch is the slab kernel alone.
 #ifndef PH_WPE
 #define PH_WPE 6 // waves per SIMD the fast kernel is register-allocated for (6 workgroups per CU fit its LDS)
@@ -843,7 +844,7 @@ template <int KS> struct Slabs {
         const uint4 *b = reinterpret_cast<const uint4 *>(P) + 64 * PAR + lane;
         h[0] = h[1] = h[2] = h[3] = 0u;
 #pragma unroll
-        for (int j = 0; j < NBLK; ++j) {
+        for (int j = 0; j < (PH_ABL == 16 ? 1 : NBLK); ++j) { // (PH_ABL 16: one chain block of the k / 4 -- timing only)
             const uint4 p = b[j];
             h[0] = chain(h[0] ^ p.x);
             h[1] = chain(h[1] ^ p.y);
@@ -879,9 +880,11 @@ template <int KS> struct Slabs {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { // fmix32 up to its last multiply
             uint32_t x = h[c];
-            x ^= x >> 16;
-            x *= 0x85ebca6bu;
-            x ^= x >> 13;
+            if (PH_ABL != 17) { // (PH_ABL 17: no fmix32 -- timing only)
+                x ^= x >> 16;
+                x *= 0x85ebca6bu;
+                x ^= x >> 13;
+            }
             x *= 0xc2b2ae35u;
             h[c] = x;
         }

@@ -31,7 +31,7 @@ int main()
     const k1::Launch PL = k1::plan(k, s);
     printf("checksum %016llx %08llx  smem_slab %zu capw %u capf_slab %u  ", (unsigned long long)sum, (unsigned long long)x, PL.smem_slab, PL.capw, PL.capf_slab);
     static const char *what[] = {"full kernel", "no premix", "1 chain block of 5", "no tail/fmix", "no select stores", "no bottom_s", "no global loads", "2 workgroups per CU",
-                                 "", "", "", "slab: stage + premix + hash only", "slab: no bottom-s", "", "slab: per-read prologue + barriers only", "slab: no premix"};
+                                 "", "", "", "slab: stage + premix + hash only", "slab: no bottom-s", "", "slab: per-read prologue + barriers only", "slab: no premix", "slab: 1 chain block of 5", "slab: fmix32 cut to one multiply"};
     printf("PH_ABL=%d %-40s %.3f ms per 100k reads\n", PH_ABL, what[PH_ABL], ms);
     return 0;
 }
