@@ -295,3 +295,116 @@ def test_geometry_and_slice_bounds_of_the_sliced_index_build():
         for w in range(T // 64):
             pieces = sorted(set((ptid[w * 64:(w + 1) * 64] >> 3).tolist()))
             assert len(pieces) == 8 and all(b - a == T // 64 for a, b in zip(pieces, pieces[1:]))
+
+
+def test_sliced_index_build_restated_end_to_end():
+    """The sliced index build of csrc/mash_distance.hip (round 5) as an executable specification in numpy: the same geometry
+    (_plan4), the same intermediate item [hash & 0xFFFF : 16 | id & 0xFFFF : 16] in the same places (coarse bucket = hash >> 16,
+    segment = id >> 16, level 1 = any order inside a segment), the same compact item
+    [hash's bits below its fine bucket : shift | occurrence number + 1 : 11 - shift | counter dword : 16 | field shift : 5],
+    the repeated hashes numbered behind the placement from the logged records.  Decoding the result must give back exactly
+    the multiset {(hash, sketch, occurrence number)} of the input -- what the join relies on (same value AND occurrence number
+    < multiplicity, the counter of column `sketch`)."""
+    rng = np.random.default_rng(55)
+    CK_LOW = 21
+    for ny, s, bits, nbk_log2, field_bits in ((700, 64, 26, 17, 10), (70_000 // 50, 96, 24, 16, 10), (1300, 128, 23, 15, 16)):
+        # sketches: ascending, some hashes repeated inside a sketch, ids on both sides of 65,536 for one configuration
+        id0 = 65_000 if ny == 1400 else 0                       # (the ids the items carry: a window of a larger set)
+        Y = np.sort(rng.integers(0, 1 << bits, (ny, s), dtype=np.uint64), axis=1)
+        for q in range(0, ny, 9):
+            e = int(rng.integers(1, s))
+            Y[q, e] = Y[q, e - 1]
+        for q in range(3, ny, 40):
+            Y[q, 5:5 + 1 + q % 3] = Y[q, 5]
+        Y.sort(axis=1)
+        maxval = int(Y[:, -1].max())
+        g = _plan4(maxval, nbk_log2, s, 41, 1024)
+        assert g is not None
+        shift, nc = g["shift"], g["nc"]
+        fpc_log2 = 16 - shift
+        per = 32 // field_bits
+        ncols = id0 + ny
+        ndw = (((ncols + per - 1) // per) + 7) & ~7
+        G = 2 if ncols > 65536 else 1
+        # ---- check pass: histogram per (coarse, group), the list of repeated hashes
+        ids = id0 + np.arange(ny)
+        hist = np.zeros((nc, G), np.int64)
+        dups = []
+        for q in range(ny):
+            np.add.at(hist[:, ids[q] >> 16], (Y[q] >> np.uint64(16)).astype(np.int64), 1)
+            e = 0
+            while e < s:
+                a = 1
+                while e + a < s and Y[q, e + a] == Y[q, e]:
+                    a += 1
+                for k in range(1, a):
+                    dups.append((int(Y[q, e]), int(ids[q]), k))
+                e += a
+        c4start = np.concatenate([[0], np.cumsum(hist.reshape(-1))])
+        # ---- level 1: every item to its (coarse, group) segment, in a shuffled order inside it
+        cur = c4start[:-1].copy()
+        inter = np.zeros(ny * s, np.uint32)
+        order = rng.permutation(ny * s)
+        flatv, flati = Y.reshape(-1), np.repeat(ids, s)
+        for t in order:
+            v, i = int(flatv[t]), int(flati[t])
+            seg = (v >> 16) * G + (i >> 16)
+            inter[cur[seg]] = ((v & 0xFFFF) << 16) | (i & 0xFFFF)
+            cur[seg] += 1
+        assert (cur == c4start[1:]).all()
+        # ---- level 2: per coarse bucket, counting sort by fine bucket; compact items with occurrence number 0
+        kmul = ((1 << 32) + ndw - 1) // ndw
+        items = np.zeros(ny * s, np.uint32)
+        start = np.zeros((nc << fpc_log2) + 1, np.int64)
+        low_mask = (1 << shift) - 1
+
+        def compact_of(rem16, col, occ1):
+            k = (col * kmul) >> 32
+            assert k == col // ndw
+            return ((rem16 & low_mask) << (32 - shift)) | (occ1 << CK_LOW) | ((col - k * ndw) << 5) | (k * field_bits)
+        for c in range(nc):
+            lo, mid, hi = c4start[c * G], c4start[c * G + G - 1], c4start[c * G + G]
+            it = inter[lo:hi].astype(np.int64)
+            fine = it >> (16 + shift)
+            cnt = np.bincount(fine, minlength=1 << fpc_log2)
+            st = lo + np.concatenate([[0], np.cumsum(cnt)])[:-1]
+            start[(c << fpc_log2):((c + 1) << fpc_log2)] = st
+            cursor = st.copy()
+            for p in range(hi - lo):
+                col = int(it[p] & 0xFFFF) | (65536 if (G == 2 and lo + p >= mid) else 0)
+                items[cursor[fine[p]]] = compact_of(int(it[p] >> 16), col, 1)
+                cursor[fine[p]] += 1
+        start[nc << fpc_log2] = ny * s
+        occ_mask = ((1 << (11 - shift)) - 1) << CK_LOW
+        for v, i, k in dups:  # the number-th (0-based) of the equal items of the fine bucket, in slot order, gets the number
+            fb = v >> shift
+            want = compact_of(v & 0xFFFF, i, 1)
+            seen = 0
+            for at in range(start[fb], start[fb + 1]):
+                if ((int(items[at]) ^ want) & ~occ_mask & 0xFFFFFFFF) == 0:
+                    if seen == k:
+                        items[at] = (want & ~occ_mask) | ((k + 1) << CK_LOW)
+                        break
+                    seen += 1
+            else:
+                raise AssertionError("a logged copy without a slot")
+        # ---- decode: the multiset of (hash, sketch, occurrence number)
+        got = []
+        for fb in range(nc << fpc_log2):
+            for at in range(start[fb], start[fb + 1]):
+                w = int(items[at])
+                low = w >> (32 - shift)
+                occ = ((w & occ_mask) >> CK_LOW) - 1
+                dword, fsh = (w >> 5) & 0xFFFF, w & 31
+                col = (fsh // field_bits) * ndw + dword
+                got.append(((fb << shift) | low, col, occ))
+        want = []
+        for q in range(ny):
+            e = 0
+            while e < s:
+                a = 1
+                while e + a < s and Y[q, e + a] == Y[q, e]:
+                    a += 1
+                want += [(int(Y[q, e]), int(ids[q]), k) for k in range(a)]
+                e += a
+        assert sorted(got) == sorted(want), (ny, s, bits)
