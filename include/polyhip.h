@@ -464,7 +464,11 @@ int polyhip_sw_last_packed_half(void);
  * half-float condition below (POLYHIP_TB_HALF2=0 or POLYHIP_TB_F16=0: path 4 instead; testing aids), 6 = the half-float
  * kernel for EVERY PAIR ITS OWN B (reads against reads): reads of at most 152 symbols, at most six symbol codes, score
  * given, the half-float condition -- a lane builds its own profile from its pair's B symbols (tb_pair16_kernel;
- * POLYHIP_TB_PAIR16=0 or POLYHIP_TB_F16=0: path 2 instead; testing aids). */
+ * POLYHIP_TB_PAIR16=0 or POLYHIP_TB_F16=0: path 2 instead; testing aids), 7 = the one-wave-per-pair kernel for reads of
+ * 257..1024 symbols with its sweep on a BYTE PROFILE of the pair in LDS (eight instructions per cell instead of sixteen):
+ * gap <= -1, smax - gap <= 127, smin - gap >= -128, the planes of four pairs fit 64 KB (shared or per-pair B;
+ * POLYHIP_TB_WAVE8=0: path 4 instead; testing aid).  Paths 4 and 7 walk out of the wave's registers on the scalar unit
+ * (reads of at most 1024 symbols; POLYHIP_TB_WALKREG=0: a global load per step as before; testing aid). */
 int polyhip_sw_traceback_last_path(void);
 /* 1 when that call's byte-profile kernel (path 1) ran in its half-float form (gfx950: packed halves, two bands of rows
  * per lane, nine instructions per cell pair instead of eighteen) -- taken under the packed score pass's condition

@@ -1591,7 +1591,16 @@ struct WavePack {
     static constexpr int SP = 32 / FB;
 };
 
-template <int R>
+// P8 (R = 8 or 16; round 5): the sweep on a BYTE PROFILE of the pair in LDS.  The wave writes, per B code b, the R bytes
+// score(row, b) - gap of every lane's rows side by side (plane b: 64 lanes x R bytes), so a step costs a lane ONE ds_read
+// (b64 / b128) for its whole column instead of a table lookup per cell, the byte goes into the add by operand selection, and
+// with H + gap kept instead of H (left and up both arrive with the gap added; the profile carries - gap) the cell is
+//     x = diag' + byte;  t = max(up', left');  G = t > x;  L = left' > up';  h = max3(x, t, 0);  h' = h + gap
+// -- eight instructions against sixteen.  G compares with x, not with max(x, 0): the two differ only where h = 0, and the
+// walk never reads the bits of such a cell (it stops at h = 0).  Lanes outside the window need no select: a lane that has
+// not started sees pad codes (score 0) over zeros and stays at zero; what a lane computes past its last column is read by
+// nobody (the lane below is one column behind).  Condition (host): smax - gap <= 127, smin - gap >= -128, the planes fit.
+template <int R, bool P8 = false>
 __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
     const uint8_t *__restrict__ Bbase, const uint64_t *__restrict__ offB, const uint8_t *__restrict__ codeA,
@@ -1611,6 +1620,8 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     cA[tid] = codeA[tid];
     cB[tid] = codeB[tid];
     __syncthreads();
+    // P8: this wave's planes behind the tables, 16-byte aligned
+    uint8_t *prof8 = reinterpret_cast<uint8_t *>(T) + ((((size_t)na * nb * 4 + 512) + 15) & ~(size_t)15) + (size_t)(tid >> 6) * ((size_t)nb * R * 64);
     const uint64_t wslot = (uint64_t)blockIdx.x * (THREADS / 64) + (tid >> 6);
     const uint64_t pair = pair0 + wslot;
     if (pair >= pair1)
@@ -1628,17 +1639,25 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     }
     uint32_t len = 0;
     if (eA > 0 && eB > 0 && M > 0 && lenA <= 64u * R) {
-        const uint32_t mycols = pair_window(wcols, eA, M, smax, gap, wide);
+        const uint32_t mycols = pair_window(wcols, eA, M, smax, gap, wide & 1);
         const uint32_t c_s = eB > mycols ? eB - mycols + 1u : 1u; // first column (1-based) of the window
         const uint32_t ncol = eB - c_s + 1u;
         uint32_t ro[R];
+        constexpr int NAB = R <= 16 ? (R + 3) / 4 : 1;
+        uint32_t abytes[NAB]; // R <= 16: the lane's rows' symbols, for the walk
+#pragma unroll
+        for (int q = 0; q < NAB; ++q)
+            abytes[q] = 0u;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
             const uint32_t r = (uint32_t)lane * R + k;
             uint32_t code = (uint32_t)(na - 1);
             if (r < lenA) {
-                const uint32_t c = cA[ap[r]];
+                const uint32_t sym = ap[r];
+                const uint32_t c = cA[sym];
                 code = c == 0xFFu ? (uint32_t)(na - 1) : c;
+                if constexpr (R <= 16)
+                    abytes[k >> 2] |= sym << (8 * (k & 3));
             }
             ro[k] = code * (uint32_t)nb;
         }
@@ -1661,6 +1680,102 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
         const uint32_t steps = ncol + 63u;
         uint32_t acc = 0u; // the word being filled (R <= 16)
         bool accany = false;
+        if constexpr (P8) {
+            static_assert(R == 8 || R == 16, "byte-profile sweep: 8 or 16 rows per lane");
+            constexpr int BITS = WavePack<R>::BITS, FB = WavePack<R>::FB, SP = WavePack<R>::SP;
+            constexpr int NQ = R / 4;
+            // the planes: byte (b, lane, k) = score(row lane * R + k, b) - gap
+            for (int b = 0; b < nb; ++b) {
+                uint32_t w[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    w[q] = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        w[q] |= ((uint32_t)(T[ro[q * 4 + k] + b] - gap) & 0xFFu) << (8 * k);
+                }
+                uint32_t *dst = reinterpret_cast<uint32_t *>(prof8 + ((size_t)b * 64 + lane) * R);
+                if constexpr (R == 16)
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                else
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(w[0], w[1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            int lg[R]; // H + gap of the lane's rows, previous column
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                lg[k] = gap;
+            int tprev = gap, lastg = gap;
+            // (two steps per trip: the new H + gap of a row cannot overwrite the old one while the row below still needs it
+            // as its diagonal, so a single-step loop ends in R register copies; steps + 1 when odd -- the extra step is
+            // outside every lane's window and stores nothing)
+            auto one = [&](uint32_t s) __attribute__((always_inline)) {
+                int top_in = from_lane_below(lastg);
+                uint32_t b_in = (uint32_t)from_lane_below((int)last_b);
+                const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
+                if (lane == 0) {
+                    top_in = gap;
+                    b_in = b_new;
+                }
+                uint32_t pw[NQ];
+                {
+                    const uint8_t *src = prof8 + ((size_t)b_in * 64 + lane) * R;
+                    if constexpr (R == 16) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                        pw[0] = v.x, pw[1] = v.y, pw[2] = v.z, pw[3] = v.w;
+                    } else {
+                        const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                        pw[0] = v.x, pw[1] = v.y;
+                    }
+                }
+                const uint32_t jr = s - (uint32_t)lane; // wraps for lanes that have not started
+                const bool valid = jr < ncol;
+                int diag = tprev, up = top_in;
+                uint32_t gw = 0u, lw = 0u;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int left = lg[k];
+                    const int x = diag + (int)(int8_t)(pw[k >> 2] >> (8 * (k & 3)));
+                    const int t = max(up, left);
+#ifdef PH_TB_BITS_ALIGN // (ablation: the bit through v_sub + v_alignbit instead of v_cmp + v_addc -- no VCC between the two)
+                    gw = __builtin_amdgcn_alignbit(gw, (uint32_t)(x - t), 31);
+                    lw = __builtin_amdgcn_alignbit(lw, (uint32_t)(up - left), 31);
+#else
+                    PH_CARRY_BIT(gw, t, x);
+                    PH_CARRY_BIT(lw, left, up);
+#endif
+                    const int hg = max(max(x, t), 0) + gap;
+                    diag = left;
+                    up = hg;
+                    lg[k] = hg;
+                }
+                tprev = top_in;
+                lastg = lg[R - 1];
+                last_b = b_in;
+                const uint32_t sub = s % SP;
+                if (valid) {
+                    acc |= (gw | (lw << BITS)) << (sub * FB);
+                    accany = true;
+                }
+                if (sub == SP - 1) {
+                    if (accany)
+                        dirw[(size_t)(s / SP) * 64 * NWL] = acc;
+                    acc = 0u;
+                    accany = false;
+                }
+            };
+            const uint32_t steps2 = (steps + 1u) & ~1u;
+            for (uint32_t s = 0; s < steps2; s += 2) {
+                if ((s & 63u) == 0u) {
+                    if (s)
+                        chunk = next_chunk;
+                    next_chunk = load_chunk(s + 64u);
+                }
+                one(s);
+                one(s + 1u);
+            }
+        } else
         for (uint32_t s = 0; s < steps; ++s) {
             if ((s & 63u) == 0u) {
                 if (s)
@@ -1726,6 +1841,110 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
         uint32_t i = eA, j = eB;
         int h = (int)M;
         const uint32_t *dbase = dirbuf + wslot * ((size_t)(wcols + 63u) * 64 * NWL);
+        if (wide & 4) { // POLYHIP_TB_NOWALK=1: ablation probe -- what does the sweep cost on its own?
+        } else if (R <= 16 && !(wide & 8)) {
+            // Round 5: the walk out of the wave's REGISTERS, steered by the scalar unit.  A step of the plain walk below is
+            // one dependent HBM round trip (272 KB of direction words per 1 kb pair: nothing of it stays in a cache) and
+            // ~60 vector instructions that every lane executes for lane 0's two bytes.  Here the wave fetches, in ONE
+            // round trip, the words of the next 32 steps of the lane row the walk is in and of the one above (lane q: word
+            // wtop[q >> 5] - (q & 31) of lane row lc - (q >> 5)); a step reads its word with v_readlane and only a step that
+            // leaves the window fetches again (a diagonal leaves it after ~30 steps).  The B symbols (with their codes) come
+            // the same way, 64 at a time; the A symbols sit in the registers of the lane that owns the row.  Position,
+            // score and windows live in SGPRs (every value that comes back from the vector side goes through
+            // v_readfirstlane), so a step is ~40 scalar instructions beside the sweeps of the other waves, not 4 x 60
+            // cycles of their SIMD.  Lane len % 64 keeps a step's two bytes; 64 steps go out as one store per string (a store
+            // per step would put a wait for its completion in front of every step: the fetches share the counter).
+            constexpr int SP = WavePack<R>::SP, FB = WavePack<R>::FB, BITS = WavePack<R>::BITS;
+#define PH_SGPR(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+            uint32_t wi_ = PH_SGPR(i), wj_ = PH_SGPR(j), wlen = 0u;
+            int wh_ = (int)PH_SGPR(h);
+            const uint32_t cs_ = PH_SGPR(c_s), stride_ = PH_SGPR(stride), gap_ = PH_SGPR(gap), nb_ = PH_SGPR(nb);
+            const uint32_t padA = PH_SGPR(na - 1), padB = PH_SGPR(nb - 1);
+            const uint32_t m_ = (uint32_t)lane >> 5, x_ = (uint32_t)lane & 31u;
+            uint32_t lc = 0xFFFFFFF0u;        // lane row of window 0 (none yet)
+            uint32_t wtop0 = 0u, wtop1 = 0u;  // newest word of the two windows
+            uint32_t cw = 0u;                 // my word of them
+            uint32_t btop = 0xFFFFFFFFu;      // lane q: B[btop - q] | code << 8 (none yet: jb > btop never holds, btop - jb > 63 does)
+            uint32_t bwin = 0u;
+            uint32_t mya = 0u, myb = 0u;      // lane q: the bytes of step (wlen & ~63) + q
+            while (wh_ > 0 && wi_ > 0u && wj_ >= cs_ && wlen < stride_) {
+                const uint32_t r = wi_ - 1u, l = r / R, k = r % R;
+                const uint32_t s = (wj_ - cs_) + l, wi = s / SP;
+                const uint32_t m = lc - l;
+                const uint32_t top = m == 0u ? wtop0 : wtop1;
+                if (!(m <= 1u && wi <= top && top - wi < 32u)) { // fetch: window 0 from here, window 1 one column less
+                    lc = l;
+                    wtop0 = wi;
+                    wtop1 = s ? (s - 1u) / SP : 0u;
+                    const uint32_t wt = m_ ? wtop1 : wtop0;
+                    // (no branch on a lane's own condition here: with one, the compiler merges it with the `continue` and takes
+                    // the whole loop for divergent -- every scalar below becomes a vector instruction under an exec mask)
+                    const bool ok = (l >= m_) & (x_ <= wt) & ((m_ == 0u) | (s > 0u));
+                    cw = __hip_atomic_load(dbase + (ok ? ((size_t)(wt - x_) * 64 + (l - m_)) * NWL : (size_t)0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cw = ok ? cw : 0u;
+                    continue;
+                }
+                const uint32_t jb = wj_ - 1u;
+                if (jb > btop || btop - jb > 63u) {
+                    btop = jb;
+                    const bool okb = (uint32_t)lane <= jb;
+                    const uint32_t sym = B[okb ? jb - (uint32_t)lane : 0u];
+                    const uint32_t kb = cB[sym];
+                    bwin = okb ? sym | ((kb == 0xFFu ? padB : kb) << 8) : 0u;
+                    continue;
+                }
+                const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)cw, (int)(m * 32u + (top - wi))) >> ((s % SP) * FB);
+                const uint32_t gbit = (w >> (R - 1 - k)) & 1u;
+                const uint32_t lbit = (w >> (BITS + R - 1 - k)) & 1u;
+                uint32_t aw = abytes[0];
+#pragma unroll
+                for (int q = 1; q < NAB; ++q)
+                    aw = (k >> 2) == (uint32_t)q ? abytes[q] : aw;
+                const uint32_t sa = ((uint32_t)__builtin_amdgcn_readlane((int)aw, (int)l) >> (8u * (k & 3u))) & 0xFFu;
+                const uint32_t bw = (uint32_t)__builtin_amdgcn_readlane((int)bwin, (int)(btop - jb));
+                const uint32_t sb = bw & 0xFFu;
+                uint32_t ca, cb;
+                if (gbit == 0u) { // align.go:215-219
+                    if constexpr (P8) { // the byte profile has the score of (row, code) in one read: score - gap
+                        wh_ -= (int)(int8_t)PH_SGPR(prof8[(((bw >> 8) * 64u + l) * R) + k]) + (int)gap_;
+                    } else {
+                        const uint32_t ka = PH_SGPR(cA[sa]);
+                        wh_ -= (int)PH_SGPR(T[(ka == 0xFFu ? padA : ka) * nb_ + (bw >> 8)]);
+                    }
+                    ca = sa;
+                    cb = sb;
+                    --wi_;
+                    --wj_;
+                } else if (lbit == 0u) { // :220-223
+                    wh_ -= (int)gap_;
+                    ca = sa;
+                    cb = '-';
+                    --wi_;
+                } else { // :224-227
+                    wh_ -= (int)gap_;
+                    ca = '-';
+                    cb = sb;
+                    --wj_;
+                }
+                if ((uint32_t)lane == (wlen & 63u)) {
+                    mya = ca;
+                    myb = cb;
+                }
+                ++wlen;
+                if ((wlen & 63u) == 0u) {
+                    const uint32_t pos = wlen - 64u + (uint32_t)lane;
+                    outA[stride - 1 - pos] = (uint8_t)mya;
+                    outB[stride - 1 - pos] = (uint8_t)myb;
+                }
+            }
+#undef PH_SGPR
+            if ((uint32_t)lane < (wlen & 63u)) {
+                const uint32_t pos = (wlen & ~63u) + (uint32_t)lane;
+                outA[stride - 1 - pos] = (uint8_t)mya;
+                outB[stride - 1 - pos] = (uint8_t)myb;
+            }
+            len = wlen;
+        } else
         while (h > 0 && i > 0 && j >= c_s && len < stride) {
             const uint32_t r = i - 1u, l = r / R, k = r % R;
             const uint32_t s = (j - c_s) + l;
@@ -2314,6 +2533,9 @@ struct Plan {
     // one wave per pair for 256 < lenA <= 4096 (score known): tb_wave_kernel
     int wave_r;            // 0 = not applicable
     size_t wave_per_pair;
+    // ... with the sweep on a byte profile of the pair in LDS (tb_wave_kernel<R, true>): 257..1024 rows, scores - gap in int8
+    bool wave8_ok;
+    size_t wave8_smem;
 };
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -2345,6 +2567,9 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
         const size_t nwl = p.wave_r <= 16 ? 1 : 2 * ((p.wave_r + 31) / 32);
         p.wave_per_pair = ((size_t)p.win.wcols + 63) * 64 * nwl * 4;
         p.per_pair = std::max(p.per_pair, p.wave_per_pair);
+        p.wave8_smem = align_up(p.smem, 16) + (size_t)(THREADS / 64) * nb * p.wave_r * 64;
+        p.wave8_ok = (p.wave_r == 8 || p.wave_r == 16) && sc->gap <= -1 && -sc->gap <= 127 && (int64_t)sc->smax - sc->gap <= 127 &&
+                     (int64_t)sc->smin - sc->gap >= -128 && p.wave8_smem <= 64 * 1024;
     }
     p.pair16_ok = reg && (p.ra == 64 || p.ra == 152) && sc->ncodes <= 6 && sc->int8_ok && sc->gap <= -1 && sc->smax > 0 && lenB > 0 &&
                   (uint64_t)sc->smax * std::min<uint64_t>(max_lenA, lenB) <= 2047ull && (int64_t)sc->smax - sc->gap <= 2048;
@@ -2627,12 +2852,15 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     // every pair its own B, rows <= 152, on packed halves (path 6; POLYHIP_TB_PAIR16=0 or POLYHIP_TB_F16=0: the table kernel)
     const bool use_pair16 = p.pair16_ok && d_offB != nullptr && d_score != nullptr && d_B != nullptr && !use_wave &&
                             !env_is("POLYHIP_TB_F16", '0') && !env_is("POLYHIP_TB_PAIR16", '0');
-    k3t::g_tb_last_path = use_pair16 ? 6 : use_half2 ? 5 : use_prof ? 1 : use_wave ? 4 : (p.ra ? 2 : 3);
+    // 257..1024 rows: the one-wave-per-pair kernel's sweep on a byte profile of the pair (path 7; POLYHIP_TB_WAVE8=0: path 4)
+    const bool use_wave8 = use_wave && p.wave8_ok && !env_is("POLYHIP_TB_WAVE8", '0');
+    k3t::g_tb_last_path = use_pair16 ? 6 : use_half2 ? 5 : use_prof ? 1 : use_wave8 ? 7 : use_wave ? 4 : (p.ra ? 2 : 3);
     // only the byte-profile kernels know a deferred end cell: the fused entry point decided with traceback_uses_prof();
     // should the two conditions ever drift apart, fail here instead of walking from row 4e9
     PH_REQUIRE(!deferred || use_prof || use_half2, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
     // bit 0: the conservative per-pair window (POLYHIP_TB_WIDE=1, testing aid); bit 1: deferred end cells allowed
-    const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0) | (env_is("POLYHIP_TB_NOWALK", '1') ? 4 : 0);
+    const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0) | (env_is("POLYHIP_TB_NOWALK", '1') ? 4 : 0) |
+                     (env_is("POLYHIP_TB_WALKREG", '0') ? 8 : 0); // bit 3: the one-wave-per-pair kernel's plain walk (testing aid)
     PH_REQUIRE(work_bytes >= p.prof_bytes + 256, "polyhip_sw_traceback: workspace too small (%zu B)", work_bytes);
     const size_t usable = (work_bytes - p.prof_bytes) & ~(size_t)255;
     // (the two-lane kernel's direction words take a quarter of the one-wave-per-pair kernel's, which sizes the workspace of
@@ -2736,7 +2964,20 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err, d_score, \
                            (int)sc->smax, p.win.wcols, wide, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);           \
     } while (0)
-            if (p.wave_r == 2)
+#define PH_TBW8_LAUNCH(R_)                                                                                            \
+    do {                                                                                                              \
+        auto kern = k3t::tb_wave_kernel<R_, true>;                                                                    \
+        PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                   (int)p.wave8_smem));                                                               \
+        hipLaunchKernelGGL(kern, dim3(wblocks), dim3(k3t::THREADS), p.wave8_smem, st, d_A, d_offA, p0, p1, d_B, d_offB, \
+                           sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, d_endA, d_endB, d_err, d_score, \
+                           (int)sc->smax, p.win.wcols, wide, dirbuf, d_alnA, d_alnB, d_alnLen, aln_stride);           \
+    } while (0)
+            if (use_wave8 && p.wave_r == 8)
+                PH_TBW8_LAUNCH(8);
+            else if (use_wave8)
+                PH_TBW8_LAUNCH(16);
+            else if (p.wave_r == 2)
                 PH_TBW_LAUNCH(2);
             else if (p.wave_r == 3)
                 PH_TBW_LAUNCH(3);
@@ -2751,6 +2992,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
             else
                 PH_TBW_LAUNCH(64);
 #undef PH_TBW_LAUNCH
+#undef PH_TBW8_LAUNCH
             PH_HIP(hipGetLastError());
             continue;
         }

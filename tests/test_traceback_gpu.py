@@ -483,7 +483,8 @@ def test_three_kernels_and_both_window_bounds_agree(al, monkeypatch, tb_cell, ga
         assert a_h[p, stride - l_h[p]:].tobytes() == sa and b_h[p, stride - l_h[p]:].tobytes() == sb, p
 
 
-@pytest.mark.parametrize("maxA,LB,shared", [(300, 900, True), (700, 1500, True), (1200, 1300, False), (2600, 700, True), (4096, 300, False)])
+@pytest.mark.parametrize("maxA,LB,shared", [(300, 900, True), (700, 1500, True), (512, 600, False), (1024, 1100, False), (1200, 1300, False),
+                                            (2600, 700, True), (4096, 300, False)])
 def test_long_reads_wave_kernels(al, monkeypatch, maxA, LB, shared):
     """reads longer than the 256 rows a lane holds (257..4096): the one-wave-per-pair score kernel (path 6) and
     traceback kernel (path 4) against the generic kernels (POLYHIP_SW_WAVE=0 / POLYHIP_TB_WAVE=0) on every pair and
@@ -512,7 +513,17 @@ def test_long_reads_wave_kernels(al, monkeypatch, maxA, LB, shared):
     else:
         B, offB = _pack(refs)
     got = align.sw_align_packed(sc, A, offA, B, offB)
-    assert (align.last_path(), align.sw_traceback_last_path()) == (6, 4)
+    # (up to 1024 rows the traceback kernel sweeps on a byte profile of the pair in LDS: path 7; POLYHIP_TB_WAVE8=0: its
+    # table form, path 4 -- every pair equal)
+    assert (align.last_path(), align.sw_traceback_last_path()) == (6, 7 if maxA <= 1024 else 4)
+    if maxA <= 1024:
+        monkeypatch.setenv("POLYHIP_TB_WAVE8", "0")
+        tab = align.sw_align_packed(sc, A, offA, B, offB)
+        monkeypatch.delenv("POLYHIP_TB_WAVE8", raising=False)
+        assert (align.last_path(), align.sw_traceback_last_path()) == (6, 4)
+        for g, w in zip(got[:4], tab[:4]):
+            assert (np.asarray(g) == np.asarray(w)).all()
+        assert got[4] == tab[4] and got[5] == tab[5]
     monkeypatch.setenv("POLYHIP_SW_WAVE", "0")
     monkeypatch.setenv("POLYHIP_TB_WAVE", "0")
     base = align.sw_align_packed(sc, A, offA, B, offB)
@@ -525,6 +536,53 @@ def test_long_reads_wave_kernels(al, monkeypatch, maxA, LB, shared):
         sa = sa if isinstance(sa, bytes) else sa.encode()
         sb = sb if isinstance(sb, bytes) else sb.encode()
         assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s, ea, eb) and got[4][p] == sa and got[5][p] == sb, p
+
+
+@pytest.mark.parametrize("hi,lo,gap,path", [(118, -100, -9, 7), (119, -100, -9, 4), (40, -137, -9, 7), (40, -138, -9, 4), (9, -9, -118, 7), (9, -9, -119, 4)])
+def test_long_reads_byte_profile_limits(al, monkeypatch, hi, lo, gap, path):
+    """the byte-profile sweep of the one-wave-per-pair traceback (path 7) keeps score - gap in a byte: matrices at both ends
+    of that range take it, one step beyond they take the table form (path 4); every pair equal to the generic kernel, a
+    sample equal to the oracle.  Six symbols, ragged lengths around 16 rows per lane, shared and per-pair B in one go."""
+    align = al[0]
+    rng = np.random.default_rng(hi * 1000 - lo)
+    syms = "ACGTNU"
+    mat = rng.integers(lo, hi + 1, (6, 6))
+    mat[0, 0], mat[1, 2] = hi, lo
+    mat[np.arange(6), np.arange(6)] = np.maximum(mat[np.arange(6), np.arange(6)], 1)
+    scores = [[int(v) for v in row] for row in mat]
+    sc = _scoring(al, syms, scores, gap)
+    om = orc.SubstitutionMatrix(syms, syms, scores)
+    n, maxA = 40, 600
+    symb = np.frombuffer(syms.encode(), np.uint8)
+    refs = [symb[rng.integers(0, 6, int(rng.integers(200, 900)))].tobytes() for _ in range(n)]
+    reads = []
+    for p in range(n):
+        L = int(rng.integers(257, maxA + 1)) if p else maxA
+        src = refs[p] * (L // len(refs[p]) + 2)
+        at = int(rng.integers(0, len(refs[p])))
+        r = bytearray(src[at:at + L])
+        for q in rng.integers(0, L, L // 12):
+            r[q] = int(symb[rng.integers(0, 6)])
+        reads.append(bytes(r))
+    A, offA = _pack(reads)
+    for shared in (True, False):
+        B, offB = (_pack([refs[0]])[0], None) if shared else _pack(refs)
+        got = align.sw_align_packed(sc, A, offA, B, offB)
+        assert align.sw_traceback_last_path() == path
+        monkeypatch.setenv("POLYHIP_SW_WAVE", "0")
+        monkeypatch.setenv("POLYHIP_TB_WAVE", "0")
+        base = align.sw_align_packed(sc, A, offA, B, offB)
+        assert align.sw_traceback_last_path() == 3
+        monkeypatch.delenv("POLYHIP_SW_WAVE", raising=False)
+        monkeypatch.delenv("POLYHIP_TB_WAVE", raising=False)
+        for g, w in zip(got[:4], base[:4]):
+            assert (np.asarray(g) == np.asarray(w)).all()
+        assert got[4] == base[4] and got[5] == base[5]
+        for p in range(0, n, 13):
+            s_, sa, sb, ea, eb = orc.smith_waterman(reads[p], refs[0] if shared else refs[p], om, gap)
+            sa = sa if isinstance(sa, bytes) else sa.encode()
+            sb = sb if isinstance(sb, bytes) else sb.encode()
+            assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s_, ea, eb) and got[4][p] == sa and got[5][p] == sb, p
 
 
 def test_long_reads_chunked_workspace(al):
@@ -562,7 +620,7 @@ def test_long_reads_chunked_workspace(al):
         ln = torch.zeros(n, dtype=torch.int32, device=dev)
         align.sw_traceback_dev(sc, A, offA, maxA, B, None, LB, ea, eb, er, a, b, ln, tbw, score_t=score)
         torch.cuda.synchronize()
-        assert align.sw_traceback_last_path() == 4
+        assert align.sw_traceback_last_path() == 7
         outs.append((a, b, ln))
     for x, y in zip(outs[0], outs[1]):
         assert torch.equal(x, y)
