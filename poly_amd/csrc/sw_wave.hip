@@ -33,7 +33,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     const int32_t *__restrict__ lutcc, int na, int nb, int gap, const uint32_t *__restrict__ binfo,
     const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, const uint32_t *__restrict__ infoM,
     const uint32_t *__restrict__ infoQ, int smax, int64_t *__restrict__ score,
-    uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+    uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err, int m0_only)
 {
     extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb] (last row / column: pad, zeros), codeA, codeB
     uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
@@ -50,6 +50,8 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     for (uint64_t w = (uint64_t)blockIdx.x * (THREADS / 64) + (tid >> 6); w < total;
          w += (uint64_t)gridDim.x * (THREADS / 64)) {
     const uint64_t pair = list ? (uint64_t)list[w] : w;
+    if (m0_only && infoM[pair] != 0u)
+        continue; // sw_wave8_kernel located this pair's maximum
 
     // shared reference, or this pair's own B
     const uint8_t *B = offB ? Bbase + offB[pair] : Bbase;
@@ -224,6 +226,216 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     } // work items
 }
 
+// ---- locate mode on a BYTE PROFILE of the pair (round 5; reads of 257..1024 rows against one reference) ----------
+// The packed pass knows the maximum M of a pair; what is left is the first cell, in row-major order, that holds it.  So
+// the sweep needs no argmax -- it needs the recurrence and one question per step, "did a cell of mine reach M?":
+//   * the wave writes, per B code b, the R bytes score(row, b) - gap of every lane's rows side by side into LDS (plane b:
+//     64 lanes x R bytes; rows behind the read's end: -128, they fade out and can never hold M), so a step costs a lane
+//     ONE ds_read (b64 / b128) instead of a table lookup per cell, and the byte goes into the add by operand selection;
+//   * H + gap is kept instead of H (left and up both arrive with the gap added, the profile carries - gap):
+//         x = diag' + byte;  t = max(up', left');  h' = max3(x, t, 0) + gap          -- four instructions per cell
+//   * the step's largest h' (one v_max3 per two cells) is compared with M + gap; only a wave in which some lane says
+//     yes looks at its rows (smaller row wins, then the earlier column: columns come in order).
+// 4.5 instructions per cell against ten (table lookup, validity select, running best per row).  A lane that has not
+// started sees pad codes over zeros and stays at zero; what a lane computes past its last column is masked out of the
+// question and read by nobody.  Pairs without a maximum from the packed pass (M = 0) are left to sw_wave_kernel
+// (m0_only).  Condition (host): gap <= -1, smax - gap <= 127, smin - gap >= -128, the planes of four pairs fit LDS.
+template <int R>
+__global__ __launch_bounds__(THREADS) void sw_wave8_kernel(
+    const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t npairs, const uint8_t *__restrict__ B,
+    uint32_t lenB, const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
+    const int32_t *__restrict__ lutcc, int na, int nb, int gap, const uint32_t *__restrict__ infoM,
+    const uint32_t *__restrict__ infoQ, int smax, int64_t *__restrict__ score, uint32_t *__restrict__ endA,
+    uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+{
+    static_assert(R == 8 || R == 16, "byte-profile sweep: 8 or 16 rows per lane");
+    constexpr int NQ = R / 4;
+    extern __shared__ __attribute__((aligned(16))) int32_t T[]; // [na][nb], codeA, codeB, then the waves' planes
+    uint8_t *cA = reinterpret_cast<uint8_t *>(T + (size_t)na * nb);
+    uint8_t *cB = cA + 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int t = tid; t < na * nb; t += THREADS)
+        T[t] = lutcc[t];
+    cA[tid] = codeA[tid];
+    cB[tid] = codeB[tid];
+    __syncthreads();
+    uint8_t *prof8 = reinterpret_cast<uint8_t *>(T) + ((((size_t)na * nb * 4 + 512) + 15) & ~(size_t)15) + (size_t)(tid >> 6) * ((size_t)nb * R * 64);
+
+    for (uint64_t pair = (uint64_t)blockIdx.x * (THREADS / 64) + (tid >> 6); pair < npairs; pair += (uint64_t)gridDim.x * (THREADS / 64)) {
+        const uint32_t M = infoM[pair], iq = infoQ[pair];
+        if (M == 0u)
+            continue; // nothing positive, or a read the packed pass did not take: sw_wave_kernel's
+        const uint64_t o0 = offA[pair];
+        const uint64_t l64 = offA[pair + 1] - o0;
+        const bool too_long = l64 > (uint64_t)(64 * R);
+        const uint32_t lenA = too_long ? 0u : (uint32_t)l64;
+        const uint8_t *ap = A + o0;
+        uint32_t ro[R]; // code * nb; 0xFFFFFFFF behind the read's end
+        uint32_t mybad = 0xFFFFFFFFu;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const uint32_t r = (uint32_t)lane * R + k;
+            uint32_t v = 0xFFFFFFFFu;
+            if (r < lenA) {
+                const uint32_t c = cA[ap[r]];
+                if (c == 0xFFu)
+                    mybad = min(mybad, r);
+                v = (c == 0xFFu ? (uint32_t)(na - 1) : c) * (uint32_t)nb;
+            }
+            ro[k] = v;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            mybad = min(mybad, (uint32_t)__shfl_xor((int)mybad, d, 64));
+        uint32_t e = 0;
+        if (too_long) {
+            e = 0xFFFFFFFFu;
+        } else if (lenA > 0 && lenB > 0) { // align.go:189-191 + matrix.go:29-36: row-major first failing cell
+            uint32_t bbad = 0xFFFFFFFFu;   // first byte of B outside SecondAlphabet
+            for (uint32_t j0 = 0; j0 < lenB && bbad == 0xFFFFFFFFu; j0 += 64) {
+                const uint32_t j = j0 + (uint32_t)lane;
+                const uint64_t bad = __ballot(j < lenB && cB[B[j]] == 0xFFu);
+                if (bad)
+                    bbad = j0 + (uint32_t)__builtin_ctzll(bad);
+            }
+            if (mybad == 0u)
+                e = (1u << 8) | ap[0];
+            else if (bbad != 0xFFFFFFFFu)
+                e = (2u << 8) | B[bbad];
+            else if (mybad != 0xFFFFFFFFu)
+                e = (1u << 8) | ap[mybad];
+        }
+        // the window (as sw_wave_kernel's locate mode): only the columns that can feed a cell worth M in the block that holds
+        // it; a maximum seen in several blocks (tie bit): every column
+        uint32_t j0 = 0, ncols = lenB;
+        if ((iq >> 31) == 0u) {
+            const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
+            const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
+            const uint32_t jend = min(4u * (iq & 0x7FFFFFFFu) + 4u, lenB);
+            j0 = jend > need ? jend - need : 0u;
+            ncols = jend - j0;
+        }
+        const uint32_t steps = (e == 0u && lenA > 0 && ncols > 0) ? ncols + 63u : 0u;
+        uint32_t besti = 0xFFFFFFFFu, bestj = 0u;
+        if (steps) {
+            for (int b = 0; b < nb; ++b) {
+                uint32_t w[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    w[q] = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t rk = ro[q * 4 + k];
+                        const int v = rk == 0xFFFFFFFFu ? -128 : T[rk + b] - gap;
+                        w[q] |= ((uint32_t)v & 0xFFu) << (8 * k);
+                    }
+                }
+                uint32_t *dst = reinterpret_cast<uint32_t *>(prof8 + ((size_t)b * 64 + lane) * R);
+                if constexpr (R == 16)
+                    *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+                else
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(w[0], w[1]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            auto load_chunk = [&](uint32_t s0) -> uint32_t { // B codes of window columns s0 + lane
+                uint32_t c = (uint32_t)(nb - 1);
+                if (s0 + (uint32_t)lane < ncols) {
+                    const uint32_t cc = cB[B[j0 + s0 + (uint32_t)lane]];
+                    c = cc == 0xFFu ? (uint32_t)(nb - 1) : cc;
+                }
+                return c;
+            };
+            uint32_t chunk = load_chunk(0), next_chunk = 0u;
+            int lg[R]; // H + gap of the lane's rows, previous column
+#pragma unroll
+            for (int k = 0; k < R; ++k)
+                lg[k] = gap;
+            int tprev = gap, lastg = gap;
+            uint32_t last_b = (uint32_t)(nb - 1);
+            const int Mg = (int)M + gap;
+            // (two steps per trip, as tb_wave_kernel's byte-profile sweep: no register copies at the loop's end)
+            auto one = [&](uint32_t s) __attribute__((always_inline)) {
+                int top_in = from_lane_below(lastg);
+                uint32_t b_in = (uint32_t)from_lane_below((int)last_b);
+                const uint32_t b_new = (uint32_t)__builtin_amdgcn_readlane((int)chunk, (int)(s & 63u));
+                if (lane == 0) {
+                    top_in = gap;
+                    b_in = b_new;
+                }
+                uint32_t pw[NQ];
+                {
+                    const uint8_t *src = prof8 + ((size_t)b_in * 64 + lane) * R;
+                    if constexpr (R == 16) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                        pw[0] = v.x, pw[1] = v.y, pw[2] = v.z, pw[3] = v.w;
+                    } else {
+                        const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                        pw[0] = v.x, pw[1] = v.y;
+                    }
+                }
+                const uint32_t jr = s - (uint32_t)lane; // wraps for lanes that have not started
+                const bool valid = jr < ncols;
+                int diag = tprev, up = top_in;
+                int m = gap;
+#pragma unroll
+                for (int k = 0; k < R; ++k) {
+                    const int left = lg[k];
+                    const int x = diag + (int)(int8_t)(pw[k >> 2] >> (8 * (k & 3)));
+                    const int t = max(up, left);
+                    const int hg = max(max(x, t), 0) + gap;
+                    m = max(m, hg);
+                    diag = left;
+                    up = hg;
+                    lg[k] = hg;
+                }
+                tprev = top_in;
+                lastg = lg[R - 1];
+                last_b = b_in;
+                if (__any(valid && m == Mg)) { // rare: a cell of this column, in some lane, holds M
+                    if (valid) {
+#pragma unroll
+                        for (int k = 0; k < R; ++k) {
+                            const uint32_t r = (uint32_t)lane * R + k;
+                            if (lg[k] == Mg && r < lenA && r < besti) {
+                                besti = r;
+                                bestj = jr;
+                            }
+                        }
+                    }
+                }
+            };
+            const uint32_t steps2 = (steps + 1u) & ~1u;
+            for (uint32_t s = 0; s < steps2; s += 2) {
+                if ((s & 63u) == 0u) {
+                    if (s)
+                        chunk = next_chunk;
+                    next_chunk = load_chunk(s + 64u);
+                }
+                one(s);
+                one(s + 1u);
+            }
+        }
+        bestj += j0; // window-relative so far
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { // the smallest row (rows are distinct across lanes)
+            const uint32_t oi = (uint32_t)__shfl_xor((int)besti, d, 64), oj = (uint32_t)__shfl_xor((int)bestj, d, 64);
+            if (oi < besti) {
+                besti = oi;
+                bestj = oj;
+            }
+        }
+        if (lane == 0) {
+            const bool hit = e == 0u && besti != 0xFFFFFFFFu;
+            score[pair] = hit ? (int64_t)M : 0;
+            endA[pair] = hit ? besti + 1u : 0u;
+            endB[pair] = hit ? bestj + 1u : 0u;
+            // (a maximum the packed pass saw and this sweep does not find cannot happen; if it ever does, say so)
+            err[pair] = (e == 0u && !hit && lenA > 0 && lenB > 0) ? 0xFFFFFFFEu : e;
+        }
+    }
+}
+
 int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
              const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
              const uint32_t *count,
@@ -235,6 +447,29 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
     const uint64_t blocks = std::min<uint64_t>((max_items + THREADS / 64 - 1) / (THREADS / 64), 4096);
     if (blocks == 0)
         return POLYHIP_OK;
+    // locate mode, 257..1024 rows, one reference: the byte-profile kernel takes every pair whose maximum the packed pass
+    // knows; the general kernel below then only the others (POLYHIP_SW_WAVE8=0: the general kernel for all; testing aid)
+    int m0_only = 0;
+    if (infoM && infoQ && !list && !d_offB && max_lenA > 256 && max_lenA <= 1024 && sc->gap <= -1 && -sc->gap <= 127 &&
+        (int64_t)sc->smax - sc->gap <= 127 && (int64_t)sc->smin - sc->gap >= -128 && !env_is("POLYHIP_SW_WAVE8", '0')) {
+        const int r8 = max_lenA <= 512 ? 8 : 16;
+        const size_t smem8 = ((smem + 15) & ~(size_t)15) + (size_t)(THREADS / 64) * nb * r8 * 64;
+        if (smem8 <= 64 * 1024) {
+            if (r8 == 8) {
+                auto kern = sw_wave8_kernel<8>;
+                PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+                hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem8, st, d_A, d_offA, npairs, d_B, lenB, sc->d_codeA,
+                                   sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, infoM, infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err);
+            } else {
+                auto kern = sw_wave8_kernel<16>;
+                PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
+                hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem8, st, d_A, d_offA, npairs, d_B, lenB, sc->d_codeA,
+                                   sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, infoM, infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err);
+            }
+            PH_HIP(hipGetLastError());
+            m0_only = 1;
+        }
+    }
 #define PH_WAVE_LAUNCH(R_)                                                                                            \
     do {                                                                                                              \
         auto kern = sw_wave_kernel<R_>;                                                                               \
@@ -242,7 +477,7 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
                                    (int)smem));                                                                       \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem, st, d_A, d_offA, npairs, d_B, d_offB, lenB, \
                            sc->d_codeA, sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, binfo, list, count, infoM,   \
-                           infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err);                                     \
+                           infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err, m0_only);                            \
     } while (0)
     if (max_lenA <= 64)
         PH_WAVE_LAUNCH(1);

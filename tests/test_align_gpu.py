@@ -453,6 +453,9 @@ def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA,
     lens = rng.integers(maxA // 3, maxA + 1, n)
     lens[0] = maxA
     lens[rng.random(n) < 0.01] = 0
+    for p in range(5, n, 1009):  # a byte outside the alphabet in a few reads (first, last or any position): the error code
+        if lens[p]:
+            reads[p, [0, lens[p] - 1, int(rng.integers(0, lens[p]))][(p // 1009) % 3]] = ord("N")
     offs = np.zeros(n + 1, np.int64)
     offs[1:] = np.cumsum(lens)
     flat = np.concatenate([reads[i, :lens[i]] for i in range(n)])
@@ -482,6 +485,15 @@ def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA,
     assert (path, path0) == (7, 6)
     assert half == (5 * min(maxA, LB) <= 2047)  # 300 and 400 rows stay below 2048: the half-float cell
     for g, w in zip(got, want):
+        assert (g == w).all()
+    assert int((want[3] != 0).sum()) >= n // 1009 - 1
+    # up to 1024 rows the locate step runs on a byte profile of the pair (sw_wave8_kernel); POLYHIP_SW_WAVE8=0: the general
+    # one-wave-per-pair kernel in locate mode
+    monkeypatch.setenv("POLYHIP_SW_WAVE8", "0")
+    got_t, path_t, _ = run(True)
+    monkeypatch.delenv("POLYHIP_SW_WAVE8", raising=False)
+    assert path_t == 7
+    for g, w in zip(got_t, want):
         assert (g == w).all()
     if half:  # ... and the int16 cell on the same batch
         got16, path16, half16 = run(True, half=False)
