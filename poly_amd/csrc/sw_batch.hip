@@ -699,8 +699,8 @@ int polyhip_sw_last_packed_half(void) { return k3::g_last_half; }
 
 } // extern "C"
 
-// the score pass; `defer` != 0 asks the packed path (3, reads of at most 256 rows) to leave the end cell of a pair to
-// the traceback kernel (k3p::SW_END_DEFERRED): *deferred says whether it did
+// the score pass; `defer` != 0 asks the packed paths (3: reads of at most 256 rows; 7: 257..1024 rows with the byte-profile
+// locate kernel) to leave the end cell of a pair to the traceback kernel (k3p::SW_END_DEFERRED): *deferred says whether it did
 int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs,
                             uint32_t max_lenA, const uint8_t *d_B, const uint64_t *d_offB, uint64_t lenB, int64_t *d_score,
                             uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, void *d_work, size_t work_bytes,
@@ -807,8 +807,13 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
                                        &count, st, &infoM, &infoQ);
         if (rc != POLYHIP_OK)
             return rc;
+        // (one call for score + strings, 257..1024 rows: the traceback kernel finds the end cell of a maximum that sits in
+        // one block during its own sweep; the locate step then only takes the ties)
+        const int do_defer = defer && k3w::wave8_ok(sc, max_lenA) ? 1 : 0;
+        if (deferred)
+            *deferred = do_defer;
         return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, nullptr, nullptr, nullptr,
-                             npairs, d_score, d_endA, d_endB, d_err, st, infoM, infoQ);
+                             npairs, d_score, d_endA, d_endB, d_err, st, infoM, infoQ, do_defer);
     }
     if (p.path == 6)
         return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, d_offB, (uint32_t)lenB, nullptr, nullptr, nullptr,

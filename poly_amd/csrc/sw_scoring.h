@@ -140,7 +140,11 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
              const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
              const uint32_t *count,
              uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st,
-             const uint32_t *infoM = nullptr, const uint32_t *infoQ = nullptr); // locate mode: see sw_wave.hip
+             const uint32_t *infoM = nullptr, const uint32_t *infoQ = nullptr, // locate mode: see sw_wave.hip
+             int defer = 0); // ... and leave the end cell of a pair with one block to the traceback kernel (wave8_ok only)
+// locate mode on a byte profile of the pair (sw_wave8_kernel): reads of 257..1024 rows, score - gap in a byte, the planes of a
+// workgroup's four pairs within 64 KB of LDS (POLYHIP_SW_WAVE8=0: never)
+bool wave8_ok(const polyhip_scoring *sc, uint32_t max_lenA);
 
 } // namespace k3w
 } // namespace polyhip

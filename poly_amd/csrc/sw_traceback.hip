@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
     const uint8_t *__restrict__ Bbase, const uint64_t *__restrict__ offB, const uint8_t *__restrict__ codeA,
     const uint8_t *__restrict__ codeB, const int32_t *__restrict__ lutcc, int na, int nb, int gap,
-    const uint32_t *__restrict__ endA, const uint32_t *__restrict__ endB, const uint32_t *__restrict__ err,
+    uint32_t *__restrict__ endA, uint32_t *__restrict__ endB, uint32_t *__restrict__ err,
     const int64_t *__restrict__ score, int smax, uint32_t wcols, int wide, uint32_t *__restrict__ dirbuf,
     uint8_t *__restrict__ alnA, uint8_t *__restrict__ alnB, uint32_t *__restrict__ alnLen, uint32_t stride)
 {
@@ -1639,9 +1639,15 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     }
     uint32_t len = 0;
     if (eA > 0 && eB > 0 && M > 0 && lenA <= 64u * R) {
-        const uint32_t mycols = pair_window(wcols, eA, M, smax, gap, wide & 1);
+        // The score pass may have left the end cell to this kernel (k3p::SW_END_DEFERRED, byte-profile form only): eB is then
+        // the last column of the only 4-column block that holds the maximum, the window is sized for the whole read (the end
+        // row is not known yet) and four columns longer, and the sweep notes the first cell worth M in row-major order
+        const bool locate = P8 && (wide & 2) && eA == k3p::SW_END_DEFERRED;
+        const uint32_t mycols = min(wcols + 4u, pair_window(wcols, locate ? lenA : eA, M, smax, gap, wide & 1) + (locate ? 4u : 0u));
         const uint32_t c_s = eB > mycols ? eB - mycols + 1u : 1u; // first column (1-based) of the window
         const uint32_t ncol = eB - c_s + 1u;
+        uint32_t besti = 0xFFFFFFFFu, bestj = 0u; // locate: the smallest row with a cell worth M, its first column (window-relative)
+        const int Mg = (int)M + gap;
         uint32_t ro[R];
         constexpr int NAB = R <= 16 ? (R + 3) / 4 : 1;
         uint32_t abytes[NAB]; // R <= 16: the lane's rows' symbols, for the walk
@@ -1661,7 +1667,7 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
             }
             ro[k] = code * (uint32_t)nb;
         }
-        uint32_t *dirw = dirbuf + wslot * ((size_t)(wcols + 63u) * 64 * NWL) + (size_t)lane * NWL;
+        uint32_t *dirw = dirbuf + wslot * ((size_t)(wcols + 67u) * 64 * NWL) + (size_t)lane * NWL;
         int Hrow[R];
 #pragma unroll
         for (int k = 0; k < R; ++k)
@@ -1753,6 +1759,24 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
                 tprev = top_in;
                 lastg = lg[R - 1];
                 last_b = b_in;
+                if (locate) { // (wave-uniform) did a cell of this column, in some lane, reach M?  Rarely: then look at the rows
+                    int m = lg[0];
+#pragma unroll
+                    for (int k = 1; k < R; ++k)
+                        m = max(m, lg[k]);
+                    if (__any(valid && m == Mg)) {
+                        if (valid) {
+#pragma unroll
+                            for (int k = 0; k < R; ++k) {
+                                const uint32_t r = (uint32_t)lane * R + k;
+                                if (lg[k] == Mg && r < lenA && r < besti) { // smaller row wins; columns come in order
+                                    besti = r;
+                                    bestj = jr;
+                                }
+                            }
+                        }
+                    }
+                }
                 const uint32_t sub = s % SP;
                 if (valid) {
                     acc |= (gw | (lw << BITS)) << (sub * FB);
@@ -1836,11 +1860,30 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (locate) { // the smallest row over the lanes (rows are distinct across lanes), its first column
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t oi = (uint32_t)__shfl_xor((int)besti, d, 64), oj = (uint32_t)__shfl_xor((int)bestj, d, 64);
+                if (oi < besti) {
+                    besti = oi;
+                    bestj = oj;
+                }
+            }
+            const bool found = besti != 0xFFFFFFFFu; // (cannot fail: the packed pass saw M in this block)
+            eA = found ? besti + 1u : 0u;
+            eB = found ? c_s + bestj : 0u;
+            if (lane == 0) {
+                endA[pair] = eA;
+                endB[pair] = eB;
+                if (!found)
+                    err[pair] = 0xFFFFFFFEu;
+            }
+        }
         // ---- walk (uniform over the wave; lane 0 writes)
         uint8_t *outA = alnA + pair * stride, *outB = alnB + pair * stride;
         uint32_t i = eA, j = eB;
         int h = (int)M;
-        const uint32_t *dbase = dirbuf + wslot * ((size_t)(wcols + 63u) * 64 * NWL);
+        const uint32_t *dbase = dirbuf + wslot * ((size_t)(wcols + 67u) * 64 * NWL);
         if (wide & 4) { // POLYHIP_TB_NOWALK=1: ablation probe -- what does the sweep cost on its own?
         } else if (R <= 16 && !(wide & 8)) {
             // Round 5: the walk out of the wave's REGISTERS, steered by the scalar unit.  A step of the plain walk below is
@@ -2565,7 +2608,7 @@ static Plan plan(const polyhip_scoring *sc, uint32_t max_lenA, uint64_t lenB)
     if (max_lenA > 152 && max_lenA <= 4096 && p.smem <= 60 * 1024 && (size_t)na * nb < 65536) {
         p.wave_r = max_lenA <= 256 ? 4 : max_lenA <= 512 ? 8 : max_lenA <= 1024 ? 16 : max_lenA <= 2048 ? 32 : 64;
         const size_t nwl = p.wave_r <= 16 ? 1 : 2 * ((p.wave_r + 31) / 32);
-        p.wave_per_pair = ((size_t)p.win.wcols + 63) * 64 * nwl * 4;
+        p.wave_per_pair = ((size_t)p.win.wcols + 4 + 63) * 64 * nwl * 4; // (+ 4 columns: a deferred end cell's window starts at a block's end)
         p.per_pair = std::max(p.per_pair, p.wave_per_pair);
         p.wave8_smem = align_up(p.smem, 16) + (size_t)(THREADS / 64) * nb * p.wave_r * 64;
         p.wave8_ok = (p.wave_r == 8 || p.wave_r == 16) && sc->gap <= -1 && -sc->gap <= 127 && (int64_t)sc->smax - sc->gap <= 127 &&
@@ -2818,6 +2861,8 @@ static bool traceback_uses_prof(const polyhip_scoring *sc, uint32_t max_lenA, ui
     const bool wave_ok = p.wave_r != 0 && !env_is("POLYHIP_TB_WAVE", '0');
     if (p.prof_ok && p.half2_ok && !env_is("POLYHIP_TB_PROF", '0') && !env_is("POLYHIP_TB_F16", '0') && !env_is("POLYHIP_TB_HALF2", '0'))
         return true; // its two-lanes-per-pair form (153..256 rows)
+    if (p.ra == 0 && wave_ok && p.wave8_ok && !env_is("POLYHIP_TB_WAVE8", '0'))
+        return true; // 257..1024 rows: the one-wave-per-pair kernel on a byte profile of the pair (path 7)
     return p.prof_ok && !(p.ra == 256 && wave_ok) && !env_is("POLYHIP_TB_PROF", '0');
 }
 
@@ -2857,7 +2902,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     k3t::g_tb_last_path = use_pair16 ? 6 : use_half2 ? 5 : use_prof ? 1 : use_wave8 ? 7 : use_wave ? 4 : (p.ra ? 2 : 3);
     // only the byte-profile kernels know a deferred end cell: the fused entry point decided with traceback_uses_prof();
     // should the two conditions ever drift apart, fail here instead of walking from row 4e9
-    PH_REQUIRE(!deferred || use_prof || use_half2, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
+    PH_REQUIRE(!deferred || use_prof || use_half2 || use_wave8, "polyhip_sw_align_batch: end cells were deferred but the byte-profile traceback is not taken");
     // bit 0: the conservative per-pair window (POLYHIP_TB_WIDE=1, testing aid); bit 1: deferred end cells allowed
     const int wide = (env_is("POLYHIP_TB_WIDE", '1') ? 1 : 0) | (deferred ? 2 : 0) | (env_is("POLYHIP_TB_NOWALK", '1') ? 4 : 0) |
                      (env_is("POLYHIP_TB_WALKREG", '0') ? 8 : 0); // bit 3: the one-wave-per-pair kernel's plain walk (testing aid)

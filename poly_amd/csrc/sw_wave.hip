@@ -246,7 +246,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave8_kernel(
     uint32_t lenB, const uint8_t *__restrict__ codeA, const uint8_t *__restrict__ codeB,
     const int32_t *__restrict__ lutcc, int na, int nb, int gap, const uint32_t *__restrict__ infoM,
     const uint32_t *__restrict__ infoQ, int smax, int64_t *__restrict__ score, uint32_t *__restrict__ endA,
-    uint32_t *__restrict__ endB, uint32_t *__restrict__ err)
+    uint32_t *__restrict__ endB, uint32_t *__restrict__ err, int defer)
 {
     static_assert(R == 8 || R == 16, "byte-profile sweep: 8 or 16 rows per lane");
     constexpr int NQ = R / 4;
@@ -314,6 +314,18 @@ __global__ __launch_bounds__(THREADS) void sw_wave8_kernel(
             const uint32_t jend = min(4u * (iq & 0x7FFFFFFFu) + 4u, lenB);
             j0 = jend > need ? jend - need : 0u;
             ncols = jend - j0;
+        }
+        // defer != 0 (polyhip_sw_align_batch_dev: the strings are wanted too): a maximum that sits in ONE block is left to
+        // the traceback kernel, which sweeps these columns anyway -- score = M, endA = SW_END_DEFERRED, endB = the 1-based
+        // last column of that block (tb_wave_kernel<R, true> finds the first cell worth M during its sweep)
+        if (defer && e == 0u && lenA > 0 && ncols > 0 && (iq >> 31) == 0u) {
+            if (lane == 0) {
+                score[pair] = (int64_t)M;
+                endA[pair] = k3p::SW_END_DEFERRED;
+                endB[pair] = j0 + ncols;
+                err[pair] = 0u;
+            }
+            continue;
         }
         const uint32_t steps = (e == 0u && lenA > 0 && ncols > 0) ? ncols + 63u : 0u;
         uint32_t besti = 0xFFFFFFFFu, bestj = 0u;
@@ -436,11 +448,21 @@ __global__ __launch_bounds__(THREADS) void sw_wave8_kernel(
     }
 }
 
+bool wave8_ok(const polyhip_scoring *sc, uint32_t max_lenA)
+{
+    const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
+    const size_t smem = (size_t)na * nb * 4 + 512;
+    const int r8 = max_lenA <= 512 ? 8 : 16;
+    const size_t smem8 = ((smem + 15) & ~(size_t)15) + (size_t)(THREADS / 64) * nb * r8 * 64;
+    return max_lenA > 256 && max_lenA <= 1024 && sc->gap <= -1 && -sc->gap <= 127 && (int64_t)sc->smax - sc->gap <= 127 &&
+           (int64_t)sc->smin - sc->gap >= -128 && smem8 <= 64 * 1024 && !env_is("POLYHIP_SW_WAVE8", '0');
+}
+
 int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_offA, uint64_t npairs, uint32_t max_lenA,
              const uint8_t *d_B, const uint64_t *d_offB, uint32_t lenB, const uint32_t *binfo, const uint32_t *list,
              const uint32_t *count,
              uint64_t max_items, int64_t *d_score, uint32_t *d_endA, uint32_t *d_endB, uint32_t *d_err, hipStream_t st,
-             const uint32_t *infoM, const uint32_t *infoQ)
+             const uint32_t *infoM, const uint32_t *infoQ, int defer)
 {
     const int na = sc->ncodes + 1, nb = sc->ncodesB + 1;
     const size_t smem = (size_t)na * nb * 4 + 512;
@@ -450,21 +472,21 @@ int wave_run(const polyhip_scoring *sc, const uint8_t *d_A, const uint64_t *d_of
     // locate mode, 257..1024 rows, one reference: the byte-profile kernel takes every pair whose maximum the packed pass
     // knows; the general kernel below then only the others (POLYHIP_SW_WAVE8=0: the general kernel for all; testing aid)
     int m0_only = 0;
-    if (infoM && infoQ && !list && !d_offB && max_lenA > 256 && max_lenA <= 1024 && sc->gap <= -1 && -sc->gap <= 127 &&
-        (int64_t)sc->smax - sc->gap <= 127 && (int64_t)sc->smin - sc->gap >= -128 && !env_is("POLYHIP_SW_WAVE8", '0')) {
+    PH_REQUIRE(!defer || (infoM && infoQ && !list && !d_offB && wave8_ok(sc, max_lenA)), "polyhip_sw_batch: end cells deferred without the byte-profile locate kernel");
+    if (infoM && infoQ && !list && !d_offB && wave8_ok(sc, max_lenA)) {
         const int r8 = max_lenA <= 512 ? 8 : 16;
         const size_t smem8 = ((smem + 15) & ~(size_t)15) + (size_t)(THREADS / 64) * nb * r8 * 64;
-        if (smem8 <= 64 * 1024) {
+        {
             if (r8 == 8) {
                 auto kern = sw_wave8_kernel<8>;
                 PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
                 hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem8, st, d_A, d_offA, npairs, d_B, lenB, sc->d_codeA,
-                                   sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, infoM, infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err);
+                                   sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, infoM, infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err, defer);
             } else {
                 auto kern = sw_wave8_kernel<16>;
                 PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem8));
                 hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), smem8, st, d_A, d_offA, npairs, d_B, lenB, sc->d_codeA,
-                                   sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, infoM, infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err);
+                                   sc->d_codeB, sc->d_lutcc, na, nb, (int)sc->gap, infoM, infoQ, (int)sc->smax, d_score, d_endA, d_endB, d_err, defer);
             }
             PH_HIP(hipGetLastError());
             m0_only = 1;

@@ -735,7 +735,7 @@ def test_config4_full_size_mutated_batch(al, monkeypatch, tb_cell):
     del chk
 
 
-@pytest.mark.parametrize("L", [150, 250])
+@pytest.mark.parametrize("L", [150, 250, 600, 1000])
 @pytest.mark.parametrize("kind", ["random", "repeats", "ragged_bad"])
 def test_fused_align_equals_two_passes(al, monkeypatch, tb_cell, kind, L):
     """polyhip_sw_align_batch_dev (deferred end cell, found by the traceback kernel in its last block) against
@@ -745,7 +745,11 @@ def test_fused_align_equals_two_passes(al, monkeypatch, tb_cell, kind, L):
     align = al[0]
     dev = torch.device("cuda:0")
     rng = np.random.default_rng({"random": 1, "repeats": 2, "ragged_bad": 3}[kind])
-    LB, n = 4000, 100_000 if L == 150 else 60_000  # L = 250: two lanes per pair in both passes (tb path 5; 32-bit fixture: 4)
+    # L = 250: two lanes per pair in both passes (tb path 5; 32-bit fixture: 4); L = 600, 1000: the packed multi-lane pass (7)
+    # and the one-wave-per-pair traceback on a byte profile of the pair (7), which finds the deferred end cell in its sweep
+    LB, n = 4000, {150: 100_000, 250: 60_000, 600: 16_000, 1000: 9_000}[L]
+    if L > 256 and tb_cell != "half":
+        pytest.skip("the long-read paths do not depend on the fixture")
     ref = orc.synth_dna(0xC4, LB).copy()
     if kind == "repeats":
         ref = np.tile(ref[:250], 16)
@@ -777,10 +781,13 @@ def test_fused_align_equals_two_passes(al, monkeypatch, tb_cell, kind, L):
         alnA = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
         alnB = torch.zeros((n, stride), dtype=torch.uint8, device=dev)
         work = torch.empty(align.sw_workspace_bytes(sc, n, L, LB, True), dtype=torch.uint8, device=dev)
-        tbw = torch.empty(align.sw_traceback_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
+        tbw = torch.empty(min(align.sw_traceback_workspace_bytes(sc, n, L, LB), 3 << 30), dtype=torch.uint8, device=dev)
         align.sw_align_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, alnA, alnB, ln, work, tbw)
         torch.cuda.synchronize()
-        assert align.last_path() == 3 and align.sw_traceback_last_path() == (1 if L == 150 else 5 if tb_cell == "half" else 4)
+        if L > 256:
+            assert (align.last_path(), align.sw_traceback_last_path()) == (7, 7)
+        else:
+            assert align.last_path() == 3 and align.sw_traceback_last_path() == (1 if L == 150 else 5 if tb_cell == "half" else 4)
         outs[fuse] = (score, ea, eb, er, ln, alnA, alnB)
     monkeypatch.delenv("POLYHIP_SW_FUSE", raising=False)
     for x, y in zip(outs[True][:5], outs[False][:5]):
@@ -791,7 +798,7 @@ def test_fused_align_equals_two_passes(al, monkeypatch, tb_cell, kind, L):
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
     refb = ref.tobytes()
     score, ea, eb, er, ln, alnA, alnB = (t.cpu().numpy() for t in outs[True])
-    for p in rng.choice(n, 300, replace=False):
+    for p in rng.choice(n, 300 if L <= 256 else 60, replace=False):
         a = flat[offs[p]:offs[p + 1]].tobytes()
         try:
             ws, wa, wb, wea, web = orc.smith_waterman(a, refb, om, -2)
