@@ -585,6 +585,47 @@ def test_long_reads_byte_profile_limits(al, monkeypatch, hi, lo, gap, path):
             assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s_, ea, eb) and got[4][p] == sa and got[5][p] == sb, p
 
 
+def test_long_reads_host_flavour_one_call(al, monkeypatch):
+    """polyhip_sw_align_batch / _packed (host pointers: what cgo calls) on a batch of long reads that takes the packed multi-lane
+    score pass (7) and the byte-profile one-wave-per-pair traceback (7) with the end cells left to it: every output equal to
+    POLYHIP_SW_FUSE=0 (locate in the score pass), both string layouts equal, a sample equal to the oracle"""
+    align = al[0]
+    rng = np.random.default_rng(77)
+    LB, n = 3000, 16_000
+    ref = orc.synth_dna(0xC4, LB).tobytes()
+    reads = []
+    for p in range(n):
+        L = int(rng.integers(300, 601)) if p else 600
+        at = int(rng.integers(0, LB - L + 1))
+        r = bytearray(ref[at:at + L])
+        for q in rng.integers(0, L, L // 15):
+            r[q] = b"ACGT"[int(rng.integers(0, 4))]
+        if p % 7 == 3:
+            del r[int(rng.integers(1, L - 1))]
+        reads.append(bytes(r))
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    A, offA = _pack(reads)
+    B = np.frombuffer(ref, np.uint8).copy()
+    got = align.sw_align_packed(sc, A, offA, B, None)
+    assert (align.last_path(), align.sw_traceback_last_path()) == (7, 7)
+    packed = align.sw_align_strings_packed(sc, A, offA, B, None)
+    monkeypatch.setenv("POLYHIP_SW_FUSE", "0")
+    two = align.sw_align_packed(sc, A, offA, B, None)
+    monkeypatch.delenv("POLYHIP_SW_FUSE", raising=False)
+    assert (align.last_path(), align.sw_traceback_last_path()) == (7, 7)
+    for other in (packed, two):
+        for g, w in zip(got[:4], other[:4]):
+            assert (np.asarray(g) == np.asarray(w)).all()
+        assert got[4] == other[4] and got[5] == other[5]
+    assert int(got[0].min()) > 0 and int(got[0].max()) <= 5 * 600 and int((got[3] != 0).sum()) == 0
+    for p in range(0, n, 801):
+        s_, sa, sb, ea, eb = orc.smith_waterman(reads[p], ref, om, -2)
+        sa = sa if isinstance(sa, bytes) else sa.encode()
+        sb = sb if isinstance(sb, bytes) else sb.encode()
+        assert (int(got[0][p]), int(got[1][p]), int(got[2][p])) == (s_, ea, eb) and got[4][p] == sa and got[5][p] == sb, p
+
+
 def test_long_reads_chunked_workspace(al):
     """the one-wave-per-pair traceback with a workspace that holds a third of the batch: the entry point loops over
     chunks of pairs; same strings as with the full workspace, a sample equal to the oracle"""
