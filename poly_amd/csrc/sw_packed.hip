@@ -181,7 +181,12 @@ __device__ __forceinline__ uint32_t pkf_max3(uint32_t a, uint32_t b, uint32_t c)
         const uint32_t h1 = pk_max(pk_add(pr0, (W).y), pk_subsat(pk_max(pr1, h0), gap2));     \
         const uint32_t h2 = pk_max(pk_add(pr1, (W).z), pk_subsat(pk_max(pr2, h1), gap2));     \
         const uint32_t h3 = pk_max(pk_add(pr2, (W).w), pk_subsat(pk_max(pr3, h2), gap2));     \
-        bm = pk_max(pk_max(bm, h0), pk_max(h1, pk_max(h2, h3)));                              \
+        /* (round 5) the block maximum through gfx950's three-operand half-float maximum: every H here is an integer in  \
+           [0, 30000) (packed_plan), and non-negative halves -- denormals included, the kernels run with them preserved -- \
+           order like their bit patterns; 0x7C00 (infinity, NaN) is never reached.  Two instructions instead of five.    \
+           (Not for the cell itself: diag + score can be a small negative integer, which is a NaN pattern, and this       \
+           maximum propagates NaNs.) */                                                      \
+        bm = pkf_max3(pkf_max3(bm, h0, h1), h2, h3);                                          \
         pdiag = left;                                      \
         pr0 = h0;                                          \
         pr1 = h1;                                          \
