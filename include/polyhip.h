@@ -380,7 +380,7 @@ int polyhip_sw_traceback_dev(const polyhip_scoring *sc, const uint8_t *d_A,
  * kernel, which sweeps those columns anyway, finds the row-major-first maximum in its last block: about 7 % less
  * time than the two calls.  The same holds for reads of 257..1024 symbols that take the packed multi-lane pass and the
  * one-wave-per-pair traceback on a byte profile of the pair (polyhip_sw_last_path 7 / polyhip_sw_traceback_last_path 7:
- * 80k reads of 1 kb, 94 -> 85 ms).  POLYHIP_SW_FUSE=0 in the environment keeps the two passes separate (testing aid).
+ * 80k reads of 1 kb, 92 -> 82 ms).  POLYHIP_SW_FUSE=0 in the environment keeps the two passes separate (testing aid).
  */
 int polyhip_sw_align_batch_dev(const polyhip_scoring *sc, const uint8_t *d_A,
                                const uint64_t *d_offA, uint64_t npairs,
