@@ -175,3 +175,21 @@ def test_walk_windows_always_hold_the_word_a_step_asks_for():
             assert steps > 0 and fetches <= steps + 1
             if pg == 0.0 and steps >= 200:
                 assert fetches <= steps // (14 if SP == 1 else 7) + 2, (R, SP, fetches, steps)
+
+
+def test_integers_below_0x7c00_order_like_halves():
+    """csrc/sw_packed.hip PH_PK_ROW (round 5): the int16 packed kernels take their block maximum with v_pk_maximum3_f16.  That is
+    an integer maximum as long as every operand is in [0, 0x7C00): non-negative halves -- denormals included, the kernels run
+    with them preserved -- are strictly increasing in their bit patterns, and 0x7C00 (infinity) / NaNs are never reached
+    (packed_plan: smax * min(lenA, lenB) < 30000).  The cell itself cannot use it: diag + score can be -1 .. -128, and those
+    16-bit patterns are NaNs, which an IEEE-754-2019 maximum propagates."""
+    bits = np.arange(0, 0x7C00, dtype=np.uint16)
+    h = bits.view(np.float16).astype(np.float64)
+    assert np.isfinite(h).all() and (np.diff(h) > 0).all() and h[0] == 0.0
+    assert 30000 < 0x7C00
+    rng = np.random.default_rng(11)
+    a, b, c = (rng.integers(0, 30000, 100_000).astype(np.uint16) for _ in range(3))
+    as_half = np.maximum(np.maximum(a.view(np.float16), b.view(np.float16)), c.view(np.float16)).view(np.uint16)
+    assert (as_half == np.maximum(np.maximum(a, b), c)).all()
+    neg = np.arange(-128, 0, dtype=np.int16).view(np.uint16).view(np.float16)
+    assert np.isnan(neg.astype(np.float64)).all()
