@@ -234,7 +234,7 @@ def oracle_spot_checks(extra: dict) -> dict:
     import oracle as orc
     res = {}
     sw = extra.get("smith_waterman") if isinstance(extra, dict) else None
-    for name in ("smith_waterman", "smith_waterman_250bp", "smith_waterman_1kb"):
+    for name in ("smith_waterman", "smith_waterman_250bp", "smith_waterman_500bp", "smith_waterman_1kb"):
         leg = extra.get(name) if isinstance(extra, dict) else None
         spot = leg.pop("_spot", None) if isinstance(leg, dict) else None
         if spot is None:

@@ -652,6 +652,7 @@ def run(dev, host_devices=None) -> dict:
     # (the 1 kb leg: 80k pairs fill the chip at 8 lanes per pair -- 6.1e12 cell updates/s; 20k pairs leave it a third full: 4.3e12)
     out = {}
     for name, fn in (("smith_waterman", sw), ("smith_waterman_250bp", lambda d: sw(d, 400_000, 250)),
+                     ("smith_waterman_500bp", lambda d: sw(d, 160_000, 500)),
                      ("smith_waterman_1kb", lambda d: sw(d, 80_000, 1000)),
                      ("smith_waterman_pairs", sw_pairs), ("needleman_wunsch", nw), ("santalucia_scan", tm_scan), ("mash_distance", distance),
                      ("least_rotation", rotation), ("seqhash", hashing), ("fastq_feeder", fastq_feeder),
