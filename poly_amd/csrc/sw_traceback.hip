@@ -1600,7 +1600,9 @@ struct WavePack {
 // walk never reads the bits of such a cell (it stops at h = 0).  Lanes outside the window need no select: a lane that has
 // not started sees pad codes (score 0) over zeros and stays at zero; what a lane computes past its last column is read by
 // nobody (the lane below is one column behind).  Condition (host): smax - gap <= 127, smin - gap >= -128, the planes fit.
-template <int R, bool P8 = false>
+// LOC: the instantiation that can find a deferred end cell (the one-call form); without it the kernel keeps 71 registers
+// instead of 95 (seven waves per SIMD instead of five: 39.2 against 40.6 ms per 80k x 1 kb tracebacks).
+template <int R, bool P8 = false, bool LOC = false>
 __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
     const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA, uint64_t pair0, uint64_t pair1,
     const uint8_t *__restrict__ Bbase, const uint64_t *__restrict__ offB, const uint8_t *__restrict__ codeA,
@@ -1642,7 +1644,7 @@ __global__ __launch_bounds__(THREADS) void tb_wave_kernel(
         // The score pass may have left the end cell to this kernel (k3p::SW_END_DEFERRED, byte-profile form only): eB is then
         // the last column of the only 4-column block that holds the maximum, the window is sized for the whole read (the end
         // row is not known yet) and four columns longer, and the sweep notes the first cell worth M in row-major order
-        const bool locate = P8 && (wide & 2) && eA == k3p::SW_END_DEFERRED;
+        const bool locate = P8 && LOC && (wide & 2) && eA == k3p::SW_END_DEFERRED;
         const uint32_t mycols = min(wcols + 4u, pair_window(wcols, locate ? lenA : eA, M, smax, gap, wide & 1) + (locate ? 4u : 0u));
         const uint32_t c_s = eB > mycols ? eB - mycols + 1u : 1u; // first column (1-based) of the window
         const uint32_t ncol = eB - c_s + 1u;
@@ -3011,7 +3013,7 @@ static int traceback_impl(const polyhip_scoring *sc, const uint8_t *d_A, const u
     } while (0)
 #define PH_TBW8_LAUNCH(R_)                                                                                            \
     do {                                                                                                              \
-        auto kern = k3t::tb_wave_kernel<R_, true>;                                                                    \
+        auto kern = deferred ? k3t::tb_wave_kernel<R_, true, true> : k3t::tb_wave_kernel<R_, true, false>;            \
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                    (int)p.wave8_smem));                                                               \
         hipLaunchKernelGGL(kern, dim3(wblocks), dim3(k3t::THREADS), p.wave8_smem, st, d_A, d_offA, p0, p1, d_B, d_offB, \
