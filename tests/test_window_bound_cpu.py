@@ -117,3 +117,28 @@ def test_the_bound_on_a_config4_read():
     assert pair_window(902, 150, 0, 5, -2, 0) == 902
     # a positive gap score, a matrix without a positive entry: the whole of B
     assert pair_window(300, 40, 17, 0, 1, 0) == 300 and pair_window(300, 40, 17, 5, 0, 0) == 300
+
+
+def test_window_of_a_deferred_end_cell_covers_the_pairs_own_window():
+    """Round 5, reads of 257..1024 rows in one call: the score pass leaves (M, the last column jend of the only 4-column block
+    that holds M) and the one-wave-per-pair traceback sweeps  pair_window(lenA) + 4  columns ending at jend, not knowing the
+    end row yet.  That window covers what the kernel would take knowing the end cell (eA <= lenA, jend - 3 <= eB <= jend):
+    pair_window grows with the row count, in both of its forms.  And it covers the locate kernel's own window
+    (lenA + (smax * lenA - M) / |gap| + 4 columns ending at jend), in which the first cell worth M is found."""
+    rng = np.random.default_rng(12)
+    for it in range(20000):
+        smax = int(rng.integers(1, 40))
+        gap = -int(rng.integers(1, 30))
+        lenA = int(rng.integers(1, 1025))
+        eA = int(rng.integers(1, lenA + 1))
+        M = int(rng.integers(1, smax * eA + 1))  # the end cell is in row eA: M <= smax * eA
+        wcols = 10 ** 9
+        for wide in (0, 1):
+            w_known = pair_window(wcols, eA, M, smax, gap, wide)
+            w_defer = pair_window(wcols, lenA, M, smax, gap, wide) + 4
+            assert pair_window(wcols, eA, M, smax, gap, wide) <= pair_window(wcols, min(lenA, eA + 1), M, smax, gap, wide)
+            for back in range(4):  # eB = jend - back
+                assert w_defer >= w_known + back
+        g, top = -gap, smax * lenA
+        locate_need = lenA + ((top - M) // g if top > M else 0) + 4
+        assert pair_window(wcols, lenA, M, smax, gap, 0) + 4 >= locate_need
