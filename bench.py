@@ -63,6 +63,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=400, help="reads per core in the CPU-baseline sample")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary kernels")
+    ap.add_argument("--full-out", default=os.path.join(ROOT, "gpurun_out", "bench_extra.json")
+                    if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else os.path.join(ROOT, "bench_extra.json"),
+                    help="where the FULL record goes (every leg's workload text, roofline, counter sources, CPU samples); "
+                         "stdout carries only the compact line (poly_amd/bench_line.py, at most 8 kB)")
     ap.add_argument("--host-devices", type=int, default=0,
                     help="N > 0: the PCIe-inclusive host-pointer legs (extra.e2e_host_pointers) run on the library's device list "
                          "0..N-1 (polyhip_set_devices: ONE host call fanned out over N GPUs; ids wrap around the visible devices)")
@@ -80,6 +84,27 @@ def self_launch(args) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["BENCH_SELF_LAUNCHED"] = "1"
     return subprocess.call(cmd, env=env)
+
+
+def emit(full: dict, json_fd: int, full_out: str) -> None:
+    """The full record -> side file + stderr; the compact line (<= bench_line.LIMIT bytes, json round-trip checked) ->
+    the original stdout as the LAST thing written."""
+    from poly_amd import bench_line
+    try:
+        text_full = bench_line.render_full(full)
+    except Exception as e:  # the line must still go out
+        text_full = json.dumps({"error": f"full record not serialisable: {type(e).__name__}: {e}"})
+    try:
+        with open(full_out, "w") as f:
+            f.write(text_full + "\n")
+        full = dict(full, full=os.path.relpath(full_out, ROOT) if full_out.startswith(ROOT) else full_out)
+    except OSError as e:
+        sys.stderr.write(f"bench.py: could not write {full_out}: {e}\n")
+    sys.stderr.write("bench.py full record: " + text_full + "\n")
+    sys.stderr.flush()
+    text = bench_line.render(full)
+    assert len(text) + 1 <= bench_line.LIMIT and isinstance(json.loads(text), dict)
+    os.write(json_fd, (text + "\n").encode())
 
 
 def host_cores() -> int:
@@ -689,7 +714,7 @@ def main() -> int:
                 line.setdefault("extra", {})["mash_distance_allgather"] = {
                     "error": f"watchdog: the all-gather leg did not finish within {WATCHDOG_S} s (a rank failed or a "
                              "collective hung); every other number in this line was measured before it"}
-                os.write(json_fd, (json.dumps(line) + "\n").encode())
+                emit(line, json_fd, args.full_out)
             os._exit(0)
         dog = threading.Timer(WATCHDOG_S, bail)
         dog.daemon = True
@@ -761,7 +786,7 @@ def main() -> int:
                            "sw_valu_frac": ((line.get("secondary") or {}).get("roofline") or {}).get("frac"),
                            "parity_spot_check": line.get("parity_spot_check")}
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        emit(line, json_fd, args.full_out)
     if world > 1:
         dist.destroy_process_group()
     return 0
