@@ -44,7 +44,8 @@
 // (results are then wrong by construction).  1 premix, 2 chain, 3 fmix+tail, 4 select, 5 bottom_s, 6 stage: the TILE pass.
 // The SLAB pass (round 5): 11 = stage + premix + hash only (no select, no bottom-s), 12 = no bottom-s, 14 = the per-read
 // prologue and barriers alone (no slabs, no bottom-s), 15 = no premix (the hash reads stale quads), 16 = ONE chain block of the
-// k / 4 (-11 instructions per k-mer), 17 = fmix32 cut to one multiply (-4): is the kernel bound by its instruction count at all?  None of them marks a
+// k / 4 (-11 instructions per k-mer), 17 = fmix32 cut to one multiply (-4): is the kernel bound by its instruction count at all?
+// Round 6: 21 = the fast bottom-s without its barriers, 22 = without its rank pass.  None of them marks a
 // row for the general kernel, so the timed launch is the slab kernel alone.
 #ifndef PH_WPE
 #define PH_WPE 6 // waves per SIMD the fast kernel is register-allocated for (6 workgroups per CU fit its LDS)
@@ -54,6 +55,15 @@
 #endif
 #ifndef PH_ABL
 #define PH_ABL 0
+#endif
+#ifndef PH_SELBINS
+#define PH_SELBINS 0 // EXPERIMENT (round 6, lever (a)): n > 0 = the slab pass counts the bottom-s's 2^n bins while it selects
+#endif
+#ifndef PH_SEL_ATOMIC
+#define PH_SEL_ATOMIC 0 // EXPERIMENT (round 6): 1 = a survivor's slot from a returning LDS increment on the wave's own counter
+#endif                  // (compare + shift per hash) instead of its ballot rank (compare + two mbcnt + shift-add)
+#ifndef PH_BS_WIN
+#define PH_BS_WIN 4 // the fast bottom-s ranks an element against its PH_BS_WIN neighbours on either side (0: against its whole bin)
 #endif
 #ifndef PH_BS_U
 #define PH_BS_U 4 // candidates a thread takes per trip of the bottom-s's loops (bottom_s_fast): 4 / 5 / 6 measure the same
@@ -538,10 +548,18 @@ __device__ __forceinline__ void append4(uint32_t *__restrict__ counter, uint32_t
 // or, for the slab pass, the thread's own wave's segment (segment, lane, 64, that wave's count).  FIN: the
 // candidates still lack fmix32's last `h ^= h >> 16` (the slab pass thresholds on the bits that step leaves alone).
 constexpr int BSU = PH_BS_U;
-template <bool FIN>
+constexpr uint32_t BS_MARGIN = (PH_BS_WIN + 3u) & ~3u; // dwords kept free before binned[0] and behind binned[capf)
+// (PH_ABL 21: the fast bottom-s without its workgroup barriers -- wrong results, timing only: the upper bound of what
+// overlapping one read's bottom-s with the next read's hashing could give)
+#define BS_SYNC()              \
+    do {                       \
+        if (PH_ABL != 21)      \
+            __syncthreads();   \
+    } while (0)
+template <bool FIN, bool SELB = false>
 __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t C, uint32_t nbf_log2,
                               uint32_t *__restrict__ outp, const uint32_t *__restrict__ src, uint32_t first,
-                              uint32_t step, uint32_t cnt)
+                              uint32_t step, uint32_t cnt, uint32_t *__restrict__ selbins = nullptr)
 {
     const int tid = threadIdx.x;
     auto fin = [](uint32_t h) { return FIN ? h ^ (h >> 16) : h; };
@@ -552,38 +570,52 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
     // a thread owns `per` = 4 or 8 consecutive bins = one or two 16-byte words (the caller's barrier freed P)
     uint4 *bins4 = reinterpret_cast<uint4 *>(bins);
     const int q4 = (int)(nbf / (4 * THREADS)); // 1 or 2
-    for (int q = 0; q < q4; ++q)
-        bins4[q4 * tid + q] = make_uint4(0, 0, 0, 0);
-    if (tid == 0)
-        sm.misc[8] = 0; // bins with more than BIG_BIN values
-    __syncthreads();
+    if (!SELB) {
+        for (int q = 0; q < q4; ++q)
+            bins4[q4 * tid + q] = make_uint4(0, 0, 0, 0);
+        if (tid == 0)
+            sm.misc[8] = 0; // bins with more than BIG_BIN values
+    }
+    if (PH_BS_WIN) { // the window pass below reads PH_BS_WIN entries on either side of binned[0, C): nothing there may count
+        if (tid < PH_BS_WIN)
+            sm.binned[-1 - tid] = 0u;
+        else if (tid < 2 * PH_BS_WIN)
+            sm.binned[C + (uint32_t)tid - PH_BS_WIN] = 0xFFFFFFFFu;
+    }
+    if (!SELB) // (SELB: the select counted the bins, the caller zeroed misc[8] before its barrier; the margins are read two barriers on)
+        BS_SYNC();
     // the loops over candidates are unrolled (PH_BS_U) so that the LDS round trips of a thread's elements overlap instead of
     // queueing behind each other.  A wave's segment holds ~300 survivors and the sorted buffer ~1200, i.e. 4.7 per lane / per
     // thread, so by four every loop runs a second, nearly empty trip -- but by five or six the kernel measures the same
     // (1.46-1.50 ms per 100k reads all three, profiles/r05_k1_bottom_s_unroll.log): the bottom-s is its five barriers and
     // the atomics' round trips, not its instruction count.
-    for (uint32_t i0 = first; i0 < cnt; i0 += BSU * step) {
-        uint32_t h[BSU];
+    if (!SELB) {
+        for (uint32_t i0 = first; i0 < cnt; i0 += BSU * step) {
+            uint32_t h[BSU];
 #pragma unroll
-        for (int u = 0; u < BSU; ++u)
-            h[u] = i0 + u * step < cnt ? fin(src[i0 + u * step]) : 0u;
+            for (int u = 0; u < BSU; ++u)
+                h[u] = i0 + u * step < cnt ? fin(src[i0 + u * step]) : 0u;
 #pragma unroll
-        for (int u = 0; u < BSU; ++u)
-            if (i0 + u * step < cnt)
-                atomicAdd(&bins[h[u] >> shift], 1u);
+            for (int u = 0; u < BSU; ++u)
+                if (i0 + u * step < cnt)
+                    atomicAdd(&bins[h[u] >> shift], 1u);
+        }
+        BS_SYNC();
     }
-    __syncthreads();
     {
         uint4 v[2];
         uint32_t sum = 0;
+        uint4 *cnt4 = SELB ? reinterpret_cast<uint4 *>(selbins) : bins4;
         for (int q = 0; q < 2; ++q) {
-            v[q] = q < q4 ? bins4[q4 * tid + q] : make_uint4(0, 0, 0, 0);
+            v[q] = q < q4 ? cnt4[q4 * tid + q] : make_uint4(0, 0, 0, 0);
+            if (SELB && q < q4)
+                cnt4[q4 * tid + q] = make_uint4(0, 0, 0, 0); // ready for the next read's select
             sum += v[q].x + v[q].y + v[q].z + v[q].w;
         }
         const uint32_t incl = wave_incl_scan(sum);
         if ((tid & 63) == 63)
             sm.misc[4 + (tid >> 6)] = incl;
-        __syncthreads();
+        BS_SYNC();
         uint32_t run = incl - sum;
         for (int w = 0; w < (tid >> 6); ++w)
             run += sm.misc[4 + w];
@@ -609,7 +641,7 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
             }
         }
     }
-    __syncthreads();
+    BS_SYNC();
     for (uint32_t i0 = first; i0 < cnt; i0 += BSU * step) { // afterwards bins[b] = end of bin b
         uint32_t h[BSU], at[BSU];
 #pragma unroll
@@ -624,39 +656,62 @@ __device__ void bottom_s_fast(const Smem &sm, uint32_t s, uint32_t tau, uint32_t
             if (i0 + u * step < cnt)
                 sm.binned[at[u]] = h[u];
     }
-    __syncthreads();
+    BS_SYNC();
     const uint32_t nbig = sm.misc[8];
     const bool by_waves = nbig <= BIG_LIST_CAP; // else the list is incomplete: rank every element the slow way
-    for (uint32_t j0 = tid; j0 < C; j0 += BSU * THREADS) {
-        uint32_t h[BSU], start[BSU], end[BSU];
-#pragma unroll
-        for (int u = 0; u < BSU; ++u)
-            h[u] = j0 + u * THREADS < C ? sm.binned[j0 + u * THREADS] : 0xFFFFFFFFu;
-#pragma unroll
-        for (int u = 0; u < BSU; ++u) {
-            const uint32_t b = h[u] >> shift;
-            const bool live = j0 + u * THREADS < C;
-            start[u] = live ? (b ? bins[b - 1] : 0u) : s;
-            end[u] = live ? bins[b] : s;
+    // an element against its whole bin: start of the bin + the values of the bin that sort before it (ties by slot:
+    // duplicates keep distinct ranks)
+    auto rank_in_bin = [&](uint32_t j, uint32_t hv) {
+        const uint32_t b = hv >> shift;
+        const uint32_t start = b ? bins[b - 1] : 0u, end = bins[b];
+        if (start >= s || (by_waves && end - start > BIG_BIN)) // (a whole wave places a big bin's values: rank_big_bins)
+            return;
+        uint32_t pos = start;
+        for (uint32_t x = start; x < end; ++x) {
+            const uint32_t o = sm.binned[x];
+            pos += (o < hv) || (o == hv && x < j);
         }
+        if (pos < s)
+            outp[pos] = hv;
+    };
+#if PH_BS_WIN
+    // binned[] is sorted up to the order INSIDE the bins, and with ~0.6 values per bin a bin rarely holds more than
+    // three.  So an element's place is its slot, minus the left neighbours that are larger, plus the right neighbours that
+    // are smaller: a left neighbour of another bin is smaller and a right one larger by construction, so no bin test and
+    // no bins[] lookup -- one compare and one add-with-carry per neighbour.  Exact whenever the bin cannot reach beyond
+    // the window, i.e. when the farthest neighbour on either side is of another bin; the few elements for which it is not
+    // (a bin of five or more: 0.2 % of them) are ranked against their whole bin as before.
+    if (PH_ABL != 22) { // (PH_ABL 22: no rank pass -- timing only)
+        const uint32_t lim = 1u << shift; // (a ^ b) < lim: same bin
+        for (uint32_t j = tid; j < C; j += THREADS) {
+            const uint32_t *__restrict__ w = sm.binned + j;
+            const uint32_t hv = w[0];
+            uint32_t pos = j;
+            bool far;
+            {
+                uint32_t l[PH_BS_WIN], r[PH_BS_WIN];
 #pragma unroll
-        for (int u = 0; u < BSU; ++u) {
-            if (start[u] >= s)
-                continue;
-            const uint32_t j = j0 + u * THREADS;
-            uint32_t pos = start[u];
-            if (by_waves && end[u] - start[u] > BIG_BIN)
-                continue; // a whole wave places this bin's values (rank_big_bins)
-            if (end[u] - start[u] > 1u) { // most bins hold one value
-                for (uint32_t x = start[u]; x < end[u]; ++x) {
-                    const uint32_t o = sm.binned[x];
-                    pos += (o < h[u]) || (o == h[u] && x < j); // duplicates keep distinct ranks
+                for (int d = 0; d < PH_BS_WIN; ++d) {
+                    l[d] = w[-1 - d];
+                    r[d] = w[1 + d];
                 }
+#pragma unroll
+                for (int d = 0; d < PH_BS_WIN; ++d) {
+                    pos -= l[d] > hv ? 1u : 0u;
+                    pos += r[d] < hv ? 1u : 0u;
+                }
+                far = ((l[PH_BS_WIN - 1] ^ hv) < lim) | ((r[PH_BS_WIN - 1] ^ hv) < lim);
             }
-            if (pos < s)
-                outp[pos] = h[u];
+            if (__builtin_expect(far, 0))
+                rank_in_bin(j, hv);
+            else if (pos < s)
+                outp[pos] = hv;
         }
     }
+#else
+    for (uint32_t j = tid; j < C; j += THREADS)
+        rank_in_bin(j, sm.binned[j]);
+#endif
     if (by_waves && nbig) // rare: keep it out of line (and out of the common path's register budget)
         rank_big_bins(sm.binned, bins, sm.seqb, nbig, s, [outp](uint32_t pos, uint32_t hv) { outp[pos] = hv; }); // by VALUE: a reference would
                                                                                                             // park `outp` in scratch, per read
@@ -698,8 +753,8 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_WPE,
     sm.seqb = smem_raw;                    // WAVES slices of n_seq_dw
     sm.P = sm.seqb + WAVES * n_seq_dw;     // WAVES slices of n_P_w (whole region doubles as `bins`)
     sm.cand = sm.P + n_P;
-    sm.binned = sm.cand + capf;
-    sm.misc = sm.binned + capf;
+    sm.binned = sm.cand + capf + BS_MARGIN; // (bottom_s_fast's window reads BS_MARGIN entries on either side)
+    sm.misc = sm.binned + capf + BS_MARGIN;
     sm.lut = sm.misc + 16;
 
     const uint32_t k = KS > 0 ? (uint32_t)KS : k_rt;
@@ -894,7 +949,8 @@ template <int KS> struct Slabs {
 // survivors of the lane's 4 hashes -> the wave's own segment; `cnt` is wave-uniform (kept in a scalar register)
 template <bool PARTIAL>
 __device__ __forceinline__ void append_own(uint32_t *__restrict__ seg, uint32_t capw, uint32_t &cnt, const uint32_t (&h)[4],
-                                           uint32_t nvalid, uint32_t tauq)
+                                           uint32_t nvalid, uint32_t tauq, uint32_t *__restrict__ selbins = nullptr,
+                                           uint32_t selshift = 0)
 {
     bool a[4];
     uint64_t m[4];
@@ -908,12 +964,31 @@ __device__ __forceinline__ void append_own(uint32_t *__restrict__ seg, uint32_t 
     }
     uint32_t base = __builtin_amdgcn_readfirstlane(cnt);
     cnt = base + total;
+#if PH_SEL_ATOMIC
+    {
+        // ds_inc wraps at capw - 1, so a slot is always inside the segment; the scalar count above is what tells an overflow
+        uint32_t *ctr = seg + capw; // (the experiment keeps the wave's counter behind its segment: capw is one entry smaller)
+        uint32_t slot[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (a[c])
+                slot[c] = atomicInc(ctr, capw - 1u);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (a[c])
+                seg[slot[c]] = h[c];
+        return;
+    }
+#endif
     if (cnt <= capw) { // wave-uniform; an overflowing wave stops storing and the read is redone
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint32_t *__restrict__ at = seg + base; // scalar: the lane only adds its rank among the survivors
-            if (a[c])
+            if (a[c]) {
                 at[__builtin_amdgcn_mbcnt_hi((uint32_t)(m[c] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m[c], 0u))] = h[c];
+                if (PH_SELBINS) // the bin is in the top 16 bits, which fmix32's last xor-shift leaves alone
+                    atomicAdd(&selbins[h[c] >> selshift], 1u);
+            }
             base += n[c];
         }
     }
@@ -922,7 +997,8 @@ __device__ __forceinline__ void append_own(uint32_t *__restrict__ seg, uint32_t 
 // all slabs of one read; returns this wave's survivor count (wave-uniform; > capw: the segment overflowed)
 template <int KS>
 __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv, uint32_t n_seq_dw, uint32_t n_P_w,
-                                              uint32_t *__restrict__ seg, uint32_t capw, uint32_t tauq)
+                                              uint32_t *__restrict__ seg, uint32_t capw, uint32_t tauq,
+                                              uint32_t *__restrict__ selbins = nullptr, uint32_t selshift = 0)
 {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // scalar: slab indices and ring bases stay in SGPRs
     Slabs<KS> S;
@@ -939,6 +1015,11 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
     const uint32_t a = (uint32_t)wave * spw, b = a + spw < nslab ? a + spw : nslab; // this wave hashes slabs [a, b)
     S.u_inside = rv.gbytes >= 65 * 4 ? (uint32_t)(((rv.gbytes >> 2) - 65) >> 6) + 1u : 0u;
     uint32_t cnt = 0;
+#if PH_SEL_ATOMIC
+    capw -= 1u; // the last entry of the segment is the wave's slot counter
+    if (S.lane == 0)
+        seg[capw] = 0u;
+#endif
     if (a >= b)
         return cnt;
     uint32_t l1, h1;
@@ -980,10 +1061,10 @@ __device__ __forceinline__ uint32_t run_slabs(const Smem &sm, const ReadView &rv
             if ((h[0] ^ h[1] ^ h[2] ^ h[3]) == 0x12345u)
                 seg[0] = h[0];
         } else if (__builtin_expect(left >= 256, 1)) {
-            append_own<false>(seg, capw, cnt, h, 4u, tauq);
+            append_own<false>(seg, capw, cnt, h, 4u, tauq, selbins, selshift);
         } else {
             const int64_t mine = left - 4 * S.lane;
-            append_own<true>(seg, capw, cnt, h, mine <= 0 ? 0u : (mine < 4 ? (uint32_t)mine : 4u), tauq);
+            append_own<true>(seg, capw, cnt, h, mine <= 0 ? 0u : (mine < 4 ? (uint32_t)mine : 4u), tauq, selbins, selshift);
         }
         wave_sync(); // the rings are rewritten by the next step
     }
@@ -1001,12 +1082,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB
     sm.seqb = smem_raw + 256;          // WAVES rings of n_seq_dw
     sm.P = sm.seqb + WAVES * n_seq_dw; // WAVES rings of n_P_w (whole region doubles as `bins`)
     sm.cand = sm.P + n_P;              // WAVES segments of capw
-    sm.binned = sm.cand + WAVES * capw;
-    sm.misc = sm.binned + capf;
+    sm.binned = sm.cand + WAVES * capw + BS_MARGIN;
+    sm.misc = sm.binned + capf + BS_MARGIN;
     constexpr uint32_t k = (uint32_t)KS;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     sm.lut[tid] = premix((uint32_t)tid) ^ k; // THREADS == 256; visible after the first barrier
     uint32_t *seg = sm.cand + wave * capw;
+    uint32_t *selbins = sm.misc + 16; // (PH_SELBINS only: 2^nbf_log2 counters behind everything else)
+    if (PH_SELBINS)
+        for (uint32_t b = tid; b < (1u << nbf_log2); b += THREADS)
+            selbins[b] = 0u;
 
     for (uint64_t r = blockIdx.x; r < nseq; r += gridDim.x) {
         const ReadView rv = view(seqs, offs, r, k);
@@ -1023,7 +1108,14 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB
                 tauq = (uint32_t)((target << 32) / (uint64_t)rv.nwin) | 0xFFFFu;
         }
         __syncthreads(); // the previous read is done with LDS
-        const uint32_t cw = PH_ABL == 14 ? tauq >> 31 : run_slabs<KS>(sm, rv, n_seq_dw, n_P_w, seg, capw, tauq);
+        uint32_t selshift = 0;
+        if (PH_SELBINS) {
+            const int sig = 32 - __builtin_clz(tauq | 1u);
+            selshift = sig > (int)nbf_log2 ? (uint32_t)(sig - (int)nbf_log2) : 0u; // bottom_s_fast's shift (experiment: needs >= 16)
+            if (tid == 0)
+                sm.misc[8] = 0;
+        }
+        const uint32_t cw = PH_ABL == 14 ? tauq >> 31 : run_slabs<KS>(sm, rv, n_seq_dw, n_P_w, seg, capw, tauq, selbins, selshift);
         if ((tid & 63) == 0)
             sm.misc[10 + wave] = cw;
         __syncthreads();
@@ -1034,12 +1126,17 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(PH_SLAB
         }
         const uint32_t c0 = sm.misc[10], c1 = sm.misc[11], c2 = sm.misc[12], c3 = sm.misc[13];
         const uint32_t C = c0 + c1 + c2 + c3;
-        const bool ok = max(max(c0, c1), max(c2, c3)) <= capw && C >= s && C <= capf; // enough survivors, none lost
+        const bool ok = max(max(c0, c1), max(c2, c3)) <= capw - (PH_SEL_ATOMIC ? 1u : 0u) && C >= s && C <= capf; // enough survivors, none lost
         if (ok)
-            bottom_s_fast<true>(sm, s, tauq, C, nbf_log2, outp, seg, (uint32_t)(tid & 63), 64u, cw);
-        else if (tid == 0) {
-            outp[0] = MARK0;
-            outp[1] = MARK1;
+            bottom_s_fast<true, PH_SELBINS != 0>(sm, s, tauq, C, nbf_log2, outp, seg, (uint32_t)(tid & 63), 64u, cw, selbins);
+        else {
+            if (PH_SELBINS) // (a read that is handed on leaves its counts behind)
+                for (uint32_t b = tid; b < (1u << nbf_log2); b += THREADS)
+                    selbins[b] = 0u;
+            if (tid == 0) {
+                outp[0] = MARK0;
+                outp[1] = MARK1;
+            }
         }
     }
 }
@@ -1274,7 +1371,7 @@ __global__ __launch_bounds__(THREADS) void sketch_tiny_kernel(const uint8_t *__r
 }
 
 struct Launch {
-    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, capf, cap, capw, capf_slab;
+    uint32_t n_seq_dw, n_P_w, n_P, n_P_fast, nbf_log2, nbf_log2_slab, capf, cap, capw, capf_slab;
     size_t smem_fast, smem_general, smem_slab;
 };
 
@@ -1297,7 +1394,7 @@ static Launch plan(uint32_t k, uint32_t s)
     L.capf = (s4 + PH_CAPK * rt + 64u + 63u) & ~63u;
     L.cap = s4 + TW + 64u; // general pass: shrink to s, then one more round always fits
     const size_t common = (size_t)WAVES * L.n_seq_dw + L.n_P + 16 + 256;
-    L.smem_fast = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + 2 * (size_t)L.capf) * 4;
+    L.smem_fast = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + 2 * (size_t)L.capf + 2 * BS_MARGIN) * 4;
     if (PH_ABL == 7)
         L.smem_fast = 70 * 1024; // occupancy probe
     L.smem_general = (common + 2 * (size_t)L.cap) * 4;
@@ -1312,7 +1409,15 @@ static Launch plan(uint32_t k, uint32_t s)
         L.capw = (exp_w + PH_SLAB_CW * rw + 8u + 63u) & ~63u;
         L.capf_slab = PH_SLAB_CF ? ((target + PH_SLAB_CF * rt + 8u + 63u) & ~63u) : L.capf;
     }
-    L.smem_slab = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + (size_t)WAVES * L.capw + (size_t)L.capf_slab) * 4;
+    L.smem_slab = ((size_t)WAVES * L.n_seq_dw + L.n_P_fast + 16 + 256 + (size_t)WAVES * L.capw + (size_t)L.capf_slab + 2 * BS_MARGIN) * 4;
+    L.nbf_log2_slab = L.nbf_log2;
+    if (PH_SELBINS) {
+        L.nbf_log2_slab = PH_SELBINS;
+        L.smem_slab += (size_t)4 << PH_SELBINS;
+    }
+#ifdef PH_LDS_PAD
+    L.smem_slab += PH_LDS_PAD; // occupancy probe
+#endif
     return L;
 }
 
@@ -1339,7 +1444,7 @@ static int launch(const uint8_t *d_seqs, const uint64_t *d_offs, uint64_t n, uin
             PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(slab), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)L.smem_slab));
             hipLaunchKernelGGL(slab, dim3(persistent_grid(L.smem_slab, n)), dim3(THREADS), L.smem_slab, st, d_seqs, d_offs, n, s,
-                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf_slab, L.nbf_log2);
+                               d_out, L.n_seq_dw, L.n_P_w, L.n_P_fast, L.capw, L.capf_slab, L.nbf_log2_slab);
         }
     }
     if (!slabs) {

@@ -565,6 +565,216 @@ __global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict
     }
 }
 
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+}
+
+// ---- sw_pk1_kernel's sweep with every lane's rows split over TWO lanes (round 6) ------------------------------------
+// 152 packed H rows + the row codes pin sw_pk1_kernel at 256 registers, two waves per SIMD, and two waves cannot hide the
+// packed chain's own dependency (hipcc pads five s_nop per row; VALU issue 0.82 of the busy cycles).  Here lanes 2d and
+// 2d + 1 share the two read pairs of duo d: the even lane holds rows [0, RB), the odd lane rows [RB, 2 RB) and works ONE
+// 4-column block behind, so what it needs from above -- the even lane's last row of the block before (four H, the
+// pre-subtracted diagonal, the block maximum) -- is in the even lane's registers when the step starts: six DPP row_shr:1
+// moves per step, each of which also resets the even lane to the sweep's top-of-column constants (the select takes the
+// constant on even lanes).  76 H rows + 19 code registers: 128 registers, four waves per SIMD.
+// Two tables live in LDS at fixed addresses: block t's at 0 for the even lanes, block t-1's at 1024 for the odd lanes,
+// whose code bytes carry + 64 -- so the address stays ONE SDWA shift.  When a step ends, slot 0 moves to slot 1 and the
+// staged next table to slot 0 (LDS runs a wave's instructions in order; one wave per workgroup, no barrier).  Step 0's
+// odd lanes see an all-pad table (H stays 0), the last step's even lanes sweep a stale table and nothing reads them.
+template <int RB>
+__global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+                                                        uint64_t npairs, const uint32_t *__restrict__ prof2, uint32_t nq,
+                                                        uint32_t tab_bytes, int ncp, const uint8_t *__restrict__ codeA,
+                                                        int ncodes, int gapabs, uint32_t *__restrict__ infoM,
+                                                        uint32_t *__restrict__ infoQ)
+{
+    static_assert(RB % 4 == 0 && RB <= 76, "RB");
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_pk[]; // [0, 1024) slot 0, [1024, 2048) slot 1,
+    uint8_t *codeL = lds_pk + 2048;                                  // [2048, 2304) the code bytes, [2304, 3328) staging
+    const uint32_t lane = threadIdx.x;
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk)) != 0u)
+        __builtin_trap(); // the sweep addresses the slots by immediate
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        codeL[lane + 64 * u] = codeA[lane + 64 * u];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t band = lane & 1u, duo = lane >> 1;
+    const bool odd = band != 0u;
+    const uint64_t base = (uint64_t)blockIdx.x * 64;
+    const uint64_t p0 = base + duo, p1 = base + 32 + duo;
+    uint64_t o0 = 0, o1 = 0;
+    uint32_t len0 = 0, len1 = 0;
+    if (p0 < npairs) {
+        o0 = offA[p0];
+        const uint64_t l = offA[p0 + 1] - o0;
+        len0 = l > (uint64_t)(2 * RB) ? 0u : (uint32_t)l; // too long: no score here, the locate kernel reports it
+    }
+    if (p1 < npairs) {
+        o1 = offA[p1];
+        const uint64_t l = offA[p1 + 1] - o1;
+        len1 = l > (uint64_t)(2 * RB) ? 0u : (uint32_t)l;
+    }
+    // my RB rows' code pairs, four per register (+ 64 on the odd lanes: slot 1); the bytes as aligned dwords through a
+    // bounded buffer resource, as sw_pk1_kernel
+    const uint32_t row0 = band * (uint32_t)RB;
+    const uint32_t slot_bias = odd ? 64u : 0u;
+    uint32_t rpk[RB / 4];
+    const uint64_t totalA = offA[npairs];
+    if (totalA < 0xFFFFFFF0ull) {
+        const uint32_t misA = (uint32_t)(reinterpret_cast<uintptr_t>(A) & 3u);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(A) - misA, 0,
+                                                                            (int)(((uint32_t)totalA + misA + 3u) & ~3u), 0x00020000);
+        uint32_t d0[RB / 4], d1[RB / 4];
+        {
+            const uint32_t b0 = (uint32_t)o0 + misA + row0, b1 = (uint32_t)o1 + misA + row0;
+            uint32_t a0[RB / 4 + 1], a1[RB / 4 + 1];
+#pragma unroll
+            for (int w = 0; w <= RB / 4; ++w) {
+                a0[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b0 & ~3u) + 4u * w), 0, 0);
+                a1[w] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs, (int)((b1 & ~3u) + 4u * w), 0, 0);
+            }
+#pragma unroll
+            for (int w = 0; w < RB / 4; ++w) {
+                d0[w] = __builtin_amdgcn_alignbyte(a0[w + 1], a0[w], b0 & 3u);
+                d1[w] = __builtin_amdgcn_alignbyte(a1[w + 1], a1[w], b1 & 3u);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const uint32_t i = row0 + 4u * w + h;
+                uint32_t c0 = (uint32_t)ncodes, c1 = (uint32_t)ncodes; // pad: no such row, or a byte outside FirstAlphabet
+                if (i < len0) {
+                    const uint32_t c = codeL[(d0[w] >> (8 * h)) & 0xFFu];
+                    c0 = c == 0xFFu ? c0 : c;
+                }
+                if (i < len1) {
+                    const uint32_t c = codeL[(d1[w] >> (8 * h)) & 0xFFu];
+                    c1 = c == 0xFFu ? c1 : c;
+                }
+                pk |= (c0 * (uint32_t)ncp + c1 + slot_bias) << (8 * h);
+            }
+            rpk[w] = pk;
+        }
+    } else {
+        const uint8_t *ap0 = A + o0, *ap1 = A + o1;
+#pragma unroll
+        for (int w = 0; w < RB / 4; ++w) {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int i = (int)row0 + 4 * w + h;
+                const uint32_t c0 = row_code(ap0, len0, i, codeL, (uint32_t)ncodes);
+                const uint32_t c1 = row_code(ap1, len1, i, codeL, (uint32_t)ncodes);
+                pk |= (c0 * (uint32_t)ncp + c1 + slot_bias) << (8 * h);
+            }
+            rpk[w] = pk;
+        }
+    }
+    uint32_t H[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+        H[i] = 0;
+    const uint32_t gh = half_bits(-gapabs);
+    const uint32_t gap2 = gh | (gh << 16); // -|gap| * 2^-11 in both halves
+    uint32_t best = 0, bestq = 0, ties = 0;
+
+    // block 0's table into slot 0, an all-pad table (column 0 with its + |gap| bias, as profile2_kernel) into slot 1
+    const uint32_t nent = tab_bytes >> 4;
+    const bool mine = lane < nent;
+    const uint32_t slot = lane << 4;
+    const uint8_t *tabp = reinterpret_cast<const uint8_t *>(prof2) + slot; // my entry of block t
+    if (mine)
+        reinterpret_cast<uint4 *>(lds_pk)[lane] = *reinterpret_cast<const uint4 *>(tabp);
+    {
+        const uint32_t pd = half_bits(PADS), pd0 = half_bits(PADS + gapabs);
+        reinterpret_cast<uint4 *>(lds_pk + 1024)[lane] = make_uint4(pd0 | (pd0 << 16), pd | (pd << 16), pd | (pd << 16), pd | (pd << 16));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = gap2, bm = 0;
+    for (uint32_t t = 0; t <= nq; ++t) { // even lanes: block t (t < nq); odd lanes: block t - 1
+        tabp += tab_bytes;
+        if (mine && t + 1 < nq)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)tabp,
+                                             (__attribute__((address_space(3))) void *)(lds_pk + 2304), 16, 0, 0);
+        // the band above hands its last row of block t - 1 down (odd lanes); the even lanes start at the top of the column
+        {
+            const uint32_t u0 = from_lane_above(pr0), u1 = from_lane_above(pr1), u2 = from_lane_above(pr2),
+                           u3 = from_lane_above(pr3), ud = from_lane_above(pdiag), ub = from_lane_above(bm);
+            pr0 = odd ? u0 : 0u;
+            pr1 = odd ? u1 : 0u;
+            pr2 = odd ? u2 : 0u;
+            pr3 = odd ? u3 : 0u;
+            pdiag = odd ? ud : gap2; // 0 - |gap| (PH_PKF_ROW)
+            bm = odd ? ub : 0u;
+        }
+        uint32_t pg0 = pkf_addc(pr0, gap2), pg1 = pkf_addc(pr1, gap2), pg2 = pkf_addc(pr2, gap2), pg3 = pkf_addc(pr3, gap2);
+        u32x4 wa, wb;
+        PH_PK1_ISSUE(wa, rpk[0], "BYTE_0");
+#pragma unroll
+        for (int g = 0; g < RB / 4; ++g) {
+            PH_PK1_ISSUE(wb, rpk[g], "BYTE_1");
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+            PH_PKF_ROW(4 * g, wa);
+            PH_PK1_ISSUE(wa, rpk[g], "BYTE_2");
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+            PH_PKF_ROW(4 * g + 1, wb);
+            PH_PK1_ISSUE(wb, rpk[g], "BYTE_3");
+            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+            PH_PKF_ROW(4 * g + 2, wa);
+            if (g + 1 < RB / 4) {
+                PH_PK1_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+            }
+            PH_PKF_ROW(4 * g + 3, wb);
+        }
+        if (mine) { // every row of this step has its entry: slot 1 takes block t's table, slot 0 the staged block t + 1
+            u32x4 cur, nxt;
+            asm volatile("s_waitcnt vmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2304\n\ts_waitcnt lgkmcnt(0)\n\t"
+                         "ds_write_b128 %2, %0 offset:1024\n\tds_write_b128 %2, %1"
+                         : "=&v"(cur), "=&v"(nxt)
+                         : "v"(slot)
+                         : "memory");
+        }
+        // the pair's block maximum (all 2 RB rows) is the odd lane's; a block reaching the maximum AGAIN is a tie
+        const uint32_t tb = t - 1u;
+        const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
+        if (blo > mlo) {
+            best = (best & 0xFFFF0000u) | blo;
+            bestq = (bestq & 0xFFFF0000u) | (tb & 0xFFFFu);
+            ties &= ~1u;
+        } else if (blo == mlo && blo != 0u) {
+            ties |= 1u;
+        }
+        if (bhi > mhi) {
+            best = (best & 0xFFFFu) | (bhi << 16);
+            bestq = (bestq & 0xFFFFu) | (tb << 16);
+            ties &= ~0x10000u;
+        } else if (bhi == mhi && bhi != 0u) {
+            ties |= 0x10000u;
+        }
+    }
+    if (odd) {
+        const uint32_t m0 = half_score(best & 0xFFFFu), m1 = half_score(best >> 16);
+        if (p0 < npairs) {
+            infoM[p0] = m0;
+            infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+        }
+        if (p1 < npairs) {
+            infoM[p1] = m1;
+            infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+        }
+    }
+}
+
 // ---- reads of 153 .. 256 rows: K lanes per pair ------------------------------------------------------
 // One lane cannot hold more than 152 packed rows at two workgroups per CU, and at one workgroup per CU the
 // dependent packed chain stands exposed (measured: 256 rows in one lane run no faster than the 32-bit kernel).
@@ -574,10 +784,6 @@ __global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict
 // block maximum of the bands above.  The last band's lane sees the pair's block maxima and keeps M / first
 // block / tie exactly as sw_pk_kernel does.  prof2 carries K - 1 all-pad blocks on either side (lanes ahead
 // of / behind the reference see pad columns, in which H only decays), an LDS chunk K - 1 extra blocks.
-__device__ __forceinline__ uint32_t from_lane_above(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
-}
 
 template <int RB, int K, bool F16>
 __global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
@@ -1270,7 +1476,15 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                            sc->d_lutc, sc->ncodes, p.ncp, prof2, (int)p.f16, (int)(-sc->gap));
         PH_HIP(hipGetLastError());
     }
-    if (K == 1 && p.pk1) {
+    if (K == 1 && p.pk1 && RA == 152 && !p.skip_rows && !env_is("POLYHIP_SW_PK1X2", '0')) {
+        // two lanes per lane's worth of rows, four waves per SIMD (POLYHIP_SW_PK1X2=0: one lane, two waves)
+        if constexpr (K == 1 && RA == 152) {
+            const uint64_t blocks = (npairs + 63) / 64;
+            hipLaunchKernelGGL(sw_pk1x2_kernel<RA / 2>, dim3((unsigned)blocks), dim3(64), 2048 + 256 + 1024, st, d_A, d_offA,
+                               npairs, prof2, p.nq, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
+            PH_HIP(hipGetLastError());
+        }
+    } else if (K == 1 && p.pk1) {
         if constexpr (K == 1) {
             auto kern = p.skip_rows ? sw_pk1_kernel<RA, true> : sw_pk1_kernel<RA, false>;
             const uint64_t blocks = (npairs + 127) / 128;

@@ -20,9 +20,9 @@ int main()
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) polyhip_mash_sketch_batch_dev(seqs, offs, n, k, s, out, nullptr);
+    for (int r = 0; r < 20; ++r) polyhip_mash_sketch_batch_dev(seqs, offs, n, k, s, out, nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
-    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 20;
     // checksum of all sketches: variants must agree with the baseline build word for word
     std::vector<uint32_t> ho(n * s);
     hipMemcpy(ho.data(), out, n * s * 4, hipMemcpyDeviceToHost);
@@ -32,6 +32,7 @@ int main()
     printf("checksum %016llx %08llx  smem_slab %zu capw %u capf_slab %u  ", (unsigned long long)sum, (unsigned long long)x, PL.smem_slab, PL.capw, PL.capf_slab);
     static const char *what[] = {"full kernel", "no premix", "1 chain block of 5", "no tail/fmix", "no select stores", "no bottom_s", "no global loads", "2 workgroups per CU",
                                  "", "", "", "slab: stage + premix + hash only", "slab: no bottom-s", "", "slab: per-read prologue + barriers only", "slab: no premix", "slab: 1 chain block of 5", "slab: fmix32 cut to one multiply"};
-    printf("PH_ABL=%d %-40s %.3f ms per 100k reads\n", PH_ABL, what[PH_ABL], ms);
+    const char *w = PH_ABL < (int)(sizeof what / sizeof what[0]) ? what[PH_ABL] : PH_ABL == 21 ? "slab: bottom-s without barriers" : PH_ABL == 22 ? "slab: bottom-s without its rank pass" : "";
+    printf("PH_ABL=%d PH_BS_WIN=%d PH_SELBINS=%d %-40s %.3f ms per 100k reads\n", PH_ABL, PH_BS_WIN, PH_SELBINS, w, ms);
     return 0;
 }

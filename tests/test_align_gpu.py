@@ -311,7 +311,11 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
     A = torch.from_numpy(flat.copy()).to(dev)
     offA = torch.from_numpy(offs).to(dev)
 
-    def run(refarr, packed, half=True, fixed_slot=True):
+    def run(refarr, packed, half=True, fixed_slot=True, two_lanes=True):
+        if two_lanes:   # sw_pk1x2_kernel (round 6): a lane's 152 rows over two lanes, four waves per SIMD (the default at 152 rows)
+            monkeypatch.delenv("POLYHIP_SW_PK1X2", raising=False)
+        else:           # sw_pk1_kernel: one lane per two pairs, two waves per SIMD
+            monkeypatch.setenv("POLYHIP_SW_PK1X2", "0")
         if packed:
             monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
         else:
@@ -331,6 +335,7 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         align.sw_batch_dev(sc, A, offA, L, B, None, len(refarr), score, ea, eb, er, work)
         torch.cuda.synchronize()
         monkeypatch.delenv("POLYHIP_SW_PK1", raising=False)
+        monkeypatch.delenv("POLYHIP_SW_PK1X2", raising=False)
         return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path(), align.last_packed_half()
 
     refs = [ref]
@@ -345,11 +350,12 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         got, path, half = run(refarr, True)
         got16, path16, half16 = run(refarr, True, half=False)
         gotc, pathc, halfc = run(refarr, True, fixed_slot=False)
+        got1, path1, half1 = run(refarr, True, two_lanes=False)
         want, path0, _ = run(refarr, False)
-        assert (path, path16, pathc, path0) == (3, 3, 3, 1)
-        assert (half, half16, halfc) == (True, False, True)
-        for g, g16, gc, w in zip(got, got16, gotc, want):
-            assert (g == w).all() and (g16 == w).all() and (gc == w).all()
+        assert (path, path16, pathc, path1, path0) == (3, 3, 3, 3, 1)
+        assert (half, half16, halfc, half1) == (True, False, True, True)
+        for g, g16, gc, g1, w in zip(got, got16, gotc, got1, want):
+            assert (g == w).all() and (g16 == w).all() and (gc == w).all() and (g1 == w).all()
         refb = refarr.tobytes()
         for p in range(0, n, 1501):
             a = flat[offs[p]:offs[p + 1]].tobytes()
