@@ -580,7 +580,9 @@ int polyhip_least_rotation_batch(const uint8_t *seqs, const uint64_t *offsets,
  * d_err[i]: 0, or (2 << 8) | letter for seqhash.go:157 ("Only letters
  * ATUGCYRSWKMBDHVNZ are allowed for DNA/RNA. Got letter: X"), (3 << 8) | letter
  * for seqhash.go:169 (proteins) -- the first offending letter, as the reference.
- * total_bytes = d_offsets[n] - d_offsets[0]; max_len >= every sequence length.
+ * d_offsets[0] must be 0 (the normalised copy in the workspace is addressed by the
+ * batch's own offsets; the host flavour rebases); total_bytes = d_offsets[n];
+ * max_len >= every sequence length.
  */
 size_t polyhip_seqhash_workspace_bytes(uint64_t n, uint64_t total_bytes,
                                        int circular, int double_stranded);

@@ -62,7 +62,11 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                 if res.returncode:
                     raise RuntimeError(f"hipcc failed on {cmd[-3]}")
     objs = [s[:-4] + ".o" for s in srcs]
-    if force or jobs or _newer(LIB, objs):
+    relinked = bool(force or jobs or _newer(LIB, objs))
+    # what this call actually did, for the logs (a box that ships prebuilt objects reuses all of them)
+    print(f"poly_amd.build: rebuilt {len(jobs)} objects / reused {len(srcs) - len(jobs)}; libpolyhip.so "
+          f"{'linked' if relinked else 'reused'}", file=sys.stderr, flush=True)
+    if relinked:
         cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode:

@@ -351,10 +351,17 @@ __global__ __launch_bounds__(THREADS) void normalise_stream_kernel(const uint8_t
             *reinterpret_cast<uint4 *>(norm + a0 + 16 * p) = make_uint4(o[0], o[1], o[2], o[3]); // (norm is 256-byte aligned)
         }
     }
-    if (gtid < 32) { // up to 15 bytes in front of a0 and up to 15 behind a1 (or the whole of a batch shorter than a piece)
-        const uint64_t h1 = a0 < a1 ? a0 : b1;
-        const uint64_t t = gtid < 16 ? b0 + gtid : (a0 < a1 ? a1 + (gtid - 16) : b1);
-        if ((gtid < 16 && t < h1) || (gtid >= 16 && t < b1)) {
+    if (a0 < a1) {
+        if (gtid < 32) { // up to 15 bytes in front of a0 and up to 15 behind a1
+            const uint64_t t = gtid < 16 ? b0 + gtid : a1 + (gtid - 16);
+            if (gtid < 16 ? t < a0 : t < b1) {
+                const uint32_t e = upT[seqs[t]];
+                bad |= e;
+                norm[t] = (uint8_t)e;
+            }
+        }
+    } else { // no whole aligned piece (a batch of up to 30 bytes): every byte singly
+        for (uint64_t t = b0 + gtid; t < b1; t += nth) {
             const uint32_t e = upT[seqs[t]];
             bad |= e;
             norm[t] = (uint8_t)e;
