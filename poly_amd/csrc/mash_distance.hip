@@ -1397,8 +1397,8 @@ constexpr int DENSE_THREADS = 1024; // one workgroup per CU (its LDS is the whol
 #ifndef PH_K2_DENSE_U
 #define PH_K2_DENSE_U 8
 #endif
-#ifndef PH_K2_PIPE
-#define PH_K2_PIPE 1
+#ifndef PH_K2_PIPE2
+#define PH_K2_PIPE2 0 // 1: two groups of DENSE_U buckets in flight per wave (round 6; measured in profiles/r06_k2_join_pipe.log)
 #endif
 constexpr int DENSE_U = PH_K2_DENSE_U; // buckets a wave loads back to back, 128 items of each
 static_assert(64 % DENSE_U == 0, "a chunk of 64 bucket descriptors (one per lane) is walked DENSE_U at a time by v_readlane: "
@@ -1690,6 +1690,56 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                     // which 0.43 are the flush's STORES at the HBM write rate (5.9 TB/s) and 0.15 everything else; with the walk
                     // the stores cost 0.23: a wave's next loads wait behind its own flush stores -- vmcnt is one queue.)
                     const uint32_t lane4 = (uint32_t)lane * 4u;
+#if PH_K2_PIPE2
+                    // (round 6) two groups of DENSE_U buckets in flight: group g + 1's loads are issued BEFORE group g's items
+                    // are consumed (vmcnt counts in order: the wait in front of a group's consume leaves the younger group's
+                    // loads outstanding), so a wave's eight dependent load-wait-consume rounds per row become one wait plus
+                    // seven that overlap the consume in front of them
+                    {
+                        uint32_t itA[DENSE_U][2], lenA[DENSE_U], itB[DENSE_U][2], lenB[DENSE_U];
+                        __amdgpu_buffer_rsrc_t rsA[DENSE_U], rsB[DENSE_U];
+                        auto issue = [&](uint32_t j0, uint32_t (&it)[DENSE_U][2], uint32_t (&len)[DENSE_U],
+                                         __amdgpu_buffer_rsrc_t (&rs)[DENSE_U]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int u = 0; u < DENSE_U; ++u) {
+                                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
+                                len[u] = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u)) - b;
+                                rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(items + b), 0, (int)(len[u] * 4u), 0x00020000);
+                                it[u][0] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 0, 0);
+                                it[u][1] = __builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, 256, 0);
+                            }
+                        };
+                        auto eat = [&](uint32_t j0, uint32_t (&it)[DENSE_U][2], uint32_t (&len)[DENSE_U],
+                                       __amdgpu_buffer_rsrc_t (&rs)[DENSE_U]) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int u = 0; u < DENSE_U; ++u) {
+                                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
+                                const uint32_t alim = (uint32_t)__builtin_amdgcn_readlane((int)mlim, (int)(j0 + u));
+                                consume_compact(it[u][0], key, alim);
+                                if (len[u] > 64u) { // wave-uniform
+                                    consume_compact(it[u][1], key, alim);
+                                    for (uint32_t t = 128; t < len[u]; t += 64) // rest of a long bucket
+                                        consume_compact(__builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)lane4, (int)(t * 4u), 0), key, alim);
+                                }
+                            }
+                        };
+                        if (cnt)
+                            issue(0, itA, lenA, rsA);
+                        for (uint32_t j0 = 0; j0 < cnt; j0 += 2 * DENSE_U) {
+                            const bool second = j0 + DENSE_U < cnt;
+                            if (second)
+                                issue(j0 + DENSE_U, itB, lenB, rsB);
+                            zero_step(per_group);
+                            eat(j0, itA, lenA, rsA);
+                            if (second) {
+                                if (j0 + 2 * DENSE_U < cnt)
+                                    issue(j0 + 2 * DENSE_U, itA, lenA, rsA);
+                                zero_step(per_group);
+                                eat(j0 + DENSE_U, itB, lenB, rsB);
+                            }
+                        }
+                    }
+#else
                     for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
                         uint32_t it[DENSE_U][2], len[DENSE_U];
                         __amdgpu_buffer_rsrc_t rs[DENSE_U];
@@ -1718,6 +1768,7 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                             }
                         }
                     }
+#endif
                 } else {
                     for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
                         uint2 it[DENSE_U][2];

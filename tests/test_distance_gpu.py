@@ -378,12 +378,14 @@ def test_c_abi_allgather_one_rank(mash):
     _lib.check(L.polyhip_comm_destroy(comm))
 
 
-def test_full_size_config3_row_block_properties(mash):
+def test_full_size_config3_row_block_properties(mash, monkeypatch):
     """BASELINE configs[2] at FULL size for one rank of 8: a 12,500 x 100,000 row block of the all-vs-all over
     100,000 sketches of s = 1000 (1000 families x 100 copies at 1 % substitution, sketched by K1).  Properties of
     the whole block: the diagonal shares all s hashes; the block is symmetric where it overlaps its own rows;
     counts never exceed s; 2,400 sampled cells over ALL 100,000 columns (in-family, in-block, and >= 500 in the far
-    columns) and 64 full rows equal the reference's merge (mash.go:107-135); distances are exactly 1 - count/s in fp64."""
+    columns) and 512 full rows equal the reference's merge (mash.go:107-135); distances are exactly 1 - count/s in fp64.
+    The WHOLE block is also computed on the two-level index build of round 4 (POLYHIP_K2_B4=0) and must equal the default
+    build's (the sliced 4-byte build of round 5) cell for cell."""
     import torch
     from poly_amd import bench_extra
     dev = torch.device("cuda:0")
@@ -393,8 +395,17 @@ def test_full_size_config3_row_block_properties(mash):
     X = sk[:nrows]
     counts = torch.empty((nrows, N), dtype=torch.int16, device=dev)
     work = torch.empty(mash.shared_counts_workspace_bytes(nrows, s, N, s), dtype=torch.uint8, device=dev)
+    monkeypatch.delenv("POLYHIP_K2_B4", raising=False)
     mash.shared_counts_dev(X, sk, counts, work)
     torch.cuda.synchronize()
+    # the other index build, whole block: 1.25e9 cells, not a sample
+    monkeypatch.setenv("POLYHIP_K2_B4", "0")
+    counts_two_level = torch.full_like(counts, -1)
+    mash.shared_counts_dev(X, sk, counts_two_level, work)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("POLYHIP_K2_B4", raising=False)
+    assert torch.equal(counts, counts_two_level)
+    del counts_two_level
     c = counts.to(torch.int32)
     assert bool((c.diagonal() == s).all())
     assert bool((c >= 0).all()) and bool((c <= s).all())
@@ -417,12 +428,12 @@ def test_full_size_config3_row_block_properties(mash):
     assert sum(1 for _, j in cells if j >= nrows) >= 500
     for i, j in cells:
         assert int(c_h[i, j]) == orc.mash_shared(sk_h[i], sk_h[j]), (i, j)
-    # 64 FULL rows against the reference's merge over all 100,000 columns (the oracle's C loop on every host core:
+    # 512 FULL rows against the reference's merge over all 100,000 columns (the oracle's C loop on every host core:
     # ctypes releases the GIL): every count, and with it the rows' number of nonzero cells -- a stray count anywhere
     # in a far column cannot hide
     import concurrent.futures as cf
     import os
-    rows64 = np.sort(rng.choice(nrows, 64, replace=False))
+    rows64 = np.sort(rng.choice(nrows, 512, replace=False))
     groups = np.array_split(rows64, max(1, min(len(rows64), os.cpu_count() or 1)))
     with cf.ThreadPoolExecutor(len(groups)) as ex:
         parts = list(ex.map(lambda g: orc.mash_distance_matrix(sk_h[g], sk_h), groups))
