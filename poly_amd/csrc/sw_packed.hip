@@ -36,6 +36,10 @@
 #include "common.h"
 #include "sw_scoring.h"
 
+#ifndef PH_SW_TILE64_DEFAULT
+#define PH_SW_TILE64_DEFAULT 1 // 1: reads above 152 rows take 64 rows per lane (four waves per SIMD) unless POLYHIP_SW_TILE64=0
+#endif
+
 namespace polyhip {
 namespace k3p {
 
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restri
 // of / behind the reference see pad columns, in which H only decays), an LDS chunk K - 1 extra blocks.
 
 template <int RB, int K, bool F16>
-__global__ __launch_bounds__(THREADS, 2) void sw_pkb_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
+__global__ __launch_bounds__(THREADS, RB <= 64 ? 4 : 2) void sw_pkb_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
                                                         uint64_t npairs, const uint32_t *__restrict__ prof2,
                                                         uint32_t nq, uint32_t jcb, uint32_t tab_bytes, int ncp,
                                                         const uint8_t *__restrict__ codeA, int ncodes, int gapabs,
@@ -1430,7 +1434,10 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
         return false;
     // rows per lane x lanes per pair (sw_pkb_kernel above 152 rows): the smallest tile that holds the longest read
     static const int tiles[][2] = {{64, 1}, {152, 1}, {128, 2}, {152, 2}, {128, 4}, {152, 4}, {128, 8}, {152, 8}, {128, 16}};
-    for (const auto &t : tiles)
+    // (round 6) 64 rows per lane on twice the lanes: the H column and the row codes fit 128 registers, four waves per SIMD
+    // instead of two (what sw_pk1x2_kernel does for 152 rows).  POLYHIP_SW_TILE64=0: the 128-row tiles.
+    static const int tiles64[][2] = {{64, 1}, {152, 1}, {64, 4}, {152, 2}, {64, 8}, {152, 4}, {64, 16}, {152, 8}, {128, 16}};
+    for (const auto &t : PH_SW_TILE64_DEFAULT != env_is("POLYHIP_SW_TILE64", PH_SW_TILE64_DEFAULT ? '0' : '1') ? tiles64 : tiles)
         if ((uint32_t)(t[0] * t[1]) >= max_lenA) {
             p.rb = t[0];
             p.k = t[1];
@@ -1587,6 +1594,9 @@ int packed_run(const polyhip_scoring *sc, const PackedPlan &p, const uint8_t *d_
     if (p.rb == RB_ && p.k == K_)                                                                                         \
         return launch_packed<RB_ * K_, K_>(sc, p, d_A, d_offA, npairs, d_B, lenB, prof, binfo, prof2, infoM, infoQ, list, \
                                            count, d_score, d_endA, d_endB, d_err, st, defer);
+    PH_PKB_CASE(64, 4)
+    PH_PKB_CASE(64, 8)
+    PH_PKB_CASE(64, 16)
     PH_PKB_CASE(152, 2)
     PH_PKB_CASE(128, 4)
     PH_PKB_CASE(152, 4)

@@ -506,6 +506,14 @@ def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA,
         assert (path16, half16) == (7, False)
         for g, w in zip(got16, want):
             assert (g == w).all()
+    # the default takes 64 rows per lane where a 64-row tile holds the read (round 6: four waves per SIMD);
+    # POLYHIP_SW_TILE64=0: the 128 / 152-row tiles of rounds 1-5 -- every pair equal either way
+    monkeypatch.setenv("POLYHIP_SW_TILE64", "0")
+    got128, path128, _ = run(True)
+    monkeypatch.delenv("POLYHIP_SW_TILE64", raising=False)
+    assert path128 == 7
+    for g, w in zip(got128, want):
+        assert (g == w).all()
     assert int(got[0].max()) == 5 * maxA if maxA <= LB else int(got[0].max()) >= 4 * LB  # a read longer than the reference wraps around it
     om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
     refb = ref.tobytes()
