@@ -187,8 +187,8 @@ def sw(dev, n: int = 1_000_000, LA: int = 150, LB: int = 5000, shard: int = 0):
         "frac_of_valu_issue_ceiling": cells / ms_score * 1e3 / ceiling,
         "roofline": {"bound": "valu", "achieved": cells / ms_score * 1e3 / 1e12, "peak": ceiling / 1e12,
                      "unit": "T cell updates/s", "frac": cells / ms_score * 1e3 / ceiling,
-                     "kernel": ("polyhip::k3p::sw_pk1_kernel<152,false> (half-float cells) + k3p::sw_locate16_kernel<76> + k3w::sw_wave_kernel<3> "
-                                "for the ties, all inside score_pass_ms" if half else
+                     "kernel": (f"{_k3.get('kernel', 'polyhip::k3p::sw_pk1x2_kernel<76>')} (half-float cells, two lanes per 152 rows) + "
+                                "k3p::sw_locate16_kernel<76> + k3w::sw_wave_kernel<3> for the ties, all inside score_pass_ms" if half else
                                 "polyhip::k3p::sw_pk_kernel<152,false,false> (int16 cells) + locate + tie wave, all inside score_pass_ms"),
                      "derivation": f"packed {'half-float' if half else 'int16'} recurrence: {per_blk} VALU instructions = "
                                    f"{4 * per_blk:.1f} issue cycles per 512 cells (64 lanes x 2 pairs x 4 columns), 1024 SIMDs x "

@@ -320,8 +320,13 @@ struct K2XShard {
     uint64_t h_nirr = 0, h_est = 0;
     DevBuf segtab, segptr;
 };
+// raw_type >= 0 (seqhash.Hash; only when k5_wave_takes_all(max_len)): d_seqs are the caller's bytes; the wave kernel normalises
+// them while it stages them, writes the normalised copy to d_norm_out (indexed like d_seqs) and raises *d_any_bad on a letter
+// outside the alphabet of sequence type raw_type
 int k5_least_rotation_strands_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
-                                  uint64_t *d_rot_index, uint8_t *d_rotated, uint64_t *d_rot_rc, polyhip_stream_t stream);
+                                  uint64_t *d_rot_index, uint8_t *d_rotated, uint64_t *d_rot_rc, polyhip_stream_t stream,
+                                  int raw_type = -1, uint8_t *d_norm_out = nullptr, uint32_t *d_any_bad = nullptr);
+bool k5_wave_takes_all(uint64_t max_len); // every sequence of the batch gets a wave of least_rotation_wave_kernel
 int k2_exchange_index(md::Pool &P, std::vector<K2XShard> &sh, uint64_t n, uint32_t s, uint64_t rows_blk, bool *built);
 
 } // namespace polyhip

@@ -190,6 +190,44 @@ __device__ __forceinline__ void stage_sequence(uint8_t *__restrict__ lds, const 
     }
 }
 
+// RAW staging (round 6, seqhash.Hash on sequences a wave takes alone): g holds the caller's bytes, not yet normalised.  The
+// staging maps every byte through a 16-bit table entry -- low byte = the normalised letter (strings.ToUpper, RNA U -> T:
+// seqhash.go:143-148), bit 8 = "not in the alphabet" -- on its way into LDS, and writes the normalised bytes out to `norm`
+// as well (what the comparison and BLAKE3 read afterwards): the streaming normalise pass (one read and one launch) is gone.
+// Returns the OR of the entries seen (bit 8: a letter outside the alphabet somewhere in this thread's bytes).
+__device__ __forceinline__ uint32_t stage_sequence_raw(uint8_t *__restrict__ lds, const uint8_t *__restrict__ g, uint32_t n32,
+                                                       const uint16_t *__restrict__ upT, uint8_t *__restrict__ norm, uint32_t first,
+                                                       uint32_t step)
+{
+    const uint32_t n16 = n32 >> 4;
+    uint4 *L4 = reinterpret_cast<uint4 *>(lds);
+    uint32_t bad = 0;
+    auto map4 = [&](uint32_t w) {
+        const uint32_t e0 = upT[w & 0xFFu], e1 = upT[(w >> 8) & 0xFFu], e2 = upT[(w >> 16) & 0xFFu], e3 = upT[w >> 24];
+        bad |= e0 | e1 | e2 | e3;
+        return (e0 & 0xFFu) | ((e1 & 0xFFu) << 8) | ((e2 & 0xFFu) << 16) | (e3 << 24);
+    };
+    for (uint32_t t = first; t < n16; t += step) {
+        uint4 v, o;
+        __builtin_memcpy(&v, g + 16u * t, 16);
+        o.x = map4(v.x);
+        o.y = map4(v.y);
+        o.z = map4(v.z);
+        o.w = map4(v.w);
+        L4[t] = o;
+        __builtin_memcpy(norm + 16u * t, &o, 16); // (the sequence's own, unaligned, address -- as the load)
+    }
+    if (first < (n32 & 15u)) {
+        const uint32_t e = upT[g[16u * n16 + first]];
+        bad |= e;
+        lds[16u * n16 + first] = (uint8_t)e;
+        norm[16u * n16 + first] = (uint8_t)e;
+    }
+    if (first < WRAP) // s[0..] again behind s[n-1] (n may be tiny: cyclic)
+        lds[n32 + first] = (uint8_t)upT[g[n32 >= WRAP ? first : first % n32]];
+    return bad;
+}
+
 template <bool IN_LDS>
 __global__ __launch_bounds__(THREADS) void least_rotation_kernel(const uint8_t *__restrict__ seqs,
                                                                 const uint64_t *__restrict__ offs, uint64_t nseq,
@@ -522,15 +560,37 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t mask) // set bits of ma
 __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t *__restrict__ seqs,
                                                                  const uint64_t *__restrict__ offs, uint64_t nseq,
                                                                  uint32_t lds_seq_bytes, uint64_t *__restrict__ rot,
-                                                                 uint8_t *__restrict__ rotated, uint64_t *__restrict__ rot_rc)
+                                                                 uint8_t *__restrict__ rotated, uint64_t *__restrict__ rot_rc,
+                                                                 int raw_type, uint8_t *__restrict__ norm_out,
+                                                                 uint32_t *__restrict__ any_bad)
 {
+    // raw_type >= 0 (seqhash.Hash's batch, every sequence within a wave's share): seqs are the caller's bytes of sequence
+    // type raw_type (0 DNA, 1 RNA, 2 protein); they are normalised while they are staged (stage_sequence_raw), the
+    // normalised copy goes to norm_out, a letter outside the alphabet raises *any_bad (the per-sequence pass behind this
+    // kernel then names it).  raw_type < 0: seqs are searched as they are.
     // rot_rc != nullptr: ALSO the least rotation of the reverse complement (a second staging of the same bytes, in that
     // order, while they are still in this CU's caches; the strand itself is never written anywhere)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_all[];
     __shared__ uint8_t cmpT[256];
-    cmpT[threadIdx.x] = (uint8_t)dna_complement_upper(threadIdx.x); // 256 threads
+    __shared__ uint16_t upT[256];
+    {
+        const uint32_t b = threadIdx.x; // 256 threads
+        uint32_t c = b;
+        if (raw_type >= 0) { // the table of seqhash.hip's normalise_stream_kernel
+            c = (b - 'a' < 26u) ? b - 32u : b;
+            if (raw_type == 1 && c == 'U')
+                c = 'T';
+            const char *set = raw_type == 2 ? "ACDEFGHIKLMNPQRSTVWYUO*BXZ" : "ATUGCYRSWKMBDHVNZ";
+            bool ok = false;
+            for (const char *p = set; *p; ++p)
+                ok |= (uint32_t)(uint8_t)*p == c;
+            upT[b] = (uint16_t)(c | (ok ? 0u : 0x100u));
+        }
+        cmpT[b] = (uint8_t)dna_complement_upper(c); // raw: the complement of the NORMALISED letter, straight from the raw byte
+    }
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t bad = 0;
     uint8_t *lds = lds_all + (size_t)wv * (lds_seq_bytes + 2u * WLIST * 2u);
     uint32_t *L = reinterpret_cast<uint32_t *>(lds);
     uint16_t *listA = reinterpret_cast<uint16_t *>(lds + lds_seq_bytes), *listB = listA + WLIST; // positions < 2^16
@@ -547,6 +607,11 @@ __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t 
             }
             if (rotated && n == 1 && lane == 0)
                 rotated[o0] = g[0];
+            if (raw_type >= 0 && n == 1 && lane == 0) {
+                const uint32_t e = upT[g[0]];
+                bad |= e;
+                norm_out[o0] = (uint8_t)e;
+            }
             continue;
         }
         if (n + WRAP > lds_seq_bytes) {
@@ -561,7 +626,10 @@ __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t 
         for (int strand = 0; strand < (rot_rc ? 2 : 1); ++strand) {
         // ---- stage (+ WRAP wrapped bytes), 16 bytes per lane and step
         wave_sync();
-        stage_sequence(lds, g, n32, strand != 0, cmpT, lane, 64u);
+        if (raw_type >= 0 && strand == 0)
+            bad |= stage_sequence_raw(lds, g, n32, upT, norm_out + o0, lane, 64u);
+        else
+            stage_sequence(lds, g, n32, strand != 0, cmpT, lane, 64u);
         wave_sync();
 
         uint32_t ne = n32; // the length the search runs on (an exact repetition restarts on its first block)
@@ -755,6 +823,8 @@ __global__ __launch_bounds__(256) void least_rotation_wave_kernel(const uint8_t 
         }
         } // strand
     }
+    if (raw_type >= 0 && __ballot((bad & 0x100u) != 0u) != 0ull && lane == 0)
+        atomicOr(any_bad, 1u);
 }
 
 } // namespace k5
@@ -769,8 +839,19 @@ extern "C" {
 // d_rot_rc != nullptr: also the least rotation of every sequence's reverse complement (upper-case letters, the complement
 // table of transform.go:78-109) -- what seqhash.Hash needs for a circular double-stranded sequence (seqhash.go:180-193) --
 // from ONE staging of the bytes per kernel, the second strand never written to memory
+bool polyhip::k5_wave_takes_all(uint64_t max_len)
+{
+    uint64_t wave_max = k5::WAVE_SEQ_MAX;
+    if (const char *e = getenv("POLYHIP_K5_WAVE_MAX"))
+        wave_max = std::min<uint64_t>(strtoull(e, nullptr, 10), 32768);
+    uint32_t lds_w = (uint32_t)std::min<uint64_t>(max_len, wave_max) + k5::WRAP;
+    lds_w = (lds_w + 15u) & ~15u;
+    return max_len + k5::WRAP <= lds_w;
+}
+
 int polyhip::k5_least_rotation_strands_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, uint64_t max_len,
-                                           uint64_t *d_rot_index, uint8_t *d_rotated, uint64_t *d_rot_rc, polyhip_stream_t stream)
+                                           uint64_t *d_rot_index, uint8_t *d_rotated, uint64_t *d_rot_rc, polyhip_stream_t stream,
+                                           int raw_type, uint8_t *d_norm_out, uint32_t *d_any_bad)
 {
     if (n == 0)
         return POLYHIP_OK;
@@ -788,8 +869,10 @@ int polyhip::k5_least_rotation_strands_dev(const uint8_t *d_seqs, const uint64_t
         const unsigned blocks = (unsigned)std::min<uint64_t>((n + 3) / 4, 256ull * 8ull);
         PH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k5::least_rotation_wave_kernel),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        PH_REQUIRE(raw_type < 0 || (d_norm_out && d_any_bad && max_len + k5::WRAP <= lds_w),
+                   "k5_least_rotation_strands_dev: the normalising form needs every sequence within a wave's share");
         hipLaunchKernelGGL(k5::least_rotation_wave_kernel, dim3(blocks), dim3(256), smem, st, d_seqs, d_offsets, n, lds_w,
-                           d_rot_index, d_rotated, d_rot_rc);
+                           d_rot_index, d_rotated, d_rot_rc, raw_type, d_norm_out, d_any_bad);
         PH_HIP(hipGetLastError());
     }
     if (max_len + k5::WRAP <= lds_w)

@@ -670,22 +670,34 @@ int polyhip_seqhash_batch_dev(const uint8_t *d_seqs, const uint64_t *d_offsets, 
     // only works when a letter outside the alphabet was met
     uint32_t *any_bad = reinterpret_cast<uint32_t *>(w + 8);
     const bool streaming = !env_is("POLYHIP_S2_STREAM", '0');
+    // (round 6) circular sequences that a wave of K5 takes alone: K5 normalises the bytes while it stages them and writes the
+    // normalised copy -- no streaming pass in front of it (one read of the batch and one launch less).  POLYHIP_S2_FOLD=0: off.
+    const bool fold = streaming && circular && k5_wave_takes_all(max_len) && !env_is("POLYHIP_S2_FOLD", '0');
     if (streaming) {
         PH_HIP(hipMemsetAsync(any_bad, 0, 4, st));
         PH_HIP(hipMemsetAsync(d_err, 0, n * 4, st));
         const uint64_t pieces = (total_bytes >> 4) + 2;
-        hipLaunchKernelGGL(s2::normalise_stream_kernel, dim3((unsigned)std::min<uint64_t>((pieces + s2::THREADS - 1) / s2::THREADS, 256ull * 16ull)),
-                           dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, any_bad);
+        if (!fold)
+            hipLaunchKernelGGL(s2::normalise_stream_kernel, dim3((unsigned)std::min<uint64_t>((pieces + s2::THREADS - 1) / s2::THREADS, 256ull * 16ull)),
+                               dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, any_bad);
     }
-    hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, d_err,
-                       non_ascii, streaming ? any_bad : (uint32_t *)nullptr);
+    if (!fold)
+        hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, d_err,
+                           non_ascii, streaming ? any_bad : (uint32_t *)nullptr);
     PH_HIP(hipGetLastError());
     if (circular) { // the indexes only: neither the rotated strings nor the second strand are ever written -- ONE K5 pass
                     // stages every sequence once and searches it in both reading directions
-        const int r = k5_least_rotation_strands_dev(norm, d_offsets, n, max_len, rotidx, nullptr, double_stranded ? rotidx + n : nullptr,
-                                                    stream);
+        const int r = fold ? k5_least_rotation_strands_dev(d_seqs, d_offsets, n, max_len, rotidx, nullptr,
+                                                           double_stranded ? rotidx + n : nullptr, stream, seq_type, norm, any_bad)
+                           : k5_least_rotation_strands_dev(norm, d_offsets, n, max_len, rotidx, nullptr,
+                                                           double_stranded ? rotidx + n : nullptr, stream);
         if (r != POLYHIP_OK)
             return r;
+        if (fold) { // a letter outside the alphabet was met: the per-sequence pass names it (and the first byte >= 0x80)
+            hipLaunchKernelGGL(s2::prepare_kernel, dim3(blocks), dim3(s2::THREADS), 0, st, d_seqs, d_offsets, n, seq_type, norm, d_err,
+                               non_ascii, any_bad);
+            PH_HIP(hipGetLastError());
+        }
         r0 = rotidx;
         if (double_stranded)
             r1 = rotidx + n;

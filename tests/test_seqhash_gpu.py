@@ -169,6 +169,47 @@ def test_hash_batch_matches_oracle(sh, stype, circular, ds):
         assert g == want, (s[:30], len(s))
 
 
+@pytest.mark.parametrize("stype,ds", [("DNA", True), ("DNA", False), ("RNA", True), ("PROTEIN", False)])
+def test_hash_batch_normalised_while_staged(sh, monkeypatch, stype, ds):
+    """Round 6: a circular batch whose every sequence a K5 wave takes alone (<= 7168 bytes) is normalised BY K5 while it
+    stages the bytes (no streaming pass in front).  Lower case, RNA's U, letters outside the alphabet in the first / a
+    middle / the last position (the first offending letter is named), lengths 0, 1 and around the 16-byte pieces of the
+    staging, the longest length a wave takes: equal to the oracle and to the pass it replaces (POLYHIP_S2_FOLD=0)."""
+    rng = np.random.default_rng(hash((stype, ds)) % (1 << 31))
+    alpha = b"ACDEFGHIKLMNPQRSTVWYUO*BXZacdxz" if stype == "PROTEIN" else b"ACGTacgtUuNRYSWKMBDHVZnryswkmbdhvz"
+    seqs = [b"", b"A", b"a", b"u", b"AT", b"ta", b"GAATTC", b"acgu", b"ZZZ", b"AAAA", b"aAaA", b"J", b"j"]
+    for L in list(range(2, 50)) + [63, 64, 65, 127, 1023, 1024, 1025, 2049, 4095, 4096, 5000, 7167, 7168]:
+        seqs.append(bytes(rng.choice(list(alpha), L).astype(np.uint8)))
+    for _ in range(200):
+        seqs.append(bytes(rng.choice(list(alpha[:8]), int(rng.integers(1, 3000))).astype(np.uint8)))
+    for L, at in ((40, 0), (40, 39), (40, 17), (5000, 0), (5000, 4999), (5000, 2500), (17, 16), (16, 15), (33, 32)):
+        b = bytearray(rng.choice(list(alpha[:4]), L).astype(np.uint8))
+        b[at] = ord("j")
+        seqs.append(bytes(b))
+        b[at // 2] = ord("-")  # two offending letters: the FIRST is named
+        seqs.append(bytes(b))
+    monkeypatch.delenv("POLYHIP_S2_FOLD", raising=False)
+    got = sh.HashBatch(seqs, stype, True, ds)
+    monkeypatch.setenv("POLYHIP_S2_FOLD", "0")
+    unfolded = sh.HashBatch(seqs, stype, True, ds)
+    monkeypatch.delenv("POLYHIP_S2_FOLD", raising=False)
+    nerr = 0
+    for s, g, u in zip(seqs, got, unfolded):
+        assert str(g) == str(u), (s[:20], g, u)
+        try:
+            want = orc.seqhash(s, stype, True, ds)
+        except orc.SeqhashError as e:
+            assert isinstance(g, ValueError) and str(g) == str(e), (s[:20], g, e)
+            nerr += 1
+            continue
+        assert g == want, (s[:30], len(s))
+    assert nerr >= 18
+    # ... and a batch WITHOUT any offending letter (the per-sequence pass behind K5 then returns at once)
+    clean = [q for q, g in zip(seqs, got) if not isinstance(g, Exception)]
+    got2 = sh.HashBatch(clean, stype, True, ds)
+    assert got2 == [g for g in got if not isinstance(g, Exception)]
+
+
 def test_runs_of_the_least_byte():
     """poly-A style inputs: long runs of the smallest byte (one candidate per run instead of one per position),
     runs that wrap around the origin, several runs of equal and different lengths, runs of a byte that is NOT
