@@ -25,6 +25,10 @@
 #include "common.h"
 #include "host_pipeline.h"
 
+#ifndef PH_S2_PAIR_BLOCKS
+#define PH_S2_PAIR_BLOCKS 0 // 1: chunk_cv takes two blocks per round of loads (round 6: measured SLOWER, 1.06 against 0.93 ms -- 86 registers, 5 waves per SIMD)
+#endif
+
 namespace polyhip {
 namespace s2 {
 
@@ -139,6 +143,40 @@ __device__ __forceinline__ void strand_block(const Strand &S, int64_t p, uint32_
     }
 }
 
+// 128 bytes at once (round 6): two consecutive blocks of a chunk from ONE round of loads.  A thread's blocks are 64 bytes
+// apart and a compression (~1,500 instructions) apart in time, so a 128-byte line used to be asked for two or three times
+// -- by then it had often left the caches (FETCH_SIZE 0.93 GB for 0.5 GB of sequence).
+__device__ __forceinline__ void load32(const uint8_t *p, uint32_t (&o)[32])
+{
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
+    const uint32_t sh = (uint32_t)(addr & 3u);
+    const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+    uint32_t d[33];
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        d[i] = gd[i];
+    d[32] = sh ? gd[32] : 0u;
+#pragma unroll
+    for (int i = 0; i < 32; ++i)
+        o[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+}
+// bytes [p, p + 128) of the strand, 0 <= p, p + 128 <= len
+__device__ __forceinline__ void strand_block2(const Strand &S, int64_t p, uint32_t (&w)[32])
+{
+    if (!S.rc) {
+        load32(S.data + p, w);
+    } else {
+        uint32_t d[32];
+        load32(S.data + ((int64_t)S.len - 128 - p), d);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t x = d[31 - i];
+            w[i] = (uint32_t)S.cmpT[x >> 24] | ((uint32_t)S.cmpT[(x >> 16) & 0xFFu] << 8) | ((uint32_t)S.cmpT[(x >> 8) & 0xFFu] << 16) |
+                   ((uint32_t)S.cmpT[x & 0xFFu] << 24);
+        }
+    }
+}
+
 // chaining value of chunk `idx` of the string S[rot..len) + S[0..rot) -- the rotation `rot` of the strand, never
 // materialised (round 3 wrote both strands' rotated copies out, 1 GB per 100k x 5 kb, only to read them back here) --;
 // root = this chunk is the whole input
@@ -155,6 +193,30 @@ __device__ void chunk_cv(const Strand &S, uint64_t rot, uint64_t idx, bool root,
         const uint64_t off = base + (uint64_t)b * 64;
         const uint32_t blen = (uint32_t)(clen - (uint64_t)b * 64 < 64 ? clen - (uint64_t)b * 64 : 64);
         const uint64_t src = off + rot >= len ? off + rot - len : off + rot; // where the block starts in the strand (rot < len, off < len)
+#if PH_S2_PAIR_BLOCKS
+        if (clen - (uint64_t)b * 64 >= 128 && src + 128 <= len) { // two whole blocks that lie inside the strand: one round of loads
+            uint32_t w2[32], wa[16], wb[16], o[8];
+            strand_block2(S, (int64_t)src, w2);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                wa[i] = w2[i];
+                wb[i] = w2[16 + i];
+            }
+            compress(cv, wa, idx, 64u, b == 0 ? (uint32_t)CHUNK_START : 0u, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                cv[i] = o[i];
+            ++b;
+            uint32_t flags = 0;
+            if (b == nblocks - 1)
+                flags |= CHUNK_END | (root ? (uint32_t)ROOT : 0u);
+            compress(cv, wb, idx, 64u, flags, o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                cv[i] = o[i];
+            continue;
+        }
+#endif
         uint32_t w[16];
         if (blen == 64) {
             strand_block(S, (int64_t)src, w); // (past the end of the strand these are foreign bytes: masked below)
