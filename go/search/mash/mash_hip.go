@@ -6,7 +6,11 @@
 // entry points (a single-sequence GPU call cannot win; SURVEY.md 8b).  UNCOMPILED in the authoring image.
 package mash
 
-import "github.com/bebop/poly/internal/polyhip"
+import (
+	"fmt"
+
+	"github.com/bebop/poly/internal/polyhip"
+)
 
 // Sketch is mash.go:68-104: updates mash.Sketches in place (prior state survives where the reference leaves it).
 func (mash *Mash) Sketch(sequence string) {
@@ -118,13 +122,21 @@ func SharedCountsMatrix(ms []*Mash) *SharedCounts {
 		return &SharedCounts{}
 	}
 	n, s := len(ms), ms[0].SketchSize
+	// one SketchSize for the whole set, and one a uint16 holds: anything else has no meaning as a count matrix (round-5 advice:
+	// the restriction was stated, not enforced)
+	if s > 65535 {
+		panic(fmt.Sprintf("mash.SharedCountsMatrix: SketchSize %d does not fit a uint16 count", s))
+	}
+	for i, m := range ms {
+		if m.SketchSize != s || len(m.Sketches) != s {
+			panic(fmt.Sprintf("mash.SharedCountsMatrix: sketch %d has SketchSize %d, the set's is %d", i, m.SketchSize, s))
+		}
+	}
 	res := &SharedCounts{N: n, SketchSize: s, Counts: make([]uint16, n*n)}
 	if n*n < polyhip.MinDistancePairs {
 		for i, a := range ms {
 			for j, b := range ms {
-				// similarityCPU returns sameHashes / SketchSize; the product with SketchSize is an integer below 2^16,
-				// which float64 holds exactly, and the +0.5 guards the last-bit rounding of the division
-				res.Counts[i*n+j] = uint16(a.similarityCPU(b)*float64(s) + 0.5)
+				res.Counts[i*n+j] = uint16(sharedHashes(a.Sketches, b.Sketches)) // an integer merge, no float64 round trip
 			}
 		}
 		return res
@@ -137,6 +149,25 @@ func SharedCountsMatrix(ms []*Mash) *SharedCounts {
 		panic(err)
 	}
 	return res
+}
+
+// sharedHashes counts the hashes two ascending sketches share: the merge of (*Mash).Similarity (mash.go:107-135) without its
+// final division.
+func sharedHashes(a, b []uint32) int {
+	same, i, j := 0, 0, 0
+	for i < len(a) && j < len(b) {
+		switch {
+		case a[i] == b[j]:
+			same++
+			i++
+			j++
+		case a[i] < b[j]:
+			i++
+		default:
+			j++
+		}
+	}
+	return same
 }
 
 // SketchSharedCounts is BASELINE configs[2] at size in one call: every sequence sketched (mash.go:59-104) and the shared

@@ -12,6 +12,21 @@
 
 #include "polyhip.h"
 
+// ---- ablation probes ------------------------------------------------------------------------------------------------------
+// The kernels carry compile-time probes (PH_ABL, PH_K2_NOWALK, PH_K2_J_*, PH_K2_F_*, PH_SELBINS, PH_SEL_ATOMIC ...) that take a
+// phase out or swap an experiment in; most of them produce WRONG results by construction.  They exist for the timing harnesses
+// under scripts/ (ubench/build_k1_variants.sh, build_variant.sh), which say so with -DPH_ABLATION_BUILD; a stray -D in the
+// product build stops here instead of shipping a library that computes something else (round-5 advice).
+#if !defined(PH_ABLATION_BUILD)
+#if (defined(PH_ABL) && PH_ABL != 0) || (defined(PH_SELBINS) && PH_SELBINS != 0) || (defined(PH_SEL_ATOMIC) && PH_SEL_ATOMIC != 0) || \
+    defined(PH_LDS_PAD) || defined(PH_K2_NO_SWZ) || defined(PH_K2_C4_NOPOS) || defined(PH_K2_F4_NORANK) || defined(PH_K2_F4_RANKED) ||   \
+    defined(PH_K2_F4_NOSTORE) || defined(PH_K2_F4_LINSTORE) || defined(PH_K2_ZA_NOSTORE) || defined(PH_K2_J_NOCONSUME) ||                  \
+    defined(PH_K2_J_NOATOM) || defined(PH_K2_J_L1) || defined(PH_K2_NOWALK) || defined(PH_K2_NOFLUSH) || defined(PH_K2_F_NOLDS) ||         \
+    defined(PH_K2_F_NOSTORE) || defined(PH_K2_F_PLAIN) || defined(PH_TB_BITS_ALIGN)
+#error "an ablation probe is defined in a product build: probes are for scripts/ (pass -DPH_ABLATION_BUILD there)"
+#endif
+#endif
+
 namespace polyhip {
 
 // thread-local message behind polyhip_last_error()

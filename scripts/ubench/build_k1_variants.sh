@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../.."
 build() {
     tag=${1%%:*}; flags=${1#*:}
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -pragma-unroll-threshold=100000 -w $flags \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -pragma-unroll-threshold=100000 -DPH_ABLATION_BUILD -w $flags \
         -I include -I poly_amd/csrc scripts/ubench/k1_ablate.hip poly_amd/csrc/runtime.hip poly_amd/csrc/multi_device.hip \
         -o scripts/ubench/k1_v_$tag || echo "BUILD FAILED $tag"
 }
