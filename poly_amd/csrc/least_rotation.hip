@@ -48,7 +48,10 @@ constexpr uint32_t MAX_ROUNDS = 64;      // 4 bytes per round before the serial 
 constexpr uint32_t LDS_SEQ_MAX = 120 * 1024;
 constexpr uint64_t MARK = ~0ull;       // rot[q] of a sequence the wave kernel leaves to the workgroup kernels
 constexpr uint64_t WAVE_SEQ_MAX = 7168; // longest sequence a wave takes alone (8 kB: the workgroup kernel is ahead, 0.32 vs 0.36 ms per 0.5 GB; 6 kB: behind, 0.39 vs 0.29)
-constexpr uint32_t WLIST = 1024;       // candidates one wave keeps, as 16-bit positions (random DNA: n / 256 after the first word)
+#ifndef PH_K5_WLIST
+#define PH_K5_WLIST 1024
+#endif
+constexpr uint32_t WLIST = PH_K5_WLIST; // candidates one wave keeps, as 16-bit positions (random DNA: n / 256 after the first word)
 constexpr uint32_t WRAP = 24; // bytes of s[0..] staged again behind s[n-1]: a 16-byte output piece + its funnel dword never wrap
 
 // least value of a wave, in every lane: the DPP ladder (pairs, quads, rows of 16 by rotation, then the two row broadcasts
