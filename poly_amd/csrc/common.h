@@ -21,7 +21,7 @@
 #if (defined(PH_ABL) && PH_ABL != 0) || (defined(PH_SELBINS) && PH_SELBINS != 0) || (defined(PH_SEL_ATOMIC) && PH_SEL_ATOMIC != 0) || \
     defined(PH_LDS_PAD) || defined(PH_K2_NO_SWZ) || defined(PH_K2_C4_NOPOS) || defined(PH_K2_F4_NORANK) || defined(PH_K2_F4_RANKED) ||   \
     defined(PH_K2_F4_NOSTORE) || defined(PH_K2_F4_LINSTORE) || defined(PH_K2_ZA_NOSTORE) || defined(PH_K2_J_NOCONSUME) ||                  \
-    defined(PH_K2_J_NOATOM) || defined(PH_K2_J_L1) || defined(PH_K2_NOWALK) || defined(PH_K2_NOFLUSH) || defined(PH_K2_F_NOLDS) ||         \
+    defined(PH_K2_J_NOATOM) || defined(PH_K2_J_L1) || defined(PH_K2_J_X4A) || defined(PH_K2_J_X2A) || defined(PH_K2_NOWALK) || defined(PH_K2_NOFLUSH) || defined(PH_K2_F_NOLDS) ||         \
     defined(PH_K2_F_NOSTORE) || defined(PH_K2_F_PLAIN) || defined(PH_TB_BITS_ALIGN)
 #error "an ablation probe is defined in a product build: probes are for scripts/ (pass -DPH_ABLATION_BUILD there)"
 #endif

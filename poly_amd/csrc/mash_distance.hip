@@ -1739,6 +1739,47 @@ __global__ __launch_bounds__(DENSE_THREADS) void rowjoin_dense_kernel(const uint
                             }
                         }
                     }
+#elif defined(PH_K2_J_X4A) || defined(PH_K2_J_X2A)
+                    // PROBES (round 6; counts may be wrong: a foreign item in front of the bucket can pass the key test): ONE wide
+                    // load per bucket from the bucket's start rounded DOWN to 16 (8) bytes -- is the walk bound by the number of
+                    // vector-memory instructions (2000 dword loads per row through one CU's address unit)?
+                    {
+#ifdef PH_K2_J_X4A
+                        constexpr uint32_t W = 4;
+#else
+                        constexpr uint32_t W = 2;
+#endif
+                        const uint32_t laneW = (uint32_t)lane * 4u * W;
+                        for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
+                            uint32_t it[DENSE_U][W], len[DENSE_U];
+                            __amdgpu_buffer_rsrc_t rs[DENSE_U];
+#pragma unroll
+                            for (int u = 0; u < DENSE_U; ++u) {
+                                const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)mbeg, (int)(j0 + u));
+                                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mend, (int)(j0 + u));
+                                const uint32_t ba = b & ~(W - 1u);
+                                len[u] = e - ba;
+                                rs[u] = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(items + ba), 0, (int)(len[u] * 4u), 0x00020000);
+                                if constexpr (W == 4) {
+                                    const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs[u], (int)laneW, 0, 0);
+                                    it[u][0] = v[0], it[u][1] = v[1], it[u][2] = v[2], it[u][3] = v[3];
+                                } else {
+                                    const auto v = __builtin_amdgcn_raw_buffer_load_b64(rs[u], (int)laneW, 0, 0);
+                                    it[u][0] = v[0], it[u][1] = v[1];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < DENSE_U; ++u) {
+                                const uint32_t key = (uint32_t)__builtin_amdgcn_readlane((int)mval, (int)(j0 + u));
+                                const uint32_t alim = (uint32_t)__builtin_amdgcn_readlane((int)mlim, (int)(j0 + u));
+#pragma unroll
+                                for (uint32_t w = 0; w < W; ++w)
+                                    consume_compact(it[u][w], key, alim);
+                                for (uint32_t t = 64u * W; t < len[u]; t += 64) // rest of a long bucket
+                                    consume_compact(__builtin_amdgcn_raw_buffer_load_b32(rs[u], (int)(lane * 4u), (int)(t * 4u), 0), key, alim);
+                            }
+                        }
+                    }
 #else
                     for (uint32_t j0 = 0; j0 < cnt; j0 += DENSE_U) {
                         uint32_t it[DENSE_U][2], len[DENSE_U];
