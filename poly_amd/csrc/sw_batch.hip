@@ -761,6 +761,7 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
                                      npairs, d_score, d_endA, d_endB, d_err, st);
             }
             ps.skip_rows = p.pk.skip_rows; // (same kernels as the whole batch would take)
+            ps.x2_rb = p.pk.x2_rb;
             AuxStream &aux = aux_stream(st);
             const size_t slice = (ps.work_bytes + 255) & ~(size_t)255;
             // both slices' tables once, in front of the fork (a tiny kernel queued beside a full-chip one waits for it)

@@ -586,7 +586,10 @@ __device__ __forceinline__ uint32_t from_lane_above(uint32_t v)
 // whose code bytes carry + 64 -- so the address stays ONE SDWA shift.  When a step ends, slot 0 moves to slot 1 and the
 // staged next table to slot 0 (LDS runs a wave's instructions in order; one wave per workgroup, no barrier).  Step 0's
 // odd lanes see an all-pad table (H stays 0), the last step's even lanes sweep a stale table and nothing reads them.
-template <int RB>
+// SKIP (batches whose longest read leaves four or more row groups of the 152-row tile unused): the split between the two lanes
+// follows the WAVE's longest read -- each lane takes ng = ceil(longest / 8) groups of four rows, the odd lane's rows start at
+// 4 ng -- so reads of 65..136 bp run as tight as a tile of their own would (a uniform branch per group, as sw_pk1_kernel<.., true>).
+template <int RB, bool SKIP>
 __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restrict__ A, const uint64_t *__restrict__ offA,
                                                         uint64_t npairs, const uint32_t *__restrict__ prof2, uint32_t nq,
                                                         uint32_t tab_bytes, int ncp, const uint8_t *__restrict__ codeA,
@@ -621,9 +624,17 @@ __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restri
         const uint64_t l = offA[p1 + 1] - o1;
         len1 = l > (uint64_t)(2 * RB) ? 0u : (uint32_t)l;
     }
-    // my RB rows' code pairs, four per register (+ 64 on the odd lanes: slot 1); the bytes as aligned dwords through a
+    int ng = RB / 4;
+    if (SKIP) {
+        uint32_t wl = max(len0, len1);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            wl = max(wl, (uint32_t)__shfl_xor((int)wl, d, 64));
+        ng = __builtin_amdgcn_readfirstlane((int)((wl + 7u) >> 3)); // <= RB / 4: no read is longer than 2 RB
+    }
+    // my rows' code pairs, four per register (+ 64 on the odd lanes: slot 1); the bytes as aligned dwords through a
     // bounded buffer resource, as sw_pk1_kernel
-    const uint32_t row0 = band * (uint32_t)RB;
+    const uint32_t row0 = band * 4u * (uint32_t)ng;
     const uint32_t slot_bias = odd ? 64u : 0u;
     uint32_t rpk[RB / 4];
     const uint64_t totalA = offA[npairs];
@@ -723,23 +734,27 @@ __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restri
         PH_PK1_ISSUE(wa, rpk[0], "BYTE_0");
 #pragma unroll
         for (int g = 0; g < RB / 4; ++g) {
-            PH_PK1_ISSUE(wb, rpk[g], "BYTE_1");
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-            PH_PKF_ROW(4 * g, wa);
-            PH_PK1_ISSUE(wa, rpk[g], "BYTE_2");
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
-            PH_PKF_ROW(4 * g + 1, wb);
-            PH_PK1_ISSUE(wb, rpk[g], "BYTE_3");
-            asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
-            PH_PKF_ROW(4 * g + 2, wa);
-            if (g + 1 < RB / 4) {
-                PH_PK1_ISSUE(wa, rpk[g + 1], "BYTE_0");
+            if (!SKIP || g < ng) { // wave-uniform
+                PH_PK1_ISSUE(wb, rpk[g], "BYTE_1");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PKF_ROW(4 * g, wa);
+                PH_PK1_ISSUE(wa, rpk[g], "BYTE_2");
                 asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
-            } else {
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                PH_PKF_ROW(4 * g + 1, wb);
+                PH_PK1_ISSUE(wb, rpk[g], "BYTE_3");
+                asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wa));
+                PH_PKF_ROW(4 * g + 2, wa);
+                if (g + 1 < RB / 4) {
+                    PH_PK1_ISSUE(wa, rpk[g + 1], "BYTE_0");
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(wb));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wb));
+                }
+                PH_PKF_ROW(4 * g + 3, wb);
             }
-            PH_PKF_ROW(4 * g + 3, wb);
         }
+        if (SKIP)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa)); // the read issued ahead of a skipped group
         if (mine) { // every row of this step has its entry: slot 1 takes block t's table, slot 0 the staged block t + 1
             u32x4 cur, nxt;
             asm volatile("s_waitcnt vmcnt(0)\n\tds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:2304\n\ts_waitcnt lgkmcnt(0)\n\t"
@@ -1456,6 +1471,10 @@ bool packed_plan(const polyhip_scoring *sc, uint64_t npairs, uint32_t max_lenA, 
     p.pk_smem = (size_t)(p.jcb + p.k - 1) * p.tab_bytes + 256;
     // one wave per workgroup, the block's table at a fixed LDS address (POLYHIP_SW_PK1=0: the chunk-staged kernel)
     p.pk1 = p.f16 && p.k == 1 && p.ncp * p.ncp <= 64 && !env_is("POLYHIP_SW_PK1", '0');
+    // the two-lane form of that kernel (round 6: 128 registers, four waves per SIMD; POLYHIP_SW_PK1X2=0: one lane per two pairs)
+    p.x2_rb = 0;
+    if (p.pk1 && p.ra == 152 && !env_is("POLYHIP_SW_PK1X2", '0')) // (up to 64 rows the one-lane kernel holds four waves itself)
+        p.x2_rb = 76;
     p.locate_smem = (size_t)p.lenB_pad * 8 + 256;
     if (p.ra <= 256 && p.locate_smem > 160 * 1024)
         return false; // the byte profile of the reference has to sit whole in LDS for step 2
@@ -1483,12 +1502,13 @@ static int launch_packed(const polyhip_scoring *sc, const PackedPlan &p, const u
                            sc->d_lutc, sc->ncodes, p.ncp, prof2, (int)p.f16, (int)(-sc->gap));
         PH_HIP(hipGetLastError());
     }
-    if (K == 1 && p.pk1 && RA == 152 && !p.skip_rows && !env_is("POLYHIP_SW_PK1X2", '0')) {
+    if (K == 1 && p.pk1 && p.x2_rb != 0 && 2 * p.x2_rb <= RA) {
         // two lanes per lane's worth of rows, four waves per SIMD (POLYHIP_SW_PK1X2=0: one lane, two waves)
-        if constexpr (K == 1 && RA == 152) {
+        if constexpr (K == 1) {
             const uint64_t blocks = (npairs + 63) / 64;
-            hipLaunchKernelGGL(sw_pk1x2_kernel<RA / 2>, dim3((unsigned)blocks), dim3(64), 2048 + 256 + 1024, st, d_A, d_offA,
-                               npairs, prof2, p.nq, p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
+            auto kern = p.skip_rows ? sw_pk1x2_kernel<76, true> : sw_pk1x2_kernel<76, false>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), 2048 + 256 + 1024, st, d_A, d_offA, npairs, prof2, p.nq,
+                               p.tab_bytes, p.ncp, sc->d_codeA, sc->ncodes, (int)(-sc->gap), infoM, infoQ);
             PH_HIP(hipGetLastError());
         }
     } else if (K == 1 && p.pk1) {

@@ -85,6 +85,7 @@ struct PackedPlan {
     int rb, k;                      // rows per lane; lanes per pair: 1, or 2..16 above 152 rows (sw_pkb_kernel)
     bool skip_rows;                 // the longest read leaves >= 16 rows of the tile unused: sw_pk_kernel<RA, true>
     bool pk1;                       // sw_pk1_kernel: one wave per workgroup, the block's table at a fixed LDS address
+    int x2_rb;                      // sw_pk1x2_kernel<76, skip_rows>: the two-lane form is taken (65..152 rows), 0: not
     bool f16;                       // every H < 2048: sw_pk_kernel's half-float cells (3 instructions instead of 4)
     uint32_t tab_bytes;             // bytes of one block's table: ncp * ncp * 16
     uint32_t lenB_pad, nq, jcb;     // columns (multiple of 4), 4-column blocks, blocks per LDS chunk

@@ -46,8 +46,8 @@ def main():
     json.dump(k1, open(f"{d}/k1_issue.json", "w"), indent=1)
     # ---- K3
     st, pm = tables(f"{d}/{rnd}_k3_pmc_nooverlap.md")
-    if any("sw_pk1x2_kernel<76>" in k for k in pm):  # round 6: a lane's 152 rows over two lanes, the lower lane one block behind
-        name, c = pick(pm, "sw_pk1x2_kernel<76>")
+    if any("sw_pk1x2_kernel<76, false>" in k for k in pm):  # round 6: a lane's 152 rows over two lanes, the lower lane one block behind
+        name, c = pick(pm, "sw_pk1x2_kernel<76, false>")
         waves, rows, steps = 1_000_000 / 64.0, 76, 1251
     else:
         name, c = pick(pm, "sw_pk1_kernel<152, false>")

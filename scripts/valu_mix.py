@@ -28,7 +28,7 @@ FULL = {"v_add_u32", "v_sub_u32", "v_subrev_u32", "v_and_b32", "v_or_b32", "v_xo
 KERNELS = [
     ("mash_sketch.hip", r"sketch_slab_kernelILi21E", "v_mad_u64_u32", "K1 polyhip::k1::sketch_slab_kernel<21>"),
     ("sw_packed.hip", r"sw_pk1_kernelILi152ELb0E", "v_pk_maximum3_f16", "K3 polyhip::k3p::sw_pk1_kernel<152,false>"),
-    ("sw_packed.hip", r"sw_pk1x2_kernelILi76E", "v_pk_maximum3_f16", "K3 polyhip::k3p::sw_pk1x2_kernel<76>"),
+    ("sw_packed.hip", r"sw_pk1x2_kernelILi76ELb0E", "v_pk_maximum3_f16", "K3 polyhip::k3p::sw_pk1x2_kernel<76,false>"),
 ]
 
 
