@@ -2082,6 +2082,8 @@ __global__ __launch_bounds__(THREADS) void generic_kernel(const uint32_t *__rest
                                                          const uint32_t *__restrict__ ovfX, int ovf_done,
                                                          uint16_t *__restrict__ counts, uint64_t ld)
 {
+    if (Y == nullptr)
+        return; // no raw Y sketches on this device (round-5 advice): the caller reads mode / irregular / overflow counters and reports
     const bool all = hdr[H_MODE] == MODE_GENERIC;
     const uint64_t nIrrX = hdr[H_NIRRX], nIrrY = hdr[H_NIRRY], nRegX = hdr[H_NREGX], nOvf = hdr[H_NOVF];
     const uint64_t partA = all ? nx * ny : nIrrX * ny; // (irregular row) x (every column)
@@ -2263,7 +2265,9 @@ static int shared_counts_impl(int what, const uint32_t *d_X, uint64_t nx, uint32
     PH_REQUIRE(sx <= 65535 && sy <= 65535, "polyhip_mash_shared_counts: SketchSize > 65535 does not fit the u16 counts");
     if ((join && nx == 0) || ny == 0)
         return POLYHIP_OK;
-    PH_REQUIRE(d_Y && d_work && (!join || (d_X && d_counts)), "polyhip_mash_shared_counts: null pointer");
+    // (d_Y may be null when a prebuilt index is reused and the caller holds no raw Y sketches -- the item exchange of a device
+    // list: the merge, the only reader of raw Y behind the build, then refuses instead of reading rows that are not there)
+    PH_REQUIRE((d_Y || !build) && d_work && (!join || (d_X && d_counts)), "polyhip_mash_shared_counts: null pointer");
     PH_REQUIRE(!join || ld >= ny, "polyhip_mash_shared_counts: row stride %llu < ny %llu", (unsigned long long)ld,
                (unsigned long long)ny);
     PH_REQUIRE(nx < (1ull << 31) && ny < (1ull << 31) && ny * (uint64_t)sy < (1ull << 32),
@@ -2693,6 +2697,7 @@ int polyhip::k2_rows_to_host(const uint32_t *dX, uint64_t nx, uint32_t sx, const
         PH_HIP(hipEventCreateWithFlags(&slot[q].downloaded, hipEventDisableTiming));
     }
     int rc = POLYHIP_OK;
+    PH_REQUIRE(dY || index_work, "k2_rows_to_host: no raw Y sketches and no prebuilt index");
     if (one_index && !index_work)
         rc = polyhip_mash_index_build_dev(dY, ny, sy, wp, wb, sc);
     for (uint64_t b = 0; b < nblocks && rc == POLYHIP_OK; ++b) {

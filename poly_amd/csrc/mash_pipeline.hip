@@ -239,11 +239,11 @@ int polyhip_mash_sketch_distance_matrix(const uint8_t *seqs, const uint64_t *off
                 const uint64_t i0 = sh[q].i0, m = sh[q].i1 - i0;
                 if (m == 0)
                     return (int)POLYHIP_OK;
-                // Y = the array's virtual base: a device holds ITS rows only, and the join reads Y's raw sketches nowhere
-                // but in the merge (irregular sketches, overflow rows, "merge everything"), which k2_exchange_index ruled
-                // out before it reported the index as built.  That exclusion is re-checked on what the join DID:
+                // Y = NULL: a device holds ITS rows only, and the join reads Y's raw sketches nowhere but in the merge
+                // (irregular sketches, overflow rows, "merge everything"), which k2_exchange_index ruled out before it reported
+                // the index as built and which returns at once without Y.  That exclusion is re-checked on what the join DID:
                 const uint32_t *sk = sh[q].sk(s);
-                if (int e = k2_rows_to_host(sk + i0 * (uint64_t)s, m, s, sk, n, s, counts ? counts + i0 * n : nullptr,
+                if (int e = k2_rows_to_host(sk + i0 * (uint64_t)s, m, s, nullptr, n, s, counts ? counts + i0 * n : nullptr,
                                             dist ? dist + i0 * n : nullptr, xs[q].work.p, xs[q].work_bytes))
                     return e;
                 uint32_t mode = 0, nirrx = 0, nirry = 0, novf = 0;
