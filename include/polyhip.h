@@ -459,6 +459,10 @@ int polyhip_sw_last_path(void);
  * <= 2047 and smax + |gap| <= 2048; same integers, bit for bit (halves scaled by 2^-11, every sum exact).
  * POLYHIP_SW_F16=0 keeps the int16 cell (testing aid). */
 int polyhip_sw_last_packed_half(void);
+/* ... and over how many lanes that packed pass spread the rows of a lane's two read pairs (0: no packed pass): 1 = one
+ * lane holds all rows (up to 64 rows; POLYHIP_SW_PK1X2=0), 2 = sw_pk1x2_kernel (65..152 rows: two lanes, four waves per
+ * SIMD), 2..16 = sw_pkb_kernel's lanes per pair above 152 rows (64 rows per lane; POLYHIP_SW_TILE64=0: 128 / 152). */
+int polyhip_sw_last_packed_lanes(void);
 /* ... and the last polyhip_sw_traceback_dev call: 1 = byte-profile kernel (shared B, score given,
  * the reference's profile fits LDS), 2 = register-tiled table kernel, 3 = generic kernel, 4 = one-wave-per-pair
  * kernel for reads of 153..4096 symbols (tests; POLYHIP_TB_WAVE=0 switches 4 off), 5 = the half-float byte-profile

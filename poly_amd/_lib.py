@@ -65,6 +65,7 @@ SIGNATURES = {
     "polyhip_sw_batch": (C.c_int, [_vp, _vp, _vp, _u64, _vp, _vp, _u64, _vp, _vp, _vp, _vp]),
     "polyhip_sw_last_path": (C.c_int, []),
     "polyhip_sw_last_packed_half": (C.c_int, []),
+    "polyhip_sw_last_packed_lanes": (C.c_int, []),
     "polyhip_sw_traceback_last_path": (C.c_int, []),
     "polyhip_sw_traceback_last_half": (C.c_int, []),
     "polyhip_nw_last_path": (C.c_int, []),

@@ -134,6 +134,11 @@ def last_packed_half() -> bool:
     return bool(_lib.lib().polyhip_sw_last_packed_half())
 
 
+def last_packed_lanes() -> int:
+    """lanes that shared the rows of a lane's two read pairs in the last packed score pass (0: none ran)"""
+    return int(_lib.lib().polyhip_sw_last_packed_lanes())
+
+
 def sw_traceback_last_path() -> int:
     """1 = byte-profile traceback kernel, 2 = register-tiled table kernel, 3 = generic (tests)"""
     return int(_lib.lib().polyhip_sw_traceback_last_path())

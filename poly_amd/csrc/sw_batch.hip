@@ -58,6 +58,7 @@ constexpr uint64_t WAVE_BATCH = 49152; // below this many pairs the one-wave-per
 
 static thread_local int g_last_path = 0;
 static thread_local int g_last_half = 0;
+static thread_local int g_last_lanes = 0; // lanes that share a lane's two read pairs in the last packed score pass (0: not packed)
 
 // prof[j][c] = S(symA[c], b_j) as int8; pad columns / pad code = -128.
 // Also finds the first byte of B that is not in SecondAlphabet.
@@ -696,6 +697,7 @@ void polyhip::k3::score_choice(int *path, int *half, bool set)
 extern "C" {
 int polyhip_sw_last_path(void) { return k3::g_last_path; }
 int polyhip_sw_last_packed_half(void) { return k3::g_last_half; }
+int polyhip_sw_last_packed_lanes(void) { return k3::g_last_lanes; }
 
 } // extern "C"
 
@@ -723,6 +725,7 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
     hipStream_t st = as_stream(stream);
     k3::g_last_path = p.path;
     k3::g_last_half = (p.path == 3 || p.path == 7) && p.pk.f16 ? 1 : 0;
+    k3::g_last_lanes = (p.path == 3 || p.path == 7) ? (p.pk.k > 1 ? p.pk.k : (p.pk.x2_rb ? 2 : 1)) : 0;
     if (p.path == 1 || p.path == 3 || p.path == 4) {
         uint32_t *binfo = static_cast<uint32_t *>(d_work);
         int8_t *prof = static_cast<int8_t *>(d_work) + 256;

@@ -311,6 +311,8 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
     A = torch.from_numpy(flat.copy()).to(dev)
     offA = torch.from_numpy(offs).to(dev)
 
+    lanes_seen = []
+
     def run(refarr, packed, half=True, fixed_slot=True, two_lanes=True):
         if two_lanes:   # sw_pk1x2_kernel (round 6): a lane's 152 rows over two lanes, four waves per SIMD (the default at 152 rows)
             monkeypatch.delenv("POLYHIP_SW_PK1X2", raising=False)
@@ -336,6 +338,7 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         torch.cuda.synchronize()
         monkeypatch.delenv("POLYHIP_SW_PK1", raising=False)
         monkeypatch.delenv("POLYHIP_SW_PK1X2", raising=False)
+        lanes_seen.append(align.last_packed_lanes())
         return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path(), align.last_packed_half()
 
     refs = [ref]
@@ -354,6 +357,10 @@ def test_packed_pass_equals_exact_kernel(al, monkeypatch, kind):
         want, path0, _ = run(refarr, False)
         assert (path, path16, pathc, path1, path0) == (3, 3, 3, 3, 1)
         assert (half, half16, halfc, half1) == (True, False, True, True)
+        # which form of the packed pass ran: the default spreads a lane's rows over two lanes (65..152 rows) or four (256 rows
+        # on the 64-row tile); the int16 cell and the chunk-staged kernel keep one lane, as does POLYHIP_SW_PK1X2=0; the exact
+        # kernel is no packed pass
+        assert lanes_seen[-5:] == ([4, 4, 4, 4, 0] if long_reads else [2, 1, 1, 1, 0]), lanes_seen
         for g, g16, gc, g1, w in zip(got, got16, gotc, got1, want):
             assert (g == w).all() and (g16 == w).all() and (gc == w).all() and (g1 == w).all()
         refb = refarr.tobytes()
