@@ -108,11 +108,22 @@ struct Strand {
 
 // 64 bytes from an arbitrary address: aligned dwords funnelled to the data's own alignment (the 17th dword is only touched
 // when it holds bytes of the block)
+// (the pointer reaches here through `Strand`, where the compiler loses sight of its address space and would emit FLAT loads:
+// those count on the LDS counter as well, so every wait for a byte-map lookup would also wait for the block's global loads.
+// PH_S2_GLOBAL_LOADS=0 keeps the flat form -- measured in profiles/r06_seqhash_global_loads.log)
+#ifndef PH_S2_GLOBAL_LOADS
+#define PH_S2_GLOBAL_LOADS 1
+#endif
+#if PH_S2_GLOBAL_LOADS
+typedef const __attribute__((address_space(1))) uint32_t *gptr32_t;
+#else
+typedef const uint32_t *gptr32_t;
+#endif
 __device__ __forceinline__ void load16(const uint8_t *p, uint32_t (&o)[16])
 {
     const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
     const uint32_t sh = (uint32_t)(addr & 3u);
-    const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+    gptr32_t gd = (gptr32_t)(addr - sh);
     uint32_t d[17];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -150,7 +161,7 @@ __device__ __forceinline__ void load32(const uint8_t *p, uint32_t (&o)[32])
 {
     const uintptr_t addr = reinterpret_cast<uintptr_t>(p);
     const uint32_t sh = (uint32_t)(addr & 3u);
-    const uint32_t *gd = reinterpret_cast<const uint32_t *>(addr - sh);
+    gptr32_t gd = (gptr32_t)(addr - sh);
     uint32_t d[33];
 #pragma unroll
     for (int i = 0; i < 32; ++i)
