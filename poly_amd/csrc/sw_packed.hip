@@ -36,6 +36,9 @@
 #include "common.h"
 #include "sw_scoring.h"
 
+#ifndef PH_SW_NEAR_SPAN
+#define PH_SW_NEAR_SPAN 15 // ties whose blocks lie within this many blocks of the first are resolved by sw_locate16_kernel itself
+#endif
 #ifndef PH_SW_TILE64_DEFAULT
 #define PH_SW_TILE64_DEFAULT 1 // 1: reads above 152 rows take 64 rows per lane (four waves per SIMD) unless POLYHIP_SW_TILE64=0
 #endif
@@ -202,6 +205,41 @@ __device__ __forceinline__ uint32_t pkf_max3(uint32_t a, uint32_t b, uint32_t c)
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // byte code of A[i] of one pair, pad code where the pair has no such row or the byte is not in FirstAlphabet
+// ---- what a packed kernel keeps per pair (one per 16-bit half of its registers) -----------------------------------------------
+// the running maximum `best`, the FIRST 4-column block that reached it `bestq`, and in `ties` bit 0 = "a later block reached it
+// again" with, in bits 1..15, the low 15 bits of the LAST such block (round 6: nearly every tie of configs[3] is two or three
+// neighbouring blocks -- the same alignment path coming back to its maximum --, and the locate step then only has to look at
+// those blocks instead of handing the pair to the full sweep).  No extra register, and the tie branch stays ONE instruction:
+// the block number is wave-uniform, so what goes into the field is built on the scalar unit.
+// infoQ word of a pair: bits 0..15 first block, bits 16..23 span = last - first (saturating at 255), bit 31 tie.
+__device__ __forceinline__ void track_block_max(uint32_t bm, uint32_t q, uint32_t &best, uint32_t &bestq, uint32_t &ties)
+{
+    const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
+    const uint32_t tv = ((q & 0x7FFFu) << 1) | 1u; // (scalar)
+    if (blo > mlo) {
+        best = (best & 0xFFFF0000u) | blo;
+        bestq = (bestq & 0xFFFF0000u) | (q & 0xFFFFu);
+        ties &= 0xFFFF0000u;
+    } else if (blo == mlo && blo != 0u) {
+        ties = (ties & 0xFFFF0000u) | tv;
+    }
+    if (bhi > mhi) {
+        best = (best & 0xFFFFu) | (bhi << 16);
+        bestq = (bestq & 0xFFFFu) | (q << 16);
+        ties &= 0xFFFFu;
+    } else if (bhi == mhi && bhi != 0u) {
+        ties = (ties & 0xFFFFu) | (tv << 16);
+    }
+}
+// (the span is exact while the reference has at most 32,768 blocks; sw_locate16_kernel only trusts it there)
+__device__ __forceinline__ uint32_t info_q_word(uint32_t firstq, uint32_t tfield)
+{
+    const uint32_t span = min((((tfield >> 1) & 0x7FFFu) - firstq) & 0x7FFFu, 255u);
+    return firstq | ((tfield & 1u) ? span << 16 : 0u) | ((tfield & 1u) << 31);
+}
+__device__ __forceinline__ uint32_t info_q_lo(uint32_t bestq, uint32_t ties) { return info_q_word(bestq & 0xFFFFu, ties & 0xFFFFu); }
+__device__ __forceinline__ uint32_t info_q_hi(uint32_t bestq, uint32_t ties) { return info_q_word(bestq >> 16, ties >> 16); }
+
 __device__ __forceinline__ uint32_t row_code(const uint8_t *__restrict__ ap, uint32_t lenA, int i,
                                              const uint8_t *__restrict__ codeL, uint32_t pad)
 {
@@ -329,21 +367,7 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wa)); // the read issued ahead of a skipped group
             // block maximum against the running one, per half; a block reaching the maximum AGAIN is a tie
             const uint32_t q = q0 + t;
-            const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
-            if (blo > mlo) {
-                best = (best & 0xFFFF0000u) | blo;
-                bestq = (bestq & 0xFFFF0000u) | q;
-                ties &= ~1u;
-            } else if (blo == mlo && blo != 0u) {
-                ties |= 1u;
-            }
-            if (bhi > mhi) {
-                best = (best & 0xFFFFu) | (bhi << 16);
-                bestq = (bestq & 0xFFFFu) | (q << 16);
-                ties &= ~0x10000u;
-            } else if (bhi == mhi && bhi != 0u) {
-                ties |= 0x10000u;
-            }
+            track_block_max(bm, q, best, bestq, ties);
         }
     }
 #undef PH_PK_STEP
@@ -354,11 +378,11 @@ __global__ __launch_bounds__(THREADS, 2) void sw_pk_kernel(const uint8_t *__rest
     }
     if (p0 < npairs) {
         infoM[p0] = m0;
-        infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+        infoQ[p0] = info_q_lo(bestq, ties);
     }
     if (p1 < npairs) {
         infoM[p1] = m1;
-        infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+        infoQ[p1] = info_q_hi(bestq, ties);
     }
 }
 
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_pk[]; // [0, 1024) the table slot, [1024, 1280) the code bytes,
     uint8_t *codeL = lds_pk + 1024;                                  // [1280, 2304) the next block's table arriving
     const uint32_t lane = threadIdx.x;
-    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk)) != 0u)
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)lds_pk)) != 0u)
         __builtin_trap(); // the sweep addresses the slot by immediate
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -505,7 +529,9 @@ __global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict
         // the next block's table: global memory -> the staging area behind the codes, no register held under the rows
         if (mine && t + 1 < nq)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)tabp,
-                                             (__attribute__((address_space(3))) void *)(lds_pk + 1280), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)((__attribute__((address_space(3))) uint8_t *)lds_pk + 1280), 16, 0, 0);
+        // (the LDS pointer stays in its own address space: through a generic pointer hipcc 7.2 once stopped here with "Illegal
+        // instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" -- the null check of the cast back)
         uint32_t pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = gap2, bm = 0; // 0 - |gap| (PH_PKF_ROW)
         uint32_t pg0 = 0, pg1 = 0, pg2 = 0, pg3 = 0;
         (void)pr3;
@@ -542,30 +568,16 @@ __global__ __launch_bounds__(64, 2) void sw_pk1_kernel(const uint8_t *__restrict
                          : "memory");
         }
         // block maximum against the running one, per half; a block reaching the maximum AGAIN is a tie
-        const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
-        if (blo > mlo) {
-            best = (best & 0xFFFF0000u) | blo;
-            bestq = (bestq & 0xFFFF0000u) | t;
-            ties &= ~1u;
-        } else if (blo == mlo && blo != 0u) {
-            ties |= 1u;
-        }
-        if (bhi > mhi) {
-            best = (best & 0xFFFFu) | (bhi << 16);
-            bestq = (bestq & 0xFFFFu) | (t << 16);
-            ties &= ~0x10000u;
-        } else if (bhi == mhi && bhi != 0u) {
-            ties |= 0x10000u;
-        }
+        track_block_max(bm, t, best, bestq, ties);
     }
     const uint32_t m0 = half_score(best & 0xFFFFu), m1 = half_score(best >> 16);
     if (p0 < npairs) {
         infoM[p0] = m0;
-        infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+        infoQ[p0] = info_q_lo(bestq, ties);
     }
     if (p1 < npairs) {
         infoM[p1] = m1;
-        infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+        infoQ[p1] = info_q_hi(bestq, ties);
     }
 }
 
@@ -600,7 +612,7 @@ __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restri
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_pk[]; // [0, 1024) slot 0, [1024, 2048) slot 1,
     uint8_t *codeL = lds_pk + 2048;                                  // [2048, 2304) the code bytes, [2304, 3328) staging
     const uint32_t lane = threadIdx.x;
-    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_pk)) != 0u)
+    if (static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) uint8_t *)lds_pk)) != 0u)
         __builtin_trap(); // the sweep addresses the slots by immediate
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -717,7 +729,7 @@ __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restri
         tabp += tab_bytes;
         if (mine && t + 1 < nq)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)tabp,
-                                             (__attribute__((address_space(3))) void *)(lds_pk + 2304), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)((__attribute__((address_space(3))) uint8_t *)lds_pk + 2304), 16, 0, 0);
         // the band above hands its last row of block t - 1 down (odd lanes); the even lanes start at the top of the column
         {
             const uint32_t u0 = from_lane_above(pr0), u1 = from_lane_above(pr1), u2 = from_lane_above(pr2),
@@ -765,31 +777,17 @@ __global__ __launch_bounds__(64, 4) void sw_pk1x2_kernel(const uint8_t *__restri
         }
         // the pair's block maximum (all 2 RB rows) is the odd lane's; a block reaching the maximum AGAIN is a tie
         const uint32_t tb = t - 1u;
-        const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
-        if (blo > mlo) {
-            best = (best & 0xFFFF0000u) | blo;
-            bestq = (bestq & 0xFFFF0000u) | (tb & 0xFFFFu);
-            ties &= ~1u;
-        } else if (blo == mlo && blo != 0u) {
-            ties |= 1u;
-        }
-        if (bhi > mhi) {
-            best = (best & 0xFFFFu) | (bhi << 16);
-            bestq = (bestq & 0xFFFFu) | (tb << 16);
-            ties &= ~0x10000u;
-        } else if (bhi == mhi && bhi != 0u) {
-            ties |= 0x10000u;
-        }
+        track_block_max(bm, tb, best, bestq, ties);
     }
     if (odd) {
         const uint32_t m0 = half_score(best & 0xFFFFu), m1 = half_score(best >> 16);
         if (p0 < npairs) {
             infoM[p0] = m0;
-            infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+            infoQ[p0] = info_q_lo(bestq, ties);
         }
         if (p1 < npairs) {
             infoM[p1] = m1;
-            infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+            infoQ[p1] = info_q_hi(bestq, ties);
         }
     }
 }
@@ -931,21 +929,7 @@ __global__ __launch_bounds__(THREADS, RB <= 64 ? 4 : 2) void sw_pkb_kernel(const
             outm = bm;
             // last band: bm is the pair's maximum over block s0 + t - (K - 1) (all-pad blocks give 0: no effect)
             const uint32_t q = s0 + t - (uint32_t)(K - 1);
-            const uint32_t blo = bm & 0xFFFFu, bhi = bm >> 16, mlo = best & 0xFFFFu, mhi = best >> 16;
-            if (blo > mlo) {
-                best = (best & 0xFFFF0000u) | blo;
-                bestq = (bestq & 0xFFFF0000u) | (q & 0xFFFFu);
-                ties &= ~1u;
-            } else if (blo == mlo && blo != 0u) {
-                ties |= 1u;
-            }
-            if (bhi > mhi) {
-                best = (best & 0xFFFFu) | (bhi << 16);
-                bestq = (bestq & 0xFFFFu) | (q << 16);
-                ties &= ~0x10000u;
-            } else if (bhi == mhi && bhi != 0u) {
-                ties |= 0x10000u;
-            }
+            track_block_max(bm, q, best, bestq, ties);
         }
     }
 #undef PH_PK_STEP
@@ -957,11 +941,11 @@ __global__ __launch_bounds__(THREADS, RB <= 64 ? 4 : 2) void sw_pkb_kernel(const
         }
         if (p0 < npairs) {
             infoM[p0] = m0;
-            infoQ[p0] = (bestq & 0xFFFFu) | ((ties & 1u) << 31);
+            infoQ[p0] = info_q_lo(bestq, ties);
         }
         if (p1 < npairs) {
             infoM[p1] = m1;
-            infoQ[p1] = (bestq >> 16) | ((ties >> 16) << 31);
+            infoQ[p1] = info_q_hi(bestq, ties);
         }
     }
 }
@@ -1077,7 +1061,7 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
     const int M = active ? (int)infoM[pair] : 0;
     const uint32_t iq = active ? infoQ[pair] : 0u;
     const bool tie = (iq >> 31) != 0u;
-    const uint32_t q = iq & 0x7FFFFFFFu;
+    const uint32_t q = iq & 0xFFFFu; // (bits 16..23: how far behind it the last block worth M lies -- sw_locate16_kernel uses it)
     const bool work = active && e == 0u && M > 0 && !tie;
 
     // columns that can feed a cell worth M in block q: lenA + (smax*lenA - M)/|gap| before its last column
@@ -1190,10 +1174,14 @@ __global__ __launch_bounds__(256) void profile16_kernel(const uint8_t *__restric
     do {                                                                                      \
         H = pkf_max3(pkf_add((DIAG), (W)), (UPG), (LEFTG));                                   \
         GOUT = pkf_addc(H, gap2);                                                             \
-        if (FIND)                                                                             \
+        if (FIND == 1 || FIND == 2)                                                           \
             key = (key == 0xFFFFFFFFu && ((H >> (FIND == 2 ? 16 : 0)) & 0xFFFFu) == Mh)        \
                       ? (uint32_t)(((r_ + (FIND == 2 ? RB : 0)) << 2) | (C))                  \
                       : key;                                                                  \
+        if (FIND == 3) { /* several blocks may hold a cell worth M: the least (row, block, column) of both bands */ \
+            key = min(key, (H & 0xFFFFu) == Mh ? ((uint32_t)r_ << 10) | kb0 | (uint32_t)(C) : 0xFFFFFFFFu);         \
+            key = min(key, (H >> 16) == Mh ? ((uint32_t)(r_ + RB) << 10) | kb1 | (uint32_t)(C) : 0xFFFFFFFFu);      \
+        }                                                                                     \
     } while (0)
 #define PH_L16_ROW(R, X0, X1, Y0, Y1)                                       \
     do {                                                                    \
@@ -1332,17 +1320,30 @@ __global__ __launch_bounds__(THREADS, 2) void sw_locate16_kernel(
     const int M = active ? (int)infoM[pair] : 0;
     const uint32_t iq = active ? infoQ[pair] : 0u;
     const bool tie = (iq >> 31) != 0u;
-    const uint32_t q = iq & 0x7FFFFFFFu;
-    const bool work = active && e == 0u && M > 0 && !tie;
-
+    const uint32_t q = iq & 0xFFFFu;
+    // A NEAR tie (round 6): every block worth M lies in [q, q + span] with span <= NEAR_SPAN (track_block_max) -- at configs[3]
+    // all ties are (one alignment path coming back to its maximum a block or two later).  The window then ends behind block
+    // q + span and begins where block q's window would, every cell worth M inside it is computed exactly, and the least
+    // (row, column) among them is align.go:197's answer: no full sweep.  (Not when the end cell is left to the traceback.)
+    constexpr uint32_t NEAR_SPAN = PH_SW_NEAR_SPAN;
+    uint32_t span = (iq >> 16) & 0xFFu;
     uint32_t jb0 = 0, nblk = 0;
-    if (work && !defer) {
+    bool near = false;
+    if (active && e == 0u && M > 0 && !defer && (!tie || span <= NEAR_SPAN)) {
+        if (!tie)
+            span = 0;
         const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
-        const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u;
-        const uint32_t jend = 4u * q + 4u; // one past the block's last column
+        const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u + 4u * span;
+        const uint32_t jend = 4u * (q + span) + 4u; // one past the last block's last column
         jb0 = (jend > need ? jend - need : 0u) & ~3u;
         nblk = (jend - jb0) >> 2;
+        near = tie && nblk <= 255u && nqB <= 32768u; // (the key numbers a window's blocks in eight bits; the span is exact)
+        if (tie && !near)
+            nblk = 0;
     }
+    const bool work = active && e == 0u && M > 0 && (!tie || near);
+    if (!work)
+        nblk = 0;
 
     uint32_t H[RB];
 #pragma unroll
@@ -1362,7 +1363,10 @@ __global__ __launch_bounds__(THREADS, 2) void sw_locate16_kernel(
     // band 0's last row of the block before, already in the high halves: what band 1 finds above its first row
     uint32_t hh0 = 0, hh1 = 0, hh2 = 0, hh3 = 0, hg0 = 0, hg1 = 0, hg2 = 0, hg3 = 0, hd = 0;
     auto sweep = [&](uint32_t bt, auto find_tag) { // bt = band 0's block; band 1 works on bt - 1
-        constexpr int FIND = decltype(find_tag)::value; // 0, 1 = search band 0's cells, 2 = band 1's
+        constexpr int FIND = decltype(find_tag)::value; // 0, 1 = search band 0's cells, 2 = band 1's, 3 = both, the block in the key
+        const uint32_t kb0 = min(bt, 255u) << 2, kb1 = (bt >= 1u ? min(bt - 1u, 255u) : 255u) << 2;
+        (void)kb0;
+        (void)kb1;
         const uint32_t base0 = bt < nblk ? lds_base + ((jb0 >> 2) + bt) * pstride : pad_base;
         const uint32_t base1 = bt >= 1u ? lds_base + ((jb0 >> 2) + bt - 1u) * pstride : pad_base;
         uint32_t pr0 = hh0, pr1 = hh1, pr2 = hh2, pr3 = hh3, pg0 = hg0, pg1 = hg1, pg2 = hg2, pg3 = hg3, pdiag = hd;
@@ -1400,11 +1404,23 @@ __global__ __launch_bounds__(THREADS, 2) void sw_locate16_kernel(
         hg2 = pg2 << 16;
         hg3 = pg3 << 16;
     };
-    // iterations 0 .. nmax (a lane runs nblk + 1 of them); the last two carry the search
+    // iterations 0 .. nmax (a lane runs nblk + 1 of them); the last two carry the search -- or, in a wave with a near tie, the last
+    // wspan + 2 in the form that looks at both bands and keeps the least (row, block, column): a lane without a tie finds its one
+    // block's cell that way too (nothing before its block q is worth M)
+    uint32_t wspan = near ? span : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        wspan = max(wspan, (uint32_t)__shfl_xor((int)wspan, d, 64));
+    const bool wave_near = __builtin_amdgcn_readfirstlane((int)wspan) != 0;
     for (uint32_t t = 0; t <= nmax; ++t) {
         if (nblk == 0u || t < lag)
             continue;
-        if (t + 1u == nmax)
+        if (wave_near) {
+            if (t + 1u + wspan >= nmax)
+                sweep(t - lag, std::integral_constant<int, 3>{});
+            else
+                sweep(t - lag, std::integral_constant<int, 0>{});
+        } else if (t + 1u == nmax)
             sweep(t - lag, std::integral_constant<int, 1>{});
         else if (t == nmax)
             sweep(t - lag, std::integral_constant<int, 2>{});
@@ -1414,8 +1430,8 @@ __global__ __launch_bounds__(THREADS, 2) void sw_locate16_kernel(
 
     if (!active)
         return;
-    // a tie, or (never expected) no cell found: the exact kernel decides
-    if (e == 0u && M > 0 && (tie || (!defer && key == 0xFFFFFFFFu))) {
+    // a tie that is not a near one, or (never expected) no cell found: the exact kernel decides
+    if (e == 0u && M > 0 && ((tie && !near) || (!defer && key == 0xFFFFFFFFu))) {
         list[atomicAdd(count, 1u)] = (uint32_t)pair;
         return;
     }
@@ -1424,6 +1440,9 @@ __global__ __launch_bounds__(THREADS, 2) void sw_locate16_kernel(
     if (defer) { // the traceback kernel locates the cell inside block q
         endA[pair] = hit ? SW_END_DEFERRED : 0u;
         endB[pair] = hit ? 4u * q + 4u : 0u;
+    } else if (wave_near) { // key = row << 10 | block of the window << 2 | column (a lane without a tie: its block is q)
+        endA[pair] = hit ? (key >> 10) + 1u : 0u;
+        endB[pair] = hit ? (near ? jb0 + 4u * ((key >> 2) & 0xFFu) : 4u * q) + (key & 3u) + 1u : 0u;
     } else {
         endA[pair] = hit ? (key >> 2) + 1u : 0u;
         endB[pair] = hit ? 4u * q + (key & 3u) + 1u : 0u;

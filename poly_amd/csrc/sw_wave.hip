@@ -115,7 +115,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
         if (M != 0u && (iq >> 31) == 0u) { // M == 0: nothing positive, or a read the packed pass did not take -- full sweep
             const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
             const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
-            const uint32_t jend = min(4u * (iq & 0x7FFFFFFFu) + 4u, lenB);
+            const uint32_t jend = min(4u * (iq & 0xFFFFu) + 4u, lenB);
             j0 = jend > need ? jend - need : 0u;
             ncols = jend - j0;
         }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(THREADS) void sw_wave8_kernel(
         if ((iq >> 31) == 0u) {
             const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
             const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
-            const uint32_t jend = min(4u * (iq & 0x7FFFFFFFu) + 4u, lenB);
+            const uint32_t jend = min(4u * (iq & 0xFFFFu) + 4u, lenB);
             j0 = jend > need ? jend - need : 0u;
             ncols = jend - j0;
         }
