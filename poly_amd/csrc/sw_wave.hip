@@ -112,10 +112,14 @@ __global__ __launch_bounds__(THREADS) void sw_wave_kernel(
     uint32_t j0 = 0, ncols = lenB;
     if (infoM) {
         const uint32_t M = infoM[pair], iq = infoQ[pair];
-        if (M != 0u && (iq >> 31) == 0u) { // M == 0: nothing positive, or a read the packed pass did not take -- full sweep
+        // (round 6) a NEAR tie -- every block worth M within `span` < 255 blocks of the first (infoQ bits 16..23; exact while the
+        // reference has at most 32,768 blocks) -- stretches the window over first..last instead of the whole reference: all
+        // cells worth M are inside it and computed exactly, and the first maximum of the window is the matrix's
+        const uint32_t span = (iq >> 31) ? (iq >> 16) & 0xFFu : 0u;
+        if (M != 0u && ((iq >> 31) == 0u || (span < 255u && lenB <= 131072u))) { // M == 0: nothing positive, or a read the packed pass did not take -- full sweep
             const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
-            const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
-            const uint32_t jend = min(4u * (iq & 0xFFFFu) + 4u, lenB);
+            const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u + 4u * span;
+            const uint32_t jend = min(4u * ((iq & 0xFFFFu) + span) + 4u, lenB);
             j0 = jend > need ? jend - need : 0u;
             ncols = jend - j0;
         }
@@ -308,10 +312,11 @@ __global__ __launch_bounds__(THREADS) void sw_wave8_kernel(
         // the window (as sw_wave_kernel's locate mode): only the columns that can feed a cell worth M in the block that holds
         // it; a maximum seen in several blocks (tie bit): every column
         uint32_t j0 = 0, ncols = lenB;
-        if ((iq >> 31) == 0u) {
+        const uint32_t span = (iq >> 31) ? (iq >> 16) & 0xFFu : 0u; // (a near tie: the window runs over first..last block, as above)
+        if ((iq >> 31) == 0u || (span < 255u && lenB <= 131072u)) {
             const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
-            const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u;
-            const uint32_t jend = min(4u * (iq & 0xFFFFu) + 4u, lenB);
+            const uint32_t need = lenA + (top > M ? (top - M) / g : 0u) + 4u + 4u * span;
+            const uint32_t jend = min(4u * ((iq & 0xFFFFu) + span) + 4u, lenB);
             j0 = jend > need ? jend - need : 0u;
             ncols = jend - j0;
         }
