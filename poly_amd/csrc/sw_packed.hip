@@ -956,8 +956,8 @@ __global__ __launch_bounds__(THREADS, RB <= 64 ? 4 : 2) void sw_pkb_kernel(const
 #define PH_LC_CELL(S, DIAG, UP, LEFT, HOUT, C)                                    \
     do {                                                                          \
         HOUT = max(max((DIAG) + (S), 0), max((UP), (LEFT)) + gap);                \
-        if (FIND)                                                                 \
-            key = min(key, HOUT == M ? (uint32_t)((i_ << 2) | (C)) : 0xFFFFFFFFu); \
+        if (FIND) /* the least (row, block of the window, column) worth M */       \
+            key = min(key, HOUT == M ? ((uint32_t)i_ << 10) | kbv | (uint32_t)(C) : 0xFFFFFFFFu); \
     } while (0)
 #define PH_LC_ROW(I, W)                                   \
     do {                                                  \
@@ -1061,18 +1061,28 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
     const int M = active ? (int)infoM[pair] : 0;
     const uint32_t iq = active ? infoQ[pair] : 0u;
     const bool tie = (iq >> 31) != 0u;
-    const uint32_t q = iq & 0xFFFFu; // (bits 16..23: how far behind it the last block worth M lies -- sw_locate16_kernel uses it)
-    const bool work = active && e == 0u && M > 0 && !tie;
-
-    // columns that can feed a cell worth M in block q: lenA + (smax*lenA - M)/|gap| before its last column
+    const uint32_t q = iq & 0xFFFFu;
+    // columns that can feed a cell worth M in block q: lenA + (smax*lenA - M)/|gap| before its last column.  A NEAR tie (every
+    // block worth M within PH_SW_NEAR_SPAN blocks of the first: sw_locate16_kernel has the argument) stretches the window to
+    // the last such block and searches its last span + 1 blocks; other ties go to the full sweep.
+    uint32_t span = (iq >> 16) & 0xFFu;
     uint32_t jb0 = 0, nblk = 0;
-    if (work && !defer) {
+    bool near = false;
+    if (active && e == 0u && M > 0 && !defer && (!tie || span <= (uint32_t)PH_SW_NEAR_SPAN)) {
+        if (!tie)
+            span = 0;
         const uint32_t g = (uint32_t)(-gap), top = (uint32_t)smax * lenA;
-        const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u;
-        const uint32_t jend = 4u * q + 4u; // one past the block's last column
+        const uint32_t need = lenA + (top > (uint32_t)M ? (top - (uint32_t)M) / g : 0u) + 4u + 4u * span;
+        const uint32_t jend = 4u * (q + span) + 4u; // one past the last block's last column
         jb0 = (jend > need ? jend - need : 0u) & ~3u;
         nblk = (jend - jb0) >> 2;
+        near = tie && nblk <= 255u && lenB_pad <= 131072u; // (eight bits of the key number a window's blocks; the span is exact)
+        if (tie && !near)
+            nblk = 0;
     }
+    const bool work = active && e == 0u && M > 0 && (!tie || near);
+    if (!work)
+        nblk = 0;
 
     int H[RA];
 #pragma unroll
@@ -1091,6 +1101,8 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
     const uint32_t lag = nmax - nblk;
     auto sweep = [&](uint32_t bt, auto find_tag) {
         constexpr bool FIND = decltype(find_tag)::value;
+        const uint32_t kbv = min(bt, 255u) << 2;
+        (void)kbv;
         const uint32_t blk = lds_base + ((jb0 >> 2) + bt) * (CP * 4);
         int pr0 = 0, pr1 = 0, pr2 = 0, pr3 = 0, pdiag = 0;
         uint32_t wa0, wa1, wa2, wa3, wb0, wb1, wb2, wb3;
@@ -1113,16 +1125,22 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
             wa3 = wb3;
         }
     };
-    for (uint32_t t = 0; t + 1 < nmax; ++t)
-        if (t >= lag) // (nblk == 0: lag == nmax, never)
-            sweep(t - lag, std::false_type{});
-    if (nmax > 0 && nblk > 0)
-        sweep(nblk - 1u, std::true_type{});
+    uint32_t wspan = near ? span : 0u; // the wave's widest near tie: its last wspan + 1 iterations carry the search
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        wspan = max(wspan, (uint32_t)__shfl_xor((int)wspan, d, 64));
+    for (uint32_t t = 0; t < nmax; ++t)
+        if (t >= lag) { // (nblk == 0: lag == nmax, never)
+            if (t + 1u + wspan >= nmax)
+                sweep(t - lag, std::true_type{});
+            else
+                sweep(t - lag, std::false_type{});
+        }
 
     if (!active)
         return;
-    // a tie, or (never expected) no cell found: the exact kernel decides
-    if (e == 0u && M > 0 && (tie || (!defer && key == 0xFFFFFFFFu))) {
+    // a tie that is not a near one, or (never expected) no cell found: the exact kernel decides
+    if (e == 0u && M > 0 && ((tie && !near) || (!defer && key == 0xFFFFFFFFu))) {
         list[atomicAdd(count, 1u)] = (uint32_t)pair;
         return;
     }
@@ -1131,9 +1149,9 @@ __global__ __launch_bounds__(THREADS) void sw_locate_kernel(
     if (defer) { // the traceback kernel locates the cell inside block q
         endA[pair] = hit ? SW_END_DEFERRED : 0u;
         endB[pair] = hit ? 4u * q + 4u : 0u;
-    } else {
-        endA[pair] = hit ? (key >> 2) + 1u : 0u;
-        endB[pair] = hit ? 4u * q + (key & 3u) + 1u : 0u;
+    } else { // key = row << 10 | block of the window << 2 | column (without a tie the block is q)
+        endA[pair] = hit ? (key >> 10) + 1u : 0u;
+        endB[pair] = hit ? (near ? jb0 + 4u * ((key >> 2) & 0xFFu) : 4u * q) + (key & 3u) + 1u : 0u;
     }
     err[pair] = e;
 }
