@@ -528,3 +528,86 @@ def test_long_reads_packed_banded_pass_equals_wave_kernel(al, monkeypatch, maxA,
         a = flat[offs[p]:offs[p + 1]].tobytes()
         s, _, _, ea_, eb_ = orc.smith_waterman(a, refb, om, -2)
         assert (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p])) == (s, ea_, eb_, 0), p
+
+
+@pytest.mark.parametrize("L", [150, 250, 600])
+def test_near_ties_are_located_without_the_full_sweep(al, monkeypatch, L):
+    """Round 6: a maximum that several 4-column blocks reach is resolved by the locate step itself when the blocks lie within
+    15 blocks of the first (sw_locate16_kernel up to 152 rows, sw_locate_kernel up to 256, the one-wave-per-pair locate
+    kernels beyond).  The reference carries short tandem repeats (periods of 8..72 bp, a few more copies than the reads made
+    from them), so reads align equally well at two or three shifts: spans of 2, 5, 7, 9, 10, 14, 15, 18 ... blocks -- on both
+    sides of the limit -- next to ordinary mutated reads.  Score, endA, endB and err of every pair equal the exact 32-bit /
+    full-sweep kernels (POLYHIP_SW_PACKED=0); a sample of the tie reads equals the oracle."""
+    import torch
+    align = al[0]
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(600 + L)
+    LB = 6000
+    ref = orc.synth_dna(0xC4, LB).copy()
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    regions = []
+    at = 100
+    for period in (8, 20, 28, 36, 40, 60, 64, 72):
+        copies_read = max(2, (L - 10) // period)
+        for extra in (1, 2):
+            unit = acgt[rng.integers(0, 4, period)]  # (a unit of its own per region: the first shift is inside the region)
+            ncopy = copies_read + extra
+            if at + ncopy * period + 50 > LB:
+                break
+            ref[at:at + ncopy * period] = np.tile(unit, ncopy)
+            regions.append((at, period, copies_read))
+            at += ncopy * period + int(rng.integers(30, 90))
+    assert len(regions) >= 6
+    n = 50_001 if L <= 256 else 16_500  # enough pairs for the packed pass (path 3 / 7)
+    reads, lens, is_tie = np.zeros((n, L), np.uint8), np.zeros(n, np.int64), np.zeros(n, bool)
+    for p in range(n):
+        if p % 3 == 0:  # a read made of whole periods: equally good at every shift the reference offers
+            a0, period, k = regions[(p // 3) % len(regions)]
+            r = ref[a0:a0 + k * period].copy()
+            if p % 9 == 0 and len(r) > 4:  # ... some with a substitution (the same at every shift)
+                r[int(rng.integers(0, len(r)))] = acgt[rng.integers(0, 4)]
+            is_tie[p] = True
+        else:
+            a0 = int(rng.integers(0, LB - L))
+            r = ref[a0:a0 + int(rng.integers(L // 2, L + 1))].copy()
+            hit = rng.random(len(r)) < 0.06
+            r[hit] = acgt[rng.integers(0, 4, int(hit.sum()))]
+        lens[p] = len(r)
+        reads[p, :len(r)] = r
+    lens[0] = L if L <= LB else lens[0]
+    reads[0, :L] = ref[3000:3000 + L]
+    offs = np.zeros(n + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    flat = np.concatenate([reads[i, :lens[i]] for i in range(n)])
+    sc = _scoring(al, "-ACGT", al[2].NUC_4, -2)
+    A, offA, B = torch.from_numpy(flat.copy()).to(dev), torch.from_numpy(offs).to(dev), torch.from_numpy(ref.copy()).to(dev)
+
+    def run(packed):
+        if packed:
+            monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+        else:
+            monkeypatch.setenv("POLYHIP_SW_PACKED", "0")
+        score = torch.full((n,), -7, dtype=torch.int64, device=dev)
+        ea, eb, er = (torch.full((n,), -7, dtype=torch.int32, device=dev) for _ in range(3))
+        work = torch.empty(align.sw_workspace_bytes(sc, n, L, LB), dtype=torch.uint8, device=dev)
+        align.sw_batch_dev(sc, A, offA, L, B, None, LB, score, ea, eb, er, work)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("POLYHIP_SW_PACKED", raising=False)
+        return [t.cpu().numpy() for t in (score, ea, eb, er)], align.last_path()
+
+    got, path = run(True)
+    want, path0 = run(False)
+    assert (path, path0) == ((3, 1) if L <= 256 else (7, 6))
+    for g, w in zip(got, want):
+        assert (g == w).all()
+    om = orc.SubstitutionMatrix("-ACGT", "-ACGT", orc.NUC_4_SCORES)
+    refb = ref.tobytes()
+    ties = np.nonzero(is_tie)[0]
+    for p in list(ties[:: max(1, len(ties) // 150)]) + [0, n - 1]:
+        s, _, _, ea_, eb_ = orc.smith_waterman(flat[offs[p]:offs[p + 1]].tobytes(), refb, om, -2)
+        assert (int(got[0][p]), int(got[1][p]), int(got[2][p]), int(got[3][p])) == (s, ea_, eb_, 0), p
+    # the tie reads really are ties: their end column is the FIRST of the shifts the reference offers
+    exact = [p for p in ties if p % 9 != 0][:200]
+    for p in exact:
+        a0, period, k = regions[(p // 3) % len(regions)]
+        assert int(got[0][p]) == 5 * k * period and int(got[2][p]) == a0 + k * period, p
