@@ -102,8 +102,18 @@ def emit(full: dict, json_fd: int, full_out: str) -> None:
         sys.stderr.write(f"bench.py: could not write {full_out}: {e}\n")
     sys.stderr.write("bench.py full record: " + text_full + "\n")
     sys.stderr.flush()
-    text = bench_line.render(full)
-    assert len(text) + 1 <= bench_line.LIMIT and isinstance(json.loads(text), dict)
+    try:
+        text = bench_line.render(full)
+        if len(text) + 1 > bench_line.LIMIT or not isinstance(json.loads(text), dict):
+            raise ValueError(f"compact line of {len(text)} bytes")
+    except Exception as e:  # whatever happens, a parseable line with the contract keys goes out
+        sys.stderr.write(f"bench.py: compact line failed ({type(e).__name__}: {e}); printing the bare contract line\n")
+        bare = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                          "scaling", "vs_baseline", "dtype", "data")}
+        bare["config"] = {"workload": str((full.get("config") or {}).get("workload"))[:140]}
+        rf = full.get("roofline") or {}
+        bare["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        text = json.dumps(bare, default=str)
     os.write(json_fd, (text + "\n").encode())
 
 
