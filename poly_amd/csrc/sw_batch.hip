@@ -755,13 +755,16 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
                                2 * (ps.work_bytes + 256) <= p.pk.work_bytes;
             if (!split) {
                 uint32_t *list = nullptr, *count = nullptr;
+                const uint32_t *infoM = nullptr, *infoQ = nullptr;
                 const int rc = k3p::packed_run(sc, p.pk, d_A, d_offA, npairs, d_B, (uint32_t)lenB, prof, binfo,
                                                static_cast<uint8_t *>(d_work) + p.fast_bytes, d_score, d_endA, d_endB, d_err,
-                                               &list, &count, st, nullptr, nullptr, do_defer);
+                                               &list, &count, st, &infoM, &infoQ, do_defer);
                 if (rc != POLYHIP_OK)
                     return rc;
+                // (round 6: the tie list with the packed pass's M / first block / span -- a near tie is swept on its window,
+                // not over the whole reference: sw_wave_kernel's locate mode)
                 return k3w::wave_run(sc, d_A, d_offA, npairs, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count,
-                                     npairs, d_score, d_endA, d_endB, d_err, st);
+                                     npairs, d_score, d_endA, d_endB, d_err, st, infoM, infoQ);
             }
             ps.skip_rows = p.pk.skip_rows; // (same kernels as the whole batch would take)
             ps.x2_rb = p.pk.x2_rb;
@@ -779,11 +782,12 @@ int polyhip::k3::score_pass(const polyhip_scoring *sc, const uint8_t *d_A, const
                 hipStream_t sk = (k & 1) ? aux.s : st;
                 uint8_t *wk = static_cast<uint8_t *>(d_work) + p.fast_bytes + (k & 1) * slice;
                 uint32_t *list = nullptr, *count = nullptr;
+                const uint32_t *infoM = nullptr, *infoQ = nullptr;
                 int rc = k3p::packed_run(sc, ps, d_A, d_offA + i0, m, d_B, (uint32_t)lenB, prof, binfo, wk, d_score + i0,
-                                         d_endA + i0, d_endB + i0, d_err + i0, &list, &count, sk, nullptr, nullptr, do_defer);
+                                         d_endA + i0, d_endB + i0, d_err + i0, &list, &count, sk, &infoM, &infoQ, do_defer);
                 if (rc == POLYHIP_OK)
                     rc = k3w::wave_run(sc, d_A, d_offA + i0, m, max_lenA, d_B, nullptr, (uint32_t)lenB, binfo, list, count, m,
-                                       d_score + i0, d_endA + i0, d_endB + i0, d_err + i0, sk);
+                                       d_score + i0, d_endA + i0, d_endB + i0, d_err + i0, sk, infoM, infoQ);
                 if (rc != POLYHIP_OK) {
                     (void)aux.join(st);
                     return rc;
